@@ -1,0 +1,250 @@
+"""ctypes front end of the C oracle (oracle/otmb_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED -- see the header of otmb_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libotmb_oracle.so")
+
+ERRORS = {
+    -1: "ρ contains NaNs", -2: "Tadv contains NaNs.", -3: "TκH contains NaNs.", -4: "TκVML contains NaNs.",
+    -5: "TκVdeep contains NaNs.", -6: "flux into land or outside the grid", -7: "Unknown grid type",
+    -8: "AssertionError: all fluxes missing", -9: "allocation failed",
+}
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(ERRORS.get(code, f"oracle error {code}"))
+        self.code = code
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "otmb_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB
+
+
+class _Grid(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64), ("topo", C.c_int32)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_bp = C.POINTER(C.c_uint8)
+
+
+class _TmArgs(C.Structure):
+    _fields_ = [
+        ("phi", _dp * 6), ("v3D", _dp), ("thk", _dp), ("rho", _dp), ("rho_scalar", C.c_double),
+        ("Lwet", _ip), ("Lwet3D", _ip), ("N", C.c_int64), ("g", _Grid),
+        ("edge", _dp * 4), ("dist", _dp * 4), ("area2D", _dp), ("zt", _dp), ("mlotst", _dp),
+        ("kappaH", C.c_double), ("kappaVML", C.c_double), ("kappaVdeep", C.c_double), ("upwind", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_makeindices.restype = C.c_int64
+        _lib.orc_advection_entries.restype = C.c_int64
+        _lib.orc_hdiff_entries.restype = C.c_int64
+        _lib.orc_vdiff_entries.restype = C.c_int64
+        _lib.orc_sparse.restype = C.c_int64
+        _lib.orc_spadd.restype = C.c_int64
+        _lib.orc_haversine.restype = C.c_double
+        _lib.orc_haversine.argtypes = [C.c_double] * 4
+    return _lib
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def _b(a):
+    return a.ctypes.data_as(_bp) if a is not None else None
+
+
+def _grid(shape, topo):
+    return _Grid(int(shape[0]), int(shape[1]), int(shape[2]), int(topo))
+
+
+PHI_ORDER = ("east", "west", "north", "south", "top", "bottom")
+HDIRS = ("west", "east", "south", "north")
+MATS = ("T", "Tadv", "TκH", "TκVML", "TκVdeep")
+
+
+def makeindices(v3D):
+    v3D = _f(v3D)
+    G = v3D.size
+    Lwet = np.empty(G, dtype=np.int64)
+    Lwet3D = np.empty(v3D.shape, dtype=np.int64, order="F")
+    wet3D = np.empty(v3D.shape, dtype=np.uint8, order="F")
+    N = lib().orc_makeindices(_d(v3D), C.c_int64(G), _i(Lwet), _i(Lwet3D), _b(wet3D))
+    return dict(N=int(N), Lwet=Lwet[:N].copy(), Lwet3D=Lwet3D, wet3D=wet3D)
+
+
+def facefluxes(umo, vmo, wet3D, fill, topo):
+    """umo/vmo: Float64 copies are made here (velocities.jl:125-126)."""
+    u = np.array(umo, dtype=np.float64, order="F")
+    v = np.array(vmo, dtype=np.float64, order="F")
+    wet3D = np.asfortranarray(wet3D, dtype=np.uint8)
+    g = _grid(u.shape, topo)
+    out = {k: np.empty(u.shape, dtype=np.float64, order="F") for k in PHI_ORDER}
+    rc = lib().orc_facefluxes(_d(u), _d(v), _b(wet3D), C.c_double(float(fill)), C.byref(g),
+                              _d(out["east"]), _d(out["west"]), _d(out["north"]), _d(out["south"]),
+                              _d(out["top"]), _d(out["bottom"]))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def _rho_args(rho, shape):
+    if np.ndim(rho) == 0:
+        return None, float(rho)
+    r = _f(rho)
+    assert r.shape == tuple(shape)
+    return r, 0.0
+
+
+def advection_entries(phi, v3D, rho, Lwet, Lwet3D, topo, upwind=True):
+    v3D = _f(v3D)
+    ph = [_f(phi[k]) for k in PHI_ORDER]
+    N = len(Lwet)
+    rho_a, rho_s = _rho_args(rho, v3D.shape)
+    cap = max(1, 12 * N)
+    I = np.empty(cap, np.int64); J = np.empty(cap, np.int64); V = np.empty(cap, np.float64)
+    g = _grid(v3D.shape, topo)
+    Lwet = np.ascontiguousarray(Lwet, dtype=np.int64)
+    Lwet3D = np.asfortranarray(Lwet3D, dtype=np.int64)
+    n = lib().orc_advection_entries((_dp * 6)(*[_d(p) for p in ph]), _d(v3D), _d(rho_a), C.c_double(rho_s),
+                                    _i(Lwet), _i(Lwet3D), C.c_int64(N), C.byref(g), C.c_int32(int(upwind)),
+                                    _i(I), _i(J), _d(V))
+    if n < 0:
+        raise OracleError(n)
+    return I[:n].copy(), J[:n].copy(), V[:n].copy()
+
+
+def hdiff_entries(v3D, thk, edge, dist, Lwet, Lwet3D, topo, kappaH, OmegaH=None):
+    v3D = _f(v3D); thk = _f(thk)
+    e = [_f(edge[d]) for d in HDIRS]; dd = [_f(dist[d]) for d in HDIRS]
+    N = len(Lwet); cap = max(1, 8 * N)
+    I = np.empty(cap, np.int64); J = np.empty(cap, np.int64); V = np.empty(cap, np.float64)
+    g = _grid(v3D.shape, topo)
+    Lwet = np.ascontiguousarray(Lwet, dtype=np.int64); Lwet3D = np.asfortranarray(Lwet3D, dtype=np.int64)
+    Om = None if OmegaH is None else np.ascontiguousarray(OmegaH, dtype=np.uint8)
+    n = lib().orc_hdiff_entries(_d(v3D), _d(thk), (_dp * 4)(*[_d(x) for x in e]), (_dp * 4)(*[_d(x) for x in dd]),
+                                _i(Lwet), _i(Lwet3D), C.c_int64(N), C.byref(g), C.c_double(kappaH), _b(Om),
+                                _i(I), _i(J), _d(V))
+    if n < 0:
+        raise OracleError(n)
+    return I[:n].copy(), J[:n].copy(), V[:n].copy()
+
+
+def ml_mask(zt, mlotst, Lwet, shape, topo=0):
+    N = len(Lwet)
+    Om = np.empty(max(N, 1), np.uint8)
+    zt = np.ascontiguousarray(zt, dtype=np.float64); ml = _f(mlotst)
+    Lwet = np.ascontiguousarray(Lwet, dtype=np.int64)
+    g = _grid(shape, topo)
+    lib().orc_ml_mask(_d(zt), _d(ml), _i(Lwet), C.c_int64(N), C.byref(g), _b(Om))
+    return Om[:N]
+
+
+def vdiff_entries(v3D, area2D, zt, Lwet, Lwet3D, topo, kappaV, Omega=None):
+    v3D = _f(v3D); area2D = _f(area2D); zt = np.ascontiguousarray(zt, dtype=np.float64)
+    N = len(Lwet); cap = max(1, 4 * N)
+    I = np.empty(cap, np.int64); J = np.empty(cap, np.int64); V = np.empty(cap, np.float64)
+    g = _grid(v3D.shape, topo)
+    Lwet = np.ascontiguousarray(Lwet, dtype=np.int64); Lwet3D = np.asfortranarray(Lwet3D, dtype=np.int64)
+    Om = None if Omega is None else np.ascontiguousarray(Omega, dtype=np.uint8)
+    n = lib().orc_vdiff_entries(_d(v3D), _d(area2D), _d(zt), _i(Lwet), _i(Lwet3D), C.c_int64(N), C.byref(g),
+                                C.c_double(kappaV), _b(Om), _i(I), _i(J), _d(V))
+    if n < 0:
+        raise OracleError(n)
+    return I[:n].copy(), J[:n].copy(), V[:n].copy()
+
+
+def sparse(I, J, V, m, n):
+    I = np.ascontiguousarray(I, np.int64); J = np.ascontiguousarray(J, np.int64); V = np.ascontiguousarray(V, np.float64)
+    ln = len(I)
+    colptr = np.empty(n + 1, np.int64); rowval = np.empty(max(ln, 1), np.int64); nzval = np.empty(max(ln, 1), np.float64)
+    nnz = lib().orc_sparse(_i(I), _i(J), _d(V), C.c_int64(ln), C.c_int64(m), C.c_int64(n), _i(colptr), _i(rowval), _d(nzval))
+    if nnz < 0:
+        raise OracleError(nnz)
+    return colptr, rowval[:nnz].copy(), nzval[:nnz].copy()
+
+
+def spadd(A, B, n):
+    Ap, Ai, Ax = A; Bp, Bi, Bx = B
+    cap = max(1, len(Ai) + len(Bi))
+    Cp = np.empty(n + 1, np.int64); Ci = np.empty(cap, np.int64); Cx = np.empty(cap, np.float64)
+    Ai = np.ascontiguousarray(Ai, np.int64); Bi = np.ascontiguousarray(Bi, np.int64)
+    Ax = np.ascontiguousarray(Ax, np.float64); Bx = np.ascontiguousarray(Bx, np.float64)
+    nnz = lib().orc_spadd(C.c_int64(n), _i(np.ascontiguousarray(Ap, np.int64)), _i(Ai), _d(Ax),
+                          _i(np.ascontiguousarray(Bp, np.int64)), _i(Bi), _d(Bx), _i(Cp), _i(Ci), _d(Cx))
+    return Cp, Ci[:nnz].copy(), Cx[:nnz].copy()
+
+
+def transportmatrix(phi, gm, idx, rho, mlotst, kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True,
+                    tight=False):
+    """Whole reference path (matrixbuilding.jl:128-150).  gm: gridmetrics NT/dict; idx: makeindices dict.
+    Returns {name: (colptr, rowval, nzval)} for T, Tadv, TκH, TκVML, TκVdeep (1-based Int64)."""
+    v3D = _f(gm["v3D"]); thk = _f(gm["thkcello"])
+    ph = [_f(phi[k]) for k in PHI_ORDER]
+    e = [_f(gm["edge_length_2D"][d]) for d in HDIRS]; dd = [_f(gm["distance_to_neighbour_2D"][d]) for d in HDIRS]
+    area2D = _f(gm["area2D"]); zt = np.ascontiguousarray(gm["zt"], dtype=np.float64); ml = _f(mlotst)
+    Lwet = np.ascontiguousarray(idx["Lwet"], dtype=np.int64); Lwet3D = np.asfortranarray(idx["Lwet3D"], dtype=np.int64)
+    N = len(Lwet)
+    rho_a, rho_s = _rho_args(rho, v3D.shape)
+    a = _TmArgs()
+    a.phi = (_dp * 6)(*[_d(p) for p in ph]); a.v3D = _d(v3D); a.thk = _d(thk); a.rho = _d(rho_a); a.rho_scalar = rho_s
+    a.Lwet = _i(Lwet); a.Lwet3D = _i(Lwet3D); a.N = N
+    topo = gm["gridtopology"]["kind"] if isinstance(gm["gridtopology"], dict) else int(gm["gridtopology"])
+    a.g = _grid(v3D.shape, topo)
+    a.edge = (_dp * 4)(*[_d(x) for x in e]); a.dist = (_dp * 4)(*[_d(x) for x in dd])
+    a.area2D = _d(area2D); a.zt = _d(zt); a.mlotst = _d(ml)
+    a.kappaH = kappaH; a.kappaVML = kappaVML; a.kappaVdeep = kappaVdeep; a.upwind = int(upwind)
+    n1 = max(N, 1)
+    caps = [8 * n1] * 5 if tight else [28 * n1, 12 * n1, 8 * n1, 4 * n1, 4 * n1]
+    cp = [np.empty(N + 1, np.int64) for _ in range(5)]
+    rv = [np.empty(c, np.int64) for c in caps]
+    nz = [np.empty(c, np.float64) for c in caps]
+    nnz = (C.c_int64 * 5)()
+    rc = lib().orc_transportmatrix(C.byref(a), (_ip * 5)(*[_i(x) for x in cp]), (_ip * 5)(*[_i(x) for x in rv]),
+                                   (_dp * 5)(*[_d(x) for x in nz]), nnz)
+    if rc:
+        raise OracleError(rc)
+    return {m: (cp[k], rv[k][: nnz[k]].copy(), nz[k][: nnz[k]].copy()) for k, m in enumerate(MATS)}
+
+
+def haversine(lon1, lat1, lon2, lat2):
+    return lib().orc_haversine(float(lon1), float(lat1), float(lon2), float(lat2))
+
+
+def to_scipy(csc, N):
+    """(colptr,rowval,nzval) 1-based -> scipy.sparse.csc_matrix (0-based); keeps stored zeros."""
+    import scipy.sparse as sp
+
+    colptr, rowval, nzval = csc
+    return sp.csc_matrix((nzval, rowval - 1, colptr - 1), shape=(N, N))

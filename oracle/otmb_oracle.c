@@ -1,0 +1,547 @@
+/*
+ * otmb_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE.
+ *
+ * A single-threaded, plain-C restatement of the sparse transport-operator
+ * assembly path of TMIP-code/OceanTransportMatrixBuilder.jl v0.8.3 (Julia).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's shared object; the product (libotmb_hip.so) never does.
+ *
+ * PARITY UNPINNED: the reference is pure Julia, no Julia toolchain exists in
+ * the build image, and the reference's tests hold no golden vectors for this
+ * path.  Faithfulness rests on (1) this line-by-line
+ * restatement, each function citing the reference file:line it follows,
+ * (2) an independent pure-Python transliteration (oracle/pyref.py) that must
+ * agree bit for bit, (3) scipy cross-checks of the sparse()/+ semantics and
+ * (4) the physical properties the reference's own tests assert.
+ *
+ * Third-party arithmetic that is NOT under /root/reference and is restated
+ * from its published algorithm (Project.toml compat bounds, no Manifest):
+ *   - SparseArrays.sparse(I,J,V,m,n)  (Julia stdlib >= 1.10): counting sort to
+ *     CSR, in-order duplicate combine with +, transpose to CSC; keeps zeros.
+ *   - SparseArrays.+(A,B) = map(+,A,B): column-wise sorted merge that drops
+ *     results that are exactly zero.
+ *   - Distances.haversine 0.10 (radius 6371000 m).
+ *
+ * Conventions: arrays are column-major (nx,ny,nz), i fastest; all indices
+ * handed across the API are 1-based Int64 exactly as Julia stores them;
+ * "missing"/"nothing" in Lwet3D is 0.  Build: gcc -O2 -ffp-contract=off.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_ERR_RHO_NAN (-1)      /* "ρ contains NaNs"        matrixbuilding.jl:233 */
+#define ORC_ERR_TADV_NAN (-2)     /* "Tadv contains NaNs."    matrixbuilding.jl:39  */
+#define ORC_ERR_TKH_NAN (-3)      /* "TκH contains NaNs."     matrixbuilding.jl:61  */
+#define ORC_ERR_TKVML_NAN (-4)    /* "TκVML contains NaNs."   matrixbuilding.jl:90  */
+#define ORC_ERR_TKVDEEP_NAN (-5)  /* "TκVdeep contains NaNs." matrixbuilding.jl:114 */
+#define ORC_ERR_FLUX_INTO_LAND (-6) /* Lwet3D[nothing] / push!(::Vector{Int}, missing) */
+#define ORC_ERR_UNKNOWN_TOPOLOGY (-7) /* "Unknown grid type"  gridtopology.jl:111-116 */
+#define ORC_ERR_ALL_MISSING (-8)  /* @assert velocities.jl:199-200 */
+#define ORC_ERR_ALLOC (-9)
+
+enum { ORC_BIPOLAR = 0, ORC_TRIPOLAR = 1, ORC_UNKNOWN = 2 };
+
+typedef struct {
+    int64_t nx, ny, nz;
+    int32_t topo;
+} orc_grid;
+
+/* ---- grid topology: gridtopology.jl:57-68, :94 -------------------------- */
+/* Cells are addressed by 0-based (i,j,k); a shift returns the 0-based linear
+ * index of the neighbour or -1 for Julia's `nothing`. */
+static inline int64_t lin(const orc_grid *g, int64_t i, int64_t j, int64_t k) {
+    return i + g->nx * (j + g->ny * k);
+}
+static inline int64_t ip1(const orc_grid *g, int64_t i, int64_t j, int64_t k) { /* :57 */
+    return (i + 1 < g->nx) ? lin(g, i + 1, j, k) : lin(g, 0, j, k);
+}
+static inline int64_t im1(const orc_grid *g, int64_t i, int64_t j, int64_t k) { /* :58 */
+    return (i > 0) ? lin(g, i - 1, j, k) : lin(g, g->nx - 1, j, k);
+}
+static inline int64_t jp1(const orc_grid *g, int64_t i, int64_t j, int64_t k) { /* :62, :94 */
+    if (j + 1 < g->ny) return lin(g, i, j + 1, k);
+    if (g->topo == ORC_TRIPOLAR) return lin(g, g->nx - 1 - i, g->ny - 1, k);
+    return -1;
+}
+static inline int64_t jm1(const orc_grid *g, int64_t i, int64_t j, int64_t k) { /* :63 */
+    return (j > 0) ? lin(g, i, j - 1, k) : -1;
+}
+static inline int64_t kp1(const orc_grid *g, int64_t i, int64_t j, int64_t k) { /* :67 */
+    return (k + 1 < g->nz) ? lin(g, i, j, k + 1) : -1;
+}
+static inline int64_t km1(const orc_grid *g, int64_t i, int64_t j, int64_t k) { /* :68 */
+    return (k > 0) ? lin(g, i, j, k - 1) : -1;
+}
+
+/* ---- makeindices: matrixbuilding.jl:10-24 ------------------------------- */
+/* Lwet (capacity G) gets the 1-based linear indices of wet cells ascending,
+ * Lwet3D (G) the 1-based wet rank or 0 (missing), wet3D (G) 0/1. Returns N. */
+int64_t orc_makeindices(const double *v3D, int64_t G, int64_t *Lwet, int64_t *Lwet3D,
+                        uint8_t *wet3D) {
+    int64_t N = 0;
+    for (int64_t L = 0; L < G; ++L) {
+        if (!isnan(v3D[L])) { /* :15 */
+            if (Lwet) Lwet[N] = L + 1;
+            ++N;
+            if (Lwet3D) Lwet3D[L] = N; /* :20 */
+            if (wet3D) wet3D[L] = 1;   /* :18 */
+        } else {
+            if (Lwet3D) Lwet3D[L] = 0; /* :19 missing */
+            if (wet3D) wet3D[L] = 0;
+        }
+    }
+    return N;
+}
+
+/* ---- nofluxboundaries!: velocities.jl:154-179 --------------------------- */
+int32_t orc_nofluxboundaries(double *phi_i, double *phi_j, const uint8_t *wet3D,
+                             const orc_grid *g) {
+    if (g->topo == ORC_UNKNOWN) return ORC_ERR_UNKNOWN_TOPOLOGY;
+    for (int64_t k = 0; k < g->nz; ++k)
+        for (int64_t j = 0; j < g->ny; ++j)
+            for (int64_t i = 0; i < g->nx; ++i) {
+                int64_t c = lin(g, i, j, k);
+                int64_t E = ip1(g, i, j, k); /* :163 */
+                int64_t N = jp1(g, i, j, k); /* :164 */
+                if (!wet3D[c]) { phi_i[c] = 0; phi_j[c] = 0; }     /* :167 */
+                if (E < 0 || !wet3D[E]) phi_i[c] = 0;              /* :170 */
+                if (N < 0 || !wet3D[N]) phi_j[c] = 0;              /* :173 */
+            }
+    return ORC_OK;
+}
+
+/* Julia isequal(x, fill) on Float64: bitwise-equal, or both NaN. */
+static inline int isequal_f64(double a, double b) {
+    if (isnan(a) && isnan(b)) return 1;
+    uint64_t ua, ub;
+    memcpy(&ua, &a, 8);
+    memcpy(&ub, &b, 8);
+    return ua == ub;
+}
+
+/* ---- facefluxes: velocities.jl:190-255 ---------------------------------- */
+/* umo/vmo are the caller's Float64 COPIES (facefluxesfrommasstransport
+ * converts first, :125-126) and are mutated in place as the reference does.
+ * Outputs: six (nx,ny,nz) arrays. */
+int32_t orc_facefluxes(double *umo, double *vmo, const uint8_t *wet3D, double fill,
+                       const orc_grid *g, double *east, double *west, double *north,
+                       double *south, double *top, double *bottom) {
+    int32_t rc = orc_nofluxboundaries(umo, vmo, wet3D, g); /* :192 */
+    if (rc) return rc;
+    const int64_t G = g->nx * g->ny * g->nz;
+    int all_u = 1, all_v = 1; /* :199-200 */
+    for (int64_t c = 0; c < G; ++c) {
+        if (!(isnan(umo[c]) || umo[c] == fill)) all_u = 0;
+        if (!(isnan(vmo[c]) || vmo[c] == fill)) all_v = 0;
+    }
+    if (all_u || all_v) return ORC_ERR_ALL_MISSING;
+    for (int64_t c = 0; c < G; ++c) { /* :203, :215 replace(NaN=>0, Fill=>0) */
+        east[c] = (isnan(umo[c]) || isequal_f64(umo[c], fill)) ? 0.0 : umo[c];
+        north[c] = (isnan(vmo[c]) || isequal_f64(vmo[c], fill)) ? 0.0 : vmo[c];
+    }
+    for (int64_t k = 0; k < g->nz; ++k)
+        for (int64_t j = 0; j < g->ny; ++j)
+            for (int64_t i = 0; i < g->nx; ++i) {
+                int64_t c = lin(g, i, j, k);
+                west[c] = east[im1(g, i, j, k)];       /* :206-211 (W is never nothing) */
+                int64_t S = jm1(g, i, j, k);
+                south[c] = (S < 0) ? 0.0 : north[S];   /* :219-224 */
+            }
+    const int64_t P = g->nx * g->ny;
+    for (int64_t k = g->nz - 1; k >= 0; --k) { /* :236-243 */
+        for (int64_t p = 0; p < P; ++p) {
+            int64_t c = p + P * k;
+            bottom[c] = (k == g->nz - 1) ? 0.0 : top[c + P];
+            /* @. a + b + c - d - e lowers to ((((a+b)+c)-d)-e): n-ary + folds left */
+            top[c] = (((bottom[c] + west[c]) + south[c]) - east[c]) - north[c];
+        }
+    }
+    return ORC_OK;
+}
+
+/* ---- COO triplet sink ---------------------------------------------------- */
+typedef struct {
+    int64_t *I, *J;
+    double *V;
+    int64_t len;
+} coo_t;
+static inline void push3(coo_t *c, int64_t i, int64_t j, double v) {
+    c->I[c->len] = i;
+    c->J[c->len] = j;
+    c->V[c->len] = v;
+    ++c->len;
+}
+
+/* pushTadvectionvalues!: matrixbuilding.jl:193-204 (𝑖,𝑗 1-based wet ranks) */
+static inline void push_adv(coo_t *c, int64_t wi, int64_t wj, double phi, double rho_i,
+                            double rho_j, double v_i, double v_j) {
+    double rho = (rho_i + rho_j) / 2; /* :194 */
+    double m_i = rho * v_i;           /* :195 */
+    double m_j = rho * v_j;           /* :196 */
+    push3(c, wi, wj, -phi / m_i);     /* :197-199 */
+    push3(c, wj, wj, phi / m_j);      /* :200-202 */
+}
+/* pushTmixingvalues!: matrixbuilding.jl:426-435 */
+static inline void push_mix(coo_t *c, int64_t wi, int64_t wj, double kappa, double a,
+                            double d, double V) {
+    double Tval = kappa * a / (d * V); /* :427  (κ*a)/(d*V) */
+    push3(c, wi, wi, Tval);
+    push3(c, wi, wj, -Tval);
+}
+
+static inline double jl_max0(double x) { /* Julia max(x, 0): NaN propagates */
+    if (isnan(x)) return x;
+    return (x > 0.0) ? x : 0.0;
+}
+static inline double jl_min0(double x) {
+    if (isnan(x)) return x;
+    return (x < 0.0) ? x : 0.0;
+}
+
+/* ---- advection_operator_sparse_entries: matrixbuilding.jl:221-299 -------- */
+/* phi order: [0]=east [1]=west [2]=north [3]=south [4]=top [5]=bottom.
+ * rho: 3-D array, or NULL with rho_scalar (the reference fills an array, :223).
+ * I,J,V must have capacity 12*N.  Returns the triplet count or an error. */
+int64_t orc_advection_entries(const double *const phi[6], const double *v3D, const double *rho,
+                              double rho_scalar, const int64_t *Lwet, const int64_t *Lwet3D,
+                              int64_t N, const orc_grid *g, int32_t upwind, int64_t *I,
+                              int64_t *J, double *V) {
+    const double *east = phi[0], *west = phi[1], *north = phi[2], *south = phi[3],
+                 *top = phi[4], *bottom = phi[5];
+    if (g->topo == ORC_UNKNOWN && N > 0) return ORC_ERR_UNKNOWN_TOPOLOGY;
+    for (int64_t w = 0; w < N; ++w) { /* :233 any(isnan, ρ[Lwet]) */
+        double r = rho ? rho[Lwet[w] - 1] : rho_scalar;
+        if (isnan(r)) return ORC_ERR_RHO_NAN;
+    }
+    coo_t c = {I, J, V, 0};
+#define RHO(L) (rho ? rho[L] : rho_scalar)
+#define ADV_DIR(FLUXEXPR, NBR, SIGN)                                                  \
+    do {                                                                              \
+        double f = (FLUXEXPR);                                                        \
+        if ((f > 0) || (f < 0)) {                                                     \
+            int64_t Cj = (NBR);                                                       \
+            if (Cj < 0) return ORC_ERR_FLUX_INTO_LAND;                                \
+            int64_t wj = Lwet3D[Cj];                                                  \
+            if (wj == 0) return ORC_ERR_FLUX_INTO_LAND;                               \
+            push_adv(&c, w + 1, wj, (SIGN) * f, rho_i, RHO(Cj), v_i, v3D[Cj]);        \
+        }                                                                             \
+    } while (0)
+    for (int64_t w = 0; w < N; ++w) { /* :237 */
+        int64_t L = Lwet[w] - 1;
+        int64_t i = L % g->nx, j = (L / g->nx) % g->ny, k = L / (g->nx * g->ny);
+        double v_i = v3D[L];
+        double rho_i = RHO(L);
+        ADV_DIR(upwind ? jl_max0(west[L]) : west[L] / 2, im1(g, i, j, k), 1.0);     /* :244-251 */
+        ADV_DIR(upwind ? jl_min0(east[L]) : east[L] / 2, ip1(g, i, j, k), -1.0);    /* :253-260 */
+        ADV_DIR(upwind ? jl_max0(south[L]) : south[L] / 2, jm1(g, i, j, k), 1.0);   /* :262-269 */
+        ADV_DIR(upwind ? jl_min0(north[L]) : north[L] / 2, jp1(g, i, j, k), -1.0);  /* :271-278 */
+        ADV_DIR(upwind ? jl_max0(bottom[L]) : bottom[L] / 2, kp1(g, i, j, k), 1.0); /* :280-287 */
+        if (k > 0)                                                                   /* :290 */
+            ADV_DIR(upwind ? jl_min0(top[L]) : top[L] / 2, km1(g, i, j, k), -1.0);  /* :289-296 */
+    }
+#undef ADV_DIR
+#undef RHO
+    return c.len;
+}
+
+/* ---- horizontal_diffusion_operator_sparse_entries: matrixbuilding.jl:337-418
+ * edge[d], dist[d] are (nx,ny) arrays, d: 0=west 1=east 2=south 3=north
+ * (edge_length_2D[dir], distance_to_neighbour_2D[dir]).  OmegaH: N bytes or
+ * NULL for trues(N) (:56).  Capacity 8*N. */
+int64_t orc_hdiff_entries(const double *v3D, const double *thk, const double *const edge[4],
+                          const double *const dist[4], const int64_t *Lwet,
+                          const int64_t *Lwet3D, int64_t N, const orc_grid *g, double kappaH,
+                          const uint8_t *OmegaH, int64_t *I, int64_t *J, double *V) {
+    enum { W = 0, E = 1, S = 2, Nn = 3 };
+    if (g->topo == ORC_UNKNOWN && N > 0) return ORC_ERR_UNKNOWN_TOPOLOGY;
+    coo_t c = {I, J, V, 0};
+    const int64_t P = g->nx * g->ny;
+    for (int64_t w = 0; w < N; ++w) { /* :348 */
+        if (OmegaH && !OmegaH[w]) continue; /* :349 */
+        int64_t L = Lwet[w] - 1;
+        int64_t i = L % g->nx, j = (L / g->nx) % g->ny, k = L / P;
+        int64_t s = i + g->nx * j; /* horizontalindex, gridcellgeometry.jl:197-198 */
+        double Vv = v3D[L];
+        int64_t nb[4] = {im1(g, i, j, k), ip1(g, i, j, k), jm1(g, i, j, k), jp1(g, i, j, k)};
+        int opp[4] = {E, W, Nn, (j == g->ny - 1) ? Nn : S}; /* :364,378,392,407 */
+        for (int d = 0; d < 4; ++d) {                        /* W, E, S, N */
+            int64_t Cj = nb[d];
+            if (Cj < 0) continue; /* isnothing */
+            int64_t wj = Lwet3D[Cj];
+            if (wj == 0) continue; /* ismissing */
+            if (OmegaH && !OmegaH[wj - 1]) continue;
+            int64_t sj = Cj % P;
+            /* verticalfacearea = height*width, gridcellgeometry.jl:230-234 */
+            double aij = thk[L] * edge[d][s];
+            double aji = thk[Cj] * edge[opp[d]][sj];
+            double a = fmin(aij, aji); /* NaN handled below to match Julia min */
+            if (isnan(aij) || isnan(aji)) a = NAN;
+            double dd = dist[d][s];
+            push_mix(&c, w + 1, wj, kappaH, a, dd, Vv);
+        }
+    }
+    return c.len;
+}
+
+/* ---- vertical_diffusion_operator_sparse_entries: matrixbuilding.jl:438-479
+ * Omega: N bytes or NULL for trues(N) (:109).  Capacity 4*N. */
+int64_t orc_vdiff_entries(const double *v3D, const double *area2D, const double *zt,
+                          const int64_t *Lwet, const int64_t *Lwet3D, int64_t N,
+                          const orc_grid *g, double kappaV, const uint8_t *Omega, int64_t *I,
+                          int64_t *J, double *V) {
+    if (g->topo == ORC_UNKNOWN && N > 0) return ORC_ERR_UNKNOWN_TOPOLOGY;
+    coo_t c = {I, J, V, 0};
+    const int64_t P = g->nx * g->ny;
+    for (int64_t w = 0; w < N; ++w) { /* :450 */
+        if (Omega && !Omega[w]) continue;
+        int64_t L = Lwet[w] - 1;
+        int64_t i = L % g->nx, j = (L / g->nx) % g->ny, k = L / P;
+        double Vv = v3D[L];
+        double a = area2D[i + g->nx * j];
+        int64_t nb[2] = {kp1(g, i, j, k), km1(g, i, j, k)}; /* bottom :458, top :468 */
+        int64_t kk[2] = {k + 1, k - 1};
+        for (int d = 0; d < 2; ++d) {
+            int64_t Cj = nb[d];
+            if (Cj < 0) continue;
+            int64_t wj = Lwet3D[Cj];
+            if (wj == 0) continue;
+            if (Omega && !Omega[wj - 1]) continue;
+            double dd = fabs(zt[k] - zt[kk[d]]); /* :463, :473 */
+            push_mix(&c, w + 1, wj, kappaV, a, dd, Vv);
+        }
+    }
+    return c.len;
+}
+
+/* buildTκVML mask, matrixbuilding.jl:85: Ω[𝑖] = zt[k] < mlotst[i,j], missing (NaN here) => false */
+void orc_ml_mask(const double *zt, const double *mlotst, const int64_t *Lwet, int64_t N,
+                 const orc_grid *g, uint8_t *Omega) {
+    const int64_t P = g->nx * g->ny;
+    for (int64_t w = 0; w < N; ++w) {
+        int64_t L = Lwet[w] - 1;
+        Omega[w] = (zt[L / P] < mlotst[L % P]) ? 1 : 0;
+    }
+}
+
+/* ---- SparseArrays.sparse(I,J,V,m,n) (stdlib; called at matrixbuilding.jl:41,63,92,116)
+ * Restatement of sparse!: (1) counting sort of the triplets by row into an
+ * unsorted-column CSR (stable: input order kept within a row); (2) one sweep
+ * per row combining repeated (row,col) with + in input order (first touch
+ * copies the value, later ones do acc = acc + v), counting columns;
+ * (3) counting sort of the CSR into CSC => rows ascend within a column.
+ * Stored zeros are kept.  colptr has n+1 entries, 1-based.  rowval/nzval need
+ * capacity len.  Returns nnz or ORC_ERR_ALLOC. */
+int64_t orc_sparse(const int64_t *I, const int64_t *J, const double *V, int64_t len, int64_t m,
+                   int64_t n, int64_t *colptr, int64_t *rowval, double *nzval) {
+    int64_t *csrrowptr = (int64_t *)calloc((size_t)m + 2, 8);
+    int64_t *csrcolval = (int64_t *)malloc((size_t)(len > 0 ? len : 1) * 8);
+    double *csrnzval = (double *)malloc((size_t)(len > 0 ? len : 1) * 8);
+    int64_t *klasttouch = (int64_t *)calloc((size_t)n + 1, 8);
+    if (!csrrowptr || !csrcolval || !csrnzval || !klasttouch) {
+        free(csrrowptr); free(csrcolval); free(csrnzval); free(klasttouch);
+        return ORC_ERR_ALLOC;
+    }
+    /* 1-based arrays emulated with 0-based storage: X[a] (Julia) == X[a-1] (C) */
+    for (int64_t k = 0; k < len; ++k) csrrowptr[I[k]] += 1; /* csrrowptr[Ik+1] += 1 */
+    {
+        int64_t countsum = 1;
+        csrrowptr[0] = 1;
+        for (int64_t i = 2; i <= m + 1; ++i) {
+            int64_t overwritten = csrrowptr[i - 1];
+            csrrowptr[i - 1] = countsum;
+            countsum += overwritten;
+        }
+    }
+    for (int64_t k = 0; k < len; ++k) {
+        int64_t Ik = I[k];
+        int64_t csrk = csrrowptr[Ik]; /* csrrowptr[Ik+1] */
+        csrrowptr[Ik] = csrk + 1;
+        csrcolval[csrk - 1] = J[k];
+        csrnzval[csrk - 1] = V[k];
+    }
+    for (int64_t j = 0; j <= n; ++j) colptr[j] = 0;
+    int64_t writek = 1, newcsrrowptri = 1, origcsrrowptri = 1;
+    int64_t origcsrrowptrip1 = (m >= 1) ? csrrowptr[1] : 1;
+    for (int64_t i = 1; i <= m; ++i) {
+        for (int64_t readk = origcsrrowptri; readk <= origcsrrowptrip1 - 1; ++readk) {
+            int64_t j = csrcolval[readk - 1];
+            if (klasttouch[j - 1] < newcsrrowptri) {
+                klasttouch[j - 1] = writek;
+                if (writek != readk) {
+                    csrcolval[writek - 1] = j;
+                    csrnzval[writek - 1] = csrnzval[readk - 1];
+                }
+                writek += 1;
+                colptr[j] += 1; /* csccolptr[j+1] += 1 */
+            } else {
+                int64_t klt = klasttouch[j - 1];
+                csrnzval[klt - 1] = csrnzval[klt - 1] + csrnzval[readk - 1]; /* combine = + */
+            }
+        }
+        newcsrrowptri = writek;
+        origcsrrowptri = origcsrrowptrip1;
+        if (origcsrrowptrip1 != writek) csrrowptr[i] = writek; /* csrrowptr[i+1] */
+        if (i < m) origcsrrowptrip1 = csrrowptr[i + 1];        /* csrrowptr[i+2] */
+    }
+    /* column pointers, shifted by one (reused as write cursors below) */
+    {
+        int64_t countsum = 1;
+        colptr[0] = 1;
+        for (int64_t j = 2; j <= n + 1; ++j) {
+            int64_t overwritten = colptr[j - 1];
+            colptr[j - 1] = countsum;
+            countsum += overwritten;
+        }
+    }
+    /* counting sort CSR -> CSC; rows visited ascending => sorted rows per column.
+     * colptr slot j (= Julia csccolptr[j+1]) currently holds the start of column j and is
+     * used as the write cursor; afterwards it holds the start of column j+1, i.e. the array
+     * is the final 1-based colptr. */
+    int64_t nnz = writek - 1;
+    for (int64_t i = 1; i <= m; ++i) {
+        for (int64_t csrk = csrrowptr[i - 1]; csrk <= csrrowptr[i] - 1; ++csrk) {
+            int64_t j = csrcolval[csrk - 1];
+            int64_t csck = colptr[j];
+            colptr[j] = csck + 1;
+            rowval[csck - 1] = i;
+            nzval[csck - 1] = csrnzval[csrk - 1];
+        }
+    }
+    free(csrrowptr); free(csrcolval); free(csrnzval); free(klasttouch);
+    return nnz;
+}
+
+/* ---- SparseArrays.+(A,B) = map(+,A,B)  (stdlib; matrixbuilding.jl:147) ----
+ * _map_zeropres!: per column, merge the two sorted row lists; Cx = Ax+Bx,
+ * Ax+0.0 or 0.0+Bx; store only if Cx != 0.  C arrays need capacity
+ * nnz(A)+nnz(B).  Returns nnz(C). */
+int64_t orc_spadd(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+                  const int64_t *Bp, const int64_t *Bi, const double *Bx, int64_t *Cp,
+                  int64_t *Ci, double *Cx) {
+    int64_t Ck = 1;
+    for (int64_t j = 0; j < n; ++j) {
+        Cp[j] = Ck;
+        int64_t Ak = Ap[j], stopA = Ap[j + 1];
+        int64_t Bk = Bp[j], stopB = Bp[j + 1];
+        while (Ak < stopA || Bk < stopB) {
+            double x;
+            int64_t r;
+            if (Ak < stopA && Bk < stopB && Ai[Ak - 1] == Bi[Bk - 1]) {
+                x = Ax[Ak - 1] + Bx[Bk - 1]; r = Ai[Ak - 1]; ++Ak; ++Bk;
+            } else if (Bk >= stopB || (Ak < stopA && Ai[Ak - 1] < Bi[Bk - 1])) {
+                x = Ax[Ak - 1] + 0.0; r = Ai[Ak - 1]; ++Ak;
+            } else {
+                x = 0.0 + Bx[Bk - 1]; r = Bi[Bk - 1]; ++Bk;
+            }
+            if (x != 0.0) { /* !_iszero(Cx); NaN != 0 is true and is kept */
+                Ci[Ck - 1] = r;
+                Cx[Ck - 1] = x;
+                ++Ck;
+            }
+        }
+    }
+    Cp[n] = Ck;
+    return Ck - 1;
+}
+
+/* ---- transportmatrix: matrixbuilding.jl:128-150 (+ buildT* :31-120) ------
+ * Builds the five CSC matrices.  out arrays for matrix m (0=T 1=Tadv 2=TκH
+ * 3=TκVML 4=TκVdeep): colptr[m] (N+1), rowval[m]/nzval[m] with capacities
+ * cap[m] (safe: Tadv 12N, TκH 8N, TκV* 4N, T 28N; tight: 8N each).
+ * stage_seconds (optional, 4 doubles) is filled by the caller's timer hooks. */
+typedef struct {
+    const double *phi[6];
+    const double *v3D, *thk, *rho;
+    double rho_scalar;
+    const int64_t *Lwet, *Lwet3D;
+    int64_t N;
+    orc_grid g;
+    const double *edge[4], *dist[4];
+    const double *area2D, *zt, *mlotst;
+    double kappaH, kappaVML, kappaVdeep;
+    int32_t upwind;
+} orc_tm_args;
+
+static int has_nan(const double *v, int64_t n) {
+    for (int64_t k = 0; k < n; ++k)
+        if (isnan(v[k])) return 1;
+    return 0;
+}
+
+int32_t orc_transportmatrix(const orc_tm_args *a, int64_t *const colptr[5],
+                            int64_t *const rowval[5], double *const nzval[5], int64_t nnz[5]) {
+    const int64_t N = a->N;
+    const int64_t cap = 12 * (N > 0 ? N : 1);
+    int64_t *I = (int64_t *)malloc((size_t)cap * 8), *J = (int64_t *)malloc((size_t)cap * 8);
+    double *V = (double *)malloc((size_t)cap * 8);
+    uint8_t *Om = (uint8_t *)malloc((size_t)(N > 0 ? N : 1));
+    int32_t rc = ORC_OK;
+    int64_t len;
+    if (!I || !J || !V || !Om) { rc = ORC_ERR_ALLOC; goto done; }
+    /* buildTadv :31-44 */
+    len = orc_advection_entries(a->phi, a->v3D, a->rho, a->rho_scalar, a->Lwet, a->Lwet3D, N,
+                                &a->g, a->upwind, I, J, V);
+    if (len < 0) { rc = (int32_t)len; goto done; }
+    if (has_nan(V, len)) { rc = ORC_ERR_TADV_NAN; goto done; }
+    nnz[1] = orc_sparse(I, J, V, len, N, N, colptr[1], rowval[1], nzval[1]);
+    /* buildTκH :51-66 */
+    len = orc_hdiff_entries(a->v3D, a->thk, a->edge, a->dist, a->Lwet, a->Lwet3D, N, &a->g,
+                            a->kappaH, NULL, I, J, V);
+    if (len < 0) { rc = (int32_t)len; goto done; }
+    if (has_nan(V, len)) { rc = ORC_ERR_TKH_NAN; goto done; }
+    nnz[2] = orc_sparse(I, J, V, len, N, N, colptr[2], rowval[2], nzval[2]);
+    /* buildTκVML :74-95 */
+    orc_ml_mask(a->zt, a->mlotst, a->Lwet, N, &a->g, Om);
+    len = orc_vdiff_entries(a->v3D, a->area2D, a->zt, a->Lwet, a->Lwet3D, N, &a->g,
+                            a->kappaVML, Om, I, J, V);
+    if (len < 0) { rc = (int32_t)len; goto done; }
+    if (has_nan(V, len)) { rc = ORC_ERR_TKVML_NAN; goto done; }
+    nnz[3] = orc_sparse(I, J, V, len, N, N, colptr[3], rowval[3], nzval[3]);
+    /* buildTκVdeep :103-120 */
+    len = orc_vdiff_entries(a->v3D, a->area2D, a->zt, a->Lwet, a->Lwet3D, N, &a->g,
+                            a->kappaVdeep, NULL, I, J, V);
+    if (len < 0) { rc = (int32_t)len; goto done; }
+    if (has_nan(V, len)) { rc = ORC_ERR_TKVDEEP_NAN; goto done; }
+    nnz[4] = orc_sparse(I, J, V, len, N, N, colptr[4], rowval[4], nzval[4]);
+    if (nnz[1] < 0 || nnz[2] < 0 || nnz[3] < 0 || nnz[4] < 0) { rc = ORC_ERR_ALLOC; goto done; }
+    /* T = Tadv + TκH + TκVML + TκVdeep :147 -- left fold of binary + */
+    {
+        int64_t c1 = nnz[1] + nnz[2] + 1, c2 = c1 + nnz[3];
+        int64_t *p1 = (int64_t *)malloc((size_t)(N + 1) * 8), *i1 = (int64_t *)malloc((size_t)c1 * 8);
+        double *x1 = (double *)malloc((size_t)c1 * 8);
+        int64_t *p2 = (int64_t *)malloc((size_t)(N + 1) * 8), *i2 = (int64_t *)malloc((size_t)c2 * 8);
+        double *x2 = (double *)malloc((size_t)c2 * 8);
+        if (!p1 || !i1 || !x1 || !p2 || !i2 || !x2) {
+            rc = ORC_ERR_ALLOC;
+        } else {
+            int64_t n1 = orc_spadd(N, colptr[1], rowval[1], nzval[1], colptr[2], rowval[2],
+                                   nzval[2], p1, i1, x1);
+            int64_t n2 = orc_spadd(N, p1, i1, x1, colptr[3], rowval[3], nzval[3], p2, i2, x2);
+            (void)n1;
+            (void)n2;
+            nnz[0] = orc_spadd(N, p2, i2, x2, colptr[4], rowval[4], nzval[4], colptr[0],
+                               rowval[0], nzval[0]);
+        }
+        free(p1); free(i1); free(x1); free(p2); free(i2); free(x2);
+    }
+done:
+    free(I); free(J); free(V); free(Om);
+    return rc;
+}
+
+/* ---- Distances.haversine 0.10 (radius 6371000), points are (lon°, lat°) --- */
+double orc_haversine(double lon1, double lat1, double lon2, double lat2) {
+    const double d2r = M_PI / 180.0; /* deg2rad(z) = z * (pi/180) */
+    double dl = (lon2 - lon1) * d2r;
+    double dp = (lat2 - lat1) * d2r;
+    double p1 = lat1 * d2r, p2 = lat2 * d2r;
+    double s1 = sin(dp / 2), s2 = sin(dl / 2);
+    double a = s1 * s1 + cos(p1) * cos(p2) * (s2 * s2);
+    double r = sqrt(a);
+    if (r > 1.0) r = 1.0; /* min(√a, 1) */
+    return 2 * (6371000.0 * asin(r));
+}

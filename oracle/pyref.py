@@ -1,0 +1,348 @@
+"""Second, independent CPU restatement in pure Python.  TEST INFRASTRUCTURE ONLY.
+
+A deliberately literal, slow transliteration of the reference's Julia loops (1-based
+indices, `None` for `nothing`/`missing`, explicit push!) used on SMALL grids to pin the C
+oracle: both were written separately from the reference text and must agree bit for bit.
+Python floats are IEEE binary64 and CPython never contracts a*b+c, so every operation
+rounds exactly as Julia's does.
+
+PARITY UNPINNED (no Julia toolchain, no golden vectors in the reference): see
+oracle/otmb_oracle.c.
+"""
+import math
+
+import numpy as np
+
+BIPOLAR, TRIPOLAR, UNKNOWN = 0, 1, 2
+NaN = float("nan")
+
+
+# ---- src/gridtopology.jl ---------------------------------------------------------------------
+class Topo:
+    def __init__(self, kind, nx, ny, nz):
+        self.kind, self.nx, self.ny, self.nz = kind, nx, ny, nz
+
+    def _chk(self):
+        if self.kind == UNKNOWN:
+            raise RuntimeError("Unknown grid type")  # :111-116
+
+    def ip1(self, C):  # :57
+        self._chk()
+        i, j, k = C
+        return (i + 1, j, k) if i < self.nx else (1, j, k)
+
+    def im1(self, C):  # :58
+        self._chk()
+        i, j, k = C
+        return (i - 1, j, k) if i > 1 else (self.nx, j, k)
+
+    def jp1(self, C):  # :62 and :94
+        self._chk()
+        i, j, k = C
+        if j < self.ny:
+            return (i, j + 1, k)
+        if self.kind == TRIPOLAR:
+            return (self.nx - i + 1, self.ny, k)
+        return None
+
+    def jm1(self, C):  # :63
+        self._chk()
+        i, j, k = C
+        return (i, j - 1, k) if j > 1 else None
+
+    def kp1(self, C):  # :67
+        self._chk()
+        i, j, k = C
+        return (i, j, k + 1) if k < self.nz else None
+
+    def km1(self, C):  # :68
+        self._chk()
+        i, j, k = C
+        return (i, j, k - 1) if k > 1 else None
+
+
+def _at(A, C):
+    return float(A[C[0] - 1, C[1] - 1, C[2] - 1])
+
+
+# ---- makeindices: src/matrixbuilding.jl:10-24 ------------------------------------------------
+def makeindices(v3D):
+    nx, ny, nz = v3D.shape
+    Lwet, Cwet = [], []
+    Lwet3D = {}
+    L = 0
+    for k in range(1, nz + 1):
+        for j in range(1, ny + 1):
+            for i in range(1, nx + 1):
+                L += 1
+                if not math.isnan(v3D[i - 1, j - 1, k - 1]):
+                    Lwet.append(L)
+                    Cwet.append((i, j, k))
+                    Lwet3D[(i, j, k)] = len(Lwet)
+    return dict(Lwet=Lwet, Cwet=Cwet, Lwet3D=Lwet3D, N=len(Lwet), shape=(nx, ny, nz))
+
+
+# ---- nofluxboundaries! / facefluxes: src/velocities.jl:154-255 -------------------------------
+def facefluxes(umo, vmo, wet3D, fill, topo):
+    nx, ny, nz = umo.shape
+    phi_i = np.array(umo, dtype=np.float64)  # Array{Float64} copies, :125-126
+    phi_j = np.array(vmo, dtype=np.float64)
+    wet = lambda C: bool(wet3D[C[0] - 1, C[1] - 1, C[2] - 1])
+    cells = [(i, j, k) for k in range(1, nz + 1) for j in range(1, ny + 1) for i in range(1, nx + 1)]
+    for C in cells:  # :161-175
+        E = topo.ip1(C)
+        N = topo.jp1(C)
+        idx = (C[0] - 1, C[1] - 1, C[2] - 1)
+        if not wet(C):
+            phi_i[idx] = 0.0
+            phi_j[idx] = 0.0
+        if E is None or not wet(E):
+            phi_i[idx] = 0.0
+        if N is None or not wet(N):
+            phi_j[idx] = 0.0
+    allmiss = lambda A: all(math.isnan(x) or x == fill for x in A.ravel())
+    assert not allmiss(phi_i) and not allmiss(phi_j)  # :199-200
+
+    def repl(x):  # replace(., NaN => 0.0, FillValue => 0.0) uses isequal
+        x = float(x)
+        if math.isnan(x):
+            return 0.0
+        if x == fill and math.copysign(1.0, x) == math.copysign(1.0, fill):
+            return 0.0
+        return x
+
+    east = np.vectorize(repl)(phi_i).astype(np.float64)
+    north = np.vectorize(repl)(phi_j).astype(np.float64)
+    west = np.zeros_like(east)
+    south = np.zeros_like(north)
+    for C in cells:
+        idx = (C[0] - 1, C[1] - 1, C[2] - 1)
+        W = topo.im1(C)
+        if W is not None:
+            west[idx] = _at(east, W)  # :206-211
+        S = topo.jm1(C)
+        if S is not None:
+            south[idx] = _at(north, S)  # :219-224
+    bottom = np.empty_like(east)
+    top = np.empty_like(east)
+    for k in range(nz, 0, -1):  # :236-243
+        for j in range(ny):
+            for i in range(nx):
+                b = 0.0 if k == nz else float(top[i, j, k])
+                bottom[i, j, k - 1] = b
+                top[i, j, k - 1] = (((b + float(west[i, j, k - 1])) + float(south[i, j, k - 1])) - float(east[i, j, k - 1])) - float(north[i, j, k - 1])
+    return dict(east=east, west=west, north=north, south=south, top=top, bottom=bottom)
+
+
+# ---- COO generators: src/matrixbuilding.jl:193-299, 337-479 ---------------------------------
+def _jlmax0(x):
+    return x if math.isnan(x) else (x if x > 0 else 0.0)
+
+
+def _jlmin0(x):
+    return x if math.isnan(x) else (x if x < 0 else 0.0)
+
+
+def advection_entries(phi, v3D, rho, idx, topo, upwind=True):
+    Is, Js, Vs = [], [], []
+    rho_at = (lambda C: float(rho)) if np.ndim(rho) == 0 else (lambda C: _at(rho, C))
+    if any(math.isnan(rho_at(C)) for C in idx["Cwet"]):  # :233
+        raise RuntimeError("ρ contains NaNs")
+    Lwet3D = idx["Lwet3D"]
+
+    def push(wi, Cj, ph, rho_i, v_i):  # pushTadvectionvalues! :193-204
+        if Cj is None or Cj not in Lwet3D:
+            raise RuntimeError("flux into land or outside the grid")
+        wj = Lwet3D[Cj]
+        r = (rho_i + rho_at(Cj)) / 2
+        m_i = r * v_i
+        m_j = r * _at(v3D, Cj)
+        Is.append(wi); Js.append(wj); Vs.append(-ph / m_i)
+        Is.append(wj); Js.append(wj); Vs.append(ph / m_j)
+
+    for wi, C in enumerate(idx["Cwet"], start=1):  # :237
+        v_i = _at(v3D, C)
+        rho_i = rho_at(C)
+        f = _jlmax0(_at(phi["west"], C)) if upwind else _at(phi["west"], C) / 2
+        if f > 0 or f < 0:
+            push(wi, topo.im1(C), f, rho_i, v_i)
+        f = _jlmin0(_at(phi["east"], C)) if upwind else _at(phi["east"], C) / 2
+        if f > 0 or f < 0:
+            push(wi, topo.ip1(C), -f, rho_i, v_i)
+        f = _jlmax0(_at(phi["south"], C)) if upwind else _at(phi["south"], C) / 2
+        if f > 0 or f < 0:
+            push(wi, topo.jm1(C), f, rho_i, v_i)
+        f = _jlmin0(_at(phi["north"], C)) if upwind else _at(phi["north"], C) / 2
+        if f > 0 or f < 0:
+            push(wi, topo.jp1(C), -f, rho_i, v_i)
+        f = _jlmax0(_at(phi["bottom"], C)) if upwind else _at(phi["bottom"], C) / 2
+        if f > 0 or f < 0:
+            push(wi, topo.kp1(C), f, rho_i, v_i)
+        f = _jlmin0(_at(phi["top"], C)) if upwind else _at(phi["top"], C) / 2
+        if C[2] > 1 and (f > 0 or f < 0):  # :290
+            push(wi, topo.km1(C), -f, rho_i, v_i)
+    return Is, Js, Vs
+
+
+def _jlmin(a, b):
+    if math.isnan(a) or math.isnan(b):
+        return NaN
+    return a if a < b else b
+
+
+def _pushmix(Is, Js, Vs, wi, wj, kappa, a, d, V):  # :426-435
+    Tval = kappa * a / (d * V)
+    Is.append(wi); Js.append(wi); Vs.append(Tval)
+    Is.append(wi); Js.append(wj); Vs.append(-Tval)
+
+
+def hdiff_entries(gm, idx, topo, kappaH, OmegaH=None):
+    Is, Js, Vs = [], [], []
+    v3D, thk = gm["v3D"], gm["thkcello"]
+    edge, dist = gm["edge_length_2D"], gm["distance_to_neighbour_2D"]
+    Lwet3D = idx["Lwet3D"]
+    ny = topo.ny
+    inO = (lambda w: True) if OmegaH is None else (lambda w: bool(OmegaH[w - 1]))
+    for wi, C in enumerate(idx["Cwet"], start=1):  # :348
+        if not inO(wi):
+            continue
+        i, j, k = C
+        V = _at(v3D, C)
+        for d, shift, opp in (("west", topo.im1, "east"), ("east", topo.ip1, "west"),
+                              ("south", topo.jm1, "north"), ("north", topo.jp1, "north" if j == ny else "south")):
+            Cj = shift(C)
+            if Cj is None or Cj not in Lwet3D:
+                continue
+            wj = Lwet3D[Cj]
+            if not inO(wj):
+                continue
+            aij = _at(thk, C) * float(edge[d][i - 1, j - 1])  # verticalfacearea gridcellgeometry.jl:230-234
+            aji = _at(thk, Cj) * float(edge[opp][Cj[0] - 1, Cj[1] - 1])
+            a = _jlmin(aij, aji)
+            dd = float(dist[d][i - 1, j - 1])
+            _pushmix(Is, Js, Vs, wi, wj, kappaH, a, dd, V)
+    return Is, Js, Vs
+
+
+def vdiff_entries(gm, idx, topo, kappaV, Omega=None):
+    Is, Js, Vs = [], [], []
+    v3D, area2D, zt = gm["v3D"], gm["area2D"], gm["zt"]
+    Lwet3D = idx["Lwet3D"]
+    inO = (lambda w: True) if Omega is None else (lambda w: bool(Omega[w - 1]))
+    for wi, C in enumerate(idx["Cwet"], start=1):  # :450
+        if not inO(wi):
+            continue
+        i, j, k = C
+        V = _at(v3D, C)
+        a = float(area2D[i - 1, j - 1])
+        for shift in (topo.kp1, topo.km1):  # bottom then top
+            Cj = shift(C)
+            if Cj is None or Cj not in Lwet3D:
+                continue
+            wj = Lwet3D[Cj]
+            if not inO(wj):
+                continue
+            dd = abs(float(zt[k - 1]) - float(zt[Cj[2] - 1]))
+            _pushmix(Is, Js, Vs, wi, wj, kappaV, a, dd, V)
+    return Is, Js, Vs
+
+
+def ml_mask(zt, mlotst, idx):  # :85
+    return [bool(float(zt[k - 1]) < float(mlotst[i - 1, j - 1])) for (i, j, k) in idx["Cwet"]]
+
+
+# ---- SparseArrays semantics, stated from their contract (NOT from sparse!'s loops) ----------
+def sparse(Is, Js, Vs, m, n):
+    """sparse(I,J,V,m,n): one stored entry per distinct (i,j), value = left fold of + over the
+    triplets in input order, zeros kept, rows ascending within a column."""
+    acc = {}
+    for i, j, v in zip(Is, Js, Vs):
+        if (j, i) in acc:
+            acc[(j, i)] = acc[(j, i)] + v
+        else:
+            acc[(j, i)] = v
+    keys = sorted(acc)
+    counts = [0] * (n + 1)
+    for (j, i) in keys:
+        counts[j] += 1
+    colptr = [1]
+    for j in range(1, n + 1):
+        colptr.append(colptr[-1] + counts[j])
+    return (np.array(colptr, dtype=np.int64), np.array([i for (j, i) in keys], dtype=np.int64),
+            np.array([acc[k] for k in keys], dtype=np.float64))
+
+
+def spadd(A, B, n):
+    """A + B = map(+, A, B): union pattern, missing operand is 0.0, exact-zero results dropped."""
+    def cols(M):
+        p, r, x = M
+        return [{int(r[q - 1]): float(x[q - 1]) for q in range(int(p[j]), int(p[j + 1]))} for j in range(n)]
+    ca, cb = cols(A), cols(B)
+    colptr, rowval, nzval = [1], [], []
+    for j in range(n):
+        for i in sorted(set(ca[j]) | set(cb[j])):
+            s = ca[j].get(i, 0.0) + cb[j].get(i, 0.0)
+            if s != 0.0:
+                rowval.append(i); nzval.append(s)
+        colptr.append(len(rowval) + 1)
+    return np.array(colptr, dtype=np.int64), np.array(rowval, dtype=np.int64), np.array(nzval, dtype=np.float64)
+
+
+def transportmatrix(phi, gm, idx, topo, rho, mlotst, kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True):
+    N = idx["N"]
+
+    def chk(Vs, name):
+        if any(math.isnan(v) for v in Vs):
+            raise RuntimeError(f"{name} contains NaNs.")
+
+    I, J, V = advection_entries(phi, gm["v3D"], rho, idx, topo, upwind); chk(V, "Tadv")
+    Tadv = sparse(I, J, V, N, N)
+    I, J, V = hdiff_entries(gm, idx, topo, kappaH); chk(V, "TκH")
+    TkH = sparse(I, J, V, N, N)
+    I, J, V = vdiff_entries(gm, idx, topo, kappaVML, ml_mask(gm["zt"], mlotst, idx)); chk(V, "TκVML")
+    TkVML = sparse(I, J, V, N, N)
+    I, J, V = vdiff_entries(gm, idx, topo, kappaVdeep, None); chk(V, "TκVdeep")
+    TkVdeep = sparse(I, J, V, N, N)
+    T = spadd(spadd(spadd(Tadv, TkH, N), TkVML, N), TkVdeep, N)  # :147 left fold
+    return {"T": T, "Tadv": Tadv, "TκH": TkH, "TκVML": TkVML, "TκVdeep": TkVdeep}
+
+
+# ---- Distances.haversine / makegridmetrics pieces: src/gridcellgeometry.jl ------------------
+def haversine(A, B, radius=6371000.0):
+    d2r = math.pi / 180
+    dl = (B[0] - A[0]) * d2r
+    dp = (B[1] - A[1]) * d2r
+    p1, p2 = A[1] * d2r, B[1] * d2r
+    a = math.sin(dp / 2) ** 2 + math.cos(p1) * math.cos(p2) * math.sin(dl / 2) ** 2
+    return 2 * (radius * math.asin(min(math.sqrt(a), 1.0)))
+
+
+def midpointonsphere(A, B):  # :249-255
+    if abs(A[0] - B[0]) < 180:
+        return ((A[0] + B[0]) / 2, (A[1] + B[1]) / 2)
+    return ((A[0] + B[0]) / 2 + 180, (A[1] + B[1]) / 2 + 0)
+
+
+def gridmetrics_2d(lon, lat, lonv, latv, kind):
+    """edge_length_2D, distance_to_edge_2D, distance_to_neighbour_2D (:304-308) by scalar loops."""
+    nx, ny = lon.shape
+    t = Topo(kind, nx, ny, 1)
+    vidx = {"south": (1, 2), "east": (2, 3), "north": (3, 4), "west": (1, 4)}
+    shifts = {"south": t.jm1, "east": t.ip1, "north": t.jp1, "west": t.im1}
+    el = {d: np.empty((nx, ny)) for d in vidx}
+    de = {d: np.empty((nx, ny)) for d in vidx}
+    dn = {d: np.empty((nx, ny)) for d in vidx}
+    for d, (a, b) in vidx.items():
+        for i in range(1, nx + 1):
+            for j in range(1, ny + 1):
+                A = (float(lonv[a - 1, i - 1, j - 1]), float(latv[a - 1, i - 1, j - 1]))
+                B = (float(lonv[b - 1, i - 1, j - 1]), float(latv[b - 1, i - 1, j - 1]))
+                Cc = (float(lon[i - 1, j - 1]), float(lat[i - 1, j - 1]))
+                el[d][i - 1, j - 1] = haversine(A, B)
+                de[d][i - 1, j - 1] = haversine(Cc, midpointonsphere(A, B))
+                Jn = shifts[d]((i, j, 1))
+                if Jn is None:
+                    dn[d][i - 1, j - 1] = NaN
+                else:
+                    dn[d][i - 1, j - 1] = haversine(Cc, (float(lon[Jn[0] - 1, Jn[1] - 1]), float(lat[Jn[0] - 1, Jn[1] - 1])))
+    return el, de, dn
