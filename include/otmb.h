@@ -1,0 +1,131 @@
+/*
+ * otmb.h -- C ABI of libotmb_hip.so: the MI355X (gfx950) implementation of the sparse
+ * transport-operator assembly path of TMIP-code/OceanTransportMatrixBuilder.jl v0.8.3.
+ *
+ * The reference is pure Julia and has no FFI layer; its
+ * boundary for this path is the keyword-argument API exported at
+ * src/OceanTransportMatrixBuilder.jl:31-36.  Each entry point below names the reference
+ * function it replaces; julia/OceanTransportMatrixBuilderAMD.jl binds them with `ccall`
+ * behind the reference's own function names.
+ *
+ * Conventions
+ *  - Arrays are Julia's: column-major (nx,ny,nz), i fastest; Float64 values; Int64 indices,
+ *    1-based exactly as Julia stores them (colptr, rowval, Lwet, Lwet3D).  `missing` in
+ *    Lwet3D is 0; `missing`/`nothing` in Float64 inputs is NaN.
+ *  - `_dev` entry points take DEVICE pointers and enqueue on the context's stream; the
+ *    entry points without the suffix take HOST pointers (what Julia's ccall passes) and
+ *    stage through device memory owned by the context.
+ *  - Every function returns an otmb_status; otmb_last_error(ctx) gives the message, which
+ *    for the reference's own failures is the reference's exact error string.
+ *  - A context is bound to one GPU, is not shared between threads, and has no global state.
+ */
+#ifndef OTMB_H
+#define OTMB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct otmb_ctx otmb_ctx;
+
+typedef enum {
+    OTMB_OK = 0,
+    OTMB_ERR_RHO_NAN = 1,          /* "ρ contains NaNs"        src/matrixbuilding.jl:233 */
+    OTMB_ERR_TADV_NAN = 2,         /* "Tadv contains NaNs."    src/matrixbuilding.jl:39  */
+    OTMB_ERR_TKH_NAN = 3,          /* "TκH contains NaNs."     src/matrixbuilding.jl:61  */
+    OTMB_ERR_TKVML_NAN = 4,        /* "TκVML contains NaNs."   src/matrixbuilding.jl:90  */
+    OTMB_ERR_TKVDEEP_NAN = 5,      /* "TκVdeep contains NaNs." src/matrixbuilding.jl:114 */
+    OTMB_ERR_FLUX_INTO_LAND = 6,   /* reference throws from Lwet3D[nothing] / push!(…, missing) */
+    OTMB_ERR_UNKNOWN_TOPOLOGY = 7, /* "Unknown grid type"      src/gridtopology.jl:111-116 */
+    OTMB_ERR_ALL_MISSING = 8,      /* AssertionError           src/velocities.jl:199-200 */
+    OTMB_ERR_ALLOC = 9,
+    OTMB_ERR_HIP = 10,
+    OTMB_ERR_INVALID_ARG = 11,
+    OTMB_ERR_NO_PLAN = 12,         /* fill/fetch without a successful plan */
+    OTMB_ERR_NONCANONICAL_INDICES = 13, /* Lwet3D is not what makeindices(v3D) returns */
+    OTMB_ERR_CAPACITY = 14
+} otmb_status;
+
+/* gridmetrics.gridtopology (src/gridtopology.jl:1-16) */
+typedef enum { OTMB_BIPOLAR = 0, OTMB_TRIPOLAR = 1, OTMB_UNKNOWN_TOPOLOGY = 2 } otmb_topology;
+
+/* order of the face-flux arrays: the fields of the NamedTuple returned at src/velocities.jl:245-252 */
+enum { OTMB_EAST = 0, OTMB_WEST = 1, OTMB_NORTH = 2, OTMB_SOUTH = 3, OTMB_TOP = 4, OTMB_BOTTOM = 5 };
+/* order of the per-direction (nx,ny) metric arrays edge_length_2D[dir], distance_to_neighbour_2D[dir] */
+enum { OTMB_DIR_WEST = 0, OTMB_DIR_EAST = 1, OTMB_DIR_SOUTH = 2, OTMB_DIR_NORTH = 3 };
+/* order of the five returned matrices: (; T, Tadv, TκH, TκVML, TκVdeep), src/matrixbuilding.jl:149 */
+enum { OTMB_T = 0, OTMB_TADV = 1, OTMB_TKH = 2, OTMB_TKVML = 3, OTMB_TKVDEEP = 4 };
+
+/* ---- context ------------------------------------------------------------------------------ */
+int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out);
+void otmb_ctx_destroy(otmb_ctx *ctx);
+/* Borrow a hipStream_t (e.g. torch's current stream) for every _dev call; NULL = the ctx's own. */
+int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *hip_stream);
+int32_t otmb_ctx_synchronize(otmb_ctx *ctx);
+const char *otmb_last_error(const otmb_ctx *ctx);
+const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
+const char *otmb_version(void);
+
+/* ---- makeindices(v3D)  -- src/matrixbuilding.jl:10-24 ------------------------------------- *
+ * wet = !isnan(v3D).  Outputs (any may be NULL): lwet3d (nx*ny*nz) wet rank or 0;
+ * lwet (capacity nx*ny*nz; first N valid) ascending 1-based linear indices of wet cells;
+ * wet3d (nx*ny*nz bytes, 0/1).  *n_wet receives N (host memory in both variants).        */
+int32_t otmb_makeindices_dev(otmb_ctx *ctx, const double *v3d, int64_t nx, int64_t ny, int64_t nz,
+                             int64_t *lwet3d, int64_t *lwet, uint8_t *wet3d, int64_t *n_wet);
+int32_t otmb_makeindices(otmb_ctx *ctx, const double *v3d, int64_t nx, int64_t ny, int64_t nz,
+                         int64_t *lwet3d, int64_t *lwet, uint8_t *wet3d, int64_t *n_wet);
+
+/* ---- facefluxes(umo, vmo, gridmetrics, indices; FillValue) -- src/velocities.jl:190-255,
+ *      including nofluxboundaries! (:154-179) and the Float64 conversion of
+ *      facefluxesfrommasstransport (:118-130).
+ * umo/vmo: (nx,ny,nz), Float64 (src_is_f32 == 0) or Float32 (== 1, the CMIP on-disk type);
+ * they are NOT modified (the reference mutates only its converted copies).  `fill` is the
+ * _FillValue promoted to Float64.  phi[6]: outputs in OTMB_EAST..OTMB_BOTTOM order.         */
+int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                            const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                            int32_t topology, double *const phi[6]);
+int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                        const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                        int32_t topology, double *const phi[6]);
+
+/* ---- transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind)
+ *      -- src/matrixbuilding.jl:128-150 with buildTadv/TκH/TκVML/TκVdeep (:31-120), the three
+ *      *_operator_sparse_entries generators (:221-299, :337-418, :438-479), sparse() x4 and
+ *      T = Tadv + TκH + TκVML + TκVdeep (:147), fused: each wet cell's column of all five
+ *      matrices is produced directly in CSC order.                                          */
+typedef struct {
+    int64_t nx, ny, nz;
+    int32_t topology;            /* otmb_topology */
+    int32_t upwind;              /* 1: upwind (default), 0: centred */
+    int64_t n_wet;               /* indices.N */
+    const double *phi[6];        /* ϕ.east, west, north, south, top, bottom: (nx,ny,nz) */
+    const double *v3d;           /* gridmetrics.v3D      (nx,ny,nz), NaN on land */
+    const double *thkcello;      /* gridmetrics.thkcello (nx,ny,nz) */
+    const double *rho;           /* ρ as (nx,ny,nz) array, or NULL to use rho_scalar */
+    double rho_scalar;
+    const int64_t *lwet3d;       /* indices.Lwet3D (nx,ny,nz), 0 = missing */
+    const double *edge_length[4];/* gridmetrics.edge_length_2D[dir]           (nx,ny), OTMB_DIR_* order */
+    const double *dist_nbr[4];   /* gridmetrics.distance_to_neighbour_2D[dir] (nx,ny) */
+    const double *area2d;        /* gridmetrics.area2D (nx,ny) */
+    const double *zt;            /* gridmetrics.zt (nz) */
+    const double *mlotst;        /* mlotst (nx,ny), NaN = missing */
+    double kappa_h, kappa_vml, kappa_vdeep;
+} otmb_tm_args;
+
+/* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC
+ * buffers): plan computes the five nnz counts (and raises the reference's errors); fill
+ * writes colptr[m] (n_wet+1), rowval[m] (nnz[m]) and nzval[m] (nnz[m]) for the five matrices
+ * in OTMB_T..OTMB_TKVDEEP order.  The args of the last plan are remembered by the context.  */
+int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
+int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
+                                      double *const nzval[5]);
+int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
+int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
+                                   double *const nzval[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTMB_H */

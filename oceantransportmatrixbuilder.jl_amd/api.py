@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's API for the hot path -- same function names, keyword
+arguments, return fields and error messages as the Julia originals, over the C ABI
+(HOST-pointer entry points, i.e. exactly what julia/OceanTransportMatrixBuilderAMD.jl does
+with ccall).  Arrays are numpy, Fortran-ordered, Julia shapes; indices stay 1-based.
+
+    makeindices(v3D)                                        src/matrixbuilding.jl:10-24
+    facefluxesfrommasstransport(; umo, vmo, gridmetrics, indices)   src/velocities.jl:118-130
+    facefluxes(umo, vmo, gridmetrics, indices; FillValue)           src/velocities.jl:190-255
+    transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, ...)
+                                                            src/matrixbuilding.jl:128-150
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from ._nt import NT, data_and_props
+from .capi import HDIRS, MATS, PHI_ORDER
+
+_ctx = {}
+
+
+def context(device=0):
+    if device not in _ctx:
+        _ctx[device] = capi.Context(device)
+    return _ctx[device]
+
+
+def _f64(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _topology_kind(gridmetrics):
+    t = gridmetrics["gridtopology"]
+    return int(t["kind"]) if isinstance(t, dict) else int(t)
+
+
+class SparseMatrixCSC:
+    """Julia's SparseMatrixCSC{Float64,Int64} layout: m, n, colptr (n+1), rowval, nzval; 1-based."""
+
+    def __init__(self, m, n, colptr, rowval, nzval):
+        self.m, self.n, self.colptr, self.rowval, self.nzval = m, n, colptr, rowval, nzval
+
+    @property
+    def shape(self):
+        return (self.m, self.n)
+
+    @property
+    def nnz(self):
+        return len(self.rowval)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+
+        return sp.csc_matrix((self.nzval, self.rowval - 1, self.colptr - 1), shape=(self.m, self.n))
+
+    def __iter__(self):  # (colptr, rowval, nzval)
+        return iter((self.colptr, self.rowval, self.nzval))
+
+
+def makeindices(v3D, *, device=0):
+    """matrixbuilding.jl:10-24 -> NT(wet3D, L, Lwet, N, Lwet3D, C).  Lwet3D uses 0 for `missing`;
+    L and C (lazy Linear/CartesianIndices in Julia) are the grid shape here."""
+    ctx = context(device)
+    v = _f64(v3D)
+    nx, ny, nz = v.shape
+    G = v.size
+    lwet3d = np.empty(v.shape, dtype=np.int64, order="F")
+    lwet = np.empty(G, dtype=np.int64)
+    wet3d = np.empty(v.shape, dtype=np.uint8, order="F")
+    n = C.c_int64(0)
+    ctx.check(capi.lib().otmb_makeindices(ctx.handle, v.ctypes.data, nx, ny, nz, lwet3d.ctypes.data, lwet.ctypes.data,
+                                          wet3d.ctypes.data, C.byref(n)))
+    N = int(n.value)
+    return NT(wet3D=wet3d.view(np.bool_), L=v.shape, Lwet=lwet[:N].copy(), N=N, Lwet3D=lwet3d, C=v.shape)
+
+
+def facefluxes(umo, vmo, gridmetrics, indices, *, FillValue, device=0):
+    """velocities.jl:190-255.  umo/vmo are not modified (the reference mutates its converted copies)."""
+    ctx = context(device)
+    u = np.asarray(umo)
+    v = np.asarray(vmo)
+    is32 = u.dtype == np.float32 and v.dtype == np.float32
+    dt = np.float32 if is32 else np.float64
+    u = np.asfortranarray(u, dtype=dt)
+    v = np.asfortranarray(v, dtype=dt)
+    nx, ny, nz = u.shape
+    wet = np.asfortranarray(indices["wet3D"]).view(np.uint8)
+    out = {k: np.empty(u.shape, dtype=np.float64, order="F") for k in PHI_ORDER}
+    ptrs = capi.ptr_array(6, [out[k].ctypes.data for k in PHI_ORDER])
+    ctx.check(capi.lib().otmb_facefluxes(ctx.handle, u.ctypes.data, v.ctypes.data, int(is32), wet.ctypes.data,
+                                         float(FillValue), nx, ny, nz, _topology_kind(gridmetrics), C.byref(ptrs)))
+    return NT(**out)
+
+
+def facefluxesfrommasstransport(*, umo, vmo, gridmetrics, indices, device=0):
+    """velocities.jl:118-130."""
+    u, up = data_and_props(umo)
+    v, vp = data_and_props(vmo)
+    fill = up["_FillValue"]
+    fv = vp["_FillValue"]
+    assert (fill == fv) or (np.isnan(fill) and np.isnan(fv))  # @assert isequal(...), :121
+    return facefluxes(u, v, gridmetrics, indices, FillValue=fill, device=device)
+
+
+def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep):
+    v3d = _f64(gridmetrics["v3D"])
+    nx, ny, nz = v3d.shape
+    a = capi.TmArgs()
+    a.nx, a.ny, a.nz = nx, ny, nz
+    a.topology = _topology_kind(gridmetrics)
+    a.upwind = int(bool(upwind))
+    a.n_wet = int(indices["N"])
+
+    def hold(x):
+        keep.append(x)
+        return x.ctypes.data
+
+    for k, name in enumerate(PHI_ORDER):
+        a.phi[k] = hold(_f64(phi[name]))
+    a.v3d = hold(v3d)
+    a.thkcello = hold(_f64(gridmetrics["thkcello"]))
+    if np.ndim(rho) == 0:
+        a.rho = None
+        a.rho_scalar = float(rho)
+    else:
+        r = _f64(rho)
+        assert r.shape == v3d.shape
+        a.rho = hold(r)
+    a.lwet3d = hold(np.asfortranarray(indices["Lwet3D"], dtype=np.int64))
+    for k, d in enumerate(HDIRS):
+        a.edge_length[k] = hold(_f64(gridmetrics["edge_length_2D"][d]))
+        a.dist_nbr[k] = hold(_f64(gridmetrics["distance_to_neighbour_2D"][d]))
+    a.area2d = hold(_f64(gridmetrics["area2D"]))
+    a.zt = hold(np.ascontiguousarray(gridmetrics["zt"], dtype=np.float64))
+    ml, _ = data_and_props(mlotst)
+    a.mlotst = hold(_f64(ml))
+    a.kappa_h, a.kappa_vml, a.kappa_vdeep = float(kH), float(kVML), float(kVdeep)
+    return a
+
+
+def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None, rho=None, κH=500.0, κVML=0.1,
+                    κVdeep=1.0e-5, kappaH=None, kappaVML=None, kappaVdeep=None, Tadv=None, TκH=None, TκVML=None,
+                    TκVdeep=None, upwind=True, device=0):
+    """matrixbuilding.jl:128-150 -> NT(T, Tadv, TκH, TκVML, TκVdeep), each a SparseMatrixCSC.
+    ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords."""
+    phi = ϕ if ϕ is not None else phi
+    rho = ρ if ρ is not None else rho
+    kH = κH if kappaH is None else kappaH
+    kVML = κVML if kappaVML is None else kappaVML
+    kVdeep = κVdeep if kappaVdeep is None else kappaVdeep
+    if any(x is not None for x in (Tadv, TκH, TκVML, TκVdeep)):
+        raise NotImplementedError("precomputed operators (matrixbuilding.jl:140-143) need the general sparse add path")
+    ctx = context(device)
+    keep = []
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep)
+    nnz = (C.c_int64 * 5)()
+    ctx.check(capi.lib().otmb_transportmatrix_plan(ctx.handle, C.byref(a), C.byref(nnz)))
+    N = int(indices["N"])
+    colptr = [np.empty(N + 1, dtype=np.int64) for _ in range(5)]
+    rowval = [np.empty(int(nnz[m]), dtype=np.int64) for m in range(5)]
+    nzval = [np.empty(int(nnz[m]), dtype=np.float64) for m in range(5)]
+    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
+    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
+    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
+    return NT(**{name: SparseMatrixCSC(N, N, colptr[m], rowval[m], nzval[m]) for m, name in enumerate(MATS)})

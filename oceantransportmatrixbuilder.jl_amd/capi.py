@@ -1,0 +1,124 @@
+"""ctypes binding of include/otmb.h (libotmb_hip.so).  No fallback: a missing library raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libotmb_hip.so")
+
+OK = 0
+STATUS_NAMES = {
+    1: "RHO_NAN", 2: "TADV_NAN", 3: "TKH_NAN", 4: "TKVML_NAN", 5: "TKVDEEP_NAN", 6: "FLUX_INTO_LAND",
+    7: "UNKNOWN_TOPOLOGY", 8: "ALL_MISSING", 9: "ALLOC", 10: "HIP", 11: "INVALID_ARG", 12: "NO_PLAN",
+    13: "NONCANONICAL_INDICES", 14: "CAPACITY",
+}
+PHI_ORDER = ("east", "west", "north", "south", "top", "bottom")  # OTMB_EAST..OTMB_BOTTOM
+HDIRS = ("west", "east", "south", "north")  # OTMB_DIR_*
+MATS = ("T", "Tadv", "TκH", "TκVML", "TκVdeep")  # OTMB_T..OTMB_TKVDEEP
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+
+class OtmbError(RuntimeError):
+    """Raised with the reference's own message for the reference's own failures
+    (ErrorException / AssertionError texts of src/matrixbuilding.jl:39,61,90,114,233,
+    src/gridtopology.jl:111-116, src/velocities.jl:199-200)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+        self.name = STATUS_NAMES.get(status, str(status))
+
+
+class TmArgs(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
+        ("topology", C.c_int32), ("upwind", C.c_int32), ("n_wet", C.c_int64),
+        ("phi", C.c_void_p * 6), ("v3d", C.c_void_p), ("thkcello", C.c_void_p),
+        ("rho", C.c_void_p), ("rho_scalar", C.c_double), ("lwet3d", C.c_void_p),
+        ("edge_length", C.c_void_p * 4), ("dist_nbr", C.c_void_p * 4),
+        ("area2d", C.c_void_p), ("zt", C.c_void_p), ("mlotst", C.c_void_p),
+        ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
+    ]
+
+
+# every symbol include/otmb.h declares: (restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = {
+    "otmb_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(_vp)]),
+    "otmb_ctx_destroy": (None, [_vp]),
+    "otmb_ctx_set_stream": (C.c_int32, [_vp, _vp]),
+    "otmb_ctx_synchronize": (C.c_int32, [_vp]),
+    "otmb_last_error": (C.c_char_p, [_vp]),
+    "otmb_status_string": (C.c_char_p, [C.c_int32]),
+    "otmb_version": (C.c_char_p, []),
+    "otmb_makeindices_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
+    "otmb_makeindices": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
+    "otmb_facefluxes_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
+    "otmb_facefluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
+    "otmb_transportmatrix_plan_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
+    "otmb_transportmatrix_fill_dev": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
+    "otmb_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
+    "otmb_transportmatrix_fetch": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libotmb_hip.so (built by build.py / __graft_entry__.build()).  Fails loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
+                          "(there is no CPU fallback for the product path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class Context:
+    """One otmb_ctx bound to a GPU."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        rc = lib().otmb_ctx_create(int(device), C.byref(self._h))
+        if rc != OK:
+            raise OtmbError(rc, f"otmb_ctx_create(device={device}) failed: " + lib().otmb_status_string(rc).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().otmb_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self, rc):
+        if rc != OK:
+            raise OtmbError(rc, lib().otmb_last_error(self._h).decode("utf-8"))
+
+    def set_stream(self, stream_ptr):
+        self.check(lib().otmb_ctx_set_stream(self._h, _vp(stream_ptr or 0)))
+
+    def synchronize(self):
+        self.check(lib().otmb_ctx_synchronize(self._h))
+
+
+def ptr_array(n, ptrs):
+    a = (_vp * n)()
+    for k, p in enumerate(ptrs):
+        a[k] = p
+    return a

@@ -1,0 +1,61 @@
+// otmb_common.h -- shared declarations of libotmb_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/otmb.h"
+
+typedef int64_t i64;
+typedef uint64_t u64;
+
+// One growable device buffer owned by the context (cached between calls).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct TmPlan;  // otmb_transportmatrix.hip
+
+struct otmb_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // own_stream or a borrowed one
+    std::string err;
+    // scratch for the scans / flags
+    DevBuf blocksums, blockoffs, flags;
+    int *h_flags = nullptr;  // pinned host mirror of the flag words
+    i64 *h_tot = nullptr;    // pinned host mirror of scan totals
+    TmPlan *plan = nullptr;
+    // staging for the host-pointer entry points
+    std::vector<DevBuf> stage;
+};
+
+#define OTMB_NFLAGS 16
+enum {
+    FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
+    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_U_VALID, FLAG_V_VALID
+};
+
+int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
+int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);
+void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
+int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
+
+#define HIP_TRY(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            char msg_[256];                                                             \
+            snprintf(msg_, sizeof msg_, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return otmb_fail((ctx), OTMB_ERR_HIP, msg_);                                \
+        }                                                                               \
+    } while (0)
+
+// ---- device-side scan of per-tile sums (otmb_scan.hip) -------------------------------------
+// sums: [ntiles][nf] u32 ; offs: [ntiles][nf] i64 exclusive prefix ; tot: [nf] i64 (device)
+void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *tot, i64 ntiles, int nf);

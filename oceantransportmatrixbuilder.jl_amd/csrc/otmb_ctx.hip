@@ -1,0 +1,117 @@
+// otmb_ctx.hip -- context, error strings, scratch buffers.
+#include "otmb_common.h"
+
+int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail) {
+    if (ctx) {
+        ctx->err = otmb_status_string(status);
+        if (detail && *detail) {
+            ctx->err += ": ";
+            ctx->err += detail;
+        }
+    }
+    return status;
+}
+
+int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return OTMB_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        return otmb_fail(ctx, OTMB_ERR_ALLOC, "hipMalloc");
+    }
+    b.cap = want;
+    return OTMB_OK;
+}
+
+extern "C" {
+
+const char *otmb_version(void) { return "otmb_hip 0.1.0 (gfx950)"; }
+
+const char *otmb_status_string(int32_t s) {
+    switch (s) {
+        case OTMB_OK: return "ok";
+        case OTMB_ERR_RHO_NAN: return "ρ contains NaNs";
+        case OTMB_ERR_TADV_NAN: return "Tadv contains NaNs.";
+        case OTMB_ERR_TKH_NAN: return "TκH contains NaNs.";
+        case OTMB_ERR_TKVML_NAN: return "TκVML contains NaNs.";
+        case OTMB_ERR_TKVDEEP_NAN: return "TκVdeep contains NaNs.";
+        case OTMB_ERR_FLUX_INTO_LAND: return "non-zero flux into a land cell or outside the grid";
+        case OTMB_ERR_UNKNOWN_TOPOLOGY: return "Unknown grid type";
+        case OTMB_ERR_ALL_MISSING: return "AssertionError: all umo or vmo values are NaN or _FillValue";
+        case OTMB_ERR_ALLOC: return "device allocation failed";
+        case OTMB_ERR_HIP: return "HIP error";
+        case OTMB_ERR_INVALID_ARG: return "invalid argument";
+        case OTMB_ERR_NO_PLAN: return "no transportmatrix plan";
+        case OTMB_ERR_NONCANONICAL_INDICES: return "Lwet3D is not the wet rank in linear-index order (makeindices)";
+        case OTMB_ERR_CAPACITY: return "output capacity too small";
+        default: return "unknown status";
+    }
+}
+
+int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
+    if (!out) return OTMB_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return OTMB_ERR_HIP;
+    if (device_id < 0 || device_id >= n) return OTMB_ERR_INVALID_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return OTMB_ERR_HIP;
+    otmb_ctx *c = new otmb_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return OTMB_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    if (hipHostMalloc((void **)&c->h_flags, OTMB_NFLAGS * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_tot, 16 * sizeof(i64)) != hipSuccess) {
+        otmb_ctx_destroy(c);
+        return OTMB_ERR_ALLOC;
+    }
+    if (otmb_reserve(c, c->flags, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64)) != OTMB_OK) {
+        otmb_ctx_destroy(c);
+        return OTMB_ERR_ALLOC;
+    }
+    *out = c;
+    return OTMB_OK;
+}
+
+void otmb_ctx_destroy(otmb_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    otmb_tm_plan_free(ctx);
+    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags})
+        if (b->p) (void)hipFree(b->p);
+    for (DevBuf &b : ctx->stage)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->h_tot) (void)hipHostFree(ctx->h_tot);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *s) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return OTMB_OK;
+}
+
+int32_t otmb_ctx_synchronize(otmb_ctx *ctx) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_flags[FLAG_NONCANONICAL]) {
+        ctx->h_flags[FLAG_NONCANONICAL] = 0;
+        return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
+    }
+    return OTMB_OK;
+}
+
+const char *otmb_last_error(const otmb_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+}  // extern "C"

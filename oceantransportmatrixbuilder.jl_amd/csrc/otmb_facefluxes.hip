@@ -1,0 +1,95 @@
+// otmb_facefluxes.hip -- facefluxesfrommasstransport / facefluxes / nofluxboundaries! on the
+// device (src/velocities.jl:118-130, :190-255, :154-179), fused into one pass:
+// one thread per (i,j) water column marches k = nz..1 (the continuity recurrence :236-243 is a
+// sequential chain in k with a fixed association, :242), reading umo/vmo once (plus the west and
+// south neighbours' values, which are L1/L2 hits of the same rows) and writing the six ϕ arrays
+// once.  Lanes run along i, so every access is coalesced.
+#include "otmb_common.h"
+
+#define FF_THREADS 64
+
+// replace(x, NaN => 0.0, FillValue => 0.0) -- isequal semantics (:203, :215)
+__device__ __forceinline__ double ff_replace(double x, double fill) {
+    return (isnan(x) || __double_as_longlong(x) == __double_as_longlong(fill)) ? 0.0 : x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
+    const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
+    int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
+    double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
+    int *flags) {
+    const i64 s = (i64)blockIdx.x * FF_THREADS + threadIdx.x;
+    bool uvalid = false, vvalid = false;
+    if (s < P) {
+        const int j = (int)(s / nx), i = (int)(s - (i64)j * nx);
+        const i64 sE = (i64)j * nx + ((i + 1 < nx) ? i + 1 : 0);        // i₊₁, gridtopology.jl:57
+        const i64 sW = (i64)j * nx + ((i > 0) ? i - 1 : nx - 1);        // i₋₁, :58
+        const i64 sS = (j > 0) ? s - nx : -1;                            // j₋₁, :63
+        const i64 sN = (j + 1 < ny) ? s + nx : ((topo == OTMB_TRIPOLAR) ? (i64)j * nx + (nx - 1 - i) : -1);  // :62, :94
+        double topbelow = 0.0;
+#pragma unroll 2
+        for (int k = nz - 1; k >= 0; --k) {
+            const i64 o = (i64)k * P;
+            const bool wc = wet[o + s] != 0, wE = wet[o + sE] != 0, wW = wet[o + sW] != 0;
+            const bool wS = (sS >= 0) && wet[o + sS] != 0, wN = (sN >= 0) && wet[o + sN] != 0;
+            double u = (double)umo[o + s], v = (double)vmo[o + s];  // Array{Float64}(umo), :125-126
+            // nofluxboundaries!, :167-173
+            if (!wc || !wE) u = 0.0;
+            if (!wc || !wN) v = 0.0;
+            uvalid |= !(isnan(u) || u == fill);  // :199
+            vvalid |= !(isnan(v) || v == fill);  // :200
+            const double e = ff_replace(u, fill), n = ff_replace(v, fill);
+            // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
+            double uw = (double)umo[o + sW];
+            if (!wW || !wc) uw = 0.0;
+            const double w = ff_replace(uw, fill);
+            // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
+            double so = 0.0;
+            if (sS >= 0) {
+                double vs = (double)vmo[o + sS];
+                if (!wS || !wc) vs = 0.0;
+                so = ff_replace(vs, fill);
+            }
+            const double b = (k == nz - 1) ? 0.0 : topbelow;  // :238-240
+            const double t = (((b + w) + so) - e) - n;        // :242
+            east[o + s] = e; west[o + s] = w; north[o + s] = n; south[o + s] = so; top[o + s] = t; bottom[o + s] = b;
+            topbelow = t;
+        }
+    }
+    if (__any(uvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_U_VALID] == 0) atomicExch(&flags[FLAG_U_VALID], 1);
+    if (__any(vvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_V_VALID] == 0) atomicExch(&flags[FLAG_V_VALID], 1);
+}
+
+extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                       const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                       int32_t topology, double *const phi[6]) {
+    if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    for (int f = 0; f < 6; ++f)
+        if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+    if (nx < 1 || ny < 1 || nz < 1 || nx * ny >= (1ll << 31)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);  // :163 -> gridtopology.jl:111
+    if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 P = nx * ny;
+    int *dflags = (int *)ctx->flags.p;
+    HIP_TRY(ctx, hipMemsetAsync(dflags + FLAG_U_VALID, 0, 2 * sizeof(int), ctx->stream));
+    const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
+    if (src_is_f32)
+        hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
+                           (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
+                           phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
+                           phi[OTMB_BOTTOM], dflags);
+    else
+        hipLaunchKernelGGL(facefluxes_kernel<double>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const double *)umo,
+                           (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
+                           phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
+                           phi[OTMB_BOTTOM], dflags);
+    HIP_TRY(ctx, hipGetLastError());
+    // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + FLAG_U_VALID, dflags + FLAG_U_VALID, 2 * sizeof(int),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->h_flags[FLAG_U_VALID] || !ctx->h_flags[FLAG_V_VALID]) return otmb_fail(ctx, OTMB_ERR_ALL_MISSING);
+    return OTMB_OK;
+}

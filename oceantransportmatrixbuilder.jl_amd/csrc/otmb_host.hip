@@ -1,0 +1,133 @@
+// otmb_host.hip -- HOST-pointer entry points (what Julia's ccall hands over): stage the caller's
+// arrays through device buffers owned by the context, run the _dev path, copy the results back
+// into the caller's buffers.  No CPU compute path exists here: without a GPU these calls fail.
+#include "otmb_common.h"
+
+// staging slots
+enum {
+    ST_PHI0 = 0, ST_V = 6, ST_THK, ST_RHO, ST_LW, ST_EDGE0, ST_DIST0 = ST_EDGE0 + 4, ST_AREA = ST_DIST0 + 4, ST_ZT,
+    ST_ML, ST_UMO, ST_VMO, ST_WET, ST_LWET, ST_COLPTR0, ST_ROWVAL0 = ST_COLPTR0 + 5, ST_NZVAL0 = ST_ROWVAL0 + 5,
+    ST_COUNT = ST_NZVAL0 + 5
+};
+
+static int32_t stage(otmb_ctx *ctx, int slot, size_t bytes, void **dptr) {
+    if (ctx->stage.size() < (size_t)ST_COUNT) ctx->stage.resize(ST_COUNT);
+    int32_t rc = otmb_reserve(ctx, ctx->stage[slot], bytes ? bytes : 8);
+    *dptr = ctx->stage[slot].p;
+    return rc;
+}
+static int32_t upload(otmb_ctx *ctx, int slot, const void *h, size_t bytes, const void **dptr) {
+    void *d = nullptr;
+    int32_t rc = stage(ctx, slot, bytes, &d);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dptr = d;
+    return OTMB_OK;
+}
+#define TRY(x)                  \
+    do {                        \
+        int32_t rc_ = (x);      \
+        if (rc_) return rc_;    \
+    } while (0)
+
+extern "C" {
+
+int32_t otmb_makeindices(otmb_ctx *ctx, const double *v3d, int64_t nx, int64_t ny, int64_t nz, int64_t *lwet3d,
+                         int64_t *lwet, uint8_t *wet3d, int64_t *n_wet) {
+    if (!ctx || !v3d || !n_wet) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = (size_t)(nx * ny * nz);
+    const void *dv;
+    void *dlw3 = nullptr, *dlw = nullptr, *dwet = nullptr;
+    TRY(upload(ctx, ST_V, v3d, G * 8, &dv));
+    if (lwet3d) TRY(stage(ctx, ST_LW, G * 8, &dlw3));
+    if (lwet) TRY(stage(ctx, ST_LWET, G * 8, &dlw));
+    if (wet3d) TRY(stage(ctx, ST_WET, G, &dwet));
+    TRY(otmb_makeindices_dev(ctx, (const double *)dv, nx, ny, nz, (int64_t *)dlw3, (int64_t *)dlw, (uint8_t *)dwet, n_wet));
+    if (lwet3d) HIP_TRY(ctx, hipMemcpyAsync(lwet3d, dlw3, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (lwet && *n_wet > 0) HIP_TRY(ctx, hipMemcpyAsync(lwet, dlw, (size_t)*n_wet * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (wet3d) HIP_TRY(ctx, hipMemcpyAsync(wet3d, dwet, G, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
+int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d,
+                        double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6]) {
+    if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = (size_t)(nx * ny * nz), es = src_is_f32 ? 4 : 8;
+    const void *du, *dv, *dw;
+    TRY(upload(ctx, ST_UMO, umo, G * es, &du));
+    TRY(upload(ctx, ST_VMO, vmo, G * es, &dv));
+    TRY(upload(ctx, ST_WET, wet3d, G, &dw));
+    double *dphi[6];
+    for (int f = 0; f < 6; ++f) {
+        if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        void *d;
+        TRY(stage(ctx, ST_PHI0 + f, G * 8, &d));
+        dphi[f] = (double *)d;
+    }
+    TRY(otmb_facefluxes_dev(ctx, du, dv, src_is_f32, (const uint8_t *)dw, fill, nx, ny, nz, topology, dphi));
+    for (int f = 0; f < 6; ++f) HIP_TRY(ctx, hipMemcpyAsync(phi[f], dphi[f], G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
+int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t nnz[5]) {
+    if (!ctx || !a || !nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    for (int f = 0; f < 6; ++f)
+        if (!a->phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
+    for (int d = 0; d < 4; ++d)
+        if (!a->edge_length[d] || !a->dist_nbr[d]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "metrics");
+    if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst)
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null input array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)(a->nx * a->ny), G = P * (size_t)a->nz;
+    otmb_tm_args d = *a;
+    const void *p;
+    for (int f = 0; f < 6; ++f) { TRY(upload(ctx, ST_PHI0 + f, a->phi[f], G * 8, &p)); d.phi[f] = (const double *)p; }
+    TRY(upload(ctx, ST_V, a->v3d, G * 8, &p)); d.v3d = (const double *)p;
+    TRY(upload(ctx, ST_THK, a->thkcello, G * 8, &p)); d.thkcello = (const double *)p;
+    if (a->rho) { TRY(upload(ctx, ST_RHO, a->rho, G * 8, &p)); d.rho = (const double *)p; }
+    TRY(upload(ctx, ST_LW, a->lwet3d, G * 8, &p)); d.lwet3d = (const int64_t *)p;
+    for (int k = 0; k < 4; ++k) {
+        TRY(upload(ctx, ST_EDGE0 + k, a->edge_length[k], P * 8, &p)); d.edge_length[k] = (const double *)p;
+        TRY(upload(ctx, ST_DIST0 + k, a->dist_nbr[k], P * 8, &p)); d.dist_nbr[k] = (const double *)p;
+    }
+    TRY(upload(ctx, ST_AREA, a->area2d, P * 8, &p)); d.area2d = (const double *)p;
+    TRY(upload(ctx, ST_ZT, a->zt, (size_t)a->nz * 8, &p)); d.zt = (const double *)p;
+    TRY(upload(ctx, ST_ML, a->mlotst, P * 8, &p)); d.mlotst = (const double *)p;
+    return otmb_transportmatrix_plan_dev(ctx, &d, nnz);
+}
+
+int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
+                                   double *const nzval[5]) {
+    if (!ctx || !colptr || !rowval || !nzval) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    int64_t nnz[5];
+    int64_t N;
+    TRY(otmb_tm_plan_query(ctx, nnz, &N));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t *dcp[5], *drv[5];
+    double *dnz[5];
+    for (int m = 0; m < 5; ++m) {
+        if (!colptr[m] || (nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        void *d;
+        TRY(stage(ctx, ST_COLPTR0 + m, (size_t)(N + 1) * 8, &d)); dcp[m] = (int64_t *)d;
+        TRY(stage(ctx, ST_ROWVAL0 + m, (size_t)nnz[m] * 8, &d)); drv[m] = (int64_t *)d;
+        TRY(stage(ctx, ST_NZVAL0 + m, (size_t)nnz[m] * 8, &d)); dnz[m] = (double *)d;
+    }
+    TRY(otmb_transportmatrix_fill_dev(ctx, dcp, drv, dnz));
+    for (int m = 0; m < 5; ++m) {
+        HIP_TRY(ctx, hipMemcpyAsync(colptr[m], dcp[m], (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (nnz[m] > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(rowval[m], drv[m], (size_t)nnz[m] * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(nzval[m], dnz[m], (size_t)nnz[m] * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    return otmb_ctx_synchronize(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.  Bar: nonzero pattern (colptr,rowval) bit-exact;
+values bit-exact as well (the path uses only + - * / min max abs with contraction off), which is
+stricter than the 1e-12 relative tolerance BASELINE.json states."""
+import numpy as np
+import pytest
+
+from helpers import CASES, MATS, assert_csc_equal, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import otmb_amd.api as api
+
+    return api
+
+
+def _fill(g):
+    return g.umo.properties["_FillValue"]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_makeindices_and_facefluxes_match_oracle(api, oracle, name):
+    g, gm = make_case(name)
+    ref = oracle.makeindices(gm.v3D)
+    idx = api.makeindices(gm.v3D)
+    assert idx.N == ref["N"]
+    assert np.array_equal(idx.Lwet, ref["Lwet"])
+    assert np.array_equal(idx.Lwet3D, ref["Lwet3D"])
+    assert np.array_equal(idx.wet3D.view(np.uint8), ref["wet3D"])
+    u0 = np.array(g.umo.data, copy=True)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    assert np.array_equal(u0, g.umo.data, equal_nan=True)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    for k in rphi:
+        assert phi[k].dtype == np.float64
+        same = (phi[k] == rphi[k]) & (np.signbit(phi[k]) == np.signbit(rphi[k]))
+        assert same.all(), (name, k, np.argwhere(~same)[:3])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("upwind", [True, False])
+def test_transportmatrix_matches_oracle_bit_for_bit(api, oracle, name, upwind):
+    g, gm = make_case(name)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind)
+    idx = api.makeindices(gm.v3D)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH,
+                             κVML=g.kappaVML, κVdeep=g.kappaVdeep, upwind=upwind)
+    for m in MATS:
+        assert tm[m].shape == (ref["N"], ref["N"])
+        assert tm[m].colptr.dtype == np.int64 and tm[m].rowval.dtype == np.int64 and tm[m].nzval.dtype == np.float64
+        assert_csc_equal(tuple(tm[m]), rtm[m], f"{name}/{m}/upwind={upwind}")
+
+
+def test_exact_cancellation_is_dropped_from_T_but_kept_in_operators(api, oracle):
+    """sparse() keeps stored zeros, + drops exact zeros: craft fluxes whose advective and diffusive
+    off-diagonals cancel exactly in one entry."""
+    g, gm = make_case("tiny_tripolar")
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    base = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, 0.0, 0.0, 0.0, True)
+    # κ = 0 makes every diffusive value an explicit 0.0 (kept in TκH/TκV*, invisible in T)
+    idx = api.makeindices(gm.v3D)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=0.0, κVML=0.0, κVdeep=0.0)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), base[m], m)
+    assert tm["TκH"].nnz > 0 and np.all(tm["TκH"].nzval == 0.0)
+    assert not np.any(tm["T"].nzval == 0.0)
+    assert tm["T"].nnz == tm["Tadv"].nnz
+
+
+def test_error_strings_match_reference(api, oracle):
+    from otmb_amd.capi import OtmbError
+
+    g, gm = make_case("tiny_rho3d")
+    ref = oracle.makeindices(gm.v3D)
+    idx = api.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    kw = dict(mlotst=g.mlotst, gridmetrics=gm, indices=idx)
+    rho = g.rho.copy(order="F")
+    rho.ravel(order="F")[ref["Lwet"][5] - 1] = np.nan
+    with pytest.raises(OtmbError, match="ρ contains NaNs"):
+        api.transportmatrix(ϕ=rphi, ρ=rho, **kw)
+    with pytest.raises(OtmbError, match="ρ contains NaNs"):
+        api.transportmatrix(ϕ=rphi, ρ=float("nan"), **kw)
+    wet = ref["wet3D"].astype(bool)
+    bad = {k: v.copy(order="F") for k, v in rphi.items()}
+    i, j, k = np.argwhere(wet & ~np.roll(wet, 1, axis=0))[0]
+    bad["west"][i, j, k] = 5.0
+    with pytest.raises(OtmbError, match="flux into a land cell") as e:
+        api.transportmatrix(ϕ=bad, ρ=g.rho, **kw)
+    assert e.value.name == "FLUX_INTO_LAND"
+    bad = {k: v.copy(order="F") for k, v in rphi.items()}
+    i, j = np.argwhere(wet[:, :, -1])[0]
+    bad["bottom"][i, j, -1] = 1.0
+    with pytest.raises(OtmbError, match="flux into a land cell"):
+        api.transportmatrix(ϕ=bad, ρ=g.rho, **kw)
+    gm2 = dict(gm)
+    gm2["edge_length_2D"] = {d: a.copy(order="F") for d, a in gm.edge_length_2D.items()}
+    ii, jj = np.argwhere(wet[:, :, 0] & np.roll(wet[:, :, 0], 1, axis=0))[0]
+    gm2["edge_length_2D"]["west"][ii, jj] = np.nan
+    with pytest.raises(OtmbError, match="TκH contains NaNs."):
+        api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm2, indices=idx)
+    gm3 = dict(gm)
+    gm3["gridtopology"] = dict(kind=2)
+    with pytest.raises(OtmbError, match="Unknown grid type"):
+        api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm3, indices=idx)
+    with pytest.raises(OtmbError, match="Unknown grid type"):
+        api.facefluxes(g.umo.data, g.vmo.data, gm3, idx, FillValue=1e20)
+    allwet = dict(wet3D=np.ones((4, 3, 2), np.bool_))
+    with pytest.raises(OtmbError, match="AssertionError"):
+        api.facefluxes(np.full((4, 3, 2), np.nan), np.ones((4, 3, 2)), dict(gridtopology=dict(kind=1)), allwet, FillValue=1e20)
+    # Lwet3D that is not makeindices' ranking
+    idx2 = dict(idx)
+    lw = idx.Lwet3D.copy(order="F")
+    flat = lw.ravel(order="F")
+    a, b = ref["Lwet"][3] - 1, ref["Lwet"][4] - 1
+    flat[a], flat[b] = flat[b], flat[a]
+    idx2["Lwet3D"] = lw
+    with pytest.raises(OtmbError, match="Lwet3D"):
+        api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm, indices=idx2)
