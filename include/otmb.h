@@ -67,6 +67,12 @@ int32_t otmb_ctx_synchronize(otmb_ctx *ctx);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
 const char *otmb_version(void);
+/* Optional per-kernel timing: when enabled every kernel launch is bracketed by two hipEvents on
+ * the launch stream.  collect() synchronises, adds the elapsed times per kernel id, returns the
+ * sums (ms) and launch counts since the previous collect for ids 0..n-1 and resets them.      */
+int32_t otmb_ctx_timing_enable(otmb_ctx *ctx, int32_t on);
+int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, int32_t n);
+const char *otmb_kernel_name(int32_t kernel_id);
 
 /* ---- makeindices(v3D)  -- src/matrixbuilding.jl:10-24 ------------------------------------- *
  * wet = !isnan(v3D).  Outputs (any may be NULL): lwet3d (nx*ny*nz) wet rank or 0;

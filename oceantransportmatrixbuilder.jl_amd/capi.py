@@ -52,6 +52,9 @@ SYMBOLS = {
     "otmb_last_error": (C.c_char_p, [_vp]),
     "otmb_status_string": (C.c_char_p, [C.c_int32]),
     "otmb_version": (C.c_char_p, []),
+    "otmb_ctx_timing_enable": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_ctx_timing_collect": (C.c_int32, [_vp, _dp, _ip, C.c_int32]),
+    "otmb_kernel_name": (C.c_char_p, [C.c_int32]),
     "otmb_makeindices_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
     "otmb_makeindices": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
     "otmb_facefluxes_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
@@ -115,6 +118,16 @@ class Context:
 
     def synchronize(self):
         self.check(lib().otmb_ctx_synchronize(self._h))
+
+    def timing_enable(self, on=True):
+        self.check(lib().otmb_ctx_timing_enable(self._h, int(on)))
+
+    def timing_collect(self, n=7):
+        """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        self.check(lib().otmb_ctx_timing_collect(self._h, ms, cnt, n))
+        return {lib().otmb_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(n) if cnt[k]}
 
 
 def ptr_array(n, ptrs):

@@ -21,6 +21,12 @@ struct DevBuf {
 
 struct TmPlan;  // otmb_transportmatrix.hip
 
+// kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
+enum {
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_NKERNELS
+};
+#define OTMB_TIMING_POOL 2048
+
 struct otmb_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -33,6 +39,28 @@ struct otmb_ctx {
     TmPlan *plan = nullptr;
     // staging for the host-pointer entry points
     std::vector<DevBuf> stage;
+    // optional per-kernel timing with HIP events recorded on the launch stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // 2 * OTMB_TIMING_POOL events, created on first enable
+    std::vector<int> ev_kernel;   // kernel id of each recorded pair
+    double t_ms[K_NKERNELS] = {0};
+    long t_n[K_NKERNELS] = {0};
+};
+
+// Brackets one kernel launch with events when timing is on.
+struct KernelTimer {
+    otmb_ctx *c;
+    int slot;
+    KernelTimer(otmb_ctx *ctx, int kernel_id) : c(ctx), slot(-1) {
+        if (c->timing && c->ev_kernel.size() < (size_t)OTMB_TIMING_POOL) {
+            slot = (int)c->ev_kernel.size();
+            c->ev_kernel.push_back(kernel_id);
+            (void)hipEventRecord(c->ev[2 * slot], c->stream);
+        }
+    }
+    ~KernelTimer() {
+        if (slot >= 0) (void)hipEventRecord(c->ev[2 * slot + 1], c->stream);
+    }
 };
 
 #define OTMB_NFLAGS 16

@@ -90,6 +90,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->h_tot) (void)hipHostFree(ctx->h_tot);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -110,6 +111,43 @@ int32_t otmb_ctx_synchronize(otmb_ctx *ctx) {
         return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
     }
     return OTMB_OK;
+}
+
+int32_t otmb_ctx_timing_enable(otmb_ctx *ctx, int32_t on) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on && ctx->ev.empty()) {
+        ctx->ev.resize(2 * OTMB_TIMING_POOL);
+        for (auto &e : ctx->ev) HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    ctx->timing = on != 0;
+    return OTMB_OK;
+}
+
+int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, int32_t n) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t s = 0; s < ctx->ev_kernel.size(); ++s) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[2 * s], ctx->ev[2 * s + 1]) == hipSuccess) {
+            ctx->t_ms[ctx->ev_kernel[s]] += ms;
+            ctx->t_n[ctx->ev_kernel[s]] += 1;
+        }
+    }
+    ctx->ev_kernel.clear();
+    for (int k = 0; k < n && k < K_NKERNELS; ++k) {
+        if (ms_sum) ms_sum[k] = ctx->t_ms[k];
+        if (count) count[k] = ctx->t_n[k];
+        ctx->t_ms[k] = 0;
+        ctx->t_n[k] = 0;
+    }
+    return OTMB_OK;
+}
+
+const char *otmb_kernel_name(int32_t k) {
+    static const char *names[K_NKERNELS] = {"tm_kernel<count>", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
+                                            "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>"};
+    return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 
 const char *otmb_last_error(const otmb_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -75,6 +75,8 @@ extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const voi
     int *dflags = (int *)ctx->flags.p;
     HIP_TRY(ctx, hipMemsetAsync(dflags + FLAG_U_VALID, 0, 2 * sizeof(int), ctx->stream));
     const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
+    {
+    KernelTimer kt(ctx, K_FACEFLUXES);
     if (src_is_f32)
         hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
                            (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
@@ -85,6 +87,7 @@ extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const voi
                            (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
                            phi[OTMB_BOTTOM], dflags);
+    }
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + FLAG_U_VALID, dflags + FLAG_U_VALID, 2 * sizeof(int),

@@ -56,12 +56,20 @@ extern "C" int32_t otmb_makeindices_dev(otmb_ctx *ctx, const double *v3d, int64_
     uint32_t *sums = (uint32_t *)ctx->blocksums.p;
     i64 *offs = (i64 *)ctx->blockoffs.p;
     i64 *dtot = (i64 *)((int *)ctx->flags.p + OTMB_NFLAGS);
+    {
+    KernelTimer kt(ctx, K_IDX_COUNT);
     hipLaunchKernelGGL(indices_kernel<false>, dim3((unsigned)ntiles), dim3(IX_THREADS), 0, ctx->stream, v3d, G, sums,
                        (const i64 *)nullptr, (i64 *)nullptr, (i64 *)nullptr, (uint8_t *)nullptr);
-    otmb_launch_tilescan(ctx->stream, sums, offs, dtot, ntiles, 1);
-    if (lwet3d || lwet || wet3d)
+    }
+    {
+        KernelTimer kt(ctx, K_TILESCAN);
+        otmb_launch_tilescan(ctx->stream, sums, offs, dtot, ntiles, 1);
+    }
+    if (lwet3d || lwet || wet3d) {
+        KernelTimer kt(ctx, K_IDX_WRITE);
         hipLaunchKernelGGL(indices_kernel<true>, dim3((unsigned)ntiles), dim3(IX_THREADS), 0, ctx->stream, v3d, G,
                            (uint32_t *)nullptr, (const i64 *)offs, (i64 *)lwet3d, (i64 *)lwet, wet3d);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -497,8 +497,14 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64), ctx->stream));
-    hipLaunchKernelGGL(tm_kernel<false>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
-    otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF);
+    {
+        KernelTimer kt(ctx, K_TM_COUNT);
+        hipLaunchKernelGGL(tm_kernel<false>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+    }
+    {
+        KernelTimer kt(ctx, K_TILESCAN);
+        otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
@@ -528,9 +534,15 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     }
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
-    hipLaunchKernelGGL(tm_kernel<true>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
-                       p.colptr[3], p.colptr[4], dtot, (i64)pl.args.n_wet);
+    {
+        KernelTimer kt(ctx, K_TM_FILL);
+        hipLaunchKernelGGL(tm_kernel<true>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+    }
+    {
+        KernelTimer kt(ctx, K_TM_FINISH);
+        hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
+                           p.colptr[3], p.colptr[4], dtot, (i64)pl.args.n_wet);
+    }
     HIP_TRY(ctx, hipGetLastError());
     // the fill pass can still raise OTMB_ERR_NONCANONICAL_INDICES: otmb_ctx_synchronize reports it
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

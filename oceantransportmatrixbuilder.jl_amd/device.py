@@ -1,0 +1,146 @@
+"""Device-resident driver of the hot path: torch owns the HBM buffers and the stream, the C ABI
+(`*_dev` entry points) does the work.  Used by bench.py, the GPU tests and smoke(); a Julia
+caller with device-resident data (AMDGPU.jl ROCArrays) would call the same `_dev` symbols.
+
+All arrays are flat torch tensors whose memory is Julia's column-major (nx,ny,nz) layout.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import HDIRS, MATS, PHI_ORDER
+
+
+def _flat(a, dtype=np.float64):
+    return np.asfortranarray(a, dtype=dtype).ravel(order="F")
+
+
+class DeviceAssembler:
+    """Holds one grid (gridmetrics + indices + parameters) in HBM and assembles transport matrices
+    for successive (umo, vmo) fields -- the TMIP workflow of building T for many time slices."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceAssembler needs a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.ctx = capi.Context(device)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.lib = capi.lib()
+        self.out = None
+
+    def _t(self, a, dtype=np.float64):
+        return torch.from_numpy(_flat(a, dtype)).to(self.device)
+
+    # ---- grid ---------------------------------------------------------------------------------
+    def set_grid(self, gridmetrics, mlotst, rho, kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True):
+        gm = gridmetrics
+        self.shape = tuple(int(x) for x in gm["v3D"].shape)
+        self.nx, self.ny, self.nz = self.shape
+        self.G = self.nx * self.ny * self.nz
+        t = gm["gridtopology"]
+        self.topology = int(t["kind"]) if isinstance(t, dict) else int(t)
+        self.v3d = self._t(gm["v3D"])
+        self.thk = self._t(gm["thkcello"])
+        self.edge = [self._t(gm["edge_length_2D"][d]) for d in HDIRS]
+        self.dist = [self._t(gm["distance_to_neighbour_2D"][d]) for d in HDIRS]
+        self.area = self._t(gm["area2D"])
+        self.zt = self._t(gm["zt"])
+        self.mlotst = self._t(mlotst)
+        self.rho = None if np.ndim(rho) == 0 else self._t(rho)
+        self.rho_scalar = float(rho) if np.ndim(rho) == 0 else 0.0
+        self.kappa = (float(kappaH), float(kappaVML), float(kappaVdeep))
+        self.upwind = bool(upwind)
+        self.makeindices()
+
+    def makeindices(self):
+        """otmb_makeindices_dev on the resident v3D (src/matrixbuilding.jl:10-24)."""
+        self.lwet3d = torch.empty(self.G, dtype=torch.int64, device=self.device)
+        self.lwet = torch.empty(self.G, dtype=torch.int64, device=self.device)
+        self.wet3d = torch.empty(self.G, dtype=torch.uint8, device=self.device)
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.otmb_makeindices_dev(self.ctx.handle, self.v3d.data_ptr(), self.nx, self.ny, self.nz,
+                                                     self.lwet3d.data_ptr(), self.lwet.data_ptr(),
+                                                     self.wet3d.data_ptr(), C.byref(n)))
+        self.N = int(n.value)
+        return self.N
+
+    # ---- per time slice -----------------------------------------------------------------------
+    def facefluxes(self, umo, vmo, fill):
+        """umo/vmo: flat device tensors (float64 or float32).  Returns the six ϕ tensors (reused)."""
+        if getattr(self, "phi", None) is None:
+            self.phi = [torch.empty(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
+        is32 = umo.dtype == torch.float32
+        ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
+        self.ctx.check(self.lib.otmb_facefluxes_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(is32),
+                                                    self.wet3d.data_ptr(), float(fill), self.nx, self.ny, self.nz,
+                                                    self.topology, C.byref(ptrs)))
+        return self.phi
+
+    def _args(self, phi):
+        a = capi.TmArgs()
+        a.nx, a.ny, a.nz = self.nx, self.ny, self.nz
+        a.topology, a.upwind, a.n_wet = self.topology, int(self.upwind), self.N
+        for k in range(6):
+            a.phi[k] = phi[k].data_ptr()
+        a.v3d, a.thkcello = self.v3d.data_ptr(), self.thk.data_ptr()
+        a.rho = self.rho.data_ptr() if self.rho is not None else None
+        a.rho_scalar = self.rho_scalar
+        a.lwet3d = self.lwet3d.data_ptr()
+        for k in range(4):
+            a.edge_length[k] = self.edge[k].data_ptr()
+            a.dist_nbr[k] = self.dist[k].data_ptr()
+        a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.mlotst.data_ptr()
+        a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.kappa
+        return a
+
+    def plan(self, phi):
+        a = self._args(phi)
+        nnz = (C.c_int64 * 5)()
+        self.ctx.check(self.lib.otmb_transportmatrix_plan_dev(self.ctx.handle, C.byref(a), C.byref(nnz)))
+        self.nnz = [int(x) for x in nnz]
+        return self.nnz
+
+    def fill(self):
+        """Write the five CSC matrices into device tensors (allocated once per capacity)."""
+        if self.out is None or any(self.out[m][1].numel() < self.nnz[k] for k, m in enumerate(MATS)):
+            self.out = {m: (torch.empty(self.N + 1, dtype=torch.int64, device=self.device),
+                            torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.int64, device=self.device),
+                            torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.float64, device=self.device))
+                        for k, m in enumerate(MATS)}
+        cp = capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
+        rv = capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
+        nz = capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
+        self.ctx.check(self.lib.otmb_transportmatrix_fill_dev(self.ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
+        return self.out
+
+    def transportmatrix(self, phi):
+        self.plan(phi)
+        return self.fill()
+
+    def step(self, umo, vmo, fill):
+        """One pass of the hot path: facefluxes -> plan -> fill, all device resident."""
+        return self.transportmatrix(self.facefluxes(umo, vmo, fill))
+
+    def result_to_host(self):
+        self.ctx.synchronize()
+        res = {}
+        for k, m in enumerate(MATS):
+            cp, rv, nz = self.out[m]
+            res[m] = (cp.cpu().numpy(), rv[: self.nnz[k]].cpu().numpy(), nz[: self.nnz[k]].cpu().numpy())
+        return res
+
+    # ---- accounting ---------------------------------------------------------------------------
+    def algorithmic_bytes(self):
+        """bytes the assembly must move with all five matrices returned
+        (inputs read once, outputs written once; intermediate traffic is overhead and not counted)."""
+        n3d = 9 + (1 if self.rho is not None else 0)
+        b = 8 * self.G * n3d + 80 * self.nx * self.ny + 8 * self.nz
+        b += sum(16 * z + 8 * (self.N + 1) for z in self.nnz)
+        return b
+
+    def facefluxes_bytes(self, itemsize=8):
+        """umo, vmo, wet3D read once; six ϕ arrays written once."""
+        return self.G * (2 * itemsize + 1 + 6 * 8)
