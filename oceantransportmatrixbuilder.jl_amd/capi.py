@@ -68,6 +68,26 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's); if libotmb_hip.so pulled in /opt/rocm's copy first and torch was
+    imported afterwards, two runtimes would initialise and the second fails.  Loading torch's copy
+    (when torch is installed) before anything else makes every later NEEDED entry resolve to it."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load libotmb_hip.so (built by build.py / __graft_entry__.build()).  Fails loudly if absent."""
     global _lib
@@ -75,6 +95,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')}` "
                           "(there is no CPU fallback for the product path)")
+        _preload_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)
