@@ -14,8 +14,9 @@ struct Cell {
 __device__ __forceinline__ Cell cell_of(i64 L, int nx, int ny, i64 P) {
     Cell c;
     c.L = L;
-    unsigned k = (unsigned)((u64)L / (u64)P);
-    unsigned r = (unsigned)(L - (i64)k * P);
+    // 32-bit division: the host rejects grids with 2^32 or more cells
+    unsigned k = (unsigned)L / (unsigned)P;
+    unsigned r = (unsigned)L - k * (unsigned)P;
     unsigned j = r / (unsigned)nx;
     c.k = (int)k;
     c.j = (int)j;

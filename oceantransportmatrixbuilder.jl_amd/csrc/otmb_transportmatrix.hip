@@ -310,6 +310,188 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
     }
 }
 
+// ---- fast path ---------------------------------------------------------------------------------
+// Regular cells: nx >= 3 and not on the tripolar seam row, i.e. the W/E/S/N/A/B neighbours are
+// distinct cells.  Same arithmetic as build_column, organised for the hardware:
+//  * every load is unconditional and issued up front (addresses depend on (i,j,k) only; a
+//    neighbour that does not exist is clamped to the cell itself and masked afterwards), so one
+//    memory round trip covers the whole stencil instead of one per `if`;
+//  * 32-bit byte offsets from tile-uniform base pointers (scalar base + vector offset loads);
+//  * accumulators start at -0.0: (-0.0) + x == x bit for bit for every x, which is exactly
+//    sparse()'s "first touch copies, later ones add" without tracking the first touch.
+struct TileBase {  // array pointers advanced to the tile's lowest neighbour (uniform per workgroup)
+    const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb;
+};
+__device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
+__device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
+#define NEG0 (-0.0)
+
+__device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
+                                            i64 c, Column &col) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
+    const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
+    const unsigned nx8 = (unsigned)nx * 8u, P8 = (unsigned)p.P * 8u;
+    const unsigned oE = oC + (unsigned)(di_e * 8), oW = oC + (unsigned)(di_w * 8);
+    const unsigned oS = hS ? oC - nx8 : oC, oN = hN ? oC + nx8 : oC;
+    const unsigned oA = hA ? oC - P8 : oC, oB = hB ? oC + P8 : oC;
+    const unsigned s2 = ((unsigned)j * (unsigned)nx + (unsigned)i) * 8u;
+    const unsigned sE = s2 + (unsigned)(di_e * 8), sW = s2 + (unsigned)(di_w * 8);
+    const unsigned sS = hS ? s2 - nx8 : s2, sN = hN ? s2 + nx8 : s2;
+
+    // ---- all loads ----
+    const i64 lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN), lA = ldi(tb.lw, oA),
+              lB = ldi(tb.lw, oB);
+    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
+                 gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
+    const double vC = ldd(tb.v, oC), vE = ldd(tb.v, oE), vW = ldd(tb.v, oW), vS = ldd(tb.v, oS), vN = ldd(tb.v, oN),
+                 vA = ldd(tb.v, oA), vB = ldd(tb.v, oB);
+    double rC, rE, rW, rS, rN, rA, rB;
+    if (tb.rho) {
+        rC = ldd(tb.rho, oC); rE = ldd(tb.rho, oE); rW = ldd(tb.rho, oW); rS = ldd(tb.rho, oS); rN = ldd(tb.rho, oN);
+        rA = ldd(tb.rho, oA); rB = ldd(tb.rho, oB);
+    } else {
+        rC = rE = rW = rS = rN = rA = rB = p.rho_s;
+    }
+    const double tC = ldd(tb.thk, oC), tE = ldd(tb.thk, oE), tW = ldd(tb.thk, oW), tS = ldd(tb.thk, oS),
+                 tN = ldd(tb.thk, oN);
+    const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
+               *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
+    const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
+               *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
+    const double eW_c = ldd(eWp, s2), eE_c = ldd(eEp, s2), eS_c = ldd(eSp, s2), eN_c = ldd(eNp, s2);
+    const double dW_c = ldd(dWp, s2), dE_c = ldd(dEp, s2), dS_c = ldd(dSp, s2), dN_c = ldd(dNp, s2);
+    const double eE_w = ldd(eEp, sW), dE_w = ldd(dEp, sW);  // west cell's east edge / distance to its east nbr
+    const double eW_e = ldd(eWp, sE), dW_e = ldd(dWp, sE);
+    const double eN_s = ldd(eNp, sS), dN_s = ldd(dNp, sS);
+    const double eS_n = ldd(eSp, sN), dS_n = ldd(dSp, sN);  // oppdir = south away from the seam row (:407)
+    const double ar = ldd((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
+    const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
+
+    const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
+    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
+
+    // ---- advective pushes towards this cell (:244-296) ----
+    const double fE = wE ? sel_pos(gE0, up) : 0.0;  // east cell pushes its west flux
+    const double fW = wW ? sel_neg(gW0, up) : 0.0;  // west cell pushes its east flux
+    const double fS = wS ? sel_neg(gS0, up) : 0.0;  // south cell pushes its north flux
+    const double fN = wN ? sel_pos(gN0, up) : 0.0;  // north cell pushes its south flux
+    const double fA = wA ? sel_pos(gA0, up) : 0.0;  // cell above pushes its bottom flux
+    const double fB = wB ? sel_neg(gB0, up) : 0.0;  // cell below pushes its top flux (its k > 1, :290)
+    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
+    if (c == 0) {
+        if (aE | aW | aS | aN | aA | aB) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+        return;
+    }
+    if ((j == 0) | (j == ny - 1) | (k == nz - 1)) {  // own pushes towards `nothing`
+        bool bad = false;
+        if (j == 0) bad |= nonzero(sel_pos(ldd(tb.ps, oC), up));
+        if (j == ny - 1) bad |= nonzero(sel_neg(ldd(tb.pn, oC), up));  // regular path: no seam here
+        if (k == nz - 1) bad |= nonzero(sel_pos(ldd(tb.pb, oC), up));
+        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+    }
+    if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+
+    // row order of the column: A, S, row-mates by i, N, B.  Row-mates: W, SELF, E -- except at the
+    // periodic wrap (i == 0: SELF, E, W(nx-1);  i == nx-1: E(0), W, SELF)
+    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
+    {
+        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
+        col.bef[S_A] = 0;
+        col.bef[S_S] = 1u << S_A;
+        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
+        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
+        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
+        col.bef[S_FQ] = 0;
+        col.bef[S_N] = lo | bS | bE | bW;
+        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
+    }
+    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
+    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
+
+    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
+    {
+#define ADV1(PHI, RX, VX, OFF, DG)                \
+    const double rb##OFF = ((RX) + rC) / 2;       \
+    const double OFF = -(PHI) / (rb##OFF * (VX)); \
+    const double DG = (PHI) / (rb##OFF * vC);
+        ADV1(fA, rA, vA, oA_, dA_)
+        ADV1(-fS, rS, vS, oS_, dS_)
+        ADV1(-fW, rW, vW, oW_, dW_)
+        ADV1(fE, rE, vE, oE_, dE_)
+        ADV1(fN, rN, vN, oN_, dN_)
+        ADV1(-fB, rB, vB, oB_, dB_)
+#undef ADV1
+        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
+                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
+        if (bad) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
+        // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
+        double d = NEG0;
+        d += aA ? dA_ : NEG0;
+        d += aS ? dS_ : NEG0;
+        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
+        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
+        d += m1;
+        d += m2;
+        d += aN ? dN_ : NEG0;
+        d += aB ? dB_ : NEG0;
+        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
+        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
+        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
+                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+    }
+    // ---- TκH (:348-415, :426-435) ----
+    {
+#define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
+    const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
+    const double OWN = (p.kH * a##OWN) / ((D_C) * vC);       \
+    const double IN = (p.kH * a##OWN) / ((D_X) * (VX));
+        H1(tW, eW_c, eE_w, dW_c, dE_w, vW, ownW, inW)
+        H1(tE, eE_c, eW_e, dE_c, dW_e, vE, ownE, inE)
+        H1(tS, eS_c, eN_s, dS_c, dN_s, vS, ownS, inS)
+        H1(tN, eN_c, eS_n, dN_c, dS_n, vN, ownN, inN)
+#undef H1
+        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
+                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
+        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
+        double h = NEG0;  // own pushes in direction order W, E, S, N
+        h += wW ? ownW : NEG0;
+        h += wE ? ownE : NEG0;
+        h += wS ? ownS : NEG0;
+        h += wN ? ownN : NEG0;
+        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
+        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
+        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
+                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
+    }
+    // ---- TκVdeep / TκVML (:450-477) ----
+    {
+        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
+        const double nD = p.kDeep * ar;
+        const double ownB = nD / (dB * vC), inB = nD / (dB * vB), ownA = nD / (dA * vC), inA = nD / (dA * vA);
+        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
+        double d = NEG0;  // own pushes: bottom then top
+        d += wB ? ownB : NEG0;
+        d += wA ? ownA : NEG0;
+        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
+        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+        const bool omC = ztk < mld;  // Ω (:85); NaN compares false
+        const bool mB = wB & omC & (ztb < mld), mA = wA & omC & (zta < mld);
+        col.pml = 0;
+        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
+        if (mA | mB) {
+            const double nM = p.kML * ar;
+            const double mownB = nM / (dB * vC), minB = nM / (dB * vB), mownA = nM / (dA * vC), minA = nM / (dA * vA);
+            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
+            double m = NEG0;
+            m += mB ? mownB : NEG0;
+            m += mA ? mownA : NEG0;
+            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
+            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
+        }
+    }
+}
+
 // T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)
 __device__ __forceinline__ double t_value(const Column &col, int s) {
     const double a = ((col.padv >> s) & 1u) ? col.adv[s] : 0.0;
@@ -327,6 +509,21 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     i64 run[TM_NF];
 #pragma unroll
     for (int f = 0; f < TM_NF; ++f) run[f] = FILL ? p.tileoffs[tile * TM_NF + f] : 0;
+    // tile-uniform base pointers: every neighbour of every cell of the tile is at a non-negative
+    // 32-bit byte offset from them ((2P + tile) * 8 < 4 GiB is checked on the host)
+    const i64 tile0 = tile * TM_TILE;
+    const i64 base_elem = (tile0 > p.P) ? tile0 - p.P : 0;
+    TileBase tb;
+    tb.lw = (const char *)(p.lw + base_elem);
+    tb.v = (const char *)(p.v + base_elem);
+    tb.thk = (const char *)(p.thk + base_elem);
+    tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
+    tb.pe = (const char *)(p.phi[OTMB_EAST] + base_elem);
+    tb.pw = (const char *)(p.phi[OTMB_WEST] + base_elem);
+    tb.pn = (const char *)(p.phi[OTMB_NORTH] + base_elem);
+    tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
+    tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
+    tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
 
     for (int ch = 0; ch < TM_CHUNKS; ++ch) {
         const i64 L = tile * TM_TILE + (i64)ch * TM_THREADS + tid;
@@ -336,8 +533,11 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
         unsigned pT = 0;
         if (inb) {
             const Cell cell = cell_of(L, p.nx, p.ny, p.P);
-            c = p.lw[L];
-            build_column(p, cell, c, col);
+            const unsigned oC = (unsigned)(L - base_elem) * 8u;
+            c = ldi(tb.lw, oC);
+            const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
+            if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+            else build_column(p, cell, c, col);
         }
         unsigned nT = 0, nA = 0, nH = 0, nM = 0, nD = 0;
         if (c != 0) {
@@ -473,7 +673,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     if (ctx->plan) ctx->plan->valid = false;
     if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
     const i64 G = a->nx * a->ny * a->nz;
-    if (a->nx * a->ny >= (1ll << 31) || G >= (1ll << 40)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
+    if (a->nx * a->ny >= (1ll << 27) || G >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
     if (a->topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);
     if (a->topology != OTMB_BIPOLAR && a->topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     for (int f = 0; f < 6; ++f)
