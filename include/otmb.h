@@ -96,6 +96,17 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
                         const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                         int32_t topology, double *const phi[6]);
 
+/* Depth-slab variant for multi-GPU runs (no counterpart in the single-process reference; it continues
+ * the bottom-up continuity recurrence of src/velocities.jl:236-243 across slabs without re-association):
+ * the nz levels handed in are levels [k0,k1) of a deeper grid and top_below (nx*ny, NULL for the deepest
+ * slab) is ϕtop of level k1 from the slab below.  Asynchronous; the :199-200 assertion concerns the
+ * whole grid, so each slab's two validity flags are read with otmb_facefluxes_slab_flags (synchronises)
+ * and OR-ed across slabs by the caller.                                                             */
+int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                 const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                 int32_t topology, double *const phi[6], const double *top_below);
+int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid);
+
 /* ---- transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind)
  *      -- src/matrixbuilding.jl:128-150 with buildTadv/TκH/TκVML/TκVdeep (:31-120), the three
  *      *_operator_sparse_entries generators (:221-299, :337-418, :438-479), sparse() x4 and
@@ -127,6 +138,15 @@ typedef struct {
 int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                       double *const nzval[5]);
+/* Depth-slab partition (multi-GPU).  The wet index is k-slowest (src/matrixbuilding.jl:14-15), so a slab
+ * of levels owns a contiguous column range of every matrix.  set_slab (before plan): the local grid
+ * passed to plan holds levels [k_own0,k_own1) owned by this rank plus halo levels that act as
+ * neighbours only; lwet3d holds GLOBAL wet ranks and wet_base = (global rank of the first owned wet
+ * cell) - 1; args.n_wet = owned wet cells.  set_nnz_base (after plan, before fill): entries of each
+ * matrix owned by the slabs above, so that colptr (n_wet+1 entries, local columns) is written with
+ * global offsets and the slabs' arrays concatenate into the global CSC.  k_own1 < 0 resets.        */
+int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t k_own0, int64_t k_own1, int64_t wet_base);
+int32_t otmb_transportmatrix_set_nnz_base(otmb_ctx *ctx, const int64_t nnz_base[5]);
 int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                    double *const nzval[5]);

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    int *flags) {
+    const double *__restrict__ top_below, int *flags) {
     const i64 s = (i64)blockIdx.x * FF_THREADS + threadIdx.x;
     bool uvalid = false, vvalid = false;
     if (s < P) {
@@ -27,7 +27,9 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
         const i64 sW = (i64)j * nx + ((i > 0) ? i - 1 : nx - 1);        // i₋₁, :58
         const i64 sS = (j > 0) ? s - nx : -1;                            // j₋₁, :63
         const i64 sN = (j + 1 < ny) ? s + nx : ((topo == OTMB_TRIPOLAR) ? (i64)j * nx + (nx - 1 - i) : -1);  // :62, :94
-        double topbelow = 0.0;
+        // seafloor ϕbottom is zero (:238); for a depth slab that is not the deepest, the plane handed up
+        // by the slab below (its ϕtop at its first level) continues the chain without re-association
+        double topbelow = top_below ? top_below[s] : 0.0;
 #pragma unroll 2
         for (int k = nz - 1; k >= 0; --k) {
             const i64 o = (i64)k * P;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
                 if (!wS || !wc) vs = 0.0;
                 so = ff_replace(vs, fill);
             }
-            const double b = (k == nz - 1) ? 0.0 : topbelow;  // :238-240
+            const double b = topbelow;  // :238-240
             const double t = (((b + w) + so) - e) - n;        // :242
             east[o + s] = e; west[o + s] = w; north[o + s] = n; south[o + s] = so; top[o + s] = t; bottom[o + s] = b;
             topbelow = t;
@@ -61,9 +63,9 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     if (__any(vvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_V_VALID] == 0) atomicExch(&flags[FLAG_V_VALID], 1);
 }
 
-extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
-                                       const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
-                                       int32_t topology, double *const phi[6]) {
+static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                               const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                               int32_t topology, double *const phi[6], const double *top_below, bool check_missing) {
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -81,18 +83,43 @@ extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const voi
         hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
                            (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], dflags);
+                           phi[OTMB_BOTTOM], top_below, dflags);
     else
         hipLaunchKernelGGL(facefluxes_kernel<double>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const double *)umo,
                            (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], dflags);
+                           phi[OTMB_BOTTOM], top_below, dflags);
     }
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + FLAG_U_VALID, dflags + FLAG_U_VALID, 2 * sizeof(int),
                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (!check_missing) return OTMB_OK;  // slab: the caller combines the flags of all slabs
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->h_flags[FLAG_U_VALID] || !ctx->h_flags[FLAG_V_VALID]) return otmb_fail(ctx, OTMB_ERR_ALL_MISSING);
+    return OTMB_OK;
+}
+
+extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                       const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                       int32_t topology, double *const phi[6]) {
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, nullptr, true);
+}
+
+// Depth-slab variant: the levels handed in are levels [k0,k1) of a deeper grid.  top_below (nx*ny, may
+// be NULL for the deepest slab) is ϕtop of level k1 computed by the slab below.  Asynchronous: the
+// "all values missing" assertion (:199-200) concerns the whole grid, so the two validity flags are
+// returned through otmb_facefluxes_slab_flags after a synchronize and combined by the caller.
+extern "C" int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                            const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                            int32_t topology, double *const phi[6], const double *top_below) {
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, false);
+}
+
+extern "C" int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid) {
+    if (!ctx || !u_valid || !v_valid) return OTMB_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *u_valid = ctx->h_flags[FLAG_U_VALID];
+    *v_valid = ctx->h_flags[FLAG_V_VALID];
     return OTMB_OK;
 }

@@ -38,6 +38,12 @@ struct TmParams {
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
     i64 P, G;
+    // depth-slab partition (multi-GPU): this rank owns levels [k_own0, k_own1) of the local grid, whose
+    // other levels are halos that only act as neighbours; wet_base = global wet rank of the first owned
+    // wet cell minus 1; nnz_base[m] = entries of matrix m owned by lower-ranked slabs.
+    int k_own0, k_own1;
+    i64 wet_base;
+    i64 nnz_base[5];
     // outputs (FILL)
     i64 *colptr[5], *rowval[5];
     double *nzval[5];
@@ -52,6 +58,9 @@ struct TmPlan {
     i64 ntiles;
     i64 nnz[5];
     bool valid;
+    // slab (defaults: whole grid owned)
+    i64 k_own0 = 0, k_own1 = -1, wet_base = 0;
+    i64 nnz_base[5] = {0, 0, 0, 0, 0};
 };
 
 // slots of a column: the cells that can hold a row of column c
@@ -535,9 +544,14 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
             const Cell cell = cell_of(L, p.nx, p.ny, p.P);
             const unsigned oC = (unsigned)(L - base_elem) * 8u;
             c = ldi(tb.lw, oC);
+            if (cell.k < p.k_own0 || cell.k >= p.k_own1) c = -1;  // halo level: neighbour only
             const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
-            if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
-            else build_column(p, cell, c, col);
+            if (c >= 0) {
+                if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+                else build_column(p, cell, c, col);
+            } else {
+                c = 0;
+            }
         }
         unsigned nT = 0, nA = 0, nH = 0, nM = 0, nD = 0;
         if (c != 0) {
@@ -571,11 +585,11 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
             const i64 off[5] = {run[0] + (i64)(excl & 0x7ff), run[1] + (i64)((excl >> 11) & 0x7ff),
                                 run[2] + (i64)((excl >> 22) & 0x7ff), run[3] + (i64)((excl >> 33) & 0x3ff),
                                 run[4] + (i64)((excl >> 43) & 0x3ff)};
-            const i64 wetrank = run[5] + (i64)((excl >> 53) & 0x1ff);  // wet cells before this one
-            if (c != wetrank + 1) raise_flag(p.flags, FLAG_NONCANONICAL);
+            const i64 wetrank = run[5] + (i64)((excl >> 53) & 0x1ff);  // owned wet cells before this one
+            if (c != p.wet_base + wetrank + 1) raise_flag(p.flags, FLAG_NONCANONICAL);
             else {
 #pragma unroll
-                for (int m = 0; m < 5; ++m) p.colptr[m][c - 1] = off[m] + 1;
+                for (int m = 0; m < 5; ++m) p.colptr[m][wetrank] = p.nnz_base[m] + off[m] + 1;
                 const unsigned pm[5] = {pT, col.padv, col.phh, col.pml, col.pdp};
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
@@ -621,14 +635,16 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     }
 }
 
-__global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, const i64 *tot, i64 N) {
+__global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, const i64 *tot, i64 N, i64 b0,
+                                 i64 b1, i64 b2, i64 b3, i64 b4) {
     if (threadIdx.x == 0) {
-        c0[N] = tot[0] + 1; c1[N] = tot[1] + 1; c2[N] = tot[2] + 1; c3[N] = tot[3] + 1; c4[N] = tot[4] + 1;
+        c0[N] = b0 + tot[0] + 1; c1[N] = b1 + tot[1] + 1; c2[N] = b2 + tot[2] + 1; c3[N] = b3 + tot[3] + 1;
+        c4[N] = b4 + tot[4] + 1;
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------
-static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx) {
+static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
     for (int f = 0; f < 6; ++f) p.phi[f] = a.phi[f];
     p.v = a.v3d; p.thk = a.thkcello; p.rho = a.rho; p.rho_s = a.rho_scalar; p.lw = a.lwet3d;
@@ -637,6 +653,11 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx) {
     p.kH = a.kappa_h; p.kML = a.kappa_vml; p.kDeep = a.kappa_vdeep;
     p.nx = (int)a.nx; p.ny = (int)a.ny; p.nz = (int)a.nz; p.topo = a.topology; p.upwind = a.upwind;
     p.P = a.nx * a.ny; p.G = p.P * a.nz;
+    p.k_own0 = 0; p.k_own1 = (int)a.nz; p.wet_base = 0;
+    if (pl && pl->k_own1 >= 0) {
+        p.k_own0 = (int)pl->k_own0; p.k_own1 = (int)pl->k_own1; p.wet_base = pl->wet_base;
+        for (int m = 0; m < 5; ++m) p.nnz_base[m] = pl->nnz_base[m];
+    }
     p.tilesums = (uint32_t *)ctx->blocksums.p;
     p.tileoffs = (const i64 *)ctx->blockoffs.p;
     p.flags = (int *)ctx->flags.p;
@@ -692,8 +713,10 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     TmPlan &pl = *ctx->plan;
     pl.args = *a;
     pl.ntiles = ntiles;
+    if (pl.k_own1 >= 0 && (pl.k_own0 < 0 || pl.k_own1 > a->nz || pl.k_own0 > pl.k_own1))
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "slab levels outside the local grid");
     TmParams p;
-    fill_params(p, *a, ctx);
+    fill_params(p, *a, ctx, &pl);
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64), ctx->stream));
@@ -720,6 +743,22 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     return OTMB_OK;
 }
 
+int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t k_own0, int64_t k_own1, int64_t wet_base) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    if (!ctx->plan) ctx->plan = new TmPlan();
+    ctx->plan->valid = false;
+    ctx->plan->k_own0 = k_own0; ctx->plan->k_own1 = k_own1; ctx->plan->wet_base = wet_base;
+    for (int m = 0; m < 5; ++m) ctx->plan->nnz_base[m] = 0;
+    return OTMB_OK;
+}
+
+int32_t otmb_transportmatrix_set_nnz_base(otmb_ctx *ctx, const int64_t nnz_base[5]) {
+    if (!ctx || !nnz_base) return OTMB_ERR_INVALID_ARG;
+    if (!ctx->plan || !ctx->plan->valid) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
+    for (int m = 0; m < 5; ++m) ctx->plan->nnz_base[m] = nnz_base[m];
+    return OTMB_OK;
+}
+
 int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                       double *const nzval[5]) {
     if (!ctx || !colptr || !rowval || !nzval) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
@@ -727,7 +766,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     TmPlan &pl = *ctx->plan;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     TmParams p;
-    fill_params(p, pl.args, ctx);
+    fill_params(p, pl.args, ctx, &pl);
     for (int m = 0; m < 5; ++m) {
         if (!colptr[m] || (pl.nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
@@ -741,7 +780,8 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     {
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
-                           p.colptr[3], p.colptr[4], dtot, (i64)pl.args.n_wet);
+                           p.colptr[3], p.colptr[4], dtot, (i64)pl.args.n_wet, p.nnz_base[0], p.nnz_base[1],
+                           p.nnz_base[2], p.nnz_base[3], p.nnz_base[4]);
     }
     HIP_TRY(ctx, hipGetLastError());
     // the fill pass can still raise OTMB_ERR_NONCANONICAL_INDICES: otmb_ctx_synchronize reports it

@@ -1,0 +1,344 @@
+"""Multi-GPU: depth-slab partition of the transport-matrix assembly (one process per GPU).
+
+Nothing distributed exists in the reference; this is the MI355X-side design of
+SURVEY.md section 8e.  The wet index is k-slowest (src/matrixbuilding.jl:14-15), so a slab of
+consecutive levels owns a contiguous column range of every matrix and the per-rank CSC pieces
+concatenate into the global CSC.  What crosses ranks:
+
+  setup (once per grid)   per-level wet counts (all_reduce, nz Int64)  -> global wet rank of any cell;
+                          one boundary level of {v3D, rho, wet mask} to the slab above and below
+                          (point-to-point over xGMI, nx*ny*8 B per field)
+  per (umo,vmo) field     the continuity recurrence of facefluxes (src/velocities.jl:236-243) is a chain
+                          in k with a fixed association: each slab receives ϕtop of the level below it
+                          from the next rank, continues the chain, and hands its own first-level ϕtop up
+                          (one nx*ny plane per boundary; never re-associated, so results stay bit-exact);
+                          then one all_gather of the five per-slab nnz (+2 validity flags) -> colptr bases.
+
+No COO triplet or matrix entry ever crosses ranks: every column is built entirely by the rank that
+owns its cell (gather formulation, csrc/otmb_transportmatrix.hip), using the halo levels as neighbours.
+
+`SlabRunner` is backend-agnostic: the product backend is `HipSlabBackend` (HIP kernels through the C
+ABI); the CPU tests plug in a checker backend to exercise the orchestration with gloo.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .capi import HDIRS, MATS, PHI_ORDER
+
+
+def balanced_partition(level_counts, world):
+    """Split levels 0..nz-1 into `world` consecutive slabs with >= 1 level each, wet counts as even as a
+    greedy sweep gets them (upper levels are wetter, so equal level counts would not balance)."""
+    counts = np.asarray(level_counts, dtype=np.int64)
+    nz = len(counts)
+    if world > nz:
+        raise ValueError(f"{world} ranks but only {nz} levels")
+    total = int(counts.sum())
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(cum, target, side="left"))
+        # pick the closer of k-1, k; keep >= 1 level per slab on both sides
+        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, nz)] - target):
+            k -= 1
+        k = max(k, bounds[-1] + 1)
+        k = min(k, nz - (world - r))
+        bounds.append(k)
+    bounds.append(nz)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+class Comm:
+    """torch.distributed plumbing.  backend "nccl" == RCCL over xGMI; with "gloo" (CPU tests, or several
+    ranks sharing one GPU) device tensors are staged through host memory."""
+
+    def __init__(self):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.backend = dist.get_backend() if dist.is_initialized() else "none"
+
+    def _stage(self, t):
+        return t.cpu() if (self.backend == "gloo" and t.is_cuda) else t
+
+    def exchange(self, sends, recvs):
+        """sends: [(tensor, dst)], recvs: [(tensor, src)] -- one batched point-to-point round."""
+        if self.world == 1 or (not sends and not recvs):
+            return
+        ops, staged = [], []
+        for t, dst in sends:
+            ops.append(dist.P2POp(dist.isend, self._stage(t).contiguous(), dst))
+        for t, src in recvs:
+            b = self._stage(t) if self.backend == "gloo" and t.is_cuda else t
+            if b is not t:
+                b = torch.empty_like(b)
+                staged.append((t, b))
+            ops.append(dist.P2POp(dist.irecv, b, src))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for t, b in staged:
+            t.copy_(b)
+
+    def send(self, t, dst):
+        dist.send(self._stage(t).contiguous(), dst)
+
+    def recv(self, t, src):
+        if self.backend == "gloo" and t.is_cuda:
+            b = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(b, src)
+            t.copy_(b)
+        else:
+            dist.recv(t, src)
+
+    def allreduce_sum_i64(self, arr, device):
+        t = torch.as_tensor(np.asarray(arr, dtype=np.int64))
+        if self.world > 1:
+            t = t.to(device) if self.backend != "gloo" else t
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allgather_i64(self, vals, device):
+        t = torch.as_tensor(np.asarray(vals, dtype=np.int64))
+        if self.world == 1:
+            return t.numpy()[None, :]
+        t = t.to(device) if self.backend != "gloo" else t
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return torch.stack(out).cpu().numpy()
+
+
+class SlabRunner:
+    """Orchestrates one rank's slab.  `grid` holds this rank's OWN levels [k0,k1) of the global grid (host
+    numpy, Julia shapes) plus the replicated 2-D/1-D data; see make_local_grid()."""
+
+    def __init__(self, backend, comm, grid):
+        self.be, self.comm, self.g = backend, comm, grid
+        self.rank, self.world = comm.rank, comm.world
+        self.device = backend.device
+        self.setup()
+
+    def setup(self):
+        g, cm = self.g, self.comm
+        nx, ny, nzg = g["nx"], g["ny"], g["nz_global"]
+        k0, k1 = g["k0"], g["k1"]
+        P = nx * ny
+        self.P, self.k0, self.k1 = P, k0, k1
+        self.has_above, self.has_below = self.rank > 0, self.rank < self.world - 1
+        wet_own = ~np.isnan(g["v3D"])  # makeindices: wet = !isnan(v3D)  (matrixbuilding.jl:15)
+        counts = np.zeros(nzg, dtype=np.int64)
+        counts[k0:k1] = wet_own.reshape(P, k1 - k0, order="F").sum(axis=0)
+        counts = cm.allreduce_sum_i64(counts, self.device)  # every rank learns every level's wet count
+        self.level_offset = np.concatenate([[0], np.cumsum(counts)])
+        self.n_global = int(self.level_offset[-1])
+        self.n_own = int(self.level_offset[k1] - self.level_offset[k0])
+        self.wet_base = int(self.level_offset[k0])
+
+        # ---- static halo exchange: one boundary level of v3D, rho, wet mask each way ----
+        rho3d = g["rho"] if np.ndim(g["rho"]) else None
+        nf = 2 + (rho3d is not None)
+
+        def plane(a, q):
+            return np.ascontiguousarray(np.asarray(a, dtype=np.float64)[:, :, q].ravel(order="F"))
+
+        def pack(q):
+            fields = [plane(g["v3D"], q), plane(wet_own.astype(np.float64), q)]
+            if rho3d is not None:
+                fields.append(plane(rho3d, q))
+            return torch.from_numpy(np.stack(fields)).to(self.device)
+
+        up_recv = torch.empty((nf, P), dtype=torch.float64, device=self.device) if self.has_above else None
+        dn_recv = torch.empty((nf, P), dtype=torch.float64, device=self.device) if self.has_below else None
+        sends, recvs = [], []
+        if self.has_above:
+            sends.append((pack(0), self.rank - 1))
+            recvs.append((up_recv, self.rank - 1))
+        if self.has_below:
+            sends.append((pack(k1 - k0 - 1), self.rank + 1))
+            recvs.append((dn_recv, self.rank + 1))
+        cm.exchange(sends, recvs)
+
+        # ---- extended local grid: [halo above] + owned + [halo below] ----
+        ha, hb = int(self.has_above), int(self.has_below)
+        nze = (k1 - k0) + ha + hb
+        shape = (nx, ny, nze)
+
+        def ext(own, up, dn, fillv=np.nan):
+            e = np.full(shape, fillv, dtype=np.float64, order="F")
+            e[:, :, ha:ha + (k1 - k0)] = own
+            if ha:
+                e[:, :, 0] = up.reshape(nx, ny, order="F")
+            if hb:
+                e[:, :, -1] = dn.reshape(nx, ny, order="F")
+            return e
+
+        upn = up_recv.cpu().numpy() if ha else None
+        dnn = dn_recv.cpu().numpy() if hb else None
+        v_ext = ext(g["v3D"], upn[0] if ha else None, dnn[0] if hb else None)
+        wet_ext = ext(wet_own.astype(np.float64), upn[1] if ha else None, dnn[1] if hb else None, 0.0) > 0.5
+        rho_ext = ext(rho3d, upn[2] if ha else None, dnn[2] if hb else None) if rho3d is not None else g["rho"]
+        thk_ext = ext(g["thkcello"], np.full(P, np.nan), np.full(P, np.nan))  # halos' thickness is never read
+        # GLOBAL wet ranks of the extended grid: level offset + rank inside the level (+1), 0 = missing
+        lw_ext = np.zeros(shape, dtype=np.int64, order="F")
+        for q in range(nze):
+            kg = k0 - ha + q
+            m = wet_ext[:, :, q].ravel(order="F")
+            r = np.cumsum(m) + self.level_offset[kg]
+            lw_ext[:, :, q] = np.where(m, r, 0).reshape(nx, ny, order="F")
+        zt_ext = np.asarray(g["zt_global"], dtype=np.float64)[k0 - ha:k1 + hb]
+        self.nze, self.ha, self.hb = nze, ha, hb
+        self.be.setup(dict(nx=nx, ny=ny, nz=nze, topology=g["topology"], k_own0=ha, k_own1=ha + (k1 - k0),
+                           wet_base=self.wet_base, n_own=self.n_own, v3D=v_ext, thkcello=thk_ext, rho=rho_ext,
+                           lwet3d=lw_ext, wet_own=wet_own, zt=zt_ext, edge_length_2D=g["edge_length_2D"],
+                           distance_to_neighbour_2D=g["distance_to_neighbour_2D"], area2D=g["area2D"],
+                           mlotst=g["mlotst"], kappa=g["kappa"], upwind=g["upwind"]))
+        self.top_below = torch.empty(P, dtype=torch.float64, device=self.device) if self.has_below else None
+        self.n_wet_total = self.n_global
+
+    def step(self, umo, vmo, fill):
+        """One (umo, vmo) field of this rank's own levels -> this rank's columns of the five matrices."""
+        cm = self.comm
+        if self.has_below:  # chain: wait for ϕtop of the level below my slab
+            cm.recv(self.top_below, self.rank + 1)
+        top_first = self.be.facefluxes(umo, vmo, fill, self.top_below)
+        if self.has_above:
+            cm.send(top_first, self.rank - 1)
+        nnz, uv = self.be.plan()
+        allv = cm.allgather_i64(list(nnz) + [int(uv[0]), int(uv[1])], self.device)
+        if not (allv[:, 5].any() and allv[:, 6].any()):
+            raise AssertionError("all umo or vmo values are NaN or _FillValue")  # velocities.jl:199-200
+        self.nnz_all = allv[:, :5]
+        self.nnz_base = allv[: self.rank, :5].sum(axis=0) if self.rank > 0 else np.zeros(5, dtype=np.int64)
+        self.nnz_global = allv[:, :5].sum(axis=0)
+        return self.be.fill(self.nnz_base)
+
+    def sync(self):
+        self.be.sync()
+
+
+class HipSlabBackend:
+    """Product backend: HIP kernels through the C ABI on this rank's GPU."""
+
+    def __init__(self, local_rank=0):
+        from . import capi
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipSlabBackend needs a GPU (no CPU fallback)")
+        self.capi = capi
+        self.device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(self.device)
+        self.ctx = capi.Context(local_rank)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.lib = capi.lib()
+        self.out = None
+
+    def _t(self, a, dtype=np.float64):
+        return torch.from_numpy(np.asfortranarray(a, dtype=dtype).ravel(order="F")).to(self.device)
+
+    def setup(self, s):
+        self.s = s
+        self.nx, self.ny, self.nz = s["nx"], s["ny"], s["nz"]
+        self.P = self.nx * self.ny
+        self.G = self.P * self.nz
+        self.n_own = s["n_own"]
+        self.v3d, self.thk, self.lw = self._t(s["v3D"]), self._t(s["thkcello"]), self._t(s["lwet3d"], np.int64)
+        self.rho = None if np.ndim(s["rho"]) == 0 else self._t(s["rho"])
+        self.rho_scalar = float(s["rho"]) if np.ndim(s["rho"]) == 0 else 0.0
+        self.edge = [self._t(s["edge_length_2D"][d]) for d in HDIRS]
+        self.dist_ = [self._t(s["distance_to_neighbour_2D"][d]) for d in HDIRS]
+        self.area, self.zt, self.ml = self._t(s["area2D"]), self._t(s["zt"]), self._t(s["mlotst"])
+        self.wet_own = self._t(s["wet_own"], np.uint8)
+        self.phi = [torch.zeros(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
+        self.own0 = s["k_own0"] * self.P
+        self.nown_lev = s["k_own1"] - s["k_own0"]
+
+    def facefluxes(self, umo, vmo, fill, top_below):
+        o, n = self.own0, self.nown_lev * self.P
+        views = [p[o:o + n] for p in self.phi]
+        ptrs = self.capi.ptr_array(6, [v.data_ptr() for v in views])
+        self.ctx.check(self.lib.otmb_facefluxes_slab_dev(
+            self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), self.wet_own.data_ptr(),
+            float(fill), self.nx, self.ny, self.nown_lev, self.s["topology"], C.byref(ptrs),
+            top_below.data_ptr() if top_below is not None else None))
+        top, bottom = self.phi[4], self.phi[5]  # OTMB_TOP, OTMB_BOTTOM
+        top_first = top[o:o + self.P]
+        if self.s["k_own0"] > 0:  # halo above: its ϕbottom is my first level's ϕtop (velocities.jl:240)
+            bottom[0:self.P].copy_(top_first)
+        if top_below is not None:  # halo below: its ϕtop is the plane received from the slab below
+            top[self.G - self.P:self.G].copy_(top_below)
+        return top_first
+
+    def plan(self):
+        a = self.capi.TmArgs()
+        a.nx, a.ny, a.nz = self.nx, self.ny, self.nz
+        a.topology, a.upwind, a.n_wet = self.s["topology"], int(self.s["upwind"]), self.n_own
+        for k in range(6):
+            a.phi[k] = self.phi[k].data_ptr()
+        a.v3d, a.thkcello = self.v3d.data_ptr(), self.thk.data_ptr()
+        a.rho = self.rho.data_ptr() if self.rho is not None else None
+        a.rho_scalar = self.rho_scalar
+        a.lwet3d = self.lw.data_ptr()
+        for k in range(4):
+            a.edge_length[k] = self.edge[k].data_ptr()
+            a.dist_nbr[k] = self.dist_[k].data_ptr()
+        a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.ml.data_ptr()
+        a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.s["kappa"]
+        u, v = C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
+        self.ctx.check(self.lib.otmb_transportmatrix_set_slab(self.ctx.handle, self.s["k_own0"], self.s["k_own1"],
+                                                             self.s["wet_base"]))
+        nnz = (C.c_int64 * 5)()
+        self.ctx.check(self.lib.otmb_transportmatrix_plan_dev(self.ctx.handle, C.byref(a), C.byref(nnz)))
+        self.nnz = [int(x) for x in nnz]
+        return self.nnz, (u.value, v.value)
+
+    def fill(self, nnz_base):
+        if self.out is None or any(self.out[m][1].numel() < self.nnz[k] for k, m in enumerate(MATS)):
+            self.out = {m: (torch.empty(self.n_own + 1, dtype=torch.int64, device=self.device),
+                            torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.int64, device=self.device),
+                            torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.float64, device=self.device))
+                        for k, m in enumerate(MATS)}
+        base = (C.c_int64 * 5)(*[int(x) for x in nnz_base])
+        self.ctx.check(self.lib.otmb_transportmatrix_set_nnz_base(self.ctx.handle, C.byref(base)))
+        cp = self.capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
+        rv = self.capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
+        nz = self.capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
+        self.ctx.check(self.lib.otmb_transportmatrix_fill_dev(self.ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
+        return self.out
+
+    def sync(self):
+        self.ctx.synchronize()
+
+    def result_to_host(self):
+        self.sync()
+        return {m: (self.out[m][0].cpu().numpy(), self.out[m][1][: self.nnz[k]].cpu().numpy(),
+                    self.out[m][2][: self.nnz[k]].cpu().numpy()) for k, m in enumerate(MATS)}
+
+
+def make_local_grid(gridmetrics, mlotst, rho, k0, k1, nz_global, zt_global, kappa=(500.0, 0.1, 1.0e-5), upwind=True):
+    """Bundle one rank's own levels.  `gridmetrics` are those of the OWN levels only (makegridmetrics on the
+    slab's volcello); the 2-D metrics are the same on every rank."""
+    t = gridmetrics["gridtopology"]
+    nx, ny, _ = gridmetrics["v3D"].shape
+    return dict(nx=nx, ny=ny, nz_global=nz_global, k0=k0, k1=k1, topology=int(t["kind"]) if isinstance(t, dict) else int(t),
+                v3D=gridmetrics["v3D"], thkcello=gridmetrics["thkcello"], rho=rho, zt_global=zt_global,
+                edge_length_2D=gridmetrics["edge_length_2D"], distance_to_neighbour_2D=gridmetrics["distance_to_neighbour_2D"],
+                area2D=gridmetrics["area2D"], mlotst=mlotst, kappa=kappa, upwind=upwind)
+
+
+def gather_global_csc(comm, local, n_own, nnz, device):
+    """Concatenate the ranks' pieces into the global (colptr,rowval,nzval) on every rank (tests / small grids)."""
+    out = {}
+    for k, m in enumerate(MATS):
+        cp, rv, nz = local[m]
+        pieces = [None] * comm.world
+        obj = (np.asarray(cp[:n_own]), np.asarray(rv[: nnz[k]]), np.asarray(nz[: nnz[k]]), int(cp[n_own]))
+        if comm.world > 1:
+            dist.all_gather_object(pieces, obj)
+        else:
+            pieces = [obj]
+        out[m] = (np.concatenate([p[0] for p in pieces] + [np.array([pieces[-1][3]], dtype=np.int64)]),
+                  np.concatenate([p[1] for p in pieces]), np.concatenate([p[2] for p in pieces]))
+    return out

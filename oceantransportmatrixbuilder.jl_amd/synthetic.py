@@ -170,3 +170,80 @@ def preset(name, **kw):
     nx, ny, nz, lf = PRESETS[name]
     kw.setdefault("land_fraction", lf)
     return make_grid(nx, ny, nz, **kw)
+
+
+# ---- level-sliced generation (multi-GPU depth slabs) ------------------------------------------------
+def _grid2d(nx, ny, nz, seed, land_fraction, topology):
+    """The 2-D part of a synthetic grid (identical on every rank for a given seed)."""
+    rng = np.random.default_rng([seed, 7])
+    zt, dz = levels(nz)
+    lonv, latv = vertices(nx, ny, topology)
+    lon = np.asfortranarray(lonv.mean(axis=0))
+    lat = np.asfortranarray(latv.mean(axis=0))
+    lat_s = np.deg2rad(latv[0])
+    lat_n = np.deg2rad(np.maximum(latv[3], latv[2]))
+    area = np.asfortranarray(np.maximum(R * R * np.deg2rad(360.0 / nx) * np.abs(np.sin(lat_n) - np.sin(lat_s)), 1.0e6))
+    scale = max(3, min(nx, ny) // 12)
+    f = _smooth_field(rng, nx, ny, scale)
+    land = f < np.quantile(f, land_fraction)
+    mid = nx // 2
+    land[max(0, mid - 3): mid + 3, -3:] = False
+    land[:2, -2:] = False
+    land[-2:, -2:] = False
+    zbot = np.cumsum(dz)
+    depth = zbot[-1] * (0.05 + 0.95 * _smooth_field(rng, nx, ny, max(2, scale // 2)))
+    shallow = rng.random((nx, ny)) < 0.02
+    depth = np.where(shallow, 0.6 * dz[0], depth)
+    depth = np.where(land, 0.0, depth)
+    mlotst = np.asfortranarray(np.exp(rng.uniform(np.log(10.0), np.log(1000.0), (nx, ny))))
+    mlotst[depth < 0.2 * dz[0]] = np.nan
+    return NT(zt=zt, dz=dz, lonv=lonv, latv=latv, lon=lon, lat=lat, area=area, depth=depth, mlotst=mlotst)
+
+
+def _level_thickness(g2, k0, k1):
+    dz = g2.dz[k0:k1]
+    ztop = (np.cumsum(g2.dz) - g2.dz)[k0:k1]
+    thk = np.clip(g2.depth[:, :, None] - ztop[None, None, :], 0.0, dz[None, None, :])
+    return np.where(thk < 0.2 * dz[None, None, :], 0.0, thk)
+
+
+def level_wet_counts(nx, ny, nz, *, seed=20260501, land_fraction=0.30, topology="tripolar"):
+    """Wet cells per level of the grid make_slab() slices (cheap: from the 2-D bathymetry only)."""
+    g2 = _grid2d(nx, ny, nz, seed, land_fraction, topology)
+    return np.array([(_level_thickness(g2, k, k + 1) > 0).sum() for k in range(nz)], dtype=np.int64)
+
+
+def make_slab(nx, ny, nz, k0, k1, *, seed=20260501, land_fraction=0.30, topology="tripolar", rho="scalar"):
+    """Levels [k0,k1) of a synthetic (nx,ny,nz) grid.  Every random field of level k comes from its own
+    stream (seed, k), so any rank can generate any level and the slabs of all ranks tile one consistent
+    global grid: make_slab(..., 0, nz) IS that grid.  Same fields and conventions as make_grid()."""
+    g2 = _grid2d(nx, ny, nz, seed, land_fraction, topology)
+    thk = _level_thickness(g2, k0, k1)
+    vol = np.asfortranarray(thk * g2.area[:, :, None])
+    wet = vol > 0
+    nl = k1 - k0
+    umo = np.empty((nx, ny, nl), order="F")
+    vmo = np.empty((nx, ny, nl), order="F")
+    noise = np.empty((nx, ny, nl), order="F")
+    thkmax = g2.dz.max()
+    for q, k in enumerate(range(k0, k1)):
+        r = np.random.default_rng([seed, 1000 + k])
+        sig = 1.0e9 * thk[:, :, q] / thkmax
+        umo[:, :, q] = r.standard_normal((nx, ny)) * sig
+        vmo[:, :, q] = r.standard_normal((nx, ny)) * sig
+        noise[:, :, q] = r.standard_normal((nx, ny))
+    umo[~wet] = FILL
+    vmo[~wet] = FILL
+    if rho == "scalar":
+        rho_val = 1035.0
+    else:
+        ztop = (np.cumsum(g2.dz) - g2.dz)[k0:k1]
+        zc = ztop[None, None, :] + 0.5 * thk
+        rho_val = np.asfortranarray(np.where(wet, 1025.0 + 0.004 * zc + 0.1 * noise, np.nan))
+    return NT(
+        nx=nx, ny=ny, nz=nz, k0=k0, k1=k1, seed=seed, topology=topology,
+        areacello=Cube(g2.area, _FillValue=FILL), volcello=Cube(vol, _FillValue=FILL),
+        lon=g2.lon, lat=g2.lat, lev=g2.zt, lon_vertices=g2.lonv, lat_vertices=g2.latv,
+        umo=Cube(umo, _FillValue=FILL), vmo=Cube(vmo, _FillValue=FILL), mlotst=g2.mlotst, rho=rho_val,
+        kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5,
+    )

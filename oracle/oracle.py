@@ -104,18 +104,23 @@ def makeindices(v3D):
     return dict(N=int(N), Lwet=Lwet[:N].copy(), Lwet3D=Lwet3D, wet3D=wet3D)
 
 
-def facefluxes(umo, vmo, wet3D, fill, topo):
-    """umo/vmo: Float64 copies are made here (velocities.jl:125-126)."""
+def facefluxes(umo, vmo, wet3D, fill, topo, top_below=None, return_flags=False):
+    """umo/vmo: Float64 copies are made here (velocities.jl:125-126).  top_below / return_flags:
+    depth-slab test support (see orc_facefluxes_slab)."""
     u = np.array(umo, dtype=np.float64, order="F")
     v = np.array(vmo, dtype=np.float64, order="F")
     wet3D = np.asfortranarray(wet3D, dtype=np.uint8)
     g = _grid(u.shape, topo)
     out = {k: np.empty(u.shape, dtype=np.float64, order="F") for k in PHI_ORDER}
-    rc = lib().orc_facefluxes(_d(u), _d(v), _b(wet3D), C.c_double(float(fill)), C.byref(g),
-                              _d(out["east"]), _d(out["west"]), _d(out["north"]), _d(out["south"]),
-                              _d(out["top"]), _d(out["bottom"]))
+    tb = None if top_below is None else np.ascontiguousarray(np.asarray(top_below, dtype=np.float64).ravel(order="F"))
+    flags = (C.c_int32 * 2)() if return_flags else None
+    rc = lib().orc_facefluxes_slab(_d(u), _d(v), _b(wet3D), C.c_double(float(fill)), C.byref(g),
+                                   _d(out["east"]), _d(out["west"]), _d(out["north"]), _d(out["south"]),
+                                   _d(out["top"]), _d(out["bottom"]), _d(tb), flags)
     if rc:
         raise OracleError(rc)
+    if return_flags:
+        return out, (bool(flags[0]), bool(flags[1]))
     return out
 
 

@@ -127,9 +127,14 @@ static inline int isequal_f64(double a, double b) {
 /* umo/vmo are the caller's Float64 COPIES (facefluxesfrommasstransport
  * converts first, :125-126) and are mutated in place as the reference does.
  * Outputs: six (nx,ny,nz) arrays. */
-int32_t orc_facefluxes(double *umo, double *vmo, const uint8_t *wet3D, double fill,
-                       const orc_grid *g, double *east, double *west, double *north,
-                       double *south, double *top, double *bottom) {
+/* top_below / flags: NOT in the reference -- test support for the depth-slab (multi-GPU) path.  A slab
+ * holds levels [k0,k1) of a deeper grid; top_below (nx*ny or NULL) is ϕtop of level k1, which is what
+ * ϕbottom of the slab's last level equals in the whole-grid recurrence (:240).  With flags != NULL the
+ * :199-200 assertion is not raised; flags[0..1] report whether umo / vmo hold any valid value. */
+int32_t orc_facefluxes_slab(double *umo, double *vmo, const uint8_t *wet3D, double fill,
+                            const orc_grid *g, double *east, double *west, double *north,
+                            double *south, double *top, double *bottom, const double *top_below,
+                            int32_t *flags) {
     int32_t rc = orc_nofluxboundaries(umo, vmo, wet3D, g); /* :192 */
     if (rc) return rc;
     const int64_t G = g->nx * g->ny * g->nz;
@@ -138,7 +143,8 @@ int32_t orc_facefluxes(double *umo, double *vmo, const uint8_t *wet3D, double fi
         if (!(isnan(umo[c]) || umo[c] == fill)) all_u = 0;
         if (!(isnan(vmo[c]) || vmo[c] == fill)) all_v = 0;
     }
-    if (all_u || all_v) return ORC_ERR_ALL_MISSING;
+    if (flags) { flags[0] = !all_u; flags[1] = !all_v; }
+    else if (all_u || all_v) return ORC_ERR_ALL_MISSING;
     for (int64_t c = 0; c < G; ++c) { /* :203, :215 replace(NaN=>0, Fill=>0) */
         east[c] = (isnan(umo[c]) || isequal_f64(umo[c], fill)) ? 0.0 : umo[c];
         north[c] = (isnan(vmo[c]) || isequal_f64(vmo[c], fill)) ? 0.0 : vmo[c];
@@ -155,12 +161,18 @@ int32_t orc_facefluxes(double *umo, double *vmo, const uint8_t *wet3D, double fi
     for (int64_t k = g->nz - 1; k >= 0; --k) { /* :236-243 */
         for (int64_t p = 0; p < P; ++p) {
             int64_t c = p + P * k;
-            bottom[c] = (k == g->nz - 1) ? 0.0 : top[c + P];
+            bottom[c] = (k == g->nz - 1) ? (top_below ? top_below[p] : 0.0) : top[c + P];
             /* @. a + b + c - d - e lowers to ((((a+b)+c)-d)-e): n-ary + folds left */
             top[c] = (((bottom[c] + west[c]) + south[c]) - east[c]) - north[c];
         }
     }
     return ORC_OK;
+}
+
+int32_t orc_facefluxes(double *umo, double *vmo, const uint8_t *wet3D, double fill,
+                       const orc_grid *g, double *east, double *west, double *north,
+                       double *south, double *top, double *bottom) {
+    return orc_facefluxes_slab(umo, vmo, wet3D, fill, g, east, west, north, south, top, bottom, NULL, NULL);
 }
 
 /* ---- COO triplet sink ---------------------------------------------------- */

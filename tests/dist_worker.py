@@ -1,0 +1,54 @@
+"""Worker for the multi-process slab tests (spawned by test_dist_*.py): one rank of a depth-slab run."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(rank, world, port, backend_kind, case, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import otmb_amd
+    from otmb_amd import dist as od, synthetic
+
+    nx, ny, nz, seed, rho, topo = case
+    counts = synthetic.level_wet_counts(nx, ny, nz, seed=seed, topology=topo)
+    k0, k1 = od.balanced_partition(counts, world)[rank]
+    g = synthetic.make_slab(nx, ny, nz, k0, k1, seed=seed, rho=rho, topology=topo)
+    gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev[k0:k1],
+                                  lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
+    local = od.make_local_grid(gm, g.mlotst, g.rho, k0, k1, nz, g.lev)
+    if backend_kind == "hip":
+        be = od.HipSlabBackend(0)
+    else:
+        from slab_checker_backend import OracleSlabBackend
+
+        be = OracleSlabBackend()
+    comm = od.Comm()
+    runner = od.SlabRunner(be, comm, local)
+    dev = be.device
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
+    for _ in range(2):  # twice: buffers are reused between fields
+        out = runner.step(umo, vmo, 1e20)
+    runner.sync()
+    host = be.result_to_host() if backend_kind == "hip" else out
+    glob = od.gather_global_csc(comm, host, runner.n_own, be.nnz, dev)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "global.npz"), n=runner.n_global, nnz=runner.nnz_global,
+                 **{f"{k}_{q}": glob[m][k] for q, m in enumerate(od.MATS) for k in range(3)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    rank, world, port, kind = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    nx, ny, nz, seed = (int(x) for x in sys.argv[5:9])
+    run(rank, world, port, kind, (nx, ny, nz, seed, sys.argv[9], sys.argv[10]), sys.argv[11])

@@ -1,0 +1,75 @@
+"""CPU checker backend for otmb_amd.dist.SlabRunner (TEST INFRASTRUCTURE): computes a slab's columns
+with the oracle on the slab's extended local grid so that the distributed orchestration (partition,
+halo exchange, global wet ranks, flux chain, colptr bases, concatenation) can run under gloo without
+a GPU.  The product backend is otmb_amd.dist.HipSlabBackend."""
+import numpy as np
+import torch
+
+from oracle import oracle as orc
+
+MATS = orc.MATS
+
+
+class OracleSlabBackend:
+    device = torch.device("cpu")
+
+    def setup(self, s):
+        self.s = s
+        self.nx, self.ny, self.nz = s["nx"], s["ny"], s["nz"]
+        self.P = self.nx * self.ny
+        self.k0, self.k1 = s["k_own0"], s["k_own1"]
+        thk = np.array(s["thkcello"], order="F")
+        if self.k0 > 0:
+            thk[:, :, 0] = 1.0  # halo thickness is never used for owned columns; keep the oracle's NaN check quiet
+        if self.k1 < self.nz:
+            thk[:, :, -1] = 1.0
+        self.thk = thk
+        self.phi = {k: np.zeros((self.nx, self.ny, self.nz), order="F") for k in orc.PHI_ORDER}
+
+    def facefluxes(self, umo, vmo, fill, top_below):
+        nown = self.k1 - self.k0
+        u = umo.numpy().reshape(self.nx, self.ny, nown, order="F")
+        v = vmo.numpy().reshape(self.nx, self.ny, nown, order="F")
+        tb = None if top_below is None else top_below.numpy()
+        phi, self.uv = orc.facefluxes(u, v, self.s["wet_own"].astype(np.uint8), fill, self.s["topology"], top_below=tb,
+                                      return_flags=True)
+        for k in orc.PHI_ORDER:
+            self.phi[k][:] = 0.0
+            self.phi[k][:, :, self.k0:self.k1] = phi[k]
+        top_first = np.ascontiguousarray(phi["top"][:, :, 0].ravel(order="F"))
+        if self.k0 > 0:
+            self.phi["bottom"][:, :, 0] = phi["top"][:, :, 0]
+        if tb is not None:
+            self.phi["top"][:, :, -1] = tb.reshape(self.nx, self.ny, order="F")
+        return torch.from_numpy(top_first)
+
+    def plan(self):
+        s = self.s
+        idx = orc.makeindices(s["v3D"])
+        assert np.array_equal(idx["Lwet3D"] != 0, s["lwet3d"] != 0)
+        gm = dict(v3D=s["v3D"], thkcello=self.thk, edge_length_2D=s["edge_length_2D"],
+                  distance_to_neighbour_2D=s["distance_to_neighbour_2D"], area2D=s["area2D"], zt=s["zt"],
+                  gridtopology=dict(kind=s["topology"]))
+        kH, kML, kD = s["kappa"]
+        tm = orc.transportmatrix(self.phi, gm, idx, s["rho"], s["mlotst"], kH, kML, kD, s["upwind"])
+        glob = s["lwet3d"].ravel(order="F")[idx["Lwet"] - 1]  # local wet rank -> global wet rank
+        lev = (idx["Lwet"] - 1) // self.P
+        own = np.flatnonzero((lev >= self.k0) & (lev < self.k1))
+        self.cols = {}
+        self.nnz = []
+        for m in MATS:
+            cp, rv, nz = tm[m]
+            a, b = (cp[own[0]] - 1, cp[own[-1] + 1] - 1) if len(own) else (0, 0)
+            self.cols[m] = (cp[own[0]: own[-1] + 2] - cp[own[0]] if len(own) else np.array([0]), glob[rv[a:b] - 1], nz[a:b])
+            self.nnz.append(int(b - a))
+        assert len(own) == s["n_own"]
+        if len(own):
+            assert glob[own[0]] == s["wet_base"] + 1
+        return self.nnz, self.uv
+
+    def fill(self, nnz_base):
+        self.out = {m: (self.cols[m][0] + int(nnz_base[k]) + 1, self.cols[m][1], self.cols[m][2]) for k, m in enumerate(MATS)}
+        return self.out
+
+    def sync(self):
+        pass
