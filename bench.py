@@ -76,8 +76,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # OTMB_DIST_BACKEND=gloo + OTMB_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
+        backend = os.environ.get("OTMB_DIST_BACKEND", "nccl")
+        if os.environ.get("OTMB_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
 
@@ -171,17 +178,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # per-kernel durations with HIP events on the launch stream, over a second pass of the same K steps
-    asm = runner
-    asm.ctx.timing_enable(True)
+    runner.ctx.timing_enable(True)
     for _ in range(args.steps):
         runner.step()
-    ktimes = asm.ctx.timing_collect()
-    asm.ctx.timing_enable(False)
+    ktimes = runner.ctx.timing_collect()
+    runner.ctx.timing_enable(False)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -189,7 +195,7 @@ def main():
         value = n_total * args.steps / elapsed
         kavg = {k: v[0] / v[1] for k, v in ktimes.items()}
         dom = max(kavg, key=kavg.get)
-        bytes_alg = asm.algorithmic_bytes() if dom.startswith("tm_kernel") else asm.facefluxes_bytes()
+        bytes_alg = runner.algorithmic_bytes() if dom.startswith("tm_kernel") else runner.facefluxes_bytes()
         achieved = bytes_alg / (kavg[dom] * 1e-3) / 1e9
         out = {
             "metric": "wet-cells/s assembled into T", "value": value, "unit": "wet-cells/s",
@@ -199,7 +205,7 @@ def main():
                 "workload": f"{args.workload}: synthetic ACCESS-ESM1-5-like tripolar grid {nx}x{ny}x{nz}"
                             + (f" per rank, stacked in depth x{world}" if world > 1 else "")
                             + f", facefluxes + full transportmatrix (5 CSC matrices), rho={args.rho}, upwind",
-                "wet_cells": n_total, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), asm.nnz)),
+                "wet_cells": n_total, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), runner.nnz)),
                 "seed": args.seed,
             },
             "roofline": {
@@ -208,7 +214,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": kavg[dom],
             },
             "kernels_ms": {k: round(v, 5) for k, v in kavg.items()},
-            "step_gbs": (asm.algorithmic_bytes() + asm.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
+            "step_gbs": (runner.algorithmic_bytes() + runner.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, gm, args.workload)

@@ -123,3 +123,23 @@ def test_error_strings_match_reference(api, oracle):
     idx2["Lwet3D"] = lw
     with pytest.raises(OtmbError, match="Lwet3D"):
         api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm, indices=idx2)
+
+
+# ---- golden fixtures ---------------------------------------------------------------------------
+from golden_util import GOLDEN, load  # noqa: E402
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_hip_reproduces_golden_fixtures(api, name):
+    gd = load(name)
+    idx = api.makeindices(gd["gm"]["v3D"])
+    assert np.array_equal(idx.Lwet, gd["z"]["Lwet"])
+    phi = api.facefluxes(gd["umo"], gd["vmo"], gd["gm"], idx, FillValue=gd["fill"])
+    for k in gd["phi"]:
+        assert np.array_equal(phi[k], gd["phi"][k]), k
+    kH, kML, kD = gd["kappa"]
+    for upwind in (True, False):
+        tm = api.transportmatrix(ϕ=gd["phi"], mlotst=gd["mlotst"], gridmetrics=gd["gm"], indices=idx, ρ=gd["rho"],
+                                 κH=kH, κVML=kML, κVdeep=kD, upwind=upwind)
+        for q, m in enumerate(MATS):
+            assert_csc_equal(tuple(tm[m]), gd["tm"](upwind)[q], f"{name}/{m}")

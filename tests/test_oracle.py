@@ -203,3 +203,22 @@ def test_haversine_known_answers(oracle):
     assert math.isclose(oracle.haversine(0, 0, 180, 0), math.pi * R, rel_tol=1e-15)
     assert math.isclose(oracle.haversine(10, 0, 11, 0), math.pi * R / 180, rel_tol=1e-13)
     assert math.isclose(oracle.haversine(-73.97, 40.78, 2.35, 48.86), pyref.haversine((-73.97, 40.78), (2.35, 48.86)), rel_tol=1e-15)
+
+
+# ---- golden fixtures (regression vectors made by tests/golden/make_golden.py) ------------------
+from golden_util import GOLDEN, load  # noqa: E402
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_oracle_reproduces_golden_fixtures(oracle, name):
+    gd = load(name)
+    idx = oracle.makeindices(gd["gm"]["v3D"])
+    assert np.array_equal(idx["Lwet"], gd["z"]["Lwet"])
+    phi = oracle.facefluxes(gd["umo"], gd["vmo"], idx["wet3D"], gd["fill"], gd["gm"]["gridtopology"]["kind"])
+    for k in phi:
+        assert np.array_equal(phi[k], gd["phi"][k]), k
+    kH, kML, kD = gd["kappa"]
+    for upwind in (True, False):
+        tm = oracle.transportmatrix(gd["phi"], gd["gm"], idx, gd["rho"], gd["mlotst"], kH, kML, kD, upwind)
+        for q, m in enumerate(MATS):
+            assert_csc_equal(tm[m], gd["tm"](upwind)[q], f"{name}/{m}")
