@@ -123,6 +123,7 @@ typedef struct {
     const double *rho;           /* ρ as (nx,ny,nz) array, or NULL to use rho_scalar */
     double rho_scalar;
     const int64_t *lwet3d;       /* indices.Lwet3D (nx,ny,nz), 0 = missing */
+    const int64_t *lwet;         /* indices.Lwet (n_wet): ascending 1-based linear indices of the wet cells */
     const double *edge_length[4];/* gridmetrics.edge_length_2D[dir]           (nx,ny), OTMB_DIR_* order */
     const double *dist_nbr[4];   /* gridmetrics.distance_to_neighbour_2D[dir] (nx,ny) */
     const double *area2d;        /* gridmetrics.area2D (nx,ny) */
@@ -138,14 +139,23 @@ typedef struct {
 int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                       double *const nzval[5]);
+/* One-pass variant for device-resident callers that know an upper bound of the output sizes (a column
+ * holds at most 7, 7, 5, 3, 3 entries of T, Tadv, TκH, TκVML, TκVdeep): inputs are read once and the five
+ * matrices written once (tile offsets by decoupled look-back instead of a count pass).  Asynchronous;
+ * capacity[m] = entries rowval[m]/nzval[m] can hold; colptr[m] holds n_wet+1.  otmb_transportmatrix_result
+ * synchronises, raises the reference's errors / OTMB_ERR_CAPACITY and returns the five nnz.           */
+int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t *const colptr[5],
+                                 int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
+int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);
+
 /* Depth-slab partition (multi-GPU).  The wet index is k-slowest (src/matrixbuilding.jl:14-15), so a slab
- * of levels owns a contiguous column range of every matrix.  set_slab (before plan): the local grid
- * passed to plan holds levels [k_own0,k_own1) owned by this rank plus halo levels that act as
- * neighbours only; lwet3d holds GLOBAL wet ranks and wet_base = (global rank of the first owned wet
- * cell) - 1; args.n_wet = owned wet cells.  set_nnz_base (after plan, before fill): entries of each
+ * of levels owns a contiguous column range of every matrix.  set_slab (before plan / _dev): the local
+ * grid holds this rank's levels plus halo levels that act as neighbours only; args.lwet lists the OWNED
+ * wet cells (local linear indices), args.n_wet their number, lwet3d holds GLOBAL wet ranks and wet_base
+ * = (global rank of the first owned wet cell) - 1.  set_nnz_base (before fill / _dev): entries of each
  * matrix owned by the slabs above, so that colptr (n_wet+1 entries, local columns) is written with
- * global offsets and the slabs' arrays concatenate into the global CSC.  k_own1 < 0 resets.        */
-int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t k_own0, int64_t k_own1, int64_t wet_base);
+ * global offsets and the slabs' arrays concatenate into the global CSC.  set_slab(ctx, 0) resets.   */
+int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t wet_base);
 int32_t otmb_transportmatrix_set_nnz_base(otmb_ctx *ctx, const int64_t nnz_base[5]);
 int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],

@@ -128,6 +128,7 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
         assert r.shape == v3d.shape
         a.rho = hold(r)
     a.lwet3d = hold(np.asfortranarray(indices["Lwet3D"], dtype=np.int64))
+    a.lwet = hold(np.ascontiguousarray(indices["Lwet"], dtype=np.int64))
     for k, d in enumerate(HDIRS):
         a.edge_length[k] = hold(_f64(gridmetrics["edge_length_2D"][d]))
         a.dist_nbr[k] = hold(_f64(gridmetrics["distance_to_neighbour_2D"][d]))

@@ -35,7 +35,7 @@ class TmArgs(C.Structure):
         ("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
         ("topology", C.c_int32), ("upwind", C.c_int32), ("n_wet", C.c_int64),
         ("phi", C.c_void_p * 6), ("v3d", C.c_void_p), ("thkcello", C.c_void_p),
-        ("rho", C.c_void_p), ("rho_scalar", C.c_double), ("lwet3d", C.c_void_p),
+        ("rho", C.c_void_p), ("rho_scalar", C.c_double), ("lwet3d", C.c_void_p), ("lwet", C.c_void_p),
         ("edge_length", C.c_void_p * 4), ("dist_nbr", C.c_void_p * 4),
         ("area2d", C.c_void_p), ("zt", C.c_void_p), ("mlotst", C.c_void_p),
         ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
@@ -61,7 +61,9 @@ SYMBOLS = {
     "otmb_facefluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
     "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp]),
     "otmb_facefluxes_slab_flags": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int64]),
+    "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64]),
+    "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
+    "otmb_transportmatrix_result": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_set_nnz_base": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_plan_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_fill_dev": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
@@ -147,7 +149,7 @@ class Context:
     def timing_enable(self, on=True):
         self.check(lib().otmb_ctx_timing_enable(self._h, int(on)))
 
-    def timing_collect(self, n=7):
+    def timing_collect(self, n=8):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()

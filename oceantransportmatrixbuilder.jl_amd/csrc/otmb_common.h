@@ -23,7 +23,7 @@ struct TmPlan;  // otmb_transportmatrix.hip
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 
@@ -33,7 +33,7 @@ struct otmb_ctx {
     hipStream_t stream = nullptr;  // own_stream or a borrowed one
     std::string err;
     // scratch for the scans / flags
-    DevBuf blocksums, blockoffs, flags;
+    DevBuf blocksums, blockoffs, flags, lookback;
     int *h_flags = nullptr;  // pinned host mirror of the flag words
     i64 *h_tot = nullptr;    // pinned host mirror of scan totals
     TmPlan *plan = nullptr;
@@ -66,7 +66,7 @@ struct KernelTimer {
 #define OTMB_NFLAGS 16
 enum {
     FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
-    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_U_VALID, FLAG_V_VALID
+    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_U_VALID, FLAG_V_VALID, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY
 };
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);

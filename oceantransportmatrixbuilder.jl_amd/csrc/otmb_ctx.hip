@@ -86,7 +86,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     otmb_tm_plan_free(ctx);
-    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags})
+    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->lookback})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
@@ -146,7 +146,8 @@ int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, i
 
 const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_kernel<count>", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
-                                            "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>"};
+                                            "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
+                                            "tm_kernel<onepass>"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

@@ -93,6 +93,8 @@ int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t 
     TRY(upload(ctx, ST_THK, a->thkcello, G * 8, &p)); d.thkcello = (const double *)p;
     if (a->rho) { TRY(upload(ctx, ST_RHO, a->rho, G * 8, &p)); d.rho = (const double *)p; }
     TRY(upload(ctx, ST_LW, a->lwet3d, G * 8, &p)); d.lwet3d = (const int64_t *)p;
+    if (a->n_wet > 0 && !a->lwet) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "lwet");
+    TRY(upload(ctx, ST_LWET, a->lwet, (size_t)(a->n_wet > 0 ? a->n_wet : 0) * 8, &p)); d.lwet = (const int64_t *)p;
     for (int k = 0; k < 4; ++k) {
         TRY(upload(ctx, ST_EDGE0 + k, a->edge_length[k], P * 8, &p)); d.edge_length[k] = (const double *)p;
         TRY(upload(ctx, ST_DIST0 + k, a->dist_nbr[k], P * 8, &p)); d.dist_nbr[k] = (const double *)p;

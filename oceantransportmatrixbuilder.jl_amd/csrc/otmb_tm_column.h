@@ -1,0 +1,485 @@
+// otmb_tm_column.h -- one CSC column of (T, Tadv, TκH, TκVML, TκVdeep) from the local stencil.
+//
+// Gather formulation of src/matrixbuilding.jl:221-299 (advection), :337-418 (horizontal diffusion),
+// :438-479 (vertical diffusion), sparse()'s duplicate summation (:41,63,92,116) and the sparse adds
+// (:147).  The reference scatters: wet cell 𝑖 pushes triplets into its own and its neighbours' columns,
+// then sparse() sorts and sums.  Every triplet of column c comes from c itself or from one of the <= 7
+// cells whose neighbour (in some direction) is c, so the thread that owns c rebuilds the column directly:
+//   * which triplets land in column c, and the order the reference emits them in (ascending emitting wet
+//     index, then W,E,S,N,B,T, then first/second push), is a pure function of the local stencil;
+//     duplicates are summed left-to-right in that order, first touch copies (explicit zeros, -0.0 kept);
+//   * T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep with absent operands +0.0, stored iff != 0;
+//   * rows ascend in wet index == linear index (makeindices is monotone; verified by the kernel).
+// Float64 throughout, compiled with -ffp-contract=off: every value is the reference's own expression.
+#pragma once
+#include "otmb_common.h"
+#include "otmb_topology.h"
+
+struct TmParams {
+    const double *phi[6];
+    const double *v, *thk, *rho;
+    double rho_s;
+    const i64 *lw;    // Lwet3D (global wet ranks in a slab run), 0 = missing
+    const i64 *lwet;  // Lwet: 1-based linear indices (in this grid) of the wet cells this launch owns
+    const double *edge[4], *dist[4];
+    const double *area, *zt, *ml;
+    double kH, kML, kDeep;
+    int nx, ny, nz, topo, upwind;
+    i64 P, G;
+    i64 n_own;         // number of entries of lwet = columns produced
+    i64 wet_base;      // wet rank of column 0 is wet_base + 1 (depth slabs; 0 otherwise)
+    i64 nnz_base[5];   // entries owned by lower-ranked slabs
+    i64 cap[5];        // capacity of rowval/nzval (one-pass mode)
+    // outputs
+    i64 *colptr[5], *rowval[5];
+    double *nzval[5];
+    i64 *totals;           // [5] nnz of this launch (one-pass mode)
+    // scan state
+    uint32_t *tilesums;    // [ntiles][5]  (COUNT writes)
+    const i64 *tileoffs;   // [ntiles][5]  (FILL reads)
+    u64 *status;           // [ntiles][5]  decoupled look-back words (ONEPASS)
+    int *ticket;           // dynamic tile id (ONEPASS)
+    int *flags;
+};
+
+// slots of a column: the cells that can hold a row of column c
+enum { S_A = 0, S_S = 1, S_SELF = 2, S_EC = 3, S_WC = 4, S_FQ = 5, S_N = 6, S_B = 7, NSLOT = 8 };
+
+struct Column {
+    i64 idx[NSLOT];      // wet rank of the slot's cell (row index), 0 = no such wet cell
+    double adv[NSLOT];   // Tadv values
+    double hh[NSLOT];    // TκH values   (slots SELF, EC, WC, FQ, S, N)
+    double ml[NSLOT];    // TκVML values (slots SELF, A, B)
+    double dp[NSLOT];    // TκVdeep values
+    unsigned padv, phh, pml, pdp;  // presence masks (bit = slot)
+    unsigned bef[NSLOT];  // bef[X]: slots ordered before X in the column
+};
+
+__device__ __forceinline__ void acc(double &val, unsigned &pres, int slot, double x) {
+    // sparse(): first touch copies, later ones combine acc = acc + x in emission order
+    val = ((pres >> slot) & 1u) ? val + x : x;
+    pres |= 1u << slot;
+}
+// accumulate into one of the four row-mate slots chosen at run time.  Written with value selects
+// only: an if-chain over val[slot] is turned by the optimiser into a run-time indexed access,
+// which drags the whole Column into scratch memory.
+__device__ __forceinline__ void acc_rowmate(double (&val)[NSLOT], unsigned &pres, int slot, double x) {
+    const double vS = val[S_SELF], vE = val[S_EC], vW = val[S_WC], vF = val[S_FQ];  // unconditional loads
+    const bool tS = slot == S_SELF, tE = slot == S_EC, tW = slot == S_WC, tF = slot == S_FQ;
+    const double cur = tS ? vS : (tE ? vE : (tW ? vW : vF));
+    const double nv = ((pres >> slot) & 1u) ? cur + x : x;
+    val[S_SELF] = tS ? nv : vS;
+    val[S_EC] = tE ? nv : vE;
+    val[S_WC] = tW ? nv : vW;
+    val[S_FQ] = tF ? nv : vF;
+    pres |= 1u << slot;
+}
+__device__ __forceinline__ double sel_pos(double x, int upwind) {  // max(ϕ,0) or ϕ/2  (:244,262,280)
+    return upwind ? ((x > 0.0) ? x : 0.0) : x / 2;
+}
+__device__ __forceinline__ double sel_neg(double x, int upwind) {  // min(ϕ,0) or ϕ/2  (:253,271,289)
+    return upwind ? ((x < 0.0) ? x : 0.0) : x / 2;
+}
+__device__ __forceinline__ bool nonzero(double f) { return (f > 0.0) || (f < 0.0); }
+__device__ __forceinline__ double jl_min(double a, double b) {
+    return (isnan(a) || isnan(b)) ? __builtin_nan("") : ((a < b) ? a : b);
+}
+__device__ __forceinline__ void raise_flag(int *flags, int f) {
+    if (flags[f] == 0) atomicExch(&flags[f], 1);
+}
+
+// Build the column of wet cell `cell` (c = own wet rank > 0): generic path, any topology corner case.
+__device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell, i64 c, Column &col) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const i64 L = cell.L;
+    const int i = cell.i, j = cell.j, k = cell.k;
+    const int ie = (i + 1 < nx) ? i + 1 : 0, iw = (i > 0) ? i - 1 : nx - 1;
+    const i64 LEc = cell.row0 + ie, LWc = cell.row0 + iw;
+    const i64 LS = nb_jm1(cell, nx), LNq = nb_jp1(cell, nx, ny, p.topo);
+    const i64 LA = nb_km1(cell, p.P), LB = nb_kp1(cell, nz, p.P);
+    const bool fold = (j == ny - 1) && (LNq >= 0);  // north neighbour through the tripolar seam
+    const int ifd = nx - 1 - i;
+
+    const i64 xEc = p.lw[LEc], xWc = p.lw[LWc];
+    const i64 xS = (LS >= 0) ? p.lw[LS] : 0, xNq = (LNq >= 0) ? p.lw[LNq] : 0;
+    const i64 xA = (LA >= 0) ? p.lw[LA] : 0, xB = (LB >= 0) ? p.lw[LB] : 0;
+
+    // ---- advective fluxes pushed towards this cell by its neighbours (:244-296) -------------
+    // emitter EC pushes its west flux, WC its east flux, N-side its south flux, the fold and
+    // S-side cells their north flux, the cell above its bottom flux, the cell below its top flux.
+    const double fEc = xEc ? sel_pos(p.phi[OTMB_WEST][LEc], up) : 0.0;
+    const double fWc = xWc ? sel_neg(p.phi[OTMB_EAST][LWc], up) : 0.0;
+    const double fNq = xNq ? (fold ? sel_neg(p.phi[OTMB_NORTH][LNq], up) : sel_pos(p.phi[OTMB_SOUTH][LNq], up)) : 0.0;
+    const double fS = xS ? sel_neg(p.phi[OTMB_NORTH][LS], up) : 0.0;
+    const double fA = xA ? sel_pos(p.phi[OTMB_BOTTOM][LA], up) : 0.0;
+    const double fB = xB ? sel_neg(p.phi[OTMB_TOP][LB], up) : 0.0;  // emitter has k+1 > 1 (:290)
+    const bool aEc = nonzero(fEc), aWc = nonzero(fWc), aNq = nonzero(fNq), aS = nonzero(fS), aA = nonzero(fA),
+               aB = nonzero(fB);
+
+    // own pushes (:244-296) must land in a wet cell: the reference indexes Lwet3D[C𝑗] / pushes 𝑗 without
+    // testing it, so a non-zero selected flux towards land or `nothing` throws there
+    {
+        const double ow = sel_pos(p.phi[OTMB_WEST][L], up), oe = sel_neg(p.phi[OTMB_EAST][L], up);
+        const double os = sel_pos(p.phi[OTMB_SOUTH][L], up), on = sel_neg(p.phi[OTMB_NORTH][L], up);
+        const double ob = sel_pos(p.phi[OTMB_BOTTOM][L], up), ot = (k > 0) ? sel_neg(p.phi[OTMB_TOP][L], up) : 0.0;
+        const bool bad = (nonzero(ow) && xWc == 0) || (nonzero(oe) && xEc == 0) || (nonzero(os) && xS == 0) ||
+                         (nonzero(on) && xNq == 0) || (nonzero(ob) && xB == 0) || (nonzero(ot) && xA == 0);
+        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+    }
+
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) { col.idx[s] = 0; col.adv[s] = 0; col.hh[s] = 0; col.ml[s] = 0; col.dp[s] = 0; }
+    col.padv = col.phh = col.pml = col.pdp = 0;
+
+    // canonical slot of each row-mate (cells of the same (j,k) row can coincide when nx <= 2 or
+    // on the fold: north neighbour of (nx/2) is (nx/2+1), of the centre of an odd row itself)
+    const int cEC = (ie == i) ? S_SELF : S_EC;
+    const int cWC = (iw == i) ? S_SELF : ((iw == ie) ? S_EC : S_WC);
+    const int cFQ = (ifd == i) ? S_SELF : ((ifd == ie) ? S_EC : ((ifd == iw) ? cWC : S_FQ));
+
+    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_B] = xB;
+    col.idx[S_EC] = (cEC == S_EC) ? xEc : 0;
+    col.idx[S_WC] = (cWC == S_WC) ? xWc : 0;
+    col.idx[S_FQ] = (fold && cFQ == S_FQ) ? xNq : 0;
+    col.idx[S_N] = fold ? 0 : xNq;
+
+    // order of the rows inside the column: A, S, row-mates by i, N, B
+    {
+        const unsigned lo = (1u << S_A) | (1u << S_S);
+        const unsigned mates = (1u << S_SELF) | (1u << S_EC) | (1u << S_WC) | (1u << S_FQ);
+        col.bef[S_A] = 0;
+        col.bef[S_S] = 1u << S_A;
+        col.bef[S_SELF] = lo | ((ie < i) ? 1u << S_EC : 0) | ((iw < i) ? 1u << S_WC : 0) | ((ifd < i) ? 1u << S_FQ : 0);
+        col.bef[S_EC] = lo | ((i < ie) ? 1u << S_SELF : 0) | ((iw < ie) ? 1u << S_WC : 0) | ((ifd < ie) ? 1u << S_FQ : 0);
+        col.bef[S_WC] = lo | ((i < iw) ? 1u << S_SELF : 0) | ((ie < iw) ? 1u << S_EC : 0) | ((ifd < iw) ? 1u << S_FQ : 0);
+        col.bef[S_FQ] = lo | ((i < ifd) ? 1u << S_SELF : 0) | ((ie < ifd) ? 1u << S_EC : 0) | ((iw < ifd) ? 1u << S_WC : 0);
+        col.bef[S_N] = lo | mates;
+        col.bef[S_B] = lo | mates | (1u << S_N);
+    }
+
+    const double vc = p.v[L];
+    const double rc = p.rho ? p.rho[L] : p.rho_s;
+    if (isnan(rc)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+
+    // emission order of the three row-mate emitters: ascending (i of emitter, direction W<E<S<N)
+    const int kE = ie * 4 + 0, kW = iw * 4 + 1, kF = fold ? ifd * 4 + 3 : 0x7fffffff;
+    const int rE = (kW < kE) + (kF < kE), rW = (kE < kW) + (kF < kW), rF = (kE < kF) + (kW < kF);
+
+    // ---- Tadv (pushTadvectionvalues!, :193-204): entries (row e, -ϕ/(ρ̄ v_e)), (row c, ϕ/(ρ̄ v_c)) ----
+    {
+        bool anynan = false;
+#define ADV_VALUES(ACTIVE, LX, PHI, OFF, DG)                          \
+    double OFF = 0.0, DG = 0.0;                                       \
+    if (ACTIVE) {                                                     \
+        const double rx_ = p.rho ? p.rho[LX] : p.rho_s;               \
+        const double rb_ = (rx_ + rc) / 2;                            \
+        const double mx_ = rb_ * p.v[LX];                             \
+        const double mc_ = rb_ * vc;                                  \
+        OFF = -(PHI) / mx_;                                           \
+        DG = (PHI) / mc_;                                             \
+        anynan |= isnan(OFF) | isnan(DG);                             \
+    }
+        ADV_VALUES(aA, LA, fA, oA, dA)
+        ADV_VALUES(aS, LS, -fS, oS, dS)
+        ADV_VALUES(aEc, LEc, fEc, oEc, dEc)
+        ADV_VALUES(aWc, LWc, -fWc, oWc, dWc)
+        const double phNq = fold ? -fNq : fNq;
+        ADV_VALUES(aNq, LNq, phNq, oNq, dNq)
+        ADV_VALUES(aB, LB, -fB, oB, dB)
+#undef ADV_VALUES
+        if (anynan) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
+        if (aA) { acc(col.adv[S_A], col.padv, S_A, oA); acc(col.adv[S_SELF], col.padv, S_SELF, dA); }
+        if (aS) { acc(col.adv[S_S], col.padv, S_S, oS); acc(col.adv[S_SELF], col.padv, S_SELF, dS); }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (rE == r) {
+                if (aEc) { acc_rowmate(col.adv, col.padv, cEC, oEc); acc(col.adv[S_SELF], col.padv, S_SELF, dEc); }
+            } else if (rW == r) {
+                if (aWc) { acc_rowmate(col.adv, col.padv, cWC, oWc); acc(col.adv[S_SELF], col.padv, S_SELF, dWc); }
+            } else if (rF == r) {
+                if (fold && aNq) { acc_rowmate(col.adv, col.padv, cFQ, oNq); acc(col.adv[S_SELF], col.padv, S_SELF, dNq); }
+            }
+        }
+        if (!fold && aNq) { acc(col.adv[S_N], col.padv, S_N, oNq); acc(col.adv[S_SELF], col.padv, S_SELF, dNq); }
+        if (aB) { acc(col.adv[S_B], col.padv, S_B, oB); acc(col.adv[S_SELF], col.padv, S_SELF, dB); }
+    }
+
+    // ---- TκH (:348-415, pushTmixingvalues! :426-435) ------------------------------------------
+    // For each horizontal neighbour X: a = min(thk_c*edge[c->X][c], thk_X*edge[X->c][X]) is shared by
+    // c's own push towards X (+Tval on the diagonal) and X's push towards c (-Tval' on row X).
+    {
+        const i64 s = (i64)j * nx + i;
+        const double thc = p.thk[L];
+        bool anynan = false;
+        double ownW = 0, ownE = 0, ownS = 0, ownN = 0, inW = 0, inE = 0, inS = 0, inN = 0;
+#define H_VALUES(WET, LX, SX, DCX, EDGE_XC, DIST_XC, OWN, IN)                      \
+    if (WET) {                                                                     \
+        const i64 sx_ = (SX);                                                      \
+        const double aij_ = thc * p.edge[DCX][s];                                  \
+        const double aji_ = p.thk[LX] * (EDGE_XC)[sx_];                            \
+        const double a_ = jl_min(aij_, aji_);                                      \
+        OWN = (p.kH * a_) / (p.dist[DCX][s] * vc);                                 \
+        IN = (p.kH * a_) / ((DIST_XC)[sx_] * p.v[LX]);                             \
+        anynan |= isnan(OWN) | isnan(IN);                                          \
+    }
+        H_VALUES(xWc != 0, LWc, (i64)j * nx + iw, OTMB_DIR_WEST, p.edge[OTMB_DIR_EAST], p.dist[OTMB_DIR_EAST], ownW, inW)
+        H_VALUES(xEc != 0, LEc, (i64)j * nx + ie, OTMB_DIR_EAST, p.edge[OTMB_DIR_WEST], p.dist[OTMB_DIR_WEST], ownE, inE)
+        H_VALUES(xS != 0, LS, s - nx, OTMB_DIR_SOUTH, p.edge[OTMB_DIR_NORTH], p.dist[OTMB_DIR_NORTH], ownS, inS)
+        // oppdir (:407): through the seam the neighbour's facing edge is its NORTH edge.  Pointer
+        // selects (not p.edge[runtime]) keep the kernel arguments out of scratch memory.
+        const double *edgeNc = fold ? p.edge[OTMB_DIR_NORTH] : p.edge[OTMB_DIR_SOUTH];
+        const double *distNc = fold ? p.dist[OTMB_DIR_NORTH] : p.dist[OTMB_DIR_SOUTH];
+        H_VALUES(xNq != 0, LNq, fold ? (i64)j * nx + ifd : s + nx, OTMB_DIR_NORTH, edgeNc, distNc, ownN, inN)
+#undef H_VALUES
+        if (anynan) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
+        // own pushes, direction order W, E, S, N: (c,c,+Tval); the second push (c,X,-Tval) lands in
+        // this column only when X is c itself
+        if (xWc) { acc(col.hh[S_SELF], col.phh, S_SELF, ownW); if (cWC == S_SELF) acc(col.hh[S_SELF], col.phh, S_SELF, -ownW); }
+        if (xEc) { acc(col.hh[S_SELF], col.phh, S_SELF, ownE); if (cEC == S_SELF) acc(col.hh[S_SELF], col.phh, S_SELF, -ownE); }
+        if (xS) { acc(col.hh[S_SELF], col.phh, S_SELF, ownS); }
+        if (xNq) { acc(col.hh[S_SELF], col.phh, S_SELF, ownN); if (fold && cFQ == S_SELF) acc(col.hh[S_SELF], col.phh, S_SELF, -ownN); }
+        // neighbours' second pushes (X,c,-Tval'), per row in the emitter's direction order
+        if (xS) acc(col.hh[S_S], col.phh, S_S, -inS);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (rE == r) {
+                if (xEc && cEC != S_SELF) acc_rowmate(col.hh, col.phh, cEC, -inE);
+            } else if (rW == r) {
+                if (xWc && cWC != S_SELF) acc_rowmate(col.hh, col.phh, cWC, -inW);
+            } else if (rF == r) {
+                if (fold && xNq && cFQ != S_SELF) acc_rowmate(col.hh, col.phh, cFQ, -inN);
+            }
+        }
+        if (!fold && xNq) acc(col.hh[S_N], col.phh, S_N, -inN);
+    }
+
+    // ---- TκVML / TκVdeep (:450-477) -------------------------------------------------------------
+    {
+        const i64 s = (i64)j * nx + i;
+        const double ar = p.area[s];
+        const double ztk = p.zt[k];
+        const double mld = p.ml[s];
+        const bool omc = ztk < mld;  // Ω (:85); NaN (missing) compares false
+        bool nanml = false, nandp = false;
+        if (xB) {  // from bottom (own push first, B then T)
+            const double ztb = p.zt[k + 1];
+            const double d = fabs(ztk - ztb);
+            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * p.v[LB]);
+            nandp |= isnan(ownD) | isnan(inD);
+            acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
+            acc(col.dp[S_B], col.pdp, S_B, -inD);
+            if (omc && (ztb < mld)) {
+                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * p.v[LB]);
+                nanml |= isnan(ownM) | isnan(inM);
+                acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
+                acc(col.ml[S_B], col.pml, S_B, -inM);
+            }
+        }
+        if (xA) {
+            const double zta = p.zt[k - 1];
+            const double d = fabs(ztk - zta);
+            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * p.v[LA]);
+            nandp |= isnan(ownD) | isnan(inD);
+            acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
+            acc(col.dp[S_A], col.pdp, S_A, -inD);
+            if (omc && (zta < mld)) {
+                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * p.v[LA]);
+                nanml |= isnan(ownM) | isnan(inM);
+                acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
+                acc(col.ml[S_A], col.pml, S_A, -inM);
+            }
+        }
+        if (nanml) raise_flag(p.flags, FLAG_TKVML_NAN);    // :90
+        if (nandp) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
+    }
+}
+
+// ---- fast path ---------------------------------------------------------------------------------
+// Regular cells: nx >= 3 and not on the tripolar seam row, i.e. the W/E/S/N/A/B neighbours are
+// distinct cells.  Same arithmetic as build_column, organised for the hardware:
+//  * every load is unconditional and issued up front (addresses depend on (i,j,k) only; a
+//    neighbour that does not exist is clamped to the cell itself and masked afterwards), so one
+//    memory round trip covers the whole stencil instead of one per `if`;
+//  * 32-bit byte offsets from tile-uniform base pointers (scalar base + vector offset loads);
+//  * accumulators start at -0.0: (-0.0) + x == x bit for bit for every x, which is exactly
+//    sparse()'s "first touch copies, later ones add" without tracking the first touch.
+struct TileBase {  // array pointers advanced to the tile's lowest neighbour (uniform per workgroup)
+    const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb;
+};
+__device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
+__device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
+#define NEG0 (-0.0)
+
+__device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
+                                            i64 c, Column &col) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
+    const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
+    const unsigned nx8 = (unsigned)nx * 8u, P8 = (unsigned)p.P * 8u;
+    const unsigned oE = oC + (unsigned)(di_e * 8), oW = oC + (unsigned)(di_w * 8);
+    const unsigned oS = hS ? oC - nx8 : oC, oN = hN ? oC + nx8 : oC;
+    const unsigned oA = hA ? oC - P8 : oC, oB = hB ? oC + P8 : oC;
+    const unsigned s2 = ((unsigned)j * (unsigned)nx + (unsigned)i) * 8u;
+    const unsigned sE = s2 + (unsigned)(di_e * 8), sW = s2 + (unsigned)(di_w * 8);
+    const unsigned sS = hS ? s2 - nx8 : s2, sN = hN ? s2 + nx8 : s2;
+
+    // ---- all loads ----
+    const i64 lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN), lA = ldi(tb.lw, oA),
+              lB = ldi(tb.lw, oB);
+    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
+                 gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
+    const double qW0 = ldd(tb.pw, oC), qE0 = ldd(tb.pe, oC), qS0 = ldd(tb.ps, oC), qN0 = ldd(tb.pn, oC),
+                 qB0 = ldd(tb.pb, oC), qT0 = ldd(tb.pt, oC);  // own fluxes, for the outgoing check
+    const double vC = ldd(tb.v, oC), vE = ldd(tb.v, oE), vW = ldd(tb.v, oW), vS = ldd(tb.v, oS), vN = ldd(tb.v, oN),
+                 vA = ldd(tb.v, oA), vB = ldd(tb.v, oB);
+    double rC, rE, rW, rS, rN, rA, rB;
+    if (tb.rho) {
+        rC = ldd(tb.rho, oC); rE = ldd(tb.rho, oE); rW = ldd(tb.rho, oW); rS = ldd(tb.rho, oS); rN = ldd(tb.rho, oN);
+        rA = ldd(tb.rho, oA); rB = ldd(tb.rho, oB);
+    } else {
+        rC = rE = rW = rS = rN = rA = rB = p.rho_s;
+    }
+    const double tC = ldd(tb.thk, oC), tE = ldd(tb.thk, oE), tW = ldd(tb.thk, oW), tS = ldd(tb.thk, oS),
+                 tN = ldd(tb.thk, oN);
+    const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
+               *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
+    const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
+               *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
+    const double eW_c = ldd(eWp, s2), eE_c = ldd(eEp, s2), eS_c = ldd(eSp, s2), eN_c = ldd(eNp, s2);
+    const double dW_c = ldd(dWp, s2), dE_c = ldd(dEp, s2), dS_c = ldd(dSp, s2), dN_c = ldd(dNp, s2);
+    const double eE_w = ldd(eEp, sW), dE_w = ldd(dEp, sW);  // west cell's east edge / distance to its east nbr
+    const double eW_e = ldd(eWp, sE), dW_e = ldd(dWp, sE);
+    const double eN_s = ldd(eNp, sS), dN_s = ldd(dNp, sS);
+    const double eS_n = ldd(eSp, sN), dS_n = ldd(dSp, sN);  // oppdir = south away from the seam row (:407)
+    const double ar = ldd((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
+    const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
+
+    const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
+    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
+
+    // ---- advective pushes towards this cell (:244-296) ----
+    const double fE = wE ? sel_pos(gE0, up) : 0.0;  // east cell pushes its west flux
+    const double fW = wW ? sel_neg(gW0, up) : 0.0;  // west cell pushes its east flux
+    const double fS = wS ? sel_neg(gS0, up) : 0.0;  // south cell pushes its north flux
+    const double fN = wN ? sel_pos(gN0, up) : 0.0;  // north cell pushes its south flux
+    const double fA = wA ? sel_pos(gA0, up) : 0.0;  // cell above pushes its bottom flux
+    const double fB = wB ? sel_neg(gB0, up) : 0.0;  // cell below pushes its top flux (its k > 1, :290)
+    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
+    {   // own pushes must land in a wet cell (see build_column)
+        const double ow = sel_pos(qW0, up), oe = sel_neg(qE0, up), os = sel_pos(qS0, up), on = sel_neg(qN0, up);
+        const double ob = sel_pos(qB0, up), ot = hA ? sel_neg(qT0, up) : 0.0;
+        const bool bad = (nonzero(ow) & !wW) | (nonzero(oe) & !wE) | (nonzero(os) & !wS) | (nonzero(on) & !wN) |
+                         (nonzero(ob) & !wB) | (nonzero(ot) & !wA);
+        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+    }
+    if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+
+    // row order of the column: A, S, row-mates by i, N, B.  Row-mates: W, SELF, E -- except at the
+    // periodic wrap (i == 0: SELF, E, W(nx-1);  i == nx-1: E(0), W, SELF)
+    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
+    {
+        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
+        col.bef[S_A] = 0;
+        col.bef[S_S] = 1u << S_A;
+        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
+        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
+        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
+        col.bef[S_FQ] = 0;
+        col.bef[S_N] = lo | bS | bE | bW;
+        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
+    }
+    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
+    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
+
+    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
+    {
+#define ADV1(PHI, RX, VX, OFF, DG)                \
+    const double rb##OFF = ((RX) + rC) / 2;       \
+    const double OFF = -(PHI) / (rb##OFF * (VX)); \
+    const double DG = (PHI) / (rb##OFF * vC);
+        ADV1(fA, rA, vA, oA_, dA_)
+        ADV1(-fS, rS, vS, oS_, dS_)
+        ADV1(-fW, rW, vW, oW_, dW_)
+        ADV1(fE, rE, vE, oE_, dE_)
+        ADV1(fN, rN, vN, oN_, dN_)
+        ADV1(-fB, rB, vB, oB_, dB_)
+#undef ADV1
+        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
+                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
+        if (bad) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
+        // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
+        double d = NEG0;
+        d += aA ? dA_ : NEG0;
+        d += aS ? dS_ : NEG0;
+        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
+        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
+        d += m1;
+        d += m2;
+        d += aN ? dN_ : NEG0;
+        d += aB ? dB_ : NEG0;
+        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
+        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
+        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
+                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+    }
+    // ---- TκH (:348-415, :426-435) ----
+    {
+#define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
+    const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
+    const double OWN = (p.kH * a##OWN) / ((D_C) * vC);       \
+    const double IN = (p.kH * a##OWN) / ((D_X) * (VX));
+        H1(tW, eW_c, eE_w, dW_c, dE_w, vW, ownW, inW)
+        H1(tE, eE_c, eW_e, dE_c, dW_e, vE, ownE, inE)
+        H1(tS, eS_c, eN_s, dS_c, dN_s, vS, ownS, inS)
+        H1(tN, eN_c, eS_n, dN_c, dS_n, vN, ownN, inN)
+#undef H1
+        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
+                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
+        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
+        double h = NEG0;  // own pushes in direction order W, E, S, N
+        h += wW ? ownW : NEG0;
+        h += wE ? ownE : NEG0;
+        h += wS ? ownS : NEG0;
+        h += wN ? ownN : NEG0;
+        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
+        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
+        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
+                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
+    }
+    // ---- TκVdeep / TκVML (:450-477) ----
+    {
+        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
+        const double nD = p.kDeep * ar;
+        const double ownB = nD / (dB * vC), inB = nD / (dB * vB), ownA = nD / (dA * vC), inA = nD / (dA * vA);
+        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
+        double d = NEG0;  // own pushes: bottom then top
+        d += wB ? ownB : NEG0;
+        d += wA ? ownA : NEG0;
+        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
+        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+        const bool omC = ztk < mld;  // Ω (:85); NaN compares false
+        const bool mB = wB & omC & (ztb < mld), mA = wA & omC & (zta < mld);
+        col.pml = 0;
+        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
+        if (mA | mB) {
+            const double nM = p.kML * ar;
+            const double mownB = nM / (dB * vC), minB = nM / (dB * vB), mownA = nM / (dA * vC), minA = nM / (dA * vA);
+            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
+            double m = NEG0;
+            m += mB ? mownB : NEG0;
+            m += mA ? mownA : NEG0;
+            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
+            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
+        }
+    }
+}
+
+// T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)
+__device__ __forceinline__ double t_value(const Column &col, int s) {
+    const double a = ((col.padv >> s) & 1u) ? col.adv[s] : 0.0;
+    const double h = ((col.phh >> s) & 1u) ? col.hh[s] : 0.0;
+    const double m = ((col.pml >> s) & 1u) ? col.ml[s] : 0.0;
+    const double d = ((col.pdp >> s) & 1u) ? col.dp[s] : 0.0;
+    return ((a + h) + m) + d;
+}
+

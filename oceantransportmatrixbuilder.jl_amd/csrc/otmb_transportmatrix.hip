@@ -1,527 +1,82 @@
 // otmb_transportmatrix.hip -- fused assembly of (T, Tadv, TκH, TκVML, TκVdeep) in CSC.
 //
-// Replaces, on the device, the whole of `transportmatrix` (src/matrixbuilding.jl:128-150):
-// the three COO generators (:221-299, :337-418, :438-479), the four sparse() calls
-// (:41,63,92,116) and the three sparse adds (:147).
+// Replaces, on the device, the whole of `transportmatrix` (src/matrixbuilding.jl:128-150): the three
+// COO generators, the four sparse() calls and the three sparse adds.  No COO is materialised.
 //
-// Gather formulation.  The reference scatters: wet cell 𝑖 pushes triplets into its own column
-// and its neighbours' columns, then sparse() sorts and sums.  Every triplet of column c comes
-// from c itself or from one of the <= 7 cells whose neighbour (in some direction) is c, so one
-// thread per grid cell rebuilds its own column of all five matrices directly:
-//   * which triplets land in column c, and in which order the reference emits them
-//     (ascending emitting wet index, then W,E,S,N,B,T, then first/second push) is a pure
-//     function of the local stencil -- duplicates are summed left-to-right in that order,
-//     first touch copies the value (sparse() keeps explicit zeros and -0.0);
-//   * T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep with absent operands +0.0, stored iff != 0
-//     (SparseArrays' map(+) drops exact zeros);
-//   * rows of a column ascend in wet index == linear index (makeindices is monotone; this is
-//     verified on the fly and reported as OTMB_ERR_NONCANONICAL_INDICES otherwise).
-// Two passes over the grid: COUNT (per-tile nnz of the five matrices + wet count) -> tile scan
-// -> FILL (recompute, block-scan for in-tile offsets, write colptr/rowval/nzval).  No COO is
-// ever materialised.  All arithmetic is Float64 with contraction off (-ffp-contract=off) so
-// each value is bit-identical to the reference's expression.
-#include "otmb_common.h"
-#include "otmb_topology.h"
+// Work decomposition: one thread per WET cell (driven by Lwet, so every lane works), one workgroup
+// (tile) per 256 consecutive wet cells = 256 consecutive columns of all five matrices.  Per tile:
+//   1. every thread builds its column in registers (otmb_tm_column.h);
+//   2. a packed 64-bit block scan gives each column's offset inside the tile for the five matrices;
+//   3. the tile's global offsets come from
+//        COUNT + tile scan + FILL   (two-phase C ABI: the caller allocates after plan), or
+//        ONEPASS                    (device-resident callers with known capacity): decoupled look-back
+//                                   over per-tile status words, so inputs are read once and outputs
+//                                   written once -- the algorithmic HBM traffic;
+//   4. entries are staged through LDS and streamed out with fully coalesced 8-byte-per-lane stores
+//      (a column's entries are contiguous, a tile's columns are contiguous).
+#include "otmb_tm_column.h"
 
 #define TM_THREADS 256
-#define TM_CHUNKS 4
-#define TM_TILE (TM_THREADS * TM_CHUNKS)
-#define TM_NF 6  // T, Tadv, TκH, TκVML, TκVdeep, wet
+#define TM_NF 5
+#define TM_MAXROWS 7  // rows per column: A, S, W, SELF, E, N|fold, B
+#define TM_STAGE (TM_THREADS * TM_MAXROWS)
 
-struct TmParams {
-    const double *phi[6];
-    const double *v, *thk, *rho;
-    double rho_s;
-    const i64 *lw;
-    const double *edge[4], *dist[4];
-    const double *area, *zt, *ml;
-    double kH, kML, kDeep;
-    int nx, ny, nz, topo, upwind;
-    i64 P, G;
-    // depth-slab partition (multi-GPU): this rank owns levels [k_own0, k_own1) of the local grid, whose
-    // other levels are halos that only act as neighbours; wet_base = global wet rank of the first owned
-    // wet cell minus 1; nnz_base[m] = entries of matrix m owned by lower-ranked slabs.
-    int k_own0, k_own1;
-    i64 wet_base;
-    i64 nnz_base[5];
-    // outputs (FILL)
-    i64 *colptr[5], *rowval[5];
-    double *nzval[5];
-    // scan state
-    uint32_t *tilesums;    // [ntiles][TM_NF]  (COUNT writes)
-    const i64 *tileoffs;   // [ntiles][TM_NF]  (FILL reads)
-    int *flags;
-};
+enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_ONEPASS = 2 };
 
 struct TmPlan {
     otmb_tm_args args;  // device pointers
-    i64 ntiles;
-    i64 nnz[5];
-    bool valid;
-    // slab (defaults: whole grid owned)
-    i64 k_own0 = 0, k_own1 = -1, wet_base = 0;
+    i64 ntiles = 0;
+    i64 nnz[5] = {0, 0, 0, 0, 0};
+    bool valid = false;
+    bool onepass_pending = false;
+    i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
 };
 
-// slots of a column: the cells that can hold a row of column c
-enum { S_A = 0, S_S = 1, S_SELF = 2, S_EC = 3, S_WC = 4, S_FQ = 5, S_N = 6, S_B = 7, NSLOT = 8 };
+// look-back status word: [63:62] flag (0 empty, 1 tile aggregate, 2 inclusive prefix), [61:0] value.
+// One naturally aligned 8-byte word written by ONE agent-scope store and polled with agent-scope loads:
+// data and tag travel together, so no fence is needed and nothing depends on workgroup placement.
+#define ST_AGG (1ull << 62)
+#define ST_PFX (2ull << 62)
+#define ST_VAL(x) ((x) & ((1ull << 62) - 1))
+#define LOOKBACK_SPIN_LIMIT (1 << 22)
 
-struct Column {
-    i64 idx[NSLOT];      // wet rank of the slot's cell (row index), 0 = no such wet cell
-    double adv[NSLOT];   // Tadv values
-    double hh[NSLOT];    // TκH values   (slots SELF, EC, WC, FQ, S, N)
-    double ml[NSLOT];    // TκVML values (slots SELF, A, B)
-    double dp[NSLOT];    // TκVdeep values
-    unsigned padv, phh, pml, pdp;  // presence masks (bit = slot)
-    unsigned bef[NSLOT];  // bef[X]: slots ordered before X in the column
-};
-
-__device__ __forceinline__ void acc(double &val, unsigned &pres, int slot, double x) {
-    // sparse(): first touch copies, later ones combine acc = acc + x in emission order
-    val = ((pres >> slot) & 1u) ? val + x : x;
-    pres |= 1u << slot;
+__device__ __forceinline__ void st_store(u64 *p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// accumulate into one of the four row-mate slots chosen at run time.  Written with value selects
-// only: an if-chain over val[slot] is turned by the optimiser into a run-time indexed access,
-// which drags the whole Column into scratch memory.
-__device__ __forceinline__ void acc_rowmate(double (&val)[NSLOT], unsigned &pres, int slot, double x) {
-    const double vS = val[S_SELF], vE = val[S_EC], vW = val[S_WC], vF = val[S_FQ];  // unconditional loads
-    const bool tS = slot == S_SELF, tE = slot == S_EC, tW = slot == S_WC, tF = slot == S_FQ;
-    const double cur = tS ? vS : (tE ? vE : (tW ? vW : vF));
-    const double nv = ((pres >> slot) & 1u) ? cur + x : x;
-    val[S_SELF] = tS ? nv : vS;
-    val[S_EC] = tE ? nv : vE;
-    val[S_WC] = tW ? nv : vW;
-    val[S_FQ] = tF ? nv : vF;
-    pres |= 1u << slot;
-}
-__device__ __forceinline__ double sel_pos(double x, int upwind) {  // max(ϕ,0) or ϕ/2  (:244,262,280)
-    return upwind ? ((x > 0.0) ? x : 0.0) : x / 2;
-}
-__device__ __forceinline__ double sel_neg(double x, int upwind) {  // min(ϕ,0) or ϕ/2  (:253,271,289)
-    return upwind ? ((x < 0.0) ? x : 0.0) : x / 2;
-}
-__device__ __forceinline__ bool nonzero(double f) { return (f > 0.0) || (f < 0.0); }
-__device__ __forceinline__ double jl_min(double a, double b) {
-    return (isnan(a) || isnan(b)) ? __builtin_nan("") : ((a < b) ? a : b);
-}
-__device__ __forceinline__ void raise_flag(int *flags, int f) {
-    if (flags[f] == 0) atomicExch(&flags[f], 1);
+__device__ __forceinline__ u64 st_load(const u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Build the column of wet cell `cell` (c = own wet rank, > 0), or -- for a land cell (c == 0) --
-// only check that no wet neighbour pushes a non-zero flux into it.
-__device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell, i64 c, Column &col) {
-    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
-    const i64 L = cell.L;
-    const int i = cell.i, j = cell.j, k = cell.k;
-    const int ie = (i + 1 < nx) ? i + 1 : 0, iw = (i > 0) ? i - 1 : nx - 1;
-    const i64 LEc = cell.row0 + ie, LWc = cell.row0 + iw;
-    const i64 LS = nb_jm1(cell, nx), LNq = nb_jp1(cell, nx, ny, p.topo);
-    const i64 LA = nb_km1(cell, p.P), LB = nb_kp1(cell, nz, p.P);
-    const bool fold = (j == ny - 1) && (LNq >= 0);  // north neighbour through the tripolar seam
-    const int ifd = nx - 1 - i;
-
-    const i64 xEc = p.lw[LEc], xWc = p.lw[LWc];
-    const i64 xS = (LS >= 0) ? p.lw[LS] : 0, xNq = (LNq >= 0) ? p.lw[LNq] : 0;
-    const i64 xA = (LA >= 0) ? p.lw[LA] : 0, xB = (LB >= 0) ? p.lw[LB] : 0;
-
-    // ---- advective fluxes pushed towards this cell by its neighbours (:244-296) -------------
-    // emitter EC pushes its west flux, WC its east flux, N-side its south flux, the fold and
-    // S-side cells their north flux, the cell above its bottom flux, the cell below its top flux.
-    const double fEc = xEc ? sel_pos(p.phi[OTMB_WEST][LEc], up) : 0.0;
-    const double fWc = xWc ? sel_neg(p.phi[OTMB_EAST][LWc], up) : 0.0;
-    const double fNq = xNq ? (fold ? sel_neg(p.phi[OTMB_NORTH][LNq], up) : sel_pos(p.phi[OTMB_SOUTH][LNq], up)) : 0.0;
-    const double fS = xS ? sel_neg(p.phi[OTMB_NORTH][LS], up) : 0.0;
-    const double fA = xA ? sel_pos(p.phi[OTMB_BOTTOM][LA], up) : 0.0;
-    const double fB = xB ? sel_neg(p.phi[OTMB_TOP][LB], up) : 0.0;  // emitter has k+1 > 1 (:290)
-    const bool aEc = nonzero(fEc), aWc = nonzero(fWc), aNq = nonzero(fNq), aS = nonzero(fS), aA = nonzero(fA),
-               aB = nonzero(fB);
-
-    if (c == 0) {
-        // land: the reference would index Lwet3D with `missing` for any of these pushes
-        if (aEc | aWc | aNq | aS | aA | aB) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-        return;
-    }
-    // own pushes towards `nothing` (closed south/north/bottom boundaries)
-    {
-        bool bad = false;
-        if (j == 0) bad |= nonzero(sel_pos(p.phi[OTMB_SOUTH][L], up));
-        if (j == ny - 1 && LNq < 0) bad |= nonzero(sel_neg(p.phi[OTMB_NORTH][L], up));
-        if (k == nz - 1) bad |= nonzero(sel_pos(p.phi[OTMB_BOTTOM][L], up));
-        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-    }
-
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) { col.idx[s] = 0; col.adv[s] = 0; col.hh[s] = 0; col.ml[s] = 0; col.dp[s] = 0; }
-    col.padv = col.phh = col.pml = col.pdp = 0;
-
-    // canonical slot of each row-mate (cells of the same (j,k) row can coincide when nx <= 2 or
-    // on the fold: north neighbour of (nx/2) is (nx/2+1), of the centre of an odd row itself)
-    const int cEC = (ie == i) ? S_SELF : S_EC;
-    const int cWC = (iw == i) ? S_SELF : ((iw == ie) ? S_EC : S_WC);
-    const int cFQ = (ifd == i) ? S_SELF : ((ifd == ie) ? S_EC : ((ifd == iw) ? cWC : S_FQ));
-
-    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_B] = xB;
-    col.idx[S_EC] = (cEC == S_EC) ? xEc : 0;
-    col.idx[S_WC] = (cWC == S_WC) ? xWc : 0;
-    col.idx[S_FQ] = (fold && cFQ == S_FQ) ? xNq : 0;
-    col.idx[S_N] = fold ? 0 : xNq;
-
-    // order of the rows inside the column: A, S, row-mates by i, N, B
-    {
-        const unsigned lo = (1u << S_A) | (1u << S_S);
-        const unsigned mates = (1u << S_SELF) | (1u << S_EC) | (1u << S_WC) | (1u << S_FQ);
-        col.bef[S_A] = 0;
-        col.bef[S_S] = 1u << S_A;
-        col.bef[S_SELF] = lo | ((ie < i) ? 1u << S_EC : 0) | ((iw < i) ? 1u << S_WC : 0) | ((ifd < i) ? 1u << S_FQ : 0);
-        col.bef[S_EC] = lo | ((i < ie) ? 1u << S_SELF : 0) | ((iw < ie) ? 1u << S_WC : 0) | ((ifd < ie) ? 1u << S_FQ : 0);
-        col.bef[S_WC] = lo | ((i < iw) ? 1u << S_SELF : 0) | ((ie < iw) ? 1u << S_EC : 0) | ((ifd < iw) ? 1u << S_FQ : 0);
-        col.bef[S_FQ] = lo | ((i < ifd) ? 1u << S_SELF : 0) | ((ie < ifd) ? 1u << S_EC : 0) | ((iw < ifd) ? 1u << S_WC : 0);
-        col.bef[S_N] = lo | mates;
-        col.bef[S_B] = lo | mates | (1u << S_N);
-    }
-
-    const double vc = p.v[L];
-    const double rc = p.rho ? p.rho[L] : p.rho_s;
-    if (isnan(rc)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
-
-    // emission order of the three row-mate emitters: ascending (i of emitter, direction W<E<S<N)
-    const int kE = ie * 4 + 0, kW = iw * 4 + 1, kF = fold ? ifd * 4 + 3 : 0x7fffffff;
-    const int rE = (kW < kE) + (kF < kE), rW = (kE < kW) + (kF < kW), rF = (kE < kF) + (kW < kF);
-
-    // ---- Tadv (pushTadvectionvalues!, :193-204): entries (row e, -ϕ/(ρ̄ v_e)), (row c, ϕ/(ρ̄ v_c)) ----
-    {
-        bool anynan = false;
-#define ADV_VALUES(ACTIVE, LX, PHI, OFF, DG)                          \
-    double OFF = 0.0, DG = 0.0;                                       \
-    if (ACTIVE) {                                                     \
-        const double rx_ = p.rho ? p.rho[LX] : p.rho_s;               \
-        const double rb_ = (rx_ + rc) / 2;                            \
-        const double mx_ = rb_ * p.v[LX];                             \
-        const double mc_ = rb_ * vc;                                  \
-        OFF = -(PHI) / mx_;                                           \
-        DG = (PHI) / mc_;                                             \
-        anynan |= isnan(OFF) | isnan(DG);                             \
-    }
-        ADV_VALUES(aA, LA, fA, oA, dA)
-        ADV_VALUES(aS, LS, -fS, oS, dS)
-        ADV_VALUES(aEc, LEc, fEc, oEc, dEc)
-        ADV_VALUES(aWc, LWc, -fWc, oWc, dWc)
-        const double phNq = fold ? -fNq : fNq;
-        ADV_VALUES(aNq, LNq, phNq, oNq, dNq)
-        ADV_VALUES(aB, LB, -fB, oB, dB)
-#undef ADV_VALUES
-        if (anynan) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
-        if (aA) { acc(col.adv[S_A], col.padv, S_A, oA); acc(col.adv[S_SELF], col.padv, S_SELF, dA); }
-        if (aS) { acc(col.adv[S_S], col.padv, S_S, oS); acc(col.adv[S_SELF], col.padv, S_SELF, dS); }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (rE == r) {
-                if (aEc) { acc_rowmate(col.adv, col.padv, cEC, oEc); acc(col.adv[S_SELF], col.padv, S_SELF, dEc); }
-            } else if (rW == r) {
-                if (aWc) { acc_rowmate(col.adv, col.padv, cWC, oWc); acc(col.adv[S_SELF], col.padv, S_SELF, dWc); }
-            } else if (rF == r) {
-                if (fold && aNq) { acc_rowmate(col.adv, col.padv, cFQ, oNq); acc(col.adv[S_SELF], col.padv, S_SELF, dNq); }
-            }
-        }
-        if (!fold && aNq) { acc(col.adv[S_N], col.padv, S_N, oNq); acc(col.adv[S_SELF], col.padv, S_SELF, dNq); }
-        if (aB) { acc(col.adv[S_B], col.padv, S_B, oB); acc(col.adv[S_SELF], col.padv, S_SELF, dB); }
-    }
-
-    // ---- TκH (:348-415, pushTmixingvalues! :426-435) ------------------------------------------
-    // For each horizontal neighbour X: a = min(thk_c*edge[c->X][c], thk_X*edge[X->c][X]) is shared by
-    // c's own push towards X (+Tval on the diagonal) and X's push towards c (-Tval' on row X).
-    {
-        const i64 s = (i64)j * nx + i;
-        const double thc = p.thk[L];
-        bool anynan = false;
-        double ownW = 0, ownE = 0, ownS = 0, ownN = 0, inW = 0, inE = 0, inS = 0, inN = 0;
-#define H_VALUES(WET, LX, SX, DCX, EDGE_XC, DIST_XC, OWN, IN)                      \
-    if (WET) {                                                                     \
-        const i64 sx_ = (SX);                                                      \
-        const double aij_ = thc * p.edge[DCX][s];                                  \
-        const double aji_ = p.thk[LX] * (EDGE_XC)[sx_];                            \
-        const double a_ = jl_min(aij_, aji_);                                      \
-        OWN = (p.kH * a_) / (p.dist[DCX][s] * vc);                                 \
-        IN = (p.kH * a_) / ((DIST_XC)[sx_] * p.v[LX]);                             \
-        anynan |= isnan(OWN) | isnan(IN);                                          \
-    }
-        H_VALUES(xWc != 0, LWc, (i64)j * nx + iw, OTMB_DIR_WEST, p.edge[OTMB_DIR_EAST], p.dist[OTMB_DIR_EAST], ownW, inW)
-        H_VALUES(xEc != 0, LEc, (i64)j * nx + ie, OTMB_DIR_EAST, p.edge[OTMB_DIR_WEST], p.dist[OTMB_DIR_WEST], ownE, inE)
-        H_VALUES(xS != 0, LS, s - nx, OTMB_DIR_SOUTH, p.edge[OTMB_DIR_NORTH], p.dist[OTMB_DIR_NORTH], ownS, inS)
-        // oppdir (:407): through the seam the neighbour's facing edge is its NORTH edge.  Pointer
-        // selects (not p.edge[runtime]) keep the kernel arguments out of scratch memory.
-        const double *edgeNc = fold ? p.edge[OTMB_DIR_NORTH] : p.edge[OTMB_DIR_SOUTH];
-        const double *distNc = fold ? p.dist[OTMB_DIR_NORTH] : p.dist[OTMB_DIR_SOUTH];
-        H_VALUES(xNq != 0, LNq, fold ? (i64)j * nx + ifd : s + nx, OTMB_DIR_NORTH, edgeNc, distNc, ownN, inN)
-#undef H_VALUES
-        if (anynan) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
-        // own pushes, direction order W, E, S, N: (c,c,+Tval); the second push (c,X,-Tval) lands in
-        // this column only when X is c itself
-        if (xWc) { acc(col.hh[S_SELF], col.phh, S_SELF, ownW); if (cWC == S_SELF) acc(col.hh[S_SELF], col.phh, S_SELF, -ownW); }
-        if (xEc) { acc(col.hh[S_SELF], col.phh, S_SELF, ownE); if (cEC == S_SELF) acc(col.hh[S_SELF], col.phh, S_SELF, -ownE); }
-        if (xS) { acc(col.hh[S_SELF], col.phh, S_SELF, ownS); }
-        if (xNq) { acc(col.hh[S_SELF], col.phh, S_SELF, ownN); if (fold && cFQ == S_SELF) acc(col.hh[S_SELF], col.phh, S_SELF, -ownN); }
-        // neighbours' second pushes (X,c,-Tval'), per row in the emitter's direction order
-        if (xS) acc(col.hh[S_S], col.phh, S_S, -inS);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (rE == r) {
-                if (xEc && cEC != S_SELF) acc_rowmate(col.hh, col.phh, cEC, -inE);
-            } else if (rW == r) {
-                if (xWc && cWC != S_SELF) acc_rowmate(col.hh, col.phh, cWC, -inW);
-            } else if (rF == r) {
-                if (fold && xNq && cFQ != S_SELF) acc_rowmate(col.hh, col.phh, cFQ, -inN);
-            }
-        }
-        if (!fold && xNq) acc(col.hh[S_N], col.phh, S_N, -inN);
-    }
-
-    // ---- TκVML / TκVdeep (:450-477) -------------------------------------------------------------
-    {
-        const i64 s = (i64)j * nx + i;
-        const double ar = p.area[s];
-        const double ztk = p.zt[k];
-        const double mld = p.ml[s];
-        const bool omc = ztk < mld;  // Ω (:85); NaN (missing) compares false
-        bool nanml = false, nandp = false;
-        if (xB) {  // from bottom (own push first, B then T)
-            const double ztb = p.zt[k + 1];
-            const double d = fabs(ztk - ztb);
-            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * p.v[LB]);
-            nandp |= isnan(ownD) | isnan(inD);
-            acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
-            acc(col.dp[S_B], col.pdp, S_B, -inD);
-            if (omc && (ztb < mld)) {
-                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * p.v[LB]);
-                nanml |= isnan(ownM) | isnan(inM);
-                acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
-                acc(col.ml[S_B], col.pml, S_B, -inM);
-            }
-        }
-        if (xA) {
-            const double zta = p.zt[k - 1];
-            const double d = fabs(ztk - zta);
-            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * p.v[LA]);
-            nandp |= isnan(ownD) | isnan(inD);
-            acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
-            acc(col.dp[S_A], col.pdp, S_A, -inD);
-            if (omc && (zta < mld)) {
-                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * p.v[LA]);
-                nanml |= isnan(ownM) | isnan(inM);
-                acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
-                acc(col.ml[S_A], col.pml, S_A, -inM);
-            }
-        }
-        if (nanml) raise_flag(p.flags, FLAG_TKVML_NAN);    // :90
-        if (nandp) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
-    }
-}
-
-// ---- fast path ---------------------------------------------------------------------------------
-// Regular cells: nx >= 3 and not on the tripolar seam row, i.e. the W/E/S/N/A/B neighbours are
-// distinct cells.  Same arithmetic as build_column, organised for the hardware:
-//  * every load is unconditional and issued up front (addresses depend on (i,j,k) only; a
-//    neighbour that does not exist is clamped to the cell itself and masked afterwards), so one
-//    memory round trip covers the whole stencil instead of one per `if`;
-//  * 32-bit byte offsets from tile-uniform base pointers (scalar base + vector offset loads);
-//  * accumulators start at -0.0: (-0.0) + x == x bit for bit for every x, which is exactly
-//    sparse()'s "first touch copies, later ones add" without tracking the first touch.
-struct TileBase {  // array pointers advanced to the tile's lowest neighbour (uniform per workgroup)
-    const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb;
-};
-__device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
-__device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
-#define NEG0 (-0.0)
-
-__device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
-                                            i64 c, Column &col) {
-    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
-    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
-    const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
-    const unsigned nx8 = (unsigned)nx * 8u, P8 = (unsigned)p.P * 8u;
-    const unsigned oE = oC + (unsigned)(di_e * 8), oW = oC + (unsigned)(di_w * 8);
-    const unsigned oS = hS ? oC - nx8 : oC, oN = hN ? oC + nx8 : oC;
-    const unsigned oA = hA ? oC - P8 : oC, oB = hB ? oC + P8 : oC;
-    const unsigned s2 = ((unsigned)j * (unsigned)nx + (unsigned)i) * 8u;
-    const unsigned sE = s2 + (unsigned)(di_e * 8), sW = s2 + (unsigned)(di_w * 8);
-    const unsigned sS = hS ? s2 - nx8 : s2, sN = hN ? s2 + nx8 : s2;
-
-    // ---- all loads ----
-    const i64 lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN), lA = ldi(tb.lw, oA),
-              lB = ldi(tb.lw, oB);
-    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
-                 gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
-    const double vC = ldd(tb.v, oC), vE = ldd(tb.v, oE), vW = ldd(tb.v, oW), vS = ldd(tb.v, oS), vN = ldd(tb.v, oN),
-                 vA = ldd(tb.v, oA), vB = ldd(tb.v, oB);
-    double rC, rE, rW, rS, rN, rA, rB;
-    if (tb.rho) {
-        rC = ldd(tb.rho, oC); rE = ldd(tb.rho, oE); rW = ldd(tb.rho, oW); rS = ldd(tb.rho, oS); rN = ldd(tb.rho, oN);
-        rA = ldd(tb.rho, oA); rB = ldd(tb.rho, oB);
-    } else {
-        rC = rE = rW = rS = rN = rA = rB = p.rho_s;
-    }
-    const double tC = ldd(tb.thk, oC), tE = ldd(tb.thk, oE), tW = ldd(tb.thk, oW), tS = ldd(tb.thk, oS),
-                 tN = ldd(tb.thk, oN);
-    const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
-               *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
-    const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
-               *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
-    const double eW_c = ldd(eWp, s2), eE_c = ldd(eEp, s2), eS_c = ldd(eSp, s2), eN_c = ldd(eNp, s2);
-    const double dW_c = ldd(dWp, s2), dE_c = ldd(dEp, s2), dS_c = ldd(dSp, s2), dN_c = ldd(dNp, s2);
-    const double eE_w = ldd(eEp, sW), dE_w = ldd(dEp, sW);  // west cell's east edge / distance to its east nbr
-    const double eW_e = ldd(eWp, sE), dW_e = ldd(dWp, sE);
-    const double eN_s = ldd(eNp, sS), dN_s = ldd(dNp, sS);
-    const double eS_n = ldd(eSp, sN), dS_n = ldd(dSp, sN);  // oppdir = south away from the seam row (:407)
-    const double ar = ldd((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
-    const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
-
-    const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
-    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
-
-    // ---- advective pushes towards this cell (:244-296) ----
-    const double fE = wE ? sel_pos(gE0, up) : 0.0;  // east cell pushes its west flux
-    const double fW = wW ? sel_neg(gW0, up) : 0.0;  // west cell pushes its east flux
-    const double fS = wS ? sel_neg(gS0, up) : 0.0;  // south cell pushes its north flux
-    const double fN = wN ? sel_pos(gN0, up) : 0.0;  // north cell pushes its south flux
-    const double fA = wA ? sel_pos(gA0, up) : 0.0;  // cell above pushes its bottom flux
-    const double fB = wB ? sel_neg(gB0, up) : 0.0;  // cell below pushes its top flux (its k > 1, :290)
-    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
-    if (c == 0) {
-        if (aE | aW | aS | aN | aA | aB) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-        return;
-    }
-    if ((j == 0) | (j == ny - 1) | (k == nz - 1)) {  // own pushes towards `nothing`
-        bool bad = false;
-        if (j == 0) bad |= nonzero(sel_pos(ldd(tb.ps, oC), up));
-        if (j == ny - 1) bad |= nonzero(sel_neg(ldd(tb.pn, oC), up));  // regular path: no seam here
-        if (k == nz - 1) bad |= nonzero(sel_pos(ldd(tb.pb, oC), up));
-        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-    }
-    if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
-
-    // row order of the column: A, S, row-mates by i, N, B.  Row-mates: W, SELF, E -- except at the
-    // periodic wrap (i == 0: SELF, E, W(nx-1);  i == nx-1: E(0), W, SELF)
-    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
-    {
-        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
-        col.bef[S_A] = 0;
-        col.bef[S_S] = 1u << S_A;
-        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
-        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
-        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
-        col.bef[S_FQ] = 0;
-        col.bef[S_N] = lo | bS | bE | bW;
-        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
-    }
-    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
-    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
-
-    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
-    {
-#define ADV1(PHI, RX, VX, OFF, DG)                \
-    const double rb##OFF = ((RX) + rC) / 2;       \
-    const double OFF = -(PHI) / (rb##OFF * (VX)); \
-    const double DG = (PHI) / (rb##OFF * vC);
-        ADV1(fA, rA, vA, oA_, dA_)
-        ADV1(-fS, rS, vS, oS_, dS_)
-        ADV1(-fW, rW, vW, oW_, dW_)
-        ADV1(fE, rE, vE, oE_, dE_)
-        ADV1(fN, rN, vN, oN_, dN_)
-        ADV1(-fB, rB, vB, oB_, dB_)
-#undef ADV1
-        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
-                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
-        if (bad) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
-        // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
-        double d = NEG0;
-        d += aA ? dA_ : NEG0;
-        d += aS ? dS_ : NEG0;
-        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
-        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
-        d += m1;
-        d += m2;
-        d += aN ? dN_ : NEG0;
-        d += aB ? dB_ : NEG0;
-        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
-        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
-        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
-                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
-    }
-    // ---- TκH (:348-415, :426-435) ----
-    {
-#define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
-    const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
-    const double OWN = (p.kH * a##OWN) / ((D_C) * vC);       \
-    const double IN = (p.kH * a##OWN) / ((D_X) * (VX));
-        H1(tW, eW_c, eE_w, dW_c, dE_w, vW, ownW, inW)
-        H1(tE, eE_c, eW_e, dE_c, dW_e, vE, ownE, inE)
-        H1(tS, eS_c, eN_s, dS_c, dN_s, vS, ownS, inS)
-        H1(tN, eN_c, eS_n, dN_c, dS_n, vN, ownN, inN)
-#undef H1
-        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
-                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
-        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
-        double h = NEG0;  // own pushes in direction order W, E, S, N
-        h += wW ? ownW : NEG0;
-        h += wE ? ownE : NEG0;
-        h += wS ? ownS : NEG0;
-        h += wN ? ownN : NEG0;
-        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
-        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
-        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
-                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
-    }
-    // ---- TκVdeep / TκVML (:450-477) ----
-    {
-        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
-        const double nD = p.kDeep * ar;
-        const double ownB = nD / (dB * vC), inB = nD / (dB * vB), ownA = nD / (dA * vC), inA = nD / (dA * vA);
-        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
-        double d = NEG0;  // own pushes: bottom then top
-        d += wB ? ownB : NEG0;
-        d += wA ? ownA : NEG0;
-        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
-        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
-        const bool omC = ztk < mld;  // Ω (:85); NaN compares false
-        const bool mB = wB & omC & (ztb < mld), mA = wA & omC & (zta < mld);
-        col.pml = 0;
-        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
-        if (mA | mB) {
-            const double nM = p.kML * ar;
-            const double mownB = nM / (dB * vC), minB = nM / (dB * vB), mownA = nM / (dA * vC), minA = nM / (dA * vA);
-            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
-            double m = NEG0;
-            m += mB ? mownB : NEG0;
-            m += mA ? mownA : NEG0;
-            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
-            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
-        }
-    }
-}
-
-// T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)
-__device__ __forceinline__ double t_value(const Column &col, int s) {
-    const double a = ((col.padv >> s) & 1u) ? col.adv[s] : 0.0;
-    const double h = ((col.phh >> s) & 1u) ? col.hh[s] : 0.0;
-    const double m = ((col.pml >> s) & 1u) ? col.ml[s] : 0.0;
-    const double d = ((col.pdp >> s) & 1u) ? col.dp[s] : 0.0;
-    return ((a + h) + m) + d;
-}
-
-template <bool FILL>
+template <int MODE>
 __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
+    __shared__ i64 s_prefix[TM_NF];
+    __shared__ int s_tile;
+    __shared__ i64 s_row[TM_STAGE];
+    __shared__ double s_val[TM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const i64 tile = blockIdx.x;
-    i64 run[TM_NF];
-#pragma unroll
-    for (int f = 0; f < TM_NF; ++f) run[f] = FILL ? p.tileoffs[tile * TM_NF + f] : 0;
-    // tile-uniform base pointers: every neighbour of every cell of the tile is at a non-negative
-    // 32-bit byte offset from them ((2P + tile) * 8 < 4 GiB is checked on the host)
-    const i64 tile0 = tile * TM_TILE;
-    const i64 base_elem = (tile0 > p.P) ? tile0 - p.P : 0;
+
+    i64 tile = blockIdx.x;
+    if (MODE == MODE_ONEPASS) {
+        // dynamic tile id: tiles start in ticket order, so every predecessor a tile waits for is already
+        // running or finished whatever order the hardware dispatches workgroups in
+        if (tid == 0) s_tile = atomicAdd(p.ticket, 1);
+        __syncthreads();
+        tile = s_tile;
+    }
+    const i64 w0 = tile * TM_THREADS;
+    const i64 w = w0 + tid;
+    const bool valid = w < p.n_own;
+
+    // tile-uniform base pointers: all neighbours of all cells of the tile sit at non-negative 32-bit
+    // byte offsets from them
+    const i64 Lmin = p.lwet[w0] - 1;
+    const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
+    const i64 Lmax = p.lwet[wlast] - 1;
+    const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
+    const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
+    if (!span_ok && tid == 0) raise_flag(p.flags, FLAG_NONCANONICAL);
     TileBase tb;
     tb.lw = (const char *)(p.lw + base_elem);
     tb.v = (const char *)(p.v + base_elem);
@@ -534,104 +89,167 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
     tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
 
-    for (int ch = 0; ch < TM_CHUNKS; ++ch) {
-        const i64 L = tile * TM_TILE + (i64)ch * TM_THREADS + tid;
-        const bool inb = L < p.G;
-        Column col;
-        i64 c = 0;
-        unsigned pT = 0;
-        if (inb) {
+    // ---- 1. the column ----
+    Column col;
+    unsigned pT = 0, nT = 0, nA = 0, nH = 0, nM = 0, nD = 0;
+    bool live = false;
+    if (valid && span_ok) {
+        const i64 L = p.lwet[w] - 1;
+        const i64 Lnext = (w + 1 < p.n_own) ? p.lwet[w + 1] - 1 : p.G;
+        const i64 c = p.wet_base + w + 1;  // this column's (global) wet rank
+        // Lwet ascending inside [Lmin, Lmax] and Lwet3D[Lwet[w]] == w + 1: together they make the wet
+        // rank monotone in the linear index, which is what orders the rows of a column
+        if (L < Lmin || L > Lmax || Lnext <= L) {
+            raise_flag(p.flags, FLAG_NONCANONICAL);
+        } else {
             const Cell cell = cell_of(L, p.nx, p.ny, p.P);
             const unsigned oC = (unsigned)(L - base_elem) * 8u;
-            c = ldi(tb.lw, oC);
-            if (cell.k < p.k_own0 || cell.k >= p.k_own1) c = -1;  // halo level: neighbour only
-            const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
-            if (c >= 0) {
+            if (ldi(tb.lw, oC) != c) {
+                raise_flag(p.flags, FLAG_NONCANONICAL);
+            } else {
+                const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
                 if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
                 else build_column(p, cell, c, col);
-            } else {
-                c = 0;
+                live = true;
+                const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s)
+                    if (((uni >> s) & 1u) && t_value(col, s) != 0.0) pT |= 1u << s;
+                nT = __popc(pT); nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
             }
         }
-        unsigned nT = 0, nA = 0, nH = 0, nM = 0, nD = 0;
-        if (c != 0) {
-            const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
+    }
+
+    // ---- 2. packed block scan: T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 bits ----
+    const u64 mine = (u64)nT | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43);
+    u64 incl = mine;
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-                if (((uni >> s) & 1u) && t_value(col, s) != 0.0) pT |= 1u << s;
-            nT = __popc(pT); nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    u64 before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < TM_THREADS / 64; ++q) {
+        const u64 v = wave_tot[q];
+        if (q < wid) before += v;
+        all += v;
+    }
+    const u64 excl = before + incl - mine;
+    const unsigned ex[5] = {(unsigned)(excl & 0x7ff), (unsigned)((excl >> 11) & 0x7ff), (unsigned)((excl >> 22) & 0x7ff),
+                            (unsigned)((excl >> 33) & 0x3ff), (unsigned)((excl >> 43) & 0x3ff)};
+    const unsigned agg[5] = {(unsigned)(all & 0x7ff), (unsigned)((all >> 11) & 0x7ff), (unsigned)((all >> 22) & 0x7ff),
+                             (unsigned)((all >> 33) & 0x3ff), (unsigned)((all >> 43) & 0x3ff)};
+
+    if (MODE == MODE_COUNT) {
+        if (tid < TM_NF) {
+            unsigned a = 0;
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m)
+                if (m == tid) a = agg[m];
+            p.tilesums[tile * TM_NF + tid] = a;
         }
-        // packed block scan: T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 | wet:9 bits
-        const u64 mine = (u64)nT | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43) |
-                         ((u64)(c != 0) << 53);
-        u64 incl = mine;
+        return;
+    }
+
+    // ---- 3. the tile's global offsets ----
+    if (MODE == MODE_FILL) {
+        if (tid < TM_NF) s_prefix[tid] = p.tileoffs[tile * TM_NF + tid];
+    } else {
+        if (wid == 0) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            u64 y = __shfl_up(incl, d);
-            if (lane >= d) incl += y;
-        }
-        if (lane == 63) wave_tot[wid] = incl;
-        __syncthreads();
-        u64 before = 0, all = 0;
+            for (int m = 0; m < TM_NF; ++m) {
+                u64 *st = p.status + m;  // status[t * TM_NF + m]
+                if (lane == 0) st_store(st + tile * TM_NF, (tile == 0 ? ST_PFX : ST_AGG) | (u64)agg[m]);
+                i64 excl_prefix = 0;
+                i64 look = tile - 1;  // nearest predecessor not yet accounted for
+                int spins = 0;
+                while (look >= 0) {
+                    const i64 t = look - lane;  // lane 0 inspects the nearest predecessor
+                    u64 sw = ST_PFX;             // positions before tile 0 read as "prefix 0"
+                    if (t >= 0) {
+                        sw = st_load(st + t * TM_NF);
+                        while ((sw >> 62) == 0 && spins < LOOKBACK_SPIN_LIMIT) {
+                            __builtin_amdgcn_s_sleep(1);
+                            sw = st_load(st + t * TM_NF);
+                            ++spins;
+                        }
+                    }
+                    if (__any((sw >> 62) == 0)) {  // bounded spin expired: report, never hang
+                        if (lane == 0) raise_flag(p.flags, FLAG_LOOKBACK_TIMEOUT);
+                        break;
+                    }
+                    const u64 is_pfx = __ballot((sw >> 62) == 2);
+                    // lanes up to and including the first one holding an inclusive prefix contribute
+                    const int first = is_pfx ? __builtin_ctzll(is_pfx) : 64;
+                    i64 contrib = (lane <= first) ? (i64)ST_VAL(sw) : 0;
 #pragma unroll
-        for (int w = 0; w < TM_THREADS / 64; ++w) {
-            const u64 v = wave_tot[w];
-            if (w < wid) before += v;
-            all += v;
-        }
-        __syncthreads();
-        const u64 excl = before + incl - mine;
-        if (FILL && c != 0) {
-            const i64 off[5] = {run[0] + (i64)(excl & 0x7ff), run[1] + (i64)((excl >> 11) & 0x7ff),
-                                run[2] + (i64)((excl >> 22) & 0x7ff), run[3] + (i64)((excl >> 33) & 0x3ff),
-                                run[4] + (i64)((excl >> 43) & 0x3ff)};
-            const i64 wetrank = run[5] + (i64)((excl >> 53) & 0x1ff);  // owned wet cells before this one
-            if (c != p.wet_base + wetrank + 1) raise_flag(p.flags, FLAG_NONCANONICAL);
-            else {
-#pragma unroll
-                for (int m = 0; m < 5; ++m) p.colptr[m][wetrank] = p.nnz_base[m] + off[m] + 1;
-                const unsigned pm[5] = {pT, col.padv, col.phh, col.pml, col.pdp};
-#pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    const i64 row = col.idx[s];
-                    if ((pT >> s) & 1u) {
-                        const i64 q = off[0] + __popc(pT & col.bef[s]);
-                        p.rowval[0][q] = row;
-                        p.nzval[0][q] = t_value(col, s);
-                    }
-                    if ((pm[1] >> s) & 1u) {
-                        const i64 q = off[1] + __popc(pm[1] & col.bef[s]);
-                        p.rowval[1][q] = row;
-                        p.nzval[1][q] = col.adv[s];
-                    }
-                    if ((pm[2] >> s) & 1u) {
-                        const i64 q = off[2] + __popc(pm[2] & col.bef[s]);
-                        p.rowval[2][q] = row;
-                        p.nzval[2][q] = col.hh[s];
-                    }
-                    if ((pm[3] >> s) & 1u) {
-                        const i64 q = off[3] + __popc(pm[3] & col.bef[s]);
-                        p.rowval[3][q] = row;
-                        p.nzval[3][q] = col.ml[s];
-                    }
-                    if ((pm[4] >> s) & 1u) {
-                        const i64 q = off[4] + __popc(pm[4] & col.bef[s]);
-                        p.rowval[4][q] = row;
-                        p.nzval[4][q] = col.dp[s];
-                    }
+                    for (int d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d);
+                    excl_prefix += contrib;
+                    if (is_pfx) break;
+                    look -= 64;
+                }
+                if (lane == 0) {
+                    if (tile != 0) st_store(st + tile * TM_NF, ST_PFX | (u64)(excl_prefix + agg[m]));
+                    s_prefix[m] = excl_prefix;
                 }
             }
         }
-        run[0] += (i64)(all & 0x7ff);
-        run[1] += (i64)((all >> 11) & 0x7ff);
-        run[2] += (i64)((all >> 22) & 0x7ff);
-        run[3] += (i64)((all >> 33) & 0x3ff);
-        run[4] += (i64)((all >> 43) & 0x3ff);
-        run[5] += (i64)((all >> 53) & 0x1ff);
     }
-    if (!FILL && tid == 0) {
+    __syncthreads();
+    i64 g0[5];
 #pragma unroll
-        for (int f = 0; f < TM_NF; ++f) p.tilesums[tile * TM_NF + f] = (uint32_t)run[f];
+    for (int m = 0; m < TM_NF; ++m) g0[m] = s_prefix[m];  // entries of matrix m before this tile (this launch)
+
+    if (MODE == MODE_ONEPASS && w0 + TM_THREADS >= p.n_own) {  // last tile: totals and the closing colptr entry
+        if (tid < TM_NF) {
+            i64 tot = 0;
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m)
+                if (m == tid) tot = g0[m] + agg[m];
+            p.totals[tid] = tot;
+            i64 *cp = (tid == 0) ? p.colptr[0] : (tid == 1) ? p.colptr[1] : (tid == 2) ? p.colptr[2] : (tid == 3) ? p.colptr[3] : p.colptr[4];
+            const i64 nb = (tid == 0) ? p.nnz_base[0] : (tid == 1) ? p.nnz_base[1] : (tid == 2) ? p.nnz_base[2] : (tid == 3) ? p.nnz_base[3] : p.nnz_base[4];
+            cp[p.n_own] = nb + tot + 1;
+        }
+    }
+
+    // ---- 4. write: colptr, then LDS-staged entries ----
+    if (live) {
+#pragma unroll
+        for (int m = 0; m < TM_NF; ++m) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
+    }
+    const unsigned pm[5] = {pT, col.padv, col.phh, col.pml, col.pdp};
+#pragma unroll
+    for (int m = 0; m < TM_NF; ++m) {
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if ((pm[m] >> s) & 1u) {
+                    const unsigned q = ex[m] + __popc(pm[m] & col.bef[s]);
+                    s_row[q] = col.idx[s];
+                    s_val[q] = (m == 0) ? t_value(col, s) : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned cnt = agg[m];
+        bool room = true;
+        if (MODE == MODE_ONEPASS) {
+            room = g0[m] + cnt <= p.cap[m];
+            if (!room && tid == 0) raise_flag(p.flags, FLAG_CAPACITY);
+        }
+        if (room) {
+            i64 *rv = p.rowval[m] + g0[m];
+            double *nz = p.nzval[m] + g0[m];
+            for (unsigned e = tid; e < cnt; e += TM_THREADS) {
+                rv[e] = s_row[e];
+                nz[e] = s_val[e];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -647,15 +265,16 @@ __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, co
 static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
     for (int f = 0; f < 6; ++f) p.phi[f] = a.phi[f];
-    p.v = a.v3d; p.thk = a.thkcello; p.rho = a.rho; p.rho_s = a.rho_scalar; p.lw = a.lwet3d;
+    p.v = a.v3d; p.thk = a.thkcello; p.rho = a.rho; p.rho_s = a.rho_scalar;
+    p.lw = (const i64 *)a.lwet3d; p.lwet = (const i64 *)a.lwet;
     for (int d = 0; d < 4; ++d) { p.edge[d] = a.edge_length[d]; p.dist[d] = a.dist_nbr[d]; }
     p.area = a.area2d; p.zt = a.zt; p.ml = a.mlotst;
     p.kH = a.kappa_h; p.kML = a.kappa_vml; p.kDeep = a.kappa_vdeep;
     p.nx = (int)a.nx; p.ny = (int)a.ny; p.nz = (int)a.nz; p.topo = a.topology; p.upwind = a.upwind;
     p.P = a.nx * a.ny; p.G = p.P * a.nz;
-    p.k_own0 = 0; p.k_own1 = (int)a.nz; p.wet_base = 0;
-    if (pl && pl->k_own1 >= 0) {
-        p.k_own0 = (int)pl->k_own0; p.k_own1 = (int)pl->k_own1; p.wet_base = pl->wet_base;
+    p.n_own = a.n_wet;
+    if (pl) {
+        p.wet_base = pl->wet_base;
         for (int m = 0; m < 5; ++m) p.nnz_base[m] = pl->nnz_base[m];
     }
     p.tilesums = (uint32_t *)ctx->blocksums.p;
@@ -666,12 +285,31 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
 static int32_t check_flags(otmb_ctx *ctx) {
     const int *f = ctx->h_flags;
     if (f[FLAG_NONCANONICAL]) return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
+    if (f[FLAG_LOOKBACK_TIMEOUT]) return otmb_fail(ctx, OTMB_ERR_HIP, "look-back spin limit reached");
     if (f[FLAG_RHO_NAN]) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // reference order: :233, loop, :39, :61, :90, :114
     if (f[FLAG_FLUX_INTO_LAND]) return otmb_fail(ctx, OTMB_ERR_FLUX_INTO_LAND);
     if (f[FLAG_TADV_NAN]) return otmb_fail(ctx, OTMB_ERR_TADV_NAN);
     if (f[FLAG_TKH_NAN]) return otmb_fail(ctx, OTMB_ERR_TKH_NAN);
     if (f[FLAG_TKVML_NAN]) return otmb_fail(ctx, OTMB_ERR_TKVML_NAN);
     if (f[FLAG_TKVDEEP_NAN]) return otmb_fail(ctx, OTMB_ERR_TKVDEEP_NAN);
+    if (f[FLAG_CAPACITY]) return otmb_fail(ctx, OTMB_ERR_CAPACITY);
+    return OTMB_OK;
+}
+
+static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a) {
+    if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    const i64 G = a->nx * a->ny * a->nz;
+    if (a->nx * a->ny >= (1ll << 27) || G >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
+    if (a->topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);
+    if (a->topology != OTMB_BIPOLAR && a->topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
+    for (int f = 0; f < 6; ++f)
+        if (!a->phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
+    for (int d = 0; d < 4; ++d)
+        if (!a->edge_length[d] || !a->dist_nbr[d]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "metrics");
+    if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst)
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null input array");
+    if (a->n_wet < 0 || a->n_wet > G || (a->n_wet > 0 && !a->lwet)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "lwet / n_wet");
+    if (!a->rho && a->rho_scalar != a->rho_scalar && a->n_wet > 0) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // :233
     return OTMB_OK;
 }
 
@@ -692,69 +330,53 @@ extern "C" {
 int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t nnz[5]) {
     if (!ctx || !a || !nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     if (ctx->plan) ctx->plan->valid = false;
-    if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
-    const i64 G = a->nx * a->ny * a->nz;
-    if (a->nx * a->ny >= (1ll << 27) || G >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
-    if (a->topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);
-    if (a->topology != OTMB_BIPOLAR && a->topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
-    for (int f = 0; f < 6; ++f)
-        if (!a->phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
-    for (int d = 0; d < 4; ++d)
-        if (!a->edge_length[d] || !a->dist_nbr[d]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "metrics");
-    if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst)
-        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null input array");
-    if (!a->rho && a->rho_scalar != a->rho_scalar && a->n_wet > 0) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // :233
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const i64 ntiles = (G + TM_TILE - 1) / TM_TILE;
     int32_t rc;
-    if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)ntiles * TM_NF * sizeof(uint32_t)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)ntiles * TM_NF * sizeof(i64)))) return rc;
+    if ((rc = validate_args(ctx, a))) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
+    if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64)))) return rc;
     if (!ctx->plan) ctx->plan = new TmPlan();
     TmPlan &pl = *ctx->plan;
     pl.args = *a;
     pl.ntiles = ntiles;
-    if (pl.k_own1 >= 0 && (pl.k_own0 < 0 || pl.k_own1 > a->nz || pl.k_own0 > pl.k_own1))
-        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "slab levels outside the local grid");
     TmParams p;
     fill_params(p, *a, ctx, &pl);
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64), ctx->stream));
-    {
-        KernelTimer kt(ctx, K_TM_COUNT);
-        hipLaunchKernelGGL(tm_kernel<false>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
-    }
-    {
-        KernelTimer kt(ctx, K_TILESCAN);
-        otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF);
+    if (ntiles > 0) {
+        {
+            KernelTimer kt(ctx, K_TM_COUNT);
+            hipLaunchKernelGGL(tm_kernel<MODE_COUNT>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+        }
+        {
+            KernelTimer kt(ctx, K_TILESCAN);
+            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = check_flags(ctx))) return rc;
-    if (ctx->h_tot[5] != a->n_wet) {
-        char msg[128];
-        snprintf(msg, sizeof msg, "n_wet = %lld but Lwet3D has %lld wet cells", (long long)a->n_wet, (long long)ctx->h_tot[5]);
-        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, msg);
-    }
     for (int m = 0; m < 5; ++m) nnz[m] = pl.nnz[m] = ctx->h_tot[m];
     pl.valid = true;
     return OTMB_OK;
 }
 
-int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t k_own0, int64_t k_own1, int64_t wet_base) {
+int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t wet_base) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
     if (!ctx->plan) ctx->plan = new TmPlan();
     ctx->plan->valid = false;
-    ctx->plan->k_own0 = k_own0; ctx->plan->k_own1 = k_own1; ctx->plan->wet_base = wet_base;
+    ctx->plan->wet_base = wet_base;
     for (int m = 0; m < 5; ++m) ctx->plan->nnz_base[m] = 0;
     return OTMB_OK;
 }
 
 int32_t otmb_transportmatrix_set_nnz_base(otmb_ctx *ctx, const int64_t nnz_base[5]) {
     if (!ctx || !nnz_base) return OTMB_ERR_INVALID_ARG;
-    if (!ctx->plan || !ctx->plan->valid) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
+    if (!ctx->plan) ctx->plan = new TmPlan();
     for (int m = 0; m < 5; ++m) ctx->plan->nnz_base[m] = nnz_base[m];
     return OTMB_OK;
 }
@@ -773,9 +395,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     }
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
-    {
+    if (pl.ntiles > 0) {
         KernelTimer kt(ctx, K_TM_FILL);
-        hipLaunchKernelGGL(tm_kernel<true>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     }
     {
         KernelTimer kt(ctx, K_TM_FINISH);
@@ -784,8 +406,66 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
                            p.nnz_base[2], p.nnz_base[3], p.nnz_base[4]);
     }
     HIP_TRY(ctx, hipGetLastError());
-    // the fill pass can still raise OTMB_ERR_NONCANONICAL_INDICES: otmb_ctx_synchronize reports it
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return OTMB_OK;
+}
+
+// One pass, asynchronous: the caller provides output buffers of known capacity (nnz per column is at
+// most 7, 7, 5, 3, 3 for T, Tadv, TκH, TκVML, TκVdeep).  Errors and the nnz are collected afterwards by
+// otmb_transportmatrix_result (which synchronises).
+int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *const colptr[5],
+                                 int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]) {
+    if (!ctx || !a || !colptr || !rowval || !nzval || !capacity) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    int32_t rc;
+    if ((rc = validate_args(ctx, a))) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
+    // look-back words [ntiles][5] + the ticket, zeroed on the stream before every launch
+    const size_t stbytes = (size_t)(ntiles + 1) * TM_NF * sizeof(u64);
+    if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
+    if (!ctx->plan) ctx->plan = new TmPlan();
+    TmPlan &pl = *ctx->plan;
+    pl.valid = false;
+    pl.args = *a;
+    pl.ntiles = ntiles;
+    TmParams p;
+    fill_params(p, *a, ctx, &pl);
+    for (int m = 0; m < 5; ++m) {
+        if (!colptr[m] || !rowval[m] || !nzval[m]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
+        p.cap[m] = capacity[m];
+    }
+    p.status = (u64 *)ctx->lookback.p;
+    p.ticket = (int *)((char *)ctx->lookback.p + stbytes);
+    int *dflags = (int *)ctx->flags.p;
+    i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
+    p.totals = dtot;
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->lookback.p, 0, stbytes + 64, ctx->stream));
+    if (ntiles > 0) {
+        KernelTimer kt(ctx, K_TM_ONEPASS);
+        hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+    } else {
+        KernelTimer kt(ctx, K_TM_FINISH);
+        hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
+                           p.colptr[3], p.colptr[4], dtot, (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2],
+                           p.nnz_base[3], p.nnz_base[4]);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    pl.onepass_pending = true;
+    return OTMB_OK;
+}
+
+int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]) {
+    if (!ctx || !nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (!ctx->plan || !ctx->plan->onepass_pending) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->plan->onepass_pending = false;
+    int32_t rc;
+    if ((rc = check_flags(ctx))) return rc;
+    for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m] = ctx->h_tot[m];
     return OTMB_OK;
 }
 

@@ -89,6 +89,7 @@ class DeviceAssembler:
         a.rho = self.rho.data_ptr() if self.rho is not None else None
         a.rho_scalar = self.rho_scalar
         a.lwet3d = self.lwet3d.data_ptr()
+        a.lwet = self.lwet.data_ptr()
         for k in range(4):
             a.edge_length[k] = self.edge[k].data_ptr()
             a.dist_nbr[k] = self.dist[k].data_ptr()
@@ -106,6 +107,7 @@ class DeviceAssembler:
     def fill(self):
         """Write the five CSC matrices into device tensors (allocated once per capacity)."""
         if self.out is None or any(self.out[m][1].numel() < self.nnz[k] for k, m in enumerate(MATS)):
+            self._out_cap = None
             self.out = {m: (torch.empty(self.N + 1, dtype=torch.int64, device=self.device),
                             torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.int64, device=self.device),
                             torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.float64, device=self.device))
@@ -117,15 +119,45 @@ class DeviceAssembler:
         return self.out
 
     def transportmatrix(self, phi):
+        """Two-phase protocol (what a caller that must size its outputs first does): plan, then fill."""
         self.plan(phi)
         return self.fill()
 
-    def step(self, umo, vmo, fill):
-        """One pass of the hot path: facefluxes -> plan -> fill, all device resident."""
-        return self.transportmatrix(self.facefluxes(umo, vmo, fill))
+    PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold
+
+    def transportmatrix_onepass(self, phi, sync=True):
+        """One-pass protocol: outputs preallocated at their upper bound, inputs read once, tile offsets by
+        decoupled look-back.  With sync=False the nnz/errors are collected later by result()."""
+        if self.out is None or getattr(self, "_out_cap", None) is None:
+            cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
+            self.out = {m: (torch.empty(self.N + 1, dtype=torch.int64, device=self.device),
+                            torch.empty(cap[k], dtype=torch.int64, device=self.device),
+                            torch.empty(cap[k], dtype=torch.float64, device=self.device)) for k, m in enumerate(MATS)}
+            self._out_cap = cap
+        a = self._args(phi)
+        cp = capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
+        rv = capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
+        nz = capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
+        caps = (C.c_int64 * 5)(*self._out_cap)
+        self.ctx.check(self.lib.otmb_transportmatrix_dev(self.ctx.handle, C.byref(a), C.byref(cp), C.byref(rv),
+                                                         C.byref(nz), C.byref(caps)))
+        return self.result() if sync else self.out
+
+    def result(self):
+        nnz = (C.c_int64 * 5)()
+        self.ctx.check(self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz)))
+        self.nnz = [int(x) for x in nnz]
+        return self.out
+
+    def step(self, umo, vmo, fill, onepass=True):
+        """One pass of the hot path, all device resident: facefluxes -> transportmatrix."""
+        phi = self.facefluxes(umo, vmo, fill)
+        return self.transportmatrix_onepass(phi) if onepass else self.transportmatrix(phi)
 
     def result_to_host(self):
         self.ctx.synchronize()
+        if any(self.out[m][1].numel() < self.nnz[k] for k, m in enumerate(MATS)):
+            raise RuntimeError("output buffers smaller than nnz")
         res = {}
         for k, m in enumerate(MATS):
             cp, rv, nz = self.out[m]

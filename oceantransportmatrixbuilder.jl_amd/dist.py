@@ -253,6 +253,11 @@ class HipSlabBackend:
         self.phi = [torch.zeros(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
         self.own0 = s["k_own0"] * self.P
         self.nown_lev = s["k_own1"] - s["k_own0"]
+        # Lwet of the owned cells: local linear indices (1-based) inside the extended grid, ascending
+        lw = np.asfortranarray(s["lwet3d"]).ravel(order="F")
+        own = np.flatnonzero(lw[self.own0:self.own0 + self.nown_lev * self.P]) + self.own0 + 1
+        assert len(own) == self.n_own
+        self.lwet = torch.from_numpy(own.astype(np.int64)).to(self.device)
 
     def facefluxes(self, umo, vmo, fill, top_below):
         o, n = self.own0, self.nown_lev * self.P
@@ -280,6 +285,7 @@ class HipSlabBackend:
         a.rho = self.rho.data_ptr() if self.rho is not None else None
         a.rho_scalar = self.rho_scalar
         a.lwet3d = self.lw.data_ptr()
+        a.lwet = self.lwet.data_ptr()
         for k in range(4):
             a.edge_length[k] = self.edge[k].data_ptr()
             a.dist_nbr[k] = self.dist_[k].data_ptr()
@@ -287,8 +293,7 @@ class HipSlabBackend:
         a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.s["kappa"]
         u, v = C.c_int32(0), C.c_int32(0)
         self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
-        self.ctx.check(self.lib.otmb_transportmatrix_set_slab(self.ctx.handle, self.s["k_own0"], self.s["k_own1"],
-                                                             self.s["wet_base"]))
+        self.ctx.check(self.lib.otmb_transportmatrix_set_slab(self.ctx.handle, self.s["wet_base"]))
         nnz = (C.c_int64 * 5)()
         self.ctx.check(self.lib.otmb_transportmatrix_plan_dev(self.ctx.handle, C.byref(a), C.byref(nnz)))
         self.nnz = [int(x) for x in nnz]

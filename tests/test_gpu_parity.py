@@ -143,3 +143,51 @@ def test_hip_reproduces_golden_fixtures(api, name):
                                  κH=kH, κVML=kML, κVdeep=kD, upwind=upwind)
         for q, m in enumerate(MATS):
             assert_csc_equal(tuple(tm[m]), gd["tm"](upwind)[q], f"{name}/{m}")
+
+
+# ---- device-resident driver: one-pass (look-back) and two-phase protocols -------------------------
+@pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold", "nx2", "tiny_bipolar"])
+def test_device_onepass_and_twophase_match_oracle(oracle, name):
+    import torch
+
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case(name)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    assert asm.N == ref["N"]
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    for onepass in (True, False, True):
+        asm.step(umo, vmo, _fill(g), onepass=onepass)
+        got = asm.result_to_host()
+        for m in MATS:
+            assert_csc_equal(got[m], rtm[m], f"{name}/{m}/onepass={onepass}")
+
+
+def test_onepass_many_tiles_lookback(oracle):
+    """A grid with several hundred tiles so that the decoupled look-back spans more than one 64-tile window."""
+    import torch
+
+    from helpers import gridmetrics_of
+    from otmb_amd import synthetic
+    from otmb_amd.device import DeviceAssembler
+
+    g = synthetic.make_grid(90, 80, 20, seed=77, rho="array")
+    gm = gridmetrics_of(g)
+    ref = oracle.makeindices(gm.v3D)
+    assert ref["N"] > 64 * 256 * 2
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True, tight=True)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    for _ in range(3):
+        asm.step(umo, vmo, 1e20, onepass=True)
+    got = asm.result_to_host()
+    for m in MATS:
+        assert_csc_equal(got[m], rtm[m], m)
