@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--rho", default="array", choices=["array", "scalar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20260501)
+    ap.add_argument("--protocol", default="twophase", choices=["twophase", "onepass"],
+                    help="twophase: count -> scan -> fill (what the C ABI's plan/fill does); onepass: decoupled look-back")
     return ap.parse_args()
 
 
@@ -145,7 +147,7 @@ def main():
             ctx = asm.ctx
 
             def step(self):
-                asm.step(umo, vmo, fill)
+                asm.step(umo, vmo, fill, onepass=(args.protocol == "onepass"))
 
             def sync(self):
                 asm.ctx.synchronize()

@@ -132,10 +132,14 @@ typedef struct {
     double kappa_h, kappa_vml, kappa_vdeep;
 } otmb_tm_args;
 
-/* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC
- * buffers): plan computes the five nnz counts (and raises the reference's errors); fill
- * writes colptr[m] (n_wet+1), rowval[m] (nnz[m]) and nzval[m] (nnz[m]) for the five matrices
- * in OTMB_T..OTMB_TKVDEEP order.  The args of the last plan are remembered by the context.  */
+/* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).
+ * plan: the nnz of the four operator matrices (exact: their patterns depend on the wet mask, the flux
+ *   signs and the mixed-layer mask only) and an UPPER BOUND for T = the union pattern (T drops entries
+ *   whose sum is exactly zero, src/matrixbuilding.jl:147 -- rare, and only known once values exist).
+ * fill (synchronous): writes colptr[m] (n_wet+1), rowval[m], nzval[m] for the five matrices in
+ *   OTMB_T..OTMB_TKVDEEP order, raises the reference's errors, compacts T if entries cancelled;
+ *   otmb_transportmatrix_nnz then gives the final counts (nnz[0] <= the planned bound).
+ * The args of the last plan are remembered by the context.                                           */
 int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                       double *const nzval[5]);
@@ -158,8 +162,10 @@ int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);
 int32_t otmb_transportmatrix_set_slab(otmb_ctx *ctx, int64_t wet_base);
 int32_t otmb_transportmatrix_set_nnz_base(otmb_ctx *ctx, const int64_t nnz_base[5]);
 int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
+int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]);
+/* host variant of fill: nnz_out receives the final counts (trim T's arrays to nnz_out[0]) */
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
-                                   double *const nzval[5]);
+                                   double *const nzval[5], int64_t nnz_out[5]);
 
 #ifdef __cplusplus
 }

@@ -164,5 +164,8 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
     rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
     nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
-    ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
-    return NT(**{name: SparseMatrixCSC(N, N, colptr[m], rowval[m], nzval[m]) for m, name in enumerate(MATS)})
+    final = (C.c_int64 * 5)()
+    ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
+    # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
+    return NT(**{name: SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]])
+                 for m, name in enumerate(MATS)})

@@ -68,7 +68,8 @@ SYMBOLS = {
     "otmb_transportmatrix_plan_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_fill_dev": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
     "otmb_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
-    "otmb_transportmatrix_fetch": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
+    "otmb_transportmatrix_fetch": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
+    "otmb_transportmatrix_nnz": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
 }
 
 _lib = None

@@ -33,7 +33,7 @@ struct otmb_ctx {
     hipStream_t stream = nullptr;  // own_stream or a borrowed one
     std::string err;
     // scratch for the scans / flags
-    DevBuf blocksums, blockoffs, flags, lookback;
+    DevBuf blocksums, blockoffs, flags, lookback, tcount, tfix[3];
     int *h_flags = nullptr;  // pinned host mirror of the flag words
     i64 *h_tot = nullptr;    // pinned host mirror of scan totals
     TmPlan *plan = nullptr;
@@ -66,7 +66,8 @@ struct KernelTimer {
 #define OTMB_NFLAGS 16
 enum {
     FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
-    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_U_VALID, FLAG_V_VALID, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY
+    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_U_VALID, FLAG_V_VALID, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY,
+    FLAG_T_CANCEL  // some T entry summed to exactly zero: T was written with gaps and needs compaction
 };
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
@@ -86,4 +87,6 @@ int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_tr
 
 // ---- device-side scan of per-tile sums (otmb_scan.hip) -------------------------------------
 // sums: [ntiles][nf] u32 ; offs: [ntiles][nf] i64 exclusive prefix ; tot: [nf] i64 (device)
-void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *tot, i64 ntiles, int nf);
+// gsum: scratch of (ntiles / 1024 + 1) * nf i64 (see otmb_scan_scratch)
+void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *tot, i64 ntiles, int nf, i64 *gsum);
+static inline size_t otmb_scan_scratch(i64 ntiles, int nf) { return (size_t)(ntiles / 1024 + 2) * nf * sizeof(i64); }

@@ -106,8 +106,8 @@ int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t 
 }
 
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
-                                   double *const nzval[5]) {
-    if (!ctx || !colptr || !rowval || !nzval) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+                                   double *const nzval[5], int64_t nnz_out[5]) {
+    if (!ctx || !colptr || !rowval || !nzval || !nnz_out) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     int64_t nnz[5];
     int64_t N;
     TRY(otmb_tm_plan_query(ctx, nnz, &N));
@@ -122,6 +122,8 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
         TRY(stage(ctx, ST_NZVAL0 + m, (size_t)nnz[m] * 8, &d)); dnz[m] = (double *)d;
     }
     TRY(otmb_transportmatrix_fill_dev(ctx, dcp, drv, dnz));
+    TRY(otmb_transportmatrix_nnz(ctx, nnz));  // T's count can only shrink (entries that summed to exactly zero)
+    for (int m = 0; m < 5; ++m) nnz_out[m] = nnz[m];
     for (int m = 0; m < 5; ++m) {
         HIP_TRY(ctx, hipMemcpyAsync(colptr[m], dcp[m], (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (nnz[m] > 0) {

@@ -52,7 +52,7 @@ extern "C" int32_t otmb_makeindices_dev(otmb_ctx *ctx, const double *v3d, int64_
     const i64 ntiles = (G + IX_TILE - 1) / IX_TILE;
     int32_t rc;
     if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)ntiles * sizeof(uint32_t)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)ntiles * sizeof(i64)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(ntiles + 1) * sizeof(i64) + otmb_scan_scratch(ntiles, 1)))) return rc;
     uint32_t *sums = (uint32_t *)ctx->blocksums.p;
     i64 *offs = (i64 *)ctx->blockoffs.p;
     i64 *dtot = (i64 *)((int *)ctx->flags.p + OTMB_NFLAGS);
@@ -63,7 +63,7 @@ extern "C" int32_t otmb_makeindices_dev(otmb_ctx *ctx, const double *v3d, int64_
     }
     {
         KernelTimer kt(ctx, K_TILESCAN);
-        otmb_launch_tilescan(ctx->stream, sums, offs, dtot, ntiles, 1);
+        otmb_launch_tilescan(ctx->stream, sums, offs, dtot, ntiles, 1, offs + ntiles + 1);
     }
     if (lwet3d || lwet || wet3d) {
         KernelTimer kt(ctx, K_IDX_WRITE);

@@ -34,10 +34,12 @@ struct TmParams {
     i64 *colptr[5], *rowval[5];
     double *nzval[5];
     i64 *totals;           // [5] nnz of this launch (one-pass mode)
+    uint8_t *tcount;       // [n_own] rows actually stored in T's column (<= the reserved union count)
     // scan state
     uint32_t *tilesums;    // [ntiles][5]  (COUNT writes)
     const i64 *tileoffs;   // [ntiles][5]  (FILL reads)
-    u64 *status;           // [ntiles][5]  decoupled look-back words (ONEPASS)
+    u64 *status;           // [n_tiles] status words, then [n_tiles][5] inclusive prefixes (ONEPASS)
+    i64 n_tiles;
     int *ticket;           // dynamic tile id (ONEPASS)
     int *flags;
 };
@@ -472,6 +474,39 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
             col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
         }
     }
+}
+
+// Presence only (regular cells): which rows the four operator matrices hold in this column -- a function
+// of the wet mask, the sign tests on the six incoming fluxes and the mixed-layer mask, no arithmetic.
+// The union is an upper bound of T's rows (map(+) drops only exact-zero sums).
+__device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
+                                              unsigned &padv, unsigned &phh, unsigned &pml, unsigned &pdp) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
+    const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
+    const unsigned nx8 = (unsigned)nx * 8u, P8 = (unsigned)p.P * 8u;
+    const unsigned oE = oC + (unsigned)(di_e * 8), oW = oC + (unsigned)(di_w * 8);
+    const unsigned oS = hS ? oC - nx8 : oC, oN = hN ? oC + nx8 : oC;
+    const unsigned oA = hA ? oC - P8 : oC, oB = hB ? oC + P8 : oC;
+    const unsigned s2 = ((unsigned)j * (unsigned)nx + (unsigned)i) * 8u;
+    const i64 lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN), lA = ldi(tb.lw, oA),
+              lB = ldi(tb.lw, oB);
+    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
+                 gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
+    const double mld = ldd((const char *)p.ml, s2);
+    const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
+    const bool wE = lE != 0, wW = lW != 0, wS = hS && lS != 0, wN = hN && lN != 0, wA = hA && lA != 0, wB = hB && lB != 0;
+    const bool aE = wE && nonzero(sel_pos(gE0, up)), aW = wW && nonzero(sel_neg(gW0, up));
+    const bool aS = wS && nonzero(sel_neg(gS0, up)), aN = wN && nonzero(sel_pos(gN0, up));
+    const bool aA = wA && nonzero(sel_pos(gA0, up)), aB = wB && nonzero(sel_neg(gB0, up));
+    padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
+           ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+    phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
+          ((unsigned)(wW | wE | wS | wN) << S_SELF);
+    pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+    const bool omC = ztk < mld;
+    const bool mB = wB & omC & (ztb < mld), mA = wA & omC & (zta < mld);
+    pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
 }
 
 // T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)

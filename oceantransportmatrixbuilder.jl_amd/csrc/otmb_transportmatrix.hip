@@ -31,6 +31,7 @@ struct TmPlan {
     bool onepass_pending = false;
     i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
+    void *outT[3] = {nullptr, nullptr, nullptr};  // T's colptr/rowval/nzval of the pending one-pass launch
 };
 
 // look-back status word: [63:62] flag (0 empty, 1 tile aggregate, 2 inclusive prefix), [61:0] value.
@@ -57,13 +58,23 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     __shared__ double s_val[TM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
+    // contiguous eighth of the tiles, so that a tile's south/north rows and the levels above/below, which
+    // the same XCD touched a little earlier, are L2 hits instead of fabric re-reads.  Speed only: any
+    // bijection is correct.
     i64 tile = blockIdx.x;
+    if (MODE != MODE_ONEPASS) {
+        const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
     if (MODE == MODE_ONEPASS) {
         // dynamic tile id: tiles start in ticket order, so every predecessor a tile waits for is already
         // running or finished whatever order the hardware dispatches workgroups in
+#ifndef OTMB_DBG_NOTICKET
         if (tid == 0) s_tile = atomicAdd(p.ticket, 1);
         __syncthreads();
         tile = s_tile;
+#endif
     }
     const i64 w0 = tile * TM_THREADS;
     const i64 w = w0 + tid;
@@ -90,8 +101,11 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
 
     // ---- 1. the column ----
+    // T's rows are RESERVED as the union of the four operators' rows (known without arithmetic); the rows
+    // actually stored are those whose sum is non-zero (:147).  Exact cancellation is rare: the column is
+    // written left-aligned in its reserved slots, the shortfall is flagged and the host compacts T.
     Column col;
-    unsigned pT = 0, nT = 0, nA = 0, nH = 0, nM = 0, nD = 0;
+    unsigned pT = 0, nU = 0, nA = 0, nH = 0, nM = 0, nD = 0;
     bool live = false;
     if (valid && span_ok) {
         const i64 L = p.lwet[w] - 1;
@@ -108,20 +122,28 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
                 raise_flag(p.flags, FLAG_NONCANONICAL);
             } else {
                 const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
-                if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
-                else build_column(p, cell, c, col);
+                if (MODE == MODE_COUNT && regular) {
+                    fast_presence(p, tb, oC, cell.i, cell.j, cell.k, col.padv, col.phh, col.pml, col.pdp);
+                } else {
+                    if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+                    else build_column(p, cell, c, col);
+                }
                 live = true;
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
+                nU = __popc(uni); nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
+                if (MODE != MODE_COUNT) {
 #pragma unroll
-                for (int s = 0; s < NSLOT; ++s)
-                    if (((uni >> s) & 1u) && t_value(col, s) != 0.0) pT |= 1u << s;
-                nT = __popc(pT); nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
+                    for (int s = 0; s < NSLOT; ++s)
+                        if (((uni >> s) & 1u) && t_value(col, s) != 0.0) pT |= 1u << s;
+                    if (pT != uni) raise_flag(p.flags, FLAG_T_CANCEL);
+                    p.tcount[w] = (uint8_t)__popc(pT);
+                }
             }
         }
     }
 
     // ---- 2. packed block scan: T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 bits ----
-    const u64 mine = (u64)nT | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43);
+    const u64 mine = (u64)nU | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43);
     u64 incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -158,42 +180,89 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     if (MODE == MODE_FILL) {
         if (tid < TM_NF) s_prefix[tid] = p.tileoffs[tile * TM_NF + tid];
     } else {
-        if (wid == 0) {
+#ifdef OTMB_DBG_NOLOOKBACK  // timing experiment only: fake, in-bounds offsets
+        if (tid < TM_NF) s_prefix[tid] = tile * (tid < 2 ? 1792 : (tid == 2 ? 1280 : 768));
+        if (false)
+#else
+        if (wid == 0)
+#endif
+        {
+            // One status word per tile: flag | the tile's five aggregates packed as in the block scan (55
+            // bits).  A predecessor therefore costs ONE load, whatever the number of matrices.  A tile
+            // whose inclusive prefixes are known stores them to prefix[tile][0..4] with agent-scope
+            // (write-through) stores, drains them (s_waitcnt vmcnt(0)) and only then flips its status word
+            // to ST_PFX; readers take the five prefixes with agent-scope loads after seeing the flag.
+            u64 *status = p.status;
+            i64 *prefix = (i64 *)(p.status + p.n_tiles);
+            if (tile == 0) {
+                if (lane < TM_NF) {
+                    i64 v = 0;
 #pragma unroll
-            for (int m = 0; m < TM_NF; ++m) {
-                u64 *st = p.status + m;  // status[t * TM_NF + m]
-                if (lane == 0) st_store(st + tile * TM_NF, (tile == 0 ? ST_PFX : ST_AGG) | (u64)agg[m]);
-                i64 excl_prefix = 0;
+                    for (int m = 0; m < TM_NF; ++m)
+                        if (m == lane) v = agg[m];
+                    st_store((u64 *)&prefix[lane], (u64)v);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) st_store(&status[0], ST_PFX | all);
+                if (lane < TM_NF) s_prefix[lane] = 0;
+            } else {
+                if (lane == 0) st_store(&status[tile], ST_AGG | all);
+                i64 acc[TM_NF] = {0, 0, 0, 0, 0};
                 i64 look = tile - 1;  // nearest predecessor not yet accounted for
                 int spins = 0;
-                while (look >= 0) {
+                bool ok = true;
+                while (true) {
                     const i64 t = look - lane;  // lane 0 inspects the nearest predecessor
-                    u64 sw = ST_PFX;             // positions before tile 0 read as "prefix 0"
+                    u64 sw = ST_AGG;             // positions before tile 0: empty aggregate (tile 0 always ends the walk)
                     if (t >= 0) {
-                        sw = st_load(st + t * TM_NF);
+                        sw = st_load(&status[t]);
                         while ((sw >> 62) == 0 && spins < LOOKBACK_SPIN_LIMIT) {
                             __builtin_amdgcn_s_sleep(1);
-                            sw = st_load(st + t * TM_NF);
+                            sw = st_load(&status[t]);
                             ++spins;
                         }
                     }
                     if (__any((sw >> 62) == 0)) {  // bounded spin expired: report, never hang
                         if (lane == 0) raise_flag(p.flags, FLAG_LOOKBACK_TIMEOUT);
+                        ok = false;
                         break;
                     }
                     const u64 is_pfx = __ballot((sw >> 62) == 2);
-                    // lanes up to and including the first one holding an inclusive prefix contribute
                     const int first = is_pfx ? __builtin_ctzll(is_pfx) : 64;
-                    i64 contrib = (lane <= first) ? (i64)ST_VAL(sw) : 0;
+                    // tiles nearer than the first prefix holder contribute their aggregates
+                    const u64 mineagg = (lane < first) ? sw : 0;
+                    int part[TM_NF] = {(int)(mineagg & 0x7ff), (int)((mineagg >> 11) & 0x7ff), (int)((mineagg >> 22) & 0x7ff),
+                                       (int)((mineagg >> 33) & 0x3ff), (int)((mineagg >> 43) & 0x3ff)};
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d);
-                    excl_prefix += contrib;
-                    if (is_pfx) break;
+                    for (int m = 0; m < TM_NF; ++m) {
+                        int x = part[m];
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+                        acc[m] += x;
+                    }
+                    if (is_pfx) {  // the holder's inclusive prefixes end the walk
+                        const i64 th = look - first;
+                        i64 pv = 0;
+                        if (lane < TM_NF) pv = (i64)st_load((const u64 *)&prefix[th * TM_NF + lane]);
+#pragma unroll
+                        for (int m = 0; m < TM_NF; ++m) acc[m] += __shfl(pv, m);
+                        break;
+                    }
                     look -= 64;
                 }
-                if (lane == 0) {
-                    if (tile != 0) st_store(st + tile * TM_NF, ST_PFX | (u64)(excl_prefix + agg[m]));
-                    s_prefix[m] = excl_prefix;
+                if (ok) {
+                    if (lane < TM_NF) {
+                        i64 e = 0, v = 0;
+#pragma unroll
+                        for (int m = 0; m < TM_NF; ++m)
+                            if (m == lane) { e = acc[m]; v = acc[m] + agg[m]; }
+                        st_store((u64 *)&prefix[tile * TM_NF + lane], (u64)v);
+                        s_prefix[lane] = e;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) st_store(&status[tile], ST_PFX | all);
+                } else if (lane < TM_NF) {
+                    s_prefix[lane] = 0;
                 }
             }
         }
@@ -261,6 +330,62 @@ __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, co
     }
 }
 
+// ---- rare path: T had exact-zero sums, so its columns were written left-aligned in slots reserved for the
+// union pattern.  Compact: per-column actual counts (tcount) -> scan -> move.  One thread per column.
+#define TFIX_THREADS 256
+#define TFIX_PER 4
+__global__ __launch_bounds__(TFIX_THREADS) void tfix_count(const uint8_t *__restrict__ tcount, i64 n, uint32_t *tilesums) {
+    __shared__ unsigned part[TFIX_THREADS / 64];
+    unsigned x = 0;
+    for (int q = 0; q < TFIX_PER; ++q) {
+        const i64 c = ((i64)blockIdx.x * TFIX_PER + q) * TFIX_THREADS + threadIdx.x;
+        if (c < n) x += tcount[c];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) tilesums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(TFIX_THREADS) void tfix_move(const uint8_t *__restrict__ tcount, i64 n, const i64 *__restrict__ tileoffs,
+                                                          const i64 *__restrict__ old_colptr, const i64 *__restrict__ old_row,
+                                                          const double *__restrict__ old_val, i64 nnz_base, i64 *new_colptr,
+                                                          i64 *new_row, double *new_val) {
+    __shared__ unsigned wave_tot[TFIX_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    i64 run = tileoffs[blockIdx.x];
+    for (int q = 0; q < TFIX_PER; ++q) {
+        const i64 c = ((i64)blockIdx.x * TFIX_PER + q) * TFIX_THREADS + tid;
+        const unsigned mine = (c < n) ? tcount[c] : 0;
+        unsigned incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < TFIX_THREADS / 64; ++w) {
+            const unsigned v = wave_tot[w];
+            if (w < wid) before += v;
+            all += v;
+        }
+        __syncthreads();
+        if (c < n) {
+            const i64 dst = run + before + incl - mine;  // entries before this column (this launch)
+            const i64 src = old_colptr[c] - 1 - nnz_base;
+            new_colptr[c] = nnz_base + dst + 1;
+            for (unsigned e = 0; e < mine; ++e) {
+                new_row[dst + e] = old_row[src + e];
+                new_val[dst + e] = old_val[src + e];
+            }
+        }
+        run += all;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------
 static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
@@ -313,6 +438,43 @@ static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a) {
     return OTMB_OK;
 }
 
+
+// After a fill/one-pass launch has completed: if some T entries cancelled, compact T in place (through
+// temporaries) and correct nnz[0].  The stream is idle on entry.
+static int32_t t_fixup(otmb_ctx *ctx, TmPlan &pl, i64 *colptrT, i64 *rowvalT, double *nzvalT) {
+    const i64 n = pl.args.n_wet;
+    if (n == 0) return OTMB_OK;
+    const i64 per = (i64)TFIX_THREADS * TFIX_PER;
+    const i64 nt = (n + per - 1) / per;
+    int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)(nt + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(nt + 1) * sizeof(i64) + otmb_scan_scratch(nt, 1)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tfix[0], (size_t)(n + 1) * sizeof(i64)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tfix[1], (size_t)(pl.nnz[0] + 1) * sizeof(i64)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tfix[2], (size_t)(pl.nnz[0] + 1) * sizeof(double)))) return rc;
+    int *dflags = (int *)ctx->flags.p;
+    i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS) + 8;
+    const uint8_t *tc = (const uint8_t *)ctx->tcount.p;
+    hipLaunchKernelGGL(tfix_count, dim3((unsigned)nt), dim3(TFIX_THREADS), 0, ctx->stream, tc, n, (uint32_t *)ctx->blocksums.p);
+    otmb_launch_tilescan(ctx->stream, (const uint32_t *)ctx->blocksums.p, (i64 *)ctx->blockoffs.p, dtot, nt, 1,
+                         (i64 *)ctx->blockoffs.p + (nt + 1));
+    hipLaunchKernelGGL(tfix_move, dim3((unsigned)nt), dim3(TFIX_THREADS), 0, ctx->stream, tc, n, (const i64 *)ctx->blockoffs.p,
+                       (const i64 *)colptrT, (const i64 *)rowvalT, (const double *)nzvalT, pl.nnz_base[0],
+                       (i64 *)ctx->tfix[0].p, (i64 *)ctx->tfix[1].p, (double *)ctx->tfix[2].p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot + 8, dtot, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const i64 actual = ctx->h_tot[8];
+    HIP_TRY(ctx, hipMemcpyAsync(colptrT, ctx->tfix[0].p, (size_t)n * sizeof(i64), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(rowvalT, ctx->tfix[1].p, (size_t)actual * sizeof(i64), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(nzvalT, ctx->tfix[2].p, (size_t)actual * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const i64 last = pl.nnz_base[0] + actual + 1;
+    HIP_TRY(ctx, hipMemcpyAsync(colptrT + n, &last, sizeof(i64), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pl.nnz[0] = actual;
+    return OTMB_OK;
+}
+
 void otmb_tm_plan_free(otmb_ctx *ctx) {
     delete ctx->plan;
     ctx->plan = nullptr;
@@ -335,7 +497,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
     if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
     if (!ctx->plan) ctx->plan = new TmPlan();
     TmPlan &pl = *ctx->plan;
     pl.args = *a;
@@ -352,7 +514,8 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         }
         {
             KernelTimer kt(ctx, K_TILESCAN);
-            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF);
+            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF,
+                                 (i64 *)ctx->blockoffs.p + (ntiles + 1) * TM_NF);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -393,6 +556,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
         if (!colptr[m] || (pl.nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
     }
+    int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)pl.args.n_wet + 16))) return rc;
+    p.tcount = (uint8_t *)ctx->tcount.p;
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     if (pl.ntiles > 0) {
@@ -407,6 +573,19 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // the values exist only now: raise the reference's errors, and repair T if entries cancelled
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = check_flags(ctx))) { pl.valid = false; return rc; }
+    if (ctx->h_flags[FLAG_T_CANCEL]) {
+        if ((rc = t_fixup(ctx, pl, p.colptr[0], p.rowval[0], p.nzval[0]))) return rc;
+    }
+    return OTMB_OK;
+}
+
+int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]) {
+    if (!ctx || !nnz) return OTMB_ERR_INVALID_ARG;
+    if (!ctx->plan) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
+    for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m];
     return OTMB_OK;
 }
 
@@ -421,7 +600,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
     // look-back words [ntiles][5] + the ticket, zeroed on the stream before every launch
-    const size_t stbytes = (size_t)(ntiles + 1) * TM_NF * sizeof(u64);
+    const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);
     if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
     if (!ctx->plan) ctx->plan = new TmPlan();
     TmPlan &pl = *ctx->plan;
@@ -435,7 +614,11 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
         p.cap[m] = capacity[m];
     }
+    if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)a->n_wet + 16))) return rc;
+    p.tcount = (uint8_t *)ctx->tcount.p;
+    pl.outT[0] = p.colptr[0]; pl.outT[1] = p.rowval[0]; pl.outT[2] = p.nzval[0];
     p.status = (u64 *)ctx->lookback.p;
+    p.n_tiles = ntiles + 1;
     p.ticket = (int *)((char *)ctx->lookback.p + stbytes);
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
@@ -465,7 +648,12 @@ int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]) {
     ctx->plan->onepass_pending = false;
     int32_t rc;
     if ((rc = check_flags(ctx))) return rc;
-    for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m] = ctx->h_tot[m];
+    for (int m = 0; m < 5; ++m) ctx->plan->nnz[m] = ctx->h_tot[m];
+    if (ctx->h_flags[FLAG_T_CANCEL]) {
+        TmPlan &pl = *ctx->plan;
+        if ((rc = t_fixup(ctx, pl, (i64 *)pl.outT[0], (i64 *)pl.outT[1], (double *)pl.outT[2]))) return rc;
+    }
+    for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m];
     return OTMB_OK;
 }
 

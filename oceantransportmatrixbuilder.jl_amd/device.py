@@ -116,6 +116,9 @@ class DeviceAssembler:
         rv = capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
         nz = capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
         self.ctx.check(self.lib.otmb_transportmatrix_fill_dev(self.ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
+        final = (C.c_int64 * 5)()
+        self.ctx.check(self.lib.otmb_transportmatrix_nnz(self.ctx.handle, C.byref(final)))
+        self.nnz = [int(x) for x in final]  # T's planned count is an upper bound
         return self.out
 
     def transportmatrix(self, phi):
@@ -149,7 +152,7 @@ class DeviceAssembler:
         self.nnz = [int(x) for x in nnz]
         return self.out
 
-    def step(self, umo, vmo, fill, onepass=True):
+    def step(self, umo, vmo, fill, onepass=False):
         """One pass of the hot path, all device resident: facefluxes -> transportmatrix."""
         phi = self.facefluxes(umo, vmo, fill)
         return self.transportmatrix_onepass(phi) if onepass else self.transportmatrix(phi)

@@ -209,10 +209,18 @@ class SlabRunner:
         allv = cm.allgather_i64(list(nnz) + [int(uv[0]), int(uv[1])], self.device)
         if not (allv[:, 5].any() and allv[:, 6].any()):
             raise AssertionError("all umo or vmo values are NaN or _FillValue")  # velocities.jl:199-200
-        self.nnz_all = allv[:, :5]
         self.nnz_base = allv[: self.rank, :5].sum(axis=0) if self.rank > 0 else np.zeros(5, dtype=np.int64)
+        out = self.be.fill(self.nnz_base)
+        # plan's count for T is the union-pattern bound; a slab whose T lost entries (exact-zero sums,
+        # matrixbuilding.jl:147) shifts the T offsets of every slab below it
+        t_all = cm.allgather_i64([int(self.be.nnz[0])], self.device)[:, 0]
+        t_base = int(t_all[: self.rank].sum())
+        if t_base != int(self.nnz_base[0]):
+            self.be.shift_T_colptr(t_base - int(self.nnz_base[0]))
+            self.nnz_base[0] = t_base
         self.nnz_global = allv[:, :5].sum(axis=0)
-        return self.be.fill(self.nnz_base)
+        self.nnz_global[0] = int(t_all.sum())
+        return out
 
     def sync(self):
         self.be.sync()
@@ -311,7 +319,13 @@ class HipSlabBackend:
         rv = self.capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
         nz = self.capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
         self.ctx.check(self.lib.otmb_transportmatrix_fill_dev(self.ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
+        final = (C.c_int64 * 5)()
+        self.ctx.check(self.lib.otmb_transportmatrix_nnz(self.ctx.handle, C.byref(final)))
+        self.nnz = [int(x) for x in final]
         return self.out
+
+    def shift_T_colptr(self, delta):
+        self.out[MATS[0]][0].add_(int(delta))
 
     def sync(self):
         self.ctx.synchronize()

@@ -71,5 +71,9 @@ class OracleSlabBackend:
         self.out = {m: (self.cols[m][0] + int(nnz_base[k]) + 1, self.cols[m][1], self.cols[m][2]) for k, m in enumerate(MATS)}
         return self.out
 
+    def shift_T_colptr(self, delta):
+        cp, rv, nz = self.out[MATS[0]]
+        self.out[MATS[0]] = (cp + int(delta), rv, nz)
+
     def sync(self):
         pass
