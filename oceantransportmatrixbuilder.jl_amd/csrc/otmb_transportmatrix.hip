@@ -18,6 +18,9 @@
 
 #define TM_THREADS 256
 #define TM_NF 5
+#ifndef TM_WAVES_PER_SIMD
+#define TM_WAVES_PER_SIMD 3  // measured: capping at 128 VGPRs (4 waves/SIMD) spills and is 8 % slower
+#endif
 #define TM_MAXROWS 7  // rows per column: A, S, W, SELF, E, N|fold, B
 #define TM_STAGE (TM_THREADS * TM_MAXROWS)
 
@@ -50,7 +53,7 @@ __device__ __forceinline__ u64 st_load(const u64 *p) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
+__global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
     __shared__ int s_tile;
@@ -286,39 +289,51 @@ __global__ __launch_bounds__(TM_THREADS) void tm_kernel(const TmParams p) {
     }
 
     // ---- 4. write: colptr, then LDS-staged entries ----
+    // Each wave stages the entries of ITS 64 columns in its own LDS region and streams them out itself:
+    // a wave's columns are contiguous, so its entries of matrix m are one contiguous run starting at
+    // g0[m] + (entries of the tile's earlier waves).  No workgroup barrier is needed in this phase.
     if (live) {
 #pragma unroll
         for (int m = 0; m < TM_NF; ++m) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
     }
     const unsigned pm[5] = {pT, col.padv, col.phh, col.pml, col.pdp};
+    const unsigned wb[5] = {(unsigned)(before & 0x7ff), (unsigned)((before >> 11) & 0x7ff), (unsigned)((before >> 22) & 0x7ff),
+                            (unsigned)((before >> 33) & 0x3ff), (unsigned)((before >> 43) & 0x3ff)};
+    const u64 wtot = __shfl(incl, 63);  // this wave's totals (packed)
+    const unsigned wc[5] = {(unsigned)(wtot & 0x7ff), (unsigned)((wtot >> 11) & 0x7ff), (unsigned)((wtot >> 22) & 0x7ff),
+                            (unsigned)((wtot >> 33) & 0x3ff), (unsigned)((wtot >> 43) & 0x3ff)};
+    i64 *my_row = s_row + wid * (64 * TM_MAXROWS);
+    double *my_val = s_val + wid * (64 * TM_MAXROWS);
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) {
         if (live) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 if ((pm[m] >> s) & 1u) {
-                    const unsigned q = ex[m] + __popc(pm[m] & col.bef[s]);
-                    s_row[q] = col.idx[s];
-                    s_val[q] = (m == 0) ? t_value(col, s) : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
+                    const unsigned q = ex[m] - wb[m] + __popc(pm[m] & col.bef[s]);  // position inside the wave's run
+                    my_row[q] = col.idx[s];
+                    my_val[q] = (m == 0) ? t_value(col, s) : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
                 }
             }
         }
-        __syncthreads();
-        const unsigned cnt = agg[m];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const unsigned cnt = wc[m];
         bool room = true;
         if (MODE == MODE_ONEPASS) {
-            room = g0[m] + cnt <= p.cap[m];
-            if (!room && tid == 0) raise_flag(p.flags, FLAG_CAPACITY);
+            room = g0[m] + wb[m] + cnt <= p.cap[m];
+            if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
         }
         if (room) {
-            i64 *rv = p.rowval[m] + g0[m];
-            double *nz = p.nzval[m] + g0[m];
-            for (unsigned e = tid; e < cnt; e += TM_THREADS) {
-                rv[e] = s_row[e];
-                nz[e] = s_val[e];
+            i64 *rv = p.rowval[m] + g0[m] + wb[m];
+            double *nz = p.nzval[m] + g0[m] + wb[m];
+            for (unsigned e = lane; e < cnt; e += 64) {
+                rv[e] = my_row[e];
+                nz[e] = my_val[e];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
