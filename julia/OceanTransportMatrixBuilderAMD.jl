@@ -1,0 +1,168 @@
+# OceanTransportMatrixBuilderAMD.jl -- Julia host shim over libotmb_hip.so (include/otmb.h).
+#
+# Drop-in for the hot path of OceanTransportMatrixBuilder.jl v0.8.3: the same exported names, keyword
+# arguments, return NamedTuples and error messages as the reference
+#   makeindices                 src/matrixbuilding.jl:10-24
+#   facefluxesfrommasstransport src/velocities.jl:118-130   (facefluxes :190-255, nofluxboundaries! :154-179)
+#   transportmatrix             src/matrixbuilding.jl:128-150
+# Everything else (makegridmetrics, velocity2fluxes, lump_and_spray, ...) is re-exported from the
+# reference package unchanged, so `using OceanTransportMatrixBuilderAMD` replaces
+# `using OceanTransportMatrixBuilder` in a TMIP script.
+#
+# NOTE: no Julia toolchain exists in the build image, so this file has never been executed there; it is
+# kept thin and mechanical (argument flattening + ccall) and mirrors, line for line, the Python host
+# layer oceantransportmatrixbuilder.jl_amd/api.py, which IS exercised by the GPU test-suite through the
+# same C entry points.
+module OceanTransportMatrixBuilderAMD
+
+using SparseArrays
+using Libdl
+import OceanTransportMatrixBuilder as OTMB
+
+# re-export the untouched part of the reference API
+using OceanTransportMatrixBuilder: makegridmetrics, velocity2fluxes, fluxes2velocity, facefluxesfromvelocities
+export makegridmetrics, velocity2fluxes, fluxes2velocity, facefluxesfromvelocities
+export makeindices, facefluxesfrommasstransport, facefluxes, transportmatrix
+
+const LIBPATH = get(ENV, "OTMB_HIP_LIB", joinpath(@__DIR__, "..", "oceantransportmatrixbuilder.jl_amd", "lib", "libotmb_hip.so"))
+const lib = Ref{Ptr{Cvoid}}(C_NULL)
+const ctx = Ref{Ptr{Cvoid}}(C_NULL)
+
+function __init__()
+    # one HIP runtime per process: load ROCm's before the library (AMDGPU.jl users already have it)
+    Libdl.dlopen(get(ENV, "OTMB_HIP_RUNTIME", "/opt/rocm/lib/libamdhip64.so"), Libdl.RTLD_GLOBAL)
+    lib[] = Libdl.dlopen(LIBPATH)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall(Libdl.dlsym(lib[], :otmb_ctx_create), Int32, (Int32, Ptr{Ptr{Cvoid}}), parse(Int32, get(ENV, "OTMB_DEVICE", "0")), h)
+    rc == 0 || error("otmb_ctx_create failed (status $rc): is a ROCm GPU visible?")
+    ctx[] = h[]
+    atexit(() -> ccall(Libdl.dlsym(lib[], :otmb_ctx_destroy), Cvoid, (Ptr{Cvoid},), ctx[]))
+end
+
+sym(name) = Libdl.dlsym(lib[], name)
+
+# status -> the reference's own exception types and texts (include/otmb.h, otmb_status)
+function check(rc::Int32)
+    rc == 0 && return
+    msg = unsafe_string(ccall(sym(:otmb_last_error), Cstring, (Ptr{Cvoid},), ctx[]))
+    rc == 8 && throw(AssertionError(msg))      # velocities.jl:199-200
+    rc == 11 && throw(ArgumentError(msg))
+    error(msg)                                 # ErrorException: "Tadv contains NaNs." etc.
+end
+
+topologykind(g) = g isa OTMB.BipolarGridTopology ? Int32(0) : g isa OTMB.TripolarGridTopology ? Int32(1) : Int32(2)
+
+"""
+    makeindices(v3D)
+
+Same return as the reference (matrixbuilding.jl:23): `(; wet3D, L, Lwet, N, Lwet3D, C)`.
+"""
+function makeindices(v3D)
+    v = Array{Float64,3}(v3D)
+    nx, ny, nz = size(v)
+    lwet3d = Array{Int64,3}(undef, nx, ny, nz)
+    lwet = Vector{Int64}(undef, length(v))
+    wet = Array{UInt8,3}(undef, nx, ny, nz)
+    N = Ref{Int64}(0)
+    check(ccall(sym(:otmb_makeindices), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{UInt8}, Ptr{Int64}),
+        ctx[], v, nx, ny, nz, lwet3d, lwet, wet, N))
+    resize!(lwet, N[])
+    wet3D = BitArray(wet .!= 0)
+    Lwet3D = Array{Union{Int,Missing},3}(missing, nx, ny, nz)   # the reference's element type
+    Lwet3D[lwet] .= 1:N[]
+    return (; wet3D, L = LinearIndices((nx, ny, nz)), Lwet = lwet, N = N[], Lwet3D, C = CartesianIndices((nx, ny, nz)))
+end
+
+"""
+    facefluxes(umo, vmo, gridmetrics, indices; FillValue)
+
+velocities.jl:190-255.  `umo`/`vmo` are not modified.
+"""
+function facefluxes(umo, vmo, gridmetrics, indices; FillValue)
+    is32 = eltype(umo) == Float32 && eltype(vmo) == Float32
+    T = is32 ? Float32 : Float64
+    u = Array{T,3}(umo); v = Array{T,3}(vmo)          # velocities.jl:125-126 happens on the device
+    nx, ny, nz = size(u)
+    wet = Array{UInt8,3}(indices.wet3D)
+    ϕ = [Array{Float64,3}(undef, nx, ny, nz) for _ in 1:6]   # east west north south top bottom
+    ptrs = [pointer(a) for a in ϕ]
+    GC.@preserve ϕ check(ccall(sym(:otmb_facefluxes), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{UInt8}, Float64, Int64, Int64, Int64, Int32, Ptr{Ptr{Float64}}),
+        ctx[], u, v, Int32(is32), wet, Float64(FillValue), nx, ny, nz, topologykind(gridmetrics.gridtopology), ptrs))
+    return (east = ϕ[1], west = ϕ[2], north = ϕ[3], south = ϕ[4], top = ϕ[5], bottom = ϕ[6])
+end
+
+function facefluxesfrommasstransport(; umo, vmo, gridmetrics, indices)
+    FillValue = umo.properties["_FillValue"]
+    @assert isequal(FillValue, vmo.properties["_FillValue"])     # velocities.jl:121
+    return facefluxes(umo, vmo, gridmetrics, indices; FillValue)
+end
+
+# mirror of otmb_tm_args (include/otmb.h); isbits, passed by reference
+struct TmArgs
+    nx::Int64; ny::Int64; nz::Int64
+    topology::Int32; upwind::Int32
+    n_wet::Int64
+    phi::NTuple{6,Ptr{Float64}}
+    v3d::Ptr{Float64}; thkcello::Ptr{Float64}
+    rho::Ptr{Float64}; rho_scalar::Float64
+    lwet3d::Ptr{Int64}; lwet::Ptr{Int64}
+    edge_length::NTuple{4,Ptr{Float64}}
+    dist_nbr::NTuple{4,Ptr{Float64}}
+    area2d::Ptr{Float64}; zt::Ptr{Float64}; mlotst::Ptr{Float64}
+    kappa_h::Float64; kappa_vml::Float64; kappa_vdeep::Float64
+end
+
+const HDIRS = (:west, :east, :south, :north)      # OTMB_DIR_*
+f64(a) = Array{Float64}(replace(a, missing => NaN))
+
+"""
+    transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, Tadv, TκH, TκVML, TκVdeep, upwind)
+
+matrixbuilding.jl:128-150.  Returns `(; T, Tadv, TκH, TκVML, TκVdeep)` as `SparseMatrixCSC{Float64,Int64}`;
+the library writes colptr/rowval/nzval straight into the Julia-owned vectors.
+"""
+function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
+        κH = 500.0, κVML = 0.1, κVdeep = 1.0e-5,
+        Tadv = nothing, TκH = nothing, TκVML = nothing, TκVdeep = nothing, upwind = true)
+    if !(isnothing(Tadv) && isnothing(TκH) && isnothing(TκVML) && isnothing(TκVdeep))
+        # precomputed operators (matrixbuilding.jl:140-143): build the missing ones here, add on the host
+        r = transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind)
+        A = something(Tadv, r.Tadv); H = something(TκH, r.TκH); M = something(TκVML, r.TκVML); D = something(TκVdeep, r.TκVdeep)
+        return (; T = A + H + M + D, Tadv = A, TκH = H, TκVML = M, TκVdeep = D)
+    end
+    (; v3D, thkcello, edge_length_2D, distance_to_neighbour_2D, area2D, zt, gridtopology) = gridmetrics
+    nx, ny, nz = size(v3D)
+    N = indices.N
+    ph = [f64(getproperty(ϕ, d)) for d in (:east, :west, :north, :south, :top, :bottom)]
+    v = f64(v3D); thk = f64(thkcello)
+    rho3 = ρ isa Number ? Float64[] : f64(ρ)
+    lw3 = Array{Int64,3}(replace(indices.Lwet3D, missing => 0))
+    lw = Vector{Int64}(indices.Lwet)
+    el = [f64(edge_length_2D[d]) for d in HDIRS]; dn = [f64(distance_to_neighbour_2D[d]) for d in HDIRS]
+    ar = f64(area2D); z = Vector{Float64}(zt); ml = f64(Array(mlotst))
+    nnz = zeros(Int64, 5)
+    GC.@preserve ph v thk rho3 lw3 lw el dn ar z ml begin
+        a = Ref(TmArgs(nx, ny, nz, topologykind(gridtopology), Int32(upwind), N,
+            ntuple(i -> pointer(ph[i]), 6), pointer(v), pointer(thk),
+            ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0,
+            pointer(lw3), pointer(lw), ntuple(i -> pointer(el[i]), 4), ntuple(i -> pointer(dn[i]), 4),
+            pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep)))
+        check(ccall(sym(:otmb_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), ctx[], a, nnz))
+    end
+    colptr = [Vector{Int64}(undef, N + 1) for _ in 1:5]
+    rowval = [Vector{Int64}(undef, nnz[m]) for m in 1:5]
+    nzval = [Vector{Float64}(undef, nnz[m]) for m in 1:5]
+    final = zeros(Int64, 5)
+    cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
+    GC.@preserve colptr rowval nzval check(ccall(sym(:otmb_transportmatrix_fetch), Int32,
+        (Ptr{Cvoid}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}), ctx[], cp, rv, nz, final))
+    for m in 1:5   # plan's count for T is the union-pattern bound; exact-zero sums are dropped (:147)
+        resize!(rowval[m], final[m]); resize!(nzval[m], final[m])
+    end
+    mats = [SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], rowval[m], nzval[m]) for m in 1:5]
+    return (; T = mats[1], Tadv = mats[2], TκH = mats[3], TκVML = mats[4], TκVdeep = mats[5])
+end
+
+end # module
