@@ -7,6 +7,7 @@
 #include "otmb_common.h"
 
 #define FF_THREADS 64
+#define FF_KB 8  // levels whose loads are issued together
 
 // replace(x, NaN => 0.0, FillValue => 0.0) -- isequal semantics (:203, :215)
 __device__ __forceinline__ double ff_replace(double x, double fill) {
@@ -30,33 +31,49 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
         // seafloor ϕbottom is zero (:238); for a depth slab that is not the deepest, the plane handed up
         // by the slab below (its ϕtop at its first level) continues the chain without re-association
         double topbelow = top_below ? top_below[s] : 0.0;
-#pragma unroll 2
-        for (int k = nz - 1; k >= 0; --k) {
-            const i64 o = (i64)k * P;
-            const bool wc = wet[o + s] != 0, wE = wet[o + sE] != 0, wW = wet[o + sW] != 0;
-            const bool wS = (sS >= 0) && wet[o + sS] != 0, wN = (sN >= 0) && wet[o + sN] != 0;
-            double u = (double)umo[o + s], v = (double)vmo[o + s];  // Array{Float64}(umo), :125-126
-            // nofluxboundaries!, :167-173
-            if (!wc || !wE) u = 0.0;
-            if (!wc || !wN) v = 0.0;
-            uvalid |= !(isnan(u) || u == fill);  // :199
-            vvalid |= !(isnan(v) || v == fill);  // :200
-            const double e = ff_replace(u, fill), n = ff_replace(v, fill);
-            // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
-            double uw = (double)umo[o + sW];
-            if (!wW || !wc) uw = 0.0;
-            const double w = ff_replace(uw, fill);
-            // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
-            double so = 0.0;
-            if (sS >= 0) {
-                double vs = (double)vmo[o + sS];
-                if (!wS || !wc) vs = 0.0;
-                so = ff_replace(vs, fill);
+        // clamped neighbour columns: every load below is unconditional so that the loads of FF_KB levels
+        // are all in flight together (one memory round trip per chunk instead of several per level)
+        const bool hS = sS >= 0, hN = sN >= 0;
+        const i64 cS = hS ? sS : s, cN = hN ? sN : s;
+        for (int k0 = nz - 1; k0 >= 0; k0 -= FF_KB) {
+            double u_[FF_KB], v_[FF_KB], uw_[FF_KB], vs_[FF_KB];
+            unsigned char wc_[FF_KB], wE_[FF_KB], wW_[FF_KB], wS_[FF_KB], wN_[FF_KB];
+#pragma unroll
+            for (int q = 0; q < FF_KB; ++q) {
+                const int k = (k0 - q >= 0) ? k0 - q : 0;
+                const i64 o = (i64)k * P;
+                u_[q] = (double)umo[o + s]; v_[q] = (double)vmo[o + s];  // Array{Float64}(umo), :125-126
+                uw_[q] = (double)umo[o + sW]; vs_[q] = (double)vmo[o + cS];
+                wc_[q] = wet[o + s]; wE_[q] = wet[o + sE]; wW_[q] = wet[o + sW]; wS_[q] = wet[o + cS]; wN_[q] = wet[o + cN];
             }
-            const double b = topbelow;  // :238-240
-            const double t = (((b + w) + so) - e) - n;        // :242
-            east[o + s] = e; west[o + s] = w; north[o + s] = n; south[o + s] = so; top[o + s] = t; bottom[o + s] = b;
-            topbelow = t;
+#pragma unroll
+            for (int q = 0; q < FF_KB; ++q) {
+                const int k = k0 - q;
+                if (k >= 0) {
+                    const i64 o = (i64)k * P;
+                    const bool wc = wc_[q] != 0, wE = wE_[q] != 0, wW = wW_[q] != 0;
+                    const bool wS = hS && wS_[q] != 0, wN = hN && wN_[q] != 0;
+                    double u = u_[q], v = v_[q];
+                    // nofluxboundaries!, :167-173
+                    if (!wc || !wE) u = 0.0;
+                    if (!wc || !wN) v = 0.0;
+                    uvalid |= !(isnan(u) || u == fill);  // :199
+                    vvalid |= !(isnan(v) || v == fill);  // :200
+                    const double e = ff_replace(u, fill), n = ff_replace(v, fill);
+                    // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
+                    double uw = uw_[q];
+                    if (!wW || !wc) uw = 0.0;
+                    const double w = ff_replace(uw, fill);
+                    // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
+                    double vs = vs_[q];
+                    if (!wS || !wc) vs = 0.0;
+                    const double so = hS ? ff_replace(vs, fill) : 0.0;
+                    const double b = topbelow;                  // :238-240
+                    const double t = (((b + w) + so) - e) - n;  // :242
+                    east[o + s] = e; west[o + s] = w; north[o + s] = n; south[o + s] = so; top[o + s] = t; bottom[o + s] = b;
+                    topbelow = t;
+                }
+            }
         }
     }
     if (__any(uvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_U_VALID] == 0) atomicExch(&flags[FLAG_U_VALID], 1);

@@ -16,13 +16,16 @@
 //      (a column's entries are contiguous, a tile's columns are contiguous).
 #include "otmb_tm_column.h"
 
-#define TM_THREADS 256
+#ifndef TM_THREADS
+#define TM_THREADS 256  // measured: one-wave (64-thread) tiles are no faster in fill and much worse for look-back
+#endif
 #define TM_NF 5
 #ifndef TM_WAVES_PER_SIMD
 #define TM_WAVES_PER_SIMD 3  // measured: capping at 128 VGPRs (4 waves/SIMD) spills and is 8 % slower
 #endif
 #define TM_MAXROWS 7  // rows per column: A, S, W, SELF, E, N|fold, B
-#define TM_STAGE (TM_THREADS * TM_MAXROWS)
+#define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
+#define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
 
 enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_ONEPASS = 2 };
 
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
     __shared__ int s_tile;
-    __shared__ i64 s_row[TM_STAGE];
-    __shared__ double s_val[TM_STAGE];
+    __shared__ __attribute__((aligned(16))) i64 s_row[TM_STAGE];
+    __shared__ __attribute__((aligned(16))) double s_val[TM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
@@ -302,15 +305,29 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const u64 wtot = __shfl(incl, 63);  // this wave's totals (packed)
     const unsigned wc[5] = {(unsigned)(wtot & 0x7ff), (unsigned)((wtot >> 11) & 0x7ff), (unsigned)((wtot >> 22) & 0x7ff),
                             (unsigned)((wtot >> 33) & 0x3ff), (unsigned)((wtot >> 43) & 0x3ff)};
-    i64 *my_row = s_row + wid * (64 * TM_MAXROWS);
-    double *my_val = s_val + wid * (64 * TM_MAXROWS);
+    i64 *my_row = s_row + wid * TM_WSTAGE;
+    double *my_val = s_val + wid * TM_WSTAGE;
+    typedef i64 i64x2 __attribute__((ext_vector_type(2)));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) {
+        // The run is streamed out with 16-byte stores (two entries per lane): 8-byte-per-lane stores are
+        // store-issue bound per CU (measured: the write phase cost as much as loads + arithmetic).  The
+        // run starts at an arbitrary 8-byte position, so entries are staged at LDS index q + par where par
+        // is the run's parity: LDS pairs and global pairs are then both 16-byte aligned.
+        i64 *rv = p.rowval[m] + g0[m] + wb[m];
+        double *nz = p.nzval[m] + g0[m] + wb[m];
+        const unsigned par = (unsigned)(((unsigned long long)rv >> 3) & 1ull);
+        const bool wide = ((((unsigned long long)rv) ^ ((unsigned long long)nz)) & 15ull) == 0;  // same parity for both arrays
+#ifdef OTMB_DBG_NOLDS
+        if (false) {
+#else
         if (live) {
+#endif
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 if ((pm[m] >> s) & 1u) {
-                    const unsigned q = ex[m] - wb[m] + __popc(pm[m] & col.bef[s]);  // position inside the wave's run
+                    const unsigned q = par + ex[m] - wb[m] + __popc(pm[m] & col.bef[s]);  // position inside the wave's run
                     my_row[q] = col.idx[s];
                     my_val[q] = (m == 0) ? t_value(col, s) : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
                 }
@@ -324,12 +341,30 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             room = g0[m] + wb[m] + cnt <= p.cap[m];
             if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
         }
+#ifdef OTMB_DBG_NOSTORE
+        room = false;
+#endif
         if (room) {
-            i64 *rv = p.rowval[m] + g0[m] + wb[m];
-            double *nz = p.nzval[m] + g0[m] + wb[m];
-            for (unsigned e = lane; e < cnt; e += 64) {
-                rv[e] = my_row[e];
-                nz[e] = my_val[e];
+            const unsigned end = par + cnt;  // staged entries occupy LDS indices [par, end)
+            if (wide) {
+                for (unsigned u = 2 * lane; u < end; u += 128) {
+                    const bool lo = u >= par, hi = u + 1 < end;
+                    if (lo & hi) {
+                        *(i64x2 *)(rv - par + u) = *(const i64x2 *)(my_row + u);
+                        *(f64x2 *)(nz - par + u) = *(const f64x2 *)(my_val + u);
+                    } else if (lo) {
+                        rv[u - par] = my_row[u];
+                        nz[u - par] = my_val[u];
+                    } else if (hi) {
+                        rv[u + 1 - par] = my_row[u + 1];
+                        nz[u + 1 - par] = my_val[u + 1];
+                    }
+                }
+            } else {
+                for (unsigned e = lane; e < cnt; e += 64) {
+                    rv[e] = my_row[par + e];
+                    nz[e] = my_val[par + e];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
