@@ -107,6 +107,29 @@ int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo
                                  int32_t topology, double *const phi[6], const double *top_below);
 int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid);
 
+/* ---- velocity2fluxes / fluxes2velocity -- src/velocities.jl:10-39, :50-74 (nanmean2 :89-93, nanmin2 :108);
+ *      with facefluxes they make facefluxesfromvelocities (:140-151).  Default C-grid (u on east faces, v on
+ *      north faces; the reference passes C-grid fields through, src/gridcellgeometry.jl:104).
+ * u/v (or phi_i/phi_j): (nx,ny,nz) Float64 or Float32 (src_is_f32); rho: (nx,ny,nz) or NULL with rho_scalar;
+ * edge_east/edge_north: gridmetrics.edge_length_2D[:east], [:north] (nx,ny).  Every cell is computed, as in
+ * the reference.  A bipolar topology is an error (the reference indexes thkcello[nothing] at j == ny).    */
+int32_t otmb_velocity2fluxes_dev(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, const double *rho,
+                                 double rho_scalar, const double *thkcello, const double *edge_east,
+                                 const double *edge_north, int64_t nx, int64_t ny, int64_t nz, int32_t topology,
+                                 double *phi_i, double *phi_j);
+int32_t otmb_fluxes2velocity_dev(otmb_ctx *ctx, const void *phi_i, const void *phi_j, int32_t src_is_f32,
+                                 const double *rho, double rho_scalar, const double *thkcello, const double *edge_east,
+                                 const double *edge_north, int64_t nx, int64_t ny, int64_t nz, int32_t topology,
+                                 double *u, double *v);
+int32_t otmb_velocity2fluxes(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, const double *rho,
+                             double rho_scalar, const double *thkcello, const double *edge_east,
+                             const double *edge_north, int64_t nx, int64_t ny, int64_t nz, int32_t topology,
+                             double *phi_i, double *phi_j);
+int32_t otmb_fluxes2velocity(otmb_ctx *ctx, const void *phi_i, const void *phi_j, int32_t src_is_f32, const double *rho,
+                             double rho_scalar, const double *thkcello, const double *edge_east,
+                             const double *edge_north, int64_t nx, int64_t ny, int64_t nz, int32_t topology,
+                             double *u, double *v);
+
 /* ---- transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind)
  *      -- src/matrixbuilding.jl:128-150 with buildTadv/TκH/TκVML/TκVdeep (:31-120), the three
  *      *_operator_sparse_entries generators (:221-299, :337-418, :438-479), sparse() x4 and

@@ -103,6 +103,67 @@ def facefluxesfrommasstransport(*, umo, vmo, gridmetrics, indices, device=0):
     return facefluxes(u, v, gridmetrics, indices, FillValue=fill, device=device)
 
 
+def _velocity_flux(which, a_i, a_j, gridmetrics, rho, device):
+    ctx = context(device)
+    x = np.asarray(data_and_props(a_i)[0])
+    y = np.asarray(data_and_props(a_j)[0])
+    is32 = x.dtype == np.float32 and y.dtype == np.float32
+    dt = np.float32 if is32 else np.float64
+    x = np.asfortranarray(x, dtype=dt)
+    y = np.asfortranarray(y, dtype=dt)
+    nx, ny, nz = x.shape
+    thk = _f64(gridmetrics["thkcello"])
+    ee = _f64(gridmetrics["edge_length_2D"]["east"])
+    en = _f64(gridmetrics["edge_length_2D"]["north"])
+    if np.ndim(rho) == 0:
+        rp, rs, keep = None, float(rho), None
+    else:
+        keep = _f64(rho)
+        rp, rs = keep.ctypes.data, 0.0
+    oi = np.empty(x.shape, dtype=np.float64, order="F")
+    oj = np.empty(x.shape, dtype=np.float64, order="F")
+    fn = getattr(capi.lib(), which)
+    ctx.check(fn(ctx.handle, x.ctypes.data, y.ctypes.data, int(is32), rp, rs, thk.ctypes.data, ee.ctypes.data, en.ctypes.data,
+                 nx, ny, nz, _topology_kind(gridmetrics), oi.ctypes.data, oj.ctypes.data))
+    return oi, oj
+
+
+def interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics):
+    """src/gridcellgeometry.jl:103-105: C-grid fields pass through; A-grid raises as in the reference.
+    B-grid interpolation (:106-140) is outside this round's scope."""
+    from .gridmetrics import getarakawagrid
+
+    kind, u_pos, v_pos = getarakawagrid(u_lon, u_lat, v_lon, v_lat, gridmetrics)
+    if kind == "C":
+        return u, u_lon, u_lat, v, v_lon, v_lat
+    if kind == "A":
+        raise RuntimeError("Interpolation not implemented for A-grid type")
+    raise NotImplementedError(f"B-grid({u_pos},{v_pos}) interpolation is not part of the MI355X path yet")
+
+
+def velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics, ρ, *, device=0):
+    """src/velocities.jl:10-39 -> (ϕᵢ, ϕⱼ)."""
+    u, _, _, v, _, _ = interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics)
+    return _velocity_flux("otmb_velocity2fluxes", u, v, gridmetrics, ρ, device)
+
+
+def fluxes2velocity(ϕᵢ, ϕⱼ, gridmetrics, ρ, *, device=0):
+    """src/velocities.jl:50-74 -> (u, v) on the C-grid."""
+    return _velocity_flux("otmb_fluxes2velocity", ϕᵢ, ϕⱼ, gridmetrics, ρ, device)
+
+
+def facefluxesfromvelocities(*, uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetrics, indices, ρ=None, rho=None, device=0):
+    """src/velocities.jl:140-151."""
+    rho = ρ if ρ is not None else rho
+    _, up = data_and_props(uo)
+    _, vp = data_and_props(vo)
+    fill = up["_FillValue"]
+    fv = vp["_FillValue"]
+    assert (fill == fv) or (np.isnan(fill) and np.isnan(fv))  # :143
+    umo, vmo = velocity2fluxes(uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetrics, rho, device=device)
+    return facefluxes(umo, vmo, gridmetrics, indices, FillValue=fill, device=device)
+
+
 def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep):
     v3d = _f64(gridmetrics["v3D"])
     nx, ny, nz = v3d.shape

@@ -75,6 +75,47 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
     return OTMB_OK;
 }
 
+static int32_t vf_host(otmb_ctx *ctx, bool to_velocity, const void *a_i, const void *a_j, int32_t src_is_f32, const double *rho,
+                       double rho_scalar, const double *thk, const double *ee, const double *en, int64_t nx, int64_t ny,
+                       int64_t nz, int32_t topology, double *o_i, double *o_j) {
+    if (!ctx || !a_i || !a_j || !thk || !ee || !en || !o_i || !o_j) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)(nx * ny), G = P * (size_t)nz, es = src_is_f32 ? 4 : 8;
+    const void *di, *dj, *dr = nullptr, *dt, *de, *dn;
+    TRY(upload(ctx, ST_UMO, a_i, G * es, &di));
+    TRY(upload(ctx, ST_VMO, a_j, G * es, &dj));
+    if (rho) TRY(upload(ctx, ST_RHO, rho, G * 8, &dr));
+    TRY(upload(ctx, ST_THK, thk, G * 8, &dt));
+    TRY(upload(ctx, ST_EDGE0, ee, P * 8, &de));
+    TRY(upload(ctx, ST_EDGE0 + 1, en, P * 8, &dn));
+    void *oi, *oj;
+    TRY(stage(ctx, ST_PHI0, G * 8, &oi));
+    TRY(stage(ctx, ST_PHI0 + 1, G * 8, &oj));
+    if (to_velocity)
+        TRY(otmb_fluxes2velocity_dev(ctx, di, dj, src_is_f32, (const double *)dr, rho_scalar, (const double *)dt, (const double *)de,
+                                     (const double *)dn, nx, ny, nz, topology, (double *)oi, (double *)oj));
+    else
+        TRY(otmb_velocity2fluxes_dev(ctx, di, dj, src_is_f32, (const double *)dr, rho_scalar, (const double *)dt, (const double *)de,
+                                     (const double *)dn, nx, ny, nz, topology, (double *)oi, (double *)oj));
+    HIP_TRY(ctx, hipMemcpyAsync(o_i, oi, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(o_j, oj, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
+int32_t otmb_velocity2fluxes(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, const double *rho, double rho_scalar,
+                             const double *thkcello, const double *edge_east, const double *edge_north, int64_t nx, int64_t ny,
+                             int64_t nz, int32_t topology, double *phi_i, double *phi_j) {
+    return vf_host(ctx, false, u, v, src_is_f32, rho, rho_scalar, thkcello, edge_east, edge_north, nx, ny, nz, topology, phi_i, phi_j);
+}
+
+int32_t otmb_fluxes2velocity(otmb_ctx *ctx, const void *phi_i, const void *phi_j, int32_t src_is_f32, const double *rho,
+                             double rho_scalar, const double *thkcello, const double *edge_east, const double *edge_north,
+                             int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *u, double *v) {
+    return vf_host(ctx, true, phi_i, phi_j, src_is_f32, rho, rho_scalar, thkcello, edge_east, edge_north, nx, ny, nz, topology, u, v);
+}
+
 int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t nnz[5]) {
     if (!ctx || !a || !nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");

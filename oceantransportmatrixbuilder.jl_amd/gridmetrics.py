@@ -141,3 +141,41 @@ def makegridmetrics(*, areacello, volcello, lon, lat, lev, lon_vertices, lat_ver
         distance_to_edge_2D=distance_to_edge_2D, distance_to_neighbour_2D=distance_to_neighbour_2D,
         gridtopology=NT(kind=topology, name=gt.NAMES[topology], nx=nx, ny=ny, nz=len(zt)),
     )
+
+
+# ---- Arakawa grid detection (host; decides which device path the velocity fields take) --------------
+def getarakawagrid(u_lon, u_lat, v_lon, v_lat, gridmetrics):
+    """src/gridcellgeometry.jl:50-95: where do the u and v points of cell (1,1) sit?  Returns ("A"|"B"|"C",
+    u_pos, v_pos).  (The reference's relerr > 0.01 branch calls an undefined `warn`; a warning is issued here.)"""
+    import warnings
+
+    lon, lat = gridmetrics["lon"], gridmetrics["lat"]
+    lv, tv = gridmetrics["lon_vertices"], gridmetrics["lat_vertices"]
+    up = (float(np.asarray(u_lon)[0, 0]), float(np.asarray(u_lat)[0, 0]))
+    vp = (float(np.asarray(v_lon)[0, 0]), float(np.asarray(v_lat)[0, 0]))
+    SW, SE, NE, NW = [(float(lv[q, 0, 0]), float(tv[q, 0, 0])) for q in range(4)]
+
+    def mid(A, B):
+        lo, la = midpointonsphere(np.float64(A[0]), np.float64(A[1]), np.float64(B[0]), np.float64(B[1]))
+        return (float(lo), float(la))
+
+    cell = dict(C=(float(lon[0, 0]), float(lat[0, 0])), SW=SW, SE=SE, NE=NE, NW=NW, S=mid(SW, SE), N=mid(NE, NW),
+                W=mid(SW, NW), E=mid(SE, NE))
+    hv = lambda A, B: float(haversine(np.float64(A[0]), np.float64(A[1]), np.float64(B[0]), np.float64(B[1])))
+    ud = {k: hv(P, up) for k, P in cell.items()}
+    vd = {k: hv(P, vp) for k, P in cell.items()}
+    u_pos = min(ud, key=ud.get)  # findmin: first minimum in field order
+    v_pos = min(vd, key=vd.get)
+    if u_pos == v_pos == "C":
+        kind = "A"
+    elif u_pos == v_pos and u_pos in ("NE", "NW", "SE", "SW"):
+        kind = "B"
+    elif u_pos in ("E", "W") and v_pos in ("N", "S"):
+        kind = "C"
+    else:
+        raise RuntimeError("Unknown Arakawa grid type")
+    perimeter = hv(SW, SE) + hv(SE, NE) + hv(NE, NW) + hv(NW, SW)
+    relerr = (ud[u_pos] + vd[v_pos]) / perimeter
+    if relerr > 0.01:
+        warnings.warn(f"Relative error in grid positions in {kind}GridCell({u_pos},{v_pos}) is {relerr}")
+    return kind, u_pos, v_pos

@@ -253,3 +253,17 @@ def to_scipy(csc, N):
 
     colptr, rowval, nzval = csc
     return sp.csc_matrix((nzval, rowval - 1, colptr - 1), shape=(N, N))
+
+
+def velocity_flux(a_i, a_j, rho, thk, edge_east, edge_north, topo, to_velocity=False):
+    """velocity2fluxes (to_velocity=False, velocities.jl:10-39) / fluxes2velocity (True, :50-74), C-grid."""
+    a_i = _f(a_i); a_j = _f(a_j); thk = _f(thk)
+    rho_a, rho_s = _rho_args(rho, thk.shape)
+    ee = _f(edge_east); en = _f(edge_north)
+    oi = np.empty(thk.shape, order="F"); oj = np.empty(thk.shape, order="F")
+    g = _grid(thk.shape, topo)
+    rc = lib().orc_velocity_flux(_d(a_i), _d(a_j), _d(rho_a), C.c_double(rho_s), _d(thk), _d(ee), _d(en), C.byref(g),
+                                 C.c_int32(int(to_velocity)), _d(oi), _d(oj))
+    if rc:
+        raise OracleError(rc)
+    return oi, oj

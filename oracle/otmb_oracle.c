@@ -545,6 +545,41 @@ done:
     return rc;
 }
 
+
+/* ---- velocity2fluxes / fluxes2velocity: velocities.jl:10-39, :50-74, nanmean2 :89-93, nanmin2 :108 -----
+ * Default C-grid only (interpolateontodefaultCgrid passes C-grid fields through, gridcellgeometry.jl:104).
+ * rho: 3-D array or NULL with rho_scalar (twocellnanmean(x::Number) = x, :81).  Loops over ALL cells.
+ * A bipolar top row has j₊₁ == nothing, and thkcello[nothing] throws in the reference -> error. */
+static inline double nanmean2(double a, double b) { /* Bool weights: false * NaN == 0.0 in Julia */
+    int wa = !isnan(a), wb = !isnan(b);
+    return ((wa ? a : 0.0) + (wb ? b : 0.0)) / (double)(wa + wb);
+}
+static inline double nanmin2(double a, double b) { return isnan(a) ? b : (isnan(b) ? a : (a < b ? a : b)); }
+
+int32_t orc_velocity_flux(const double *in_i, const double *in_j, const double *rho, double rho_scalar,
+                          const double *thk, const double *edge_east, const double *edge_north,
+                          const orc_grid *g, int32_t to_velocity, double *out_i, double *out_j) {
+    if (g->topo == ORC_UNKNOWN) return ORC_ERR_UNKNOWN_TOPOLOGY;
+    if (g->topo == ORC_BIPOLAR) return ORC_ERR_FLUX_INTO_LAND; /* x[nothing] at j == ny */
+    for (int64_t k = 0; k < g->nz; ++k)
+        for (int64_t j = 0; j < g->ny; ++j)
+            for (int64_t i = 0; i < g->nx; ++i) {
+                int64_t c = lin(g, i, j, k), s = i + g->nx * j;
+                int64_t E = ip1(g, i, j, k), N = jp1(g, i, j, k);
+                double mE = rho ? nanmean2(rho[c], rho[E]) : rho_scalar;
+                double mN = rho ? nanmean2(rho[c], rho[N]) : rho_scalar;
+                double tE = nanmin2(thk[c], thk[E]), tN = nanmin2(thk[c], thk[N]);
+                if (!to_velocity) {
+                    out_i[c] = in_i[c] * mE * tE * edge_east[s];  /* :31 */
+                    out_j[c] = in_j[c] * mN * tN * edge_north[s]; /* :33 */
+                } else {
+                    out_i[c] = in_i[c] / (mE * tE * edge_east[s]);  /* :68 */
+                    out_j[c] = in_j[c] / (mN * tN * edge_north[s]); /* :70 */
+                }
+            }
+    return ORC_OK;
+}
+
 /* ---- Distances.haversine 0.10 (radius 6371000), points are (lon°, lat°) --- */
 double orc_haversine(double lon1, double lat1, double lon2, double lat2) {
     const double d2r = M_PI / 180.0; /* deg2rad(z) = z * (pi/180) */

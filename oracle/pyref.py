@@ -346,3 +346,40 @@ def gridmetrics_2d(lon, lat, lonv, latv, kind):
                 else:
                     dn[d][i - 1, j - 1] = haversine(Cc, (float(lon[Jn[0] - 1, Jn[1] - 1]), float(lat[Jn[0] - 1, Jn[1] - 1])))
     return el, de, dn
+
+
+# ---- velocity2fluxes / fluxes2velocity: src/velocities.jl:10-39, :50-74 -----------------------------
+def nanmean2(a, b):  # :89-93 (false * NaN == 0.0 in Julia)
+    wa, wb = not math.isnan(a), not math.isnan(b)
+    num = (a if wa else 0.0) + (b if wb else 0.0)
+    den = int(wa) + int(wb)
+    return num / den if den else NaN
+
+
+def nanmin2(a, b):  # :108
+    return b if math.isnan(a) else (a if math.isnan(b) else min(a, b))
+
+
+def velocity_flux(a_i, a_j, rho, gm, topo, to_velocity=False):
+    thk, edge = gm["thkcello"], gm["edge_length_2D"]
+    nx, ny, nz = thk.shape
+    oi, oj = np.zeros((nx, ny, nz)), np.zeros((nx, ny, nz))
+    scalar = np.ndim(rho) == 0
+    for k in range(1, nz + 1):
+        for j in range(1, ny + 1):
+            for i in range(1, nx + 1):
+                C = (i, j, k)
+                E, N = topo.ip1(C), topo.jp1(C)
+                if N is None:
+                    raise RuntimeError("flux into land or outside the grid")  # x[nothing]
+                mE = float(rho) if scalar else nanmean2(_at(rho, C), _at(rho, E))
+                mN = float(rho) if scalar else nanmean2(_at(rho, C), _at(rho, N))
+                tE, tN = nanmin2(_at(thk, C), _at(thk, E)), nanmin2(_at(thk, C), _at(thk, N))
+                ee, en = float(edge["east"][i - 1, j - 1]), float(edge["north"][i - 1, j - 1])
+                if not to_velocity:
+                    oi[i - 1, j - 1, k - 1] = _at(a_i, C) * mE * tE * ee
+                    oj[i - 1, j - 1, k - 1] = _at(a_j, C) * mN * tN * en
+                else:
+                    oi[i - 1, j - 1, k - 1] = _at(a_i, C) / (mE * tE * ee)
+                    oj[i - 1, j - 1, k - 1] = _at(a_j, C) / (mN * tN * en)
+    return oi, oj

@@ -1,0 +1,93 @@
+"""velocity2fluxes / fluxes2velocity / facefluxesfromvelocities (src/velocities.jl:10-108,132-151):
+oracle vs the Python transliteration on CPU, HIP vs oracle on GPU (bit-exact), and the reference's own
+round-trip test u -> ϕ -> u (test/local_full.jl:300-304) on wet cells."""
+import numpy as np
+import pytest
+
+from helpers import make_case
+from oracle import pyref
+
+
+def _velocities(g, gm, seed=5, dtype=np.float64):
+    """C-grid velocity fields: u on east-face midpoints, v on north-face midpoints, fill on land."""
+    rng = np.random.default_rng(seed)
+    wet = ~np.isnan(gm.v3D)
+    u = np.where(wet, rng.standard_normal(gm.v3D.shape) * 0.1, 1e20)
+    v = np.where(wet, rng.standard_normal(gm.v3D.shape) * 0.1, 1e20)
+    lv, tv = gm.lon_vertices, gm.lat_vertices
+    u_lon, u_lat = (lv[1] + lv[2]) / 2, (tv[1] + tv[2]) / 2  # E = mid(SE, NE)
+    v_lon, v_lat = (lv[2] + lv[3]) / 2, (tv[2] + tv[3]) / 2  # N = mid(NE, NW)
+    return np.asfortranarray(u.astype(dtype)), u_lon, u_lat, np.asfortranarray(v.astype(dtype)), v_lon, v_lat
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_rho3d", "odd_nx_fold"])
+def test_oracle_velocity_flux_matches_transliteration(oracle, name):
+    g, gm = make_case(name)
+    u, _, _, v, _, _ = _velocities(g, gm)
+    kind = gm.gridtopology.kind
+    topo = pyref.Topo(kind, g.nx, g.ny, g.nz)
+    fi, fj = oracle.velocity_flux(u, v, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], kind)
+    pi, pj = pyref.velocity_flux(u, v, g.rho, gm, topo)
+    assert np.array_equal(fi, pi, equal_nan=True) and np.array_equal(fj, pj, equal_nan=True)
+    ui, uj = oracle.velocity_flux(fi, fj, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], kind, True)
+    qi, qj = pyref.velocity_flux(pi, pj, g.rho, gm, topo, True)
+    assert np.array_equal(ui, qi, equal_nan=True) and np.array_equal(uj, qj, equal_nan=True)
+
+
+def test_oracle_velocity_flux_bipolar_raises(oracle):
+    g, gm = make_case("tiny_bipolar")
+    u, _, _, v, _, _ = _velocities(g, gm)
+    with pytest.raises(oracle.OracleError):
+        oracle.velocity_flux(u, v, 1035.0, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], 0)
+
+
+def test_getarakawagrid_detects_c_grid():
+    from otmb_amd.gridmetrics import getarakawagrid
+
+    g, gm = make_case("tiny_tripolar")
+    u, u_lon, u_lat, v, v_lon, v_lat = _velocities(g, gm)
+    assert getarakawagrid(u_lon, u_lat, v_lon, v_lat, gm) == ("C", "E", "N")
+    assert getarakawagrid(gm.lon, gm.lat, gm.lon, gm.lat, gm)[0] == "A"
+    ne_lon, ne_lat = gm.lon_vertices[2], gm.lat_vertices[2]
+    assert getarakawagrid(ne_lon, ne_lat, ne_lon, ne_lat, gm) == ("B", "NE", "NE")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype", [("tiny_tripolar", np.float64), ("tiny_rho3d", np.float64), ("small_rho3d", np.float32),
+                                        ("odd_nx_fold", np.float64)])
+def test_hip_velocity_flux_matches_oracle_and_round_trips(oracle, name, dtype):
+    import otmb_amd.api as api
+
+    g, gm = make_case(name)
+    u, u_lon, u_lat, v, v_lon, v_lat = _velocities(g, gm, dtype=dtype)
+    kind = gm.gridtopology.kind
+    fi, fj = api.velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gm, g.rho)
+    ri, rj = oracle.velocity_flux(u, v, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], kind)
+    assert np.array_equal(fi, ri, equal_nan=True) and np.array_equal(fj, rj, equal_nan=True)
+    ui, uj = api.fluxes2velocity(fi, fj, gm, g.rho)
+    qi, qj = oracle.velocity_flux(ri, rj, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], kind, True)
+    assert np.array_equal(ui, qi, equal_nan=True) and np.array_equal(uj, qj, equal_nan=True)
+    # test/local_full.jl:300-304: the round trip returns the velocities on faces between two wet cells
+    wet = ~np.isnan(gm.v3D)
+    both_e = wet & np.roll(wet, -1, axis=0)
+    np.testing.assert_allclose(ui[both_e], u.astype(np.float64)[both_e], rtol=1e-12)
+    # facefluxesfromvelocities == facefluxes(velocity2fluxes(...))
+    from otmb_amd import Cube
+
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfromvelocities(uo=Cube(u, _FillValue=1e20), uo_lon=u_lon, uo_lat=u_lat, vo=Cube(v, _FillValue=1e20),
+                                       vo_lon=v_lon, vo_lat=v_lat, gridmetrics=gm, indices=idx, ρ=g.rho)
+    ref = oracle.facefluxes(ri, rj, idx.wet3D.view(np.uint8), 1e20, kind)
+    for k in ref:
+        assert np.array_equal(phi[k], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_hip_velocity2fluxes_bipolar_is_an_error():
+    import otmb_amd.api as api
+    from otmb_amd.capi import OtmbError
+
+    g, gm = make_case("tiny_bipolar")
+    u, u_lon, u_lat, v, v_lon, v_lat = _velocities(g, gm)
+    with pytest.raises(OtmbError):
+        api.velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gm, 1035.0)
