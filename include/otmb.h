@@ -190,6 +190,17 @@ int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                    double *const nzval[5], int64_t nnz_out[5]);
 
+/* ---- A + B for SparseMatrixCSC{Float64,Int64} -- SparseArrays' map(+, A, B), the `+` of
+ *      src/matrixbuilding.jl:147 used when the caller passes precomputed operators (:133-143): per column a
+ *      sorted merge, a missing operand counts as +0.0, results that are exactly zero are not stored.
+ * _dev: device pointers, two-phase (plan -> nnz, fill).  otmb_spadd: host pointers, Ci/Cx capacity nnz(A)+nnz(B). */
+int32_t otmb_spadd_plan_dev(otmb_ctx *ctx, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+                            const int64_t *Bp, const int64_t *Bi, const double *Bx, int64_t *nnz_out);
+int32_t otmb_spadd_fill_dev(otmb_ctx *ctx, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+                            const int64_t *Bp, const int64_t *Bi, const double *Bx, int64_t *Cp, int64_t *Ci, double *Cx);
+int32_t otmb_spadd(otmb_ctx *ctx, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, const int64_t *Bp,
+                   const int64_t *Bi, const double *Bx, int64_t *Cp, int64_t *Ci, double *Cx, int64_t *nnz_out);
+
 #ifdef __cplusplus
 }
 #endif

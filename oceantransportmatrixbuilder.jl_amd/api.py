@@ -58,6 +58,23 @@ class SparseMatrixCSC:
         return iter((self.colptr, self.rowval, self.nzval))
 
 
+def spadd(A, B, *, device=0):
+    """A + B with SparseArrays' semantics (union pattern, exact-zero results dropped), on the device."""
+    ctx = context(device)
+    n = A.n
+    assert A.shape == B.shape
+    arrs = [np.ascontiguousarray(x, dtype=t) for x, t in ((A.colptr, np.int64), (A.rowval, np.int64), (A.nzval, np.float64),
+                                                          (B.colptr, np.int64), (B.rowval, np.int64), (B.nzval, np.float64))]
+    cap = max(1, A.nnz + B.nnz)
+    Cp = np.empty(n + 1, dtype=np.int64)
+    Ci = np.empty(cap, dtype=np.int64)
+    Cx = np.empty(cap, dtype=np.float64)
+    nnz = C.c_int64(0)
+    ctx.check(capi.lib().otmb_spadd(ctx.handle, n, *[x.ctypes.data for x in arrs], Cp.ctypes.data, Ci.ctypes.data,
+                                    Cx.ctypes.data, C.byref(nnz)))
+    return SparseMatrixCSC(A.m, n, Cp, Ci[: nnz.value].copy(), Cx[: nnz.value].copy())
+
+
 def makeindices(v3D, *, device=0):
     """matrixbuilding.jl:10-24 -> NT(wet3D, L, Lwet, N, Lwet3D, C).  Lwet3D uses 0 for `missing`;
     L and C (lazy Linear/CartesianIndices in Julia) are the grid shape here."""
@@ -211,8 +228,15 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     kH = κH if kappaH is None else kappaH
     kVML = κVML if kappaVML is None else kappaVML
     kVdeep = κVdeep if kappaVdeep is None else kappaVdeep
-    if any(x is not None for x in (Tadv, TκH, TκVML, TκVdeep)):
-        raise NotImplementedError("precomputed operators (matrixbuilding.jl:140-143) need the general sparse add path")
+    given = dict(Tadv=Tadv, TκH=TκH, TκVML=TκVML, TκVdeep=TκVdeep)
+    if any(x is not None for x in given.values()):
+        # matrixbuilding.jl:140-143: operators passed in are used as they are; the others are built, and
+        # T = ((Tadv + TκH) + TκVML) + TκVdeep is formed with the sparse add (:147)
+        built = transportmatrix(phi=phi, mlotst=mlotst, gridmetrics=gridmetrics, indices=indices, rho=rho, kappaH=kH,
+                                kappaVML=kVML, kappaVdeep=kVdeep, upwind=upwind, device=device)
+        ops = {k: (v if v is not None else built[k]) for k, v in given.items()}
+        T = spadd(spadd(spadd(ops["Tadv"], ops["TκH"], device=device), ops["TκVML"], device=device), ops["TκVdeep"], device=device)
+        return NT(T=T, **ops)
     ctx = context(device)
     keep = []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep)

@@ -69,6 +69,9 @@ SYMBOLS = {
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_result": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_set_nnz_base": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
+    "otmb_spadd_plan_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),
+    "otmb_spadd_fill_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "otmb_spadd": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),
     "otmb_transportmatrix_plan_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_fill_dev": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
     "otmb_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),

@@ -191,3 +191,41 @@ def test_onepass_many_tiles_lookback(oracle):
     got = asm.result_to_host()
     for m in MATS:
         assert_csc_equal(got[m], rtm[m], m)
+
+
+# ---- sparse add and precomputed operators (matrixbuilding.jl:133-147) ------------------------------
+def test_spadd_matches_oracle(api, oracle):
+    from otmb_amd.api import SparseMatrixCSC
+
+    rng = np.random.default_rng(3)
+    n = 700
+
+    def rand():
+        ln = 5000
+        cp, rv, nz = oracle.sparse(rng.integers(1, n + 1, ln), rng.integers(1, n + 1, ln), rng.integers(-2, 3, ln).astype(float), n, n)
+        return SparseMatrixCSC(n, n, cp, rv, nz)
+
+    A, B = rand(), rand()
+    Cm = api.spadd(A, B)
+    ref = oracle.spadd(tuple(A), tuple(B), n)
+    assert_csc_equal(tuple(Cm), ref, "spadd")
+    assert not np.any(Cm.nzval == 0.0)
+    E = SparseMatrixCSC(n, n, np.ones(n + 1, np.int64), np.zeros(0, np.int64), np.zeros(0))
+    assert_csc_equal(tuple(api.spadd(A, E)), oracle.spadd(tuple(A), tuple(E), n), "spadd with empty")
+
+
+def test_transportmatrix_with_precomputed_operators(api, oracle):
+    g, gm = make_case("tiny_rho3d")
+    ref = oracle.makeindices(gm.v3D)
+    idx = api.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    kw = dict(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho)
+    base = api.transportmatrix(**kw)
+    other = api.transportmatrix(κH=123.0, **kw)  # a different TκH, handed in as precomputed
+    mixed = api.transportmatrix(TκH=other.TκH, **kw)
+    assert mixed.TκH is other.TκH
+    assert_csc_equal(tuple(mixed.Tadv), tuple(base.Tadv), "Tadv")
+    want = oracle.spadd(oracle.spadd(oracle.spadd(tuple(base.Tadv), tuple(other.TκH), ref["N"]), tuple(base.TκVML), ref["N"]),
+                        tuple(base.TκVdeep), ref["N"])
+    assert_csc_equal(tuple(mixed.T), want, "T from precomputed TκH")
+    assert_csc_equal(tuple(mixed.T), tuple(other.T), "same as building with κH=123")
