@@ -190,6 +190,19 @@ int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                    double *const nzval[5], int64_t nnz_out[5]);
 
+/* ---- bolus_GM_velocity(ρ, gridmetrics, indices; κGM = 600, maxslope = 0.01) -- src/RediGM.jl:46-79 with
+ *      globalverticalfacetriadderivative (src/triads.jl:84-146) and globalverticaldyadderivative
+ *      (src/dyads.jl:38-78).  Experimental in the reference, not connected to transportmatrix, and unpinned by
+ *      any reference test.  rho, z3d (gridmetrics.Z3D): (nx,ny,nz); wet3d: indices.wet3D bytes; dist_east /
+ *      dist_north: gridmetrics.distance_to_neighbour_2D[:east] / [:north].  u, v: (nx,ny,nz), NaN off Lwet.
+ *      A bipolar topology is an error (the reference evaluates k₋₁(nothing) at j == ny).               */
+int32_t otmb_bolus_gm_velocity_dev(otmb_ctx *ctx, const double *rho, const double *z3d, const uint8_t *wet3d,
+                                   const double *dist_east, const double *dist_north, int64_t nx, int64_t ny,
+                                   int64_t nz, int32_t topology, double kappa_gm, double maxslope, double *u, double *v);
+int32_t otmb_bolus_gm_velocity(otmb_ctx *ctx, const double *rho, const double *z3d, const uint8_t *wet3d,
+                               const double *dist_east, const double *dist_north, int64_t nx, int64_t ny, int64_t nz,
+                               int32_t topology, double kappa_gm, double maxslope, double *u, double *v);
+
 /* ---- A + B for SparseMatrixCSC{Float64,Int64} -- SparseArrays' map(+, A, B), the `+` of
  *      src/matrixbuilding.jl:147 used when the caller passes precomputed operators (:133-143): per column a
  *      sorted merge, a missing operand counts as +0.0, results that are exactly zero are not stored.

@@ -181,6 +181,23 @@ def facefluxesfromvelocities(*, uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetr
     return facefluxes(umo, vmo, gridmetrics, indices, FillValue=fill, device=device)
 
 
+def bolus_GM_velocity(ρ, gridmetrics, indices, *, κGM=600, maxslope=0.01, device=0):
+    """src/RediGM.jl:46-79 -> (u, v).  Experimental in the reference; parity unpinned (oracle only)."""
+    ctx = context(device)
+    rho = _f64(ρ)
+    nx, ny, nz = rho.shape
+    z3d = _f64(gridmetrics["Z3D"])
+    wet = np.asfortranarray(indices["wet3D"]).view(np.uint8)
+    de = _f64(gridmetrics["distance_to_neighbour_2D"]["east"])
+    dn = _f64(gridmetrics["distance_to_neighbour_2D"]["north"])
+    u = np.empty(rho.shape, dtype=np.float64, order="F")
+    v = np.empty(rho.shape, dtype=np.float64, order="F")
+    ctx.check(capi.lib().otmb_bolus_gm_velocity(ctx.handle, rho.ctypes.data, z3d.ctypes.data, wet.ctypes.data, de.ctypes.data,
+                                                dn.ctypes.data, nx, ny, nz, _topology_kind(gridmetrics), float(κGM),
+                                                float(maxslope), u.ctypes.data, v.ctypes.data))
+    return u, v
+
+
 def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep):
     v3d = _f64(gridmetrics["v3D"])
     nx, ny, nz = v3d.shape

@@ -104,6 +104,30 @@ static int32_t vf_host(otmb_ctx *ctx, bool to_velocity, const void *a_i, const v
     return OTMB_OK;
 }
 
+int32_t otmb_bolus_gm_velocity(otmb_ctx *ctx, const double *rho, const double *z3d, const uint8_t *wet3d, const double *dist_east,
+                               const double *dist_north, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double kappa_gm,
+                               double maxslope, double *u, double *v) {
+    if (!ctx || !rho || !z3d || !wet3d || !dist_east || !dist_north || !u || !v) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)(nx * ny), G = P * (size_t)nz;
+    const void *dr, *dz, *dw, *de, *dn;
+    TRY(upload(ctx, ST_RHO, rho, G * 8, &dr));
+    TRY(upload(ctx, ST_V, z3d, G * 8, &dz));
+    TRY(upload(ctx, ST_WET, wet3d, G, &dw));
+    TRY(upload(ctx, ST_DIST0, dist_east, P * 8, &de));
+    TRY(upload(ctx, ST_DIST0 + 1, dist_north, P * 8, &dn));
+    void *du, *dv;
+    TRY(stage(ctx, ST_PHI0, G * 8, &du));
+    TRY(stage(ctx, ST_PHI0 + 1, G * 8, &dv));
+    TRY(otmb_bolus_gm_velocity_dev(ctx, (const double *)dr, (const double *)dz, (const uint8_t *)dw, (const double *)de,
+                                   (const double *)dn, nx, ny, nz, topology, kappa_gm, maxslope, (double *)du, (double *)dv));
+    HIP_TRY(ctx, hipMemcpyAsync(u, du, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v, dv, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
 int32_t otmb_velocity2fluxes(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, const double *rho, double rho_scalar,
                              const double *thkcello, const double *edge_east, const double *edge_north, int64_t nx, int64_t ny,
                              int64_t nz, int32_t topology, double *phi_i, double *phi_j) {

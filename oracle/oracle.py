@@ -267,3 +267,17 @@ def velocity_flux(a_i, a_j, rho, thk, edge_east, edge_north, topo, to_velocity=F
     if rc:
         raise OracleError(rc)
     return oi, oj
+
+
+def bolus_gm_velocity(rho, Z3D, wet3D, dist_east, dist_north, topo, kappaGM=600.0, maxslope=0.01):
+    """bolus_GM_velocity(ρ, gridmetrics, indices; κGM, maxslope) -> (u, v)  (RediGM.jl:46-79; unpinned)."""
+    rho = _f(rho); Z3D = _f(Z3D)
+    wet3D = np.asfortranarray(wet3D, dtype=np.uint8)
+    de = _f(dist_east); dn = _f(dist_north)
+    u = np.empty(rho.shape, order="F"); v = np.empty(rho.shape, order="F")
+    g = _grid(rho.shape, topo)
+    rc = lib().orc_bolus_gm_velocity(_d(rho), _d(Z3D), _b(wet3D), _d(de), _d(dn), C.byref(g), C.c_double(kappaGM),
+                                     C.c_double(maxslope), _d(u), _d(v))
+    if rc:
+        raise OracleError(rc)
+    return u, v

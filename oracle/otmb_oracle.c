@@ -580,6 +580,80 @@ int32_t orc_velocity_flux(const double *in_i, const double *in_j, const double *
     return ORC_OK;
 }
 
+
+/* ---- bolus_GM_velocity: RediGM.jl:46-79 (experimental in the reference; never enters T; PARITY UNPINNED:
+ * no reference test asserts anything about it, test/derivatives.jl only plots).
+ * globalverticalfacetriadderivative triads.jl:134-146 (group :84-112, derivative :114-133),
+ * globalverticaldyadderivative dyads.jl:66-78 (group :38-56, derivative :57-65).
+ * dist_e / dist_n are gridmetrics.distance_to_neighbour_2D[:east] / [:north]: horizontaldistance(lon,lat,C,E)
+ * (gridcellgeometry.jl:182-188) is the same haversine between the same two centroids.
+ * wet3D: cells of indices.Lwet; every other cell of u, v stays NaN (fill(NaN, size(χ))). */
+static inline double gnan(const double *x, int64_t L) { return (L < 0) ? NAN : x[L]; } /* getindexornan */
+static inline double nansum_over_count4(const double v[4]) { /* sum(w*v)/sum(w), false*NaN == 0.0 */
+    double s = 0.0; int n = 0;
+    for (int q = 0; q < 4; ++q) { int w = !isnan(v[q]); s = (q == 0) ? (w ? v[0] : 0.0) : s + (w ? v[q] : 0.0); n += w; }
+    return s / (double)n;
+}
+static double triad_slope(const double *chi, const double *Z, const double *dist2d, const orc_grid *g,
+                          int64_t i, int64_t j, int64_t k, int dirJ) {
+    int64_t I = lin(g, i, j, k), N = km1(g, i, j, k), S = kp1(g, i, j, k);
+    int64_t E = dirJ ? jp1(g, i, j, k) : ip1(g, i, j, k);
+    int64_t NE = -1, SE = -1;
+    if (E >= 0) {
+        int64_t ie = E % g->nx, je = (E / g->nx) % g->ny;
+        NE = km1(g, ie, je, k); SE = kp1(g, ie, je, k);
+    }
+    double vC = chi[I], vN = gnan(chi, N), vS = gnan(chi, S), vE = gnan(chi, E), vNE = gnan(chi, NE), vSE = gnan(chi, SE);
+    double dCN = fabs(gnan(Z, N) - Z[I]), dCS = fabs(gnan(Z, S) - Z[I]);         /* verticaldistance(Z,I,J) = |Z[J]-Z[I]| */
+    double dCE = (E < 0) ? NAN : dist2d[i + g->nx * j];
+    double dENE = fabs(gnan(Z, NE) - gnan(Z, E)), dESE = fabs(gnan(Z, SE) - gnan(Z, E));
+    double CN = (vN - vC) / dCN, CS = (vC - vS) / dCS, CE = (vE - vC) / dCE, ENE = (vNE - vE) / dENE, ESE = (vE - vSE) / dESE;
+    double r[4] = {CE / CN, CE / CS, CE / ENE, CE / ESE};
+    return nansum_over_count4(r);
+}
+static double dyad_deriv(const double *chi, const double *Z, const orc_grid *g, int64_t i, int64_t j, int64_t k) {
+    int64_t I = lin(g, i, j, k), N = km1(g, i, j, k), S = kp1(g, i, j, k);
+    double dCN = fabs(gnan(Z, N) - Z[I]), dCS = fabs(gnan(Z, S) - Z[I]);
+    double a = (gnan(chi, N) - chi[I]) / dCN, b = (chi[I] - gnan(chi, S)) / dCS;
+    int wa = !isnan(a), wb = !isnan(b);
+    return ((wa ? a : 0.0) + (wb ? b : 0.0)) / (double)(wa + wb);
+}
+static inline double jl_clamp(double x, double lo, double hi) { return (x > hi) ? hi : ((x < lo) ? lo : x); }
+
+int32_t orc_bolus_gm_velocity(const double *rho, const double *Z3D, const uint8_t *wet3D, const double *dist_e,
+                              const double *dist_n, const orc_grid *g, double kappaGM, double maxslope,
+                              double *u, double *v) {
+    if (g->topo == ORC_UNKNOWN) return ORC_ERR_UNKNOWN_TOPOLOGY;
+    if (g->topo == ORC_BIPOLAR) return ORC_ERR_FLUX_INTO_LAND; /* k₋₁(nothing) throws at j == ny (triads.jl:87-88) */
+    const int64_t G = g->nx * g->ny * g->nz;
+    double *Si = (double *)malloc((size_t)G * 8), *Sj = (double *)malloc((size_t)G * 8);
+    if (!Si || !Sj) { free(Si); free(Sj); return ORC_ERR_ALLOC; }
+    for (int64_t k = 0; k < g->nz; ++k)
+        for (int64_t j = 0; j < g->ny; ++j)
+            for (int64_t i = 0; i < g->nx; ++i) {
+                int64_t I = lin(g, i, j, k);
+                double si = NAN, sj = NAN;
+                if (wet3D[I]) {
+                    si = triad_slope(rho, Z3D, dist_e, g, i, j, k, 0); /* RediGM.jl:52 */
+                    sj = triad_slope(rho, Z3D, dist_n, g, i, j, k, 1); /* :53 */
+                }
+                si = jl_clamp(si, -maxslope, maxslope);                /* :56-57 */
+                sj = jl_clamp(sj, -maxslope, maxslope);
+                double taper = 0.5 * (1 + tanh((0.004 - sqrt(si * si + sj * sj)) / 0.001)); /* :59-62 */
+                Si[I] = kappaGM * (taper * si);                        /* :63-64, :76-77 κGM .* Sᵢ */
+                Sj[I] = kappaGM * (taper * sj);
+            }
+    for (int64_t k = 0; k < g->nz; ++k)
+        for (int64_t j = 0; j < g->ny; ++j)
+            for (int64_t i = 0; i < g->nx; ++i) {
+                int64_t I = lin(g, i, j, k);
+                u[I] = wet3D[I] ? dyad_deriv(Si, Z3D, g, i, j, k) : NAN; /* :76 */
+                v[I] = wet3D[I] ? dyad_deriv(Sj, Z3D, g, i, j, k) : NAN; /* :77 */
+            }
+    free(Si); free(Sj);
+    return ORC_OK;
+}
+
 /* ---- Distances.haversine 0.10 (radius 6371000), points are (lon°, lat°) --- */
 double orc_haversine(double lon1, double lat1, double lon2, double lat2) {
     const double d2r = M_PI / 180.0; /* deg2rad(z) = z * (pi/180) */

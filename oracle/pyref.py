@@ -383,3 +383,69 @@ def velocity_flux(a_i, a_j, rho, gm, topo, to_velocity=False):
                     oi[i - 1, j - 1, k - 1] = _at(a_i, C) / (mE * tE * ee)
                     oj[i - 1, j - 1, k - 1] = _at(a_j, C) / (mN * tN * en)
     return oi, oj
+
+
+# ---- bolus_GM_velocity: src/RediGM.jl:46-79, src/triads.jl:69-146, src/dyads.jl:29-78 (unpinned) -----------
+def _gnan(A, I):  # getindexornan, gridtopology.jl:69
+    return NaN if I is None else _at(A, I)
+
+
+def _nanmean(vals):  # sum(w * v for ...) / sum(weights) with Bool weights
+    s, n = None, 0
+    for x in vals:
+        w = not math.isnan(x)
+        t = x if w else 0.0
+        s = t if s is None else s + t
+        n += int(w)
+    return s / n if n else NaN
+
+
+def _div(a, b):  # IEEE division (Python raises on /0)
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a != a or a == 0:
+            return NaN
+        return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
+def triad_slope(chi, Z, dist2d, topo, C, shift):  # triads.jl:84-133
+    N, S, E = topo.km1(C), topo.kp1(C), shift(C)
+    if E is None:
+        raise RuntimeError("k₋₁(nothing)")
+    NE, SE = topo.km1(E), topo.kp1(E)
+    vC, vN, vS, vE, vNE, vSE = _at(chi, C), _gnan(chi, N), _gnan(chi, S), _gnan(chi, E), _gnan(chi, NE), _gnan(chi, SE)
+    dCN, dCS = abs(_gnan(Z, N) - _at(Z, C)), abs(_gnan(Z, S) - _at(Z, C))
+    dCE = float(dist2d[C[0] - 1, C[1] - 1])
+    dENE, dESE = abs(_gnan(Z, NE) - _gnan(Z, E)), abs(_gnan(Z, SE) - _gnan(Z, E))
+    CN, CS, CE = _div(vN - vC, dCN), _div(vC - vS, dCS), _div(vE - vC, dCE)
+    ENE, ESE = _div(vNE - vE, dENE), _div(vE - vSE, dESE)
+    return _nanmean([_div(CE, CN), _div(CE, CS), _div(CE, ENE), _div(CE, ESE)])
+
+
+def dyad_deriv(chi, Z, topo, C):  # dyads.jl:38-65
+    N, S = topo.km1(C), topo.kp1(C)
+    dCN, dCS = abs(_gnan(Z, N) - _at(Z, C)), abs(_gnan(Z, S) - _at(Z, C))
+    return _nanmean([_div(_gnan(chi, N) - _at(chi, C), dCN), _div(_at(chi, C) - _gnan(chi, S), dCS)])
+
+
+def bolus_gm_velocity(rho, gm, idx, topo, kappaGM=600.0, maxslope=0.01):
+    Z, dn2 = gm["Z3D"], gm["distance_to_neighbour_2D"]
+    shape = rho.shape
+    Si, Sj = np.full(shape, NaN), np.full(shape, NaN)
+    for C in idx["Cwet"]:
+        Si[C[0] - 1, C[1] - 1, C[2] - 1] = triad_slope(rho, Z, dn2["east"], topo, C, topo.ip1)
+        Sj[C[0] - 1, C[1] - 1, C[2] - 1] = triad_slope(rho, Z, dn2["north"], topo, C, topo.jp1)
+    clamp = lambda x: maxslope if x > maxslope else (-maxslope if x < -maxslope else x)
+    Ki, Kj = np.full(shape, NaN), np.full(shape, NaN)
+    for q in np.ndindex(shape):
+        si, sj = clamp(float(Si[q])), clamp(float(Sj[q]))
+        r2 = si * si + sj * sj
+        taper = 0.5 * (1 + math.tanh((0.004 - math.sqrt(r2)) / 0.001)) if r2 == r2 else NaN
+        Ki[q] = kappaGM * (taper * si)
+        Kj[q] = kappaGM * (taper * sj)
+    u, v = np.full(shape, NaN), np.full(shape, NaN)
+    for C in idx["Cwet"]:
+        u[C[0] - 1, C[1] - 1, C[2] - 1] = dyad_deriv(Ki, Z, topo, C)
+        v[C[0] - 1, C[1] - 1, C[2] - 1] = dyad_deriv(Kj, Z, topo, C)
+    return u, v

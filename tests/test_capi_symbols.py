@@ -29,10 +29,14 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_no_cpu_fallback_in_product_path():
-    """The product package must not import the oracle."""
+    """The product package must never import, load or link the oracle (comments may mention it)."""
     pkg = os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd")
+    banned = re.compile(r"(import\s+oracle|from\s+oracle|libotmb_oracle|oracle[/\\.]o|otmb_oracle\.c|orc_[a-z_]+\()")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".jl")):
                 src = open(os.path.join(dirpath, f), encoding="utf-8").read()
-                assert "oracle" not in src.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"
+                m = banned.search(src)
+                assert m is None, f"{f} references the oracle: {m.group(0)}"
+    for f in ("julia/OceanTransportMatrixBuilderAMD.jl", "include/otmb.h"):
+        assert banned.search(open(os.path.join(ROOT, f), encoding="utf-8").read()) is None
