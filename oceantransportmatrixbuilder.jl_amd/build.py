@@ -28,15 +28,17 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra=(), name=None):
+    """name: build a VARIANT library lib/libotmb_hip_<name>.so (perf A/B in one process, tools/ab_variants.py)."""
+    lib = LIB if name is None else os.path.join(LIBDIR, f"libotmb_hip_{name}.so")
+    if name is None and not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ("" if name is None else "_" + name) + ".o")
         objs.append(obj)
         cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
         if verbose:
@@ -45,11 +47,11 @@ def build(force=False, verbose=False, extra=()):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

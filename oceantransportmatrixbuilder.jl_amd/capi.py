@@ -104,6 +104,13 @@ def _preload_hip_runtime():
                 pass
 
 
+def use_library(path):
+    """Switch the process to another build of the library (perf A/B of variants; contexts are per library)."""
+    global _lib, LIB_PATH
+    LIB_PATH = path
+    _lib = None
+
+
 def lib():
     """Load libotmb_hip.so (built by build.py / __graft_entry__.build()).  Fails loudly if absent."""
     global _lib

@@ -350,8 +350,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 for (unsigned u = 2 * lane; u < end; u += 128) {
                     const bool lo = u >= par, hi = u + 1 < end;
                     if (lo & hi) {
+#ifdef OTMB_NT_STORES
+                        __builtin_nontemporal_store(*(const i64x2 *)(my_row + u), (i64x2 *)(rv - par + u));
+                        __builtin_nontemporal_store(*(const f64x2 *)(my_val + u), (f64x2 *)(nz - par + u));
+#else
                         *(i64x2 *)(rv - par + u) = *(const i64x2 *)(my_row + u);
                         *(f64x2 *)(nz - par + u) = *(const f64x2 *)(my_val + u);
+#endif
                     } else if (lo) {
                         rv[u - par] = my_row[u];
                         nz[u - par] = my_val[u];
