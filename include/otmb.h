@@ -190,6 +190,19 @@ int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                    double *const nzval[5], int64_t nnz_out[5]);
 
+/* ---- makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices) -- the array work of
+ *      src/gridcellgeometry.jl:265-311 (device pointers; vertex permutation :158-178 and topology detection
+ *      src/gridtopology.jl:33-53 are host decisions passed in as `perm` (0-based) and `topology`).
+ * volcello (nx,ny,nz), areacello (nx,ny) with `missing` as NaN; fill_area/fill_vol: their _FillValue (NaN if none);
+ * lon, lat (nx,ny); lon_vertices, lat_vertices (4,nx,ny) as given.  Outputs: area2d, v3d, thkcello, z3d and the
+ * three groups of four (nx,ny) arrays in OTMB_DIR_* order: edge_length_2D, distance_to_edge_2D,
+ * distance_to_neighbour_2D.  Transcendentals use the device math library: ~1e-15 relative to a host build. */
+int32_t otmb_makegridmetrics_dev(otmb_ctx *ctx, const double *volcello, const double *areacello, double fill_area,
+                                 double fill_vol, const double *lon, const double *lat, const double *lon_vertices,
+                                 const double *lat_vertices, const int32_t perm[4], int64_t nx, int64_t ny, int64_t nz,
+                                 int32_t topology, double *area2d, double *v3d, double *thkcello, double *z3d,
+                                 double *const edge_length[4], double *const dist_edge[4], double *const dist_nbr[4]);
+
 /* ---- bolus_GM_velocity(ρ, gridmetrics, indices; κGM = 600, maxslope = 0.01) -- src/RediGM.jl:46-79 with
  *      globalverticalfacetriadderivative (src/triads.jl:84-146) and globalverticaldyadderivative
  *      (src/dyads.jl:38-78).  Experimental in the reference, not connected to transportmatrix, and unpinned by

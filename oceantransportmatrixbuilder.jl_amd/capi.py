@@ -69,6 +69,9 @@ SYMBOLS = {
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_result": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_set_nnz_base": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
+    "otmb_makegridmetrics_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32 * 4),
+                                              C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp,
+                                              C.POINTER(_vp * 4), C.POINTER(_vp * 4), C.POINTER(_vp * 4)]),
     "otmb_bolus_gm_velocity_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
     "otmb_bolus_gm_velocity": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
     "otmb_spadd_plan_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),
@@ -166,7 +169,7 @@ class Context:
     def timing_enable(self, on=True):
         self.check(lib().otmb_ctx_timing_enable(self._h, int(on)))
 
-    def timing_collect(self, n=10):
+    def timing_collect(self, n=11):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()

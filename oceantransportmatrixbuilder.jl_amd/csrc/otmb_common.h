@@ -23,7 +23,7 @@ struct TmPlan;  // otmb_transportmatrix.hip
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 

@@ -55,6 +55,49 @@ class DeviceAssembler:
         self.upwind = bool(upwind)
         self.makeindices()
 
+    def set_grid_from_raw(self, *, areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices, mlotst, rho,
+                          kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True):
+        """makegridmetrics on the device (otmb_makegridmetrics_dev): the raw CMIP arrays go up once, every derived
+        array stays in HBM.  Host work is limited to the vertex permutation and the topology test."""
+        from . import gridtopology as gt
+        from ._nt import data_and_props
+        from .gridmetrics import vertexpermutation
+
+        area, ap = data_and_props(areacello)
+        vol, vp = data_and_props(volcello)
+        area = np.asfortranarray(area, dtype=np.float64)
+        vol = np.asfortranarray(vol, dtype=np.float64)
+        lonv = np.asfortranarray(data_and_props(lon_vertices)[0], dtype=np.float64)
+        latv = np.asfortranarray(data_and_props(lat_vertices)[0], dtype=np.float64)
+        perm = vertexpermutation(lonv, latv)
+        topo = gt.getgridtopology(lonv[perm], latv[perm])
+        self.shape = tuple(int(x) for x in vol.shape)
+        self.nx, self.ny, self.nz = self.shape
+        self.G, P = self.nx * self.ny * self.nz, self.nx * self.ny
+        self.topology = topo
+        f64 = lambda n: torch.empty(n, dtype=torch.float64, device=self.device)
+        self.area, self.v3d, self.thk, self.z3d = f64(P), f64(self.G), f64(self.G), f64(self.G)
+        self.edge, self.dist_edge, self.dist = [f64(P) for _ in range(4)], [f64(P) for _ in range(4)], [f64(P) for _ in range(4)]
+        d_vol, d_area = self._t(vol), self._t(area)
+        d_lon, d_lat = self._t(np.asarray(data_and_props(lon)[0])), self._t(np.asarray(data_and_props(lat)[0]))
+        d_lonv, d_latv = self._t(lonv), self._t(latv)
+        pa = (C.c_int32 * 4)(*perm)
+        self.ctx.check(self.lib.otmb_makegridmetrics_dev(
+            self.ctx.handle, d_vol.data_ptr(), d_area.data_ptr(), float(ap.get("_FillValue", np.nan)),
+            float(vp.get("_FillValue", np.nan)), d_lon.data_ptr(), d_lat.data_ptr(), d_lonv.data_ptr(), d_latv.data_ptr(),
+            C.byref(pa), self.nx, self.ny, self.nz, topo, self.area.data_ptr(), self.v3d.data_ptr(), self.thk.data_ptr(),
+            self.z3d.data_ptr(), C.byref(capi.ptr_array(4, [t.data_ptr() for t in self.edge])),
+            C.byref(capi.ptr_array(4, [t.data_ptr() for t in self.dist_edge])),
+            C.byref(capi.ptr_array(4, [t.data_ptr() for t in self.dist]))))
+        self.ctx.synchronize()
+        self.zt = self._t(np.asarray(data_and_props(lev)[0]))
+        self.mlotst = self._t(mlotst)
+        self.rho = None if np.ndim(rho) == 0 else self._t(rho)
+        self.rho_scalar = float(rho) if np.ndim(rho) == 0 else 0.0
+        self.kappa = (float(kappaH), float(kappaVML), float(kappaVdeep))
+        self.upwind = bool(upwind)
+        self.makeindices()
+
     def makeindices(self):
         """otmb_makeindices_dev on the resident v3D (src/matrixbuilding.jl:10-24)."""
         self.lwet3d = torch.empty(self.G, dtype=torch.int64, device=self.device)
