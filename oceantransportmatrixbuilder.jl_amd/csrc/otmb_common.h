@@ -34,6 +34,7 @@ struct otmb_ctx {
     std::string err;
     // scratch for the scans / flags
     DevBuf blocksums, blockoffs, flags, lookback, tcount, tfix[3];
+    DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     int *h_flags = nullptr;  // pinned host mirror of the flag words
     i64 *h_tot = nullptr;    // pinned host mirror of scan totals
     TmPlan *plan = nullptr;

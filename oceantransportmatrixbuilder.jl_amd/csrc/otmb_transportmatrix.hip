@@ -377,11 +377,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     }
 }
 
-__global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, const i64 *tot, i64 N, i64 b0,
-                                 i64 b1, i64 b2, i64 b3, i64 b4) {
+// closing colptr entry of each matrix: nnz_base + nnz + 1 (values known on the host since the plan)
+__global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
     if (threadIdx.x == 0) {
-        c0[N] = b0 + tot[0] + 1; c1[N] = b1 + tot[1] + 1; c2[N] = b2 + tot[2] + 1; c3[N] = b3 + tot[3] + 1;
-        c4[N] = b4 + tot[4] + 1;
+        c0[N] = t0 + 1; c1[N] = t1 + 1; c2[N] = t2 + 1; c3[N] = t3 + 1; c4[N] = t4 + 1;
     }
 }
 
@@ -457,8 +456,8 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
         p.wet_base = pl->wet_base;
         for (int m = 0; m < 5; ++m) p.nnz_base[m] = pl->nnz_base[m];
     }
-    p.tilesums = (uint32_t *)ctx->blocksums.p;
-    p.tileoffs = (const i64 *)ctx->blockoffs.p;
+    p.tilesums = (uint32_t *)ctx->tm_sums.p;
+    p.tileoffs = (const i64 *)ctx->tm_offs.p;
     p.flags = (int *)ctx->flags.p;
 }
 
@@ -551,8 +550,8 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     if ((rc = validate_args(ctx, a))) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
-    if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
     if (!ctx->plan) ctx->plan = new TmPlan();
     TmPlan &pl = *ctx->plan;
     pl.args = *a;
@@ -569,8 +568,8 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         }
         {
             KernelTimer kt(ctx, K_TILESCAN);
-            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->blockoffs.p, dtot, ntiles, TM_NF,
-                                 (i64 *)ctx->blockoffs.p + (ntiles + 1) * TM_NF);
+            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, ntiles, TM_NF,
+                                 (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -615,7 +614,6 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)pl.args.n_wet + 16))) return rc;
     p.tcount = (uint8_t *)ctx->tcount.p;
     int *dflags = (int *)ctx->flags.p;
-    i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     if (pl.ntiles > 0) {
         KernelTimer kt(ctx, K_TM_FILL);
         hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
@@ -623,8 +621,8 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     {
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
-                           p.colptr[3], p.colptr[4], dtot, (i64)pl.args.n_wet, p.nnz_base[0], p.nnz_base[1],
-                           p.nnz_base[2], p.nnz_base[3], p.nnz_base[4]);
+                           p.colptr[3], p.colptr[4], (i64)pl.args.n_wet, p.nnz_base[0] + pl.nnz[0], p.nnz_base[1] + pl.nnz[1],
+                           p.nnz_base[2] + pl.nnz[2], p.nnz_base[3] + pl.nnz[3], p.nnz_base[4] + pl.nnz[4]);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -686,8 +684,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     } else {
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
-                           p.colptr[3], p.colptr[4], dtot, (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2],
-                           p.nnz_base[3], p.nnz_base[4]);
+                           p.colptr[3], p.colptr[4], (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2], p.nnz_base[3],
+                           p.nnz_base[4]);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

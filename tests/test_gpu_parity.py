@@ -272,3 +272,28 @@ def test_edge_grids(api, oracle, kind):
     for m in MATS:
         assert tm[m].shape == (ref["N"], ref["N"])
         assert_csc_equal(tuple(tm[m]), rtm[m], f"{kind}/{m}")
+
+
+def test_plan_survives_other_calls_before_fill(oracle):
+    """plan -> (other library calls that use scratch scans) -> fill must still be correct."""
+    import torch
+
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case("small_rho3d")
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    phi = asm.facefluxes(umo, vmo, _fill(g))
+    asm.plan(phi)
+    keep = (asm.lwet3d, asm.lwet, asm.wet3d)  # the plan points at these: they must outlive fill
+    asm.makeindices()  # same context: runs the scratch tile scans between plan and fill
+    assert keep[0].data_ptr() != asm.lwet3d.data_ptr()
+    asm.fill()
+    got = asm.result_to_host()
+    for m in MATS:
+        assert_csc_equal(got[m], rtm[m], m)
