@@ -34,8 +34,9 @@ def parse():
     ap.add_argument("--rho", default="array", choices=["array", "scalar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20260501)
-    ap.add_argument("--protocol", default="twophase", choices=["twophase", "onepass"],
-                    help="twophase: count -> scan -> fill (what the C ABI's plan/fill does); onepass: decoupled look-back")
+    ap.add_argument("--protocol", default="async", choices=["async", "twophase"],
+                    help="async: otmb_transportmatrix_dev (count -> scan -> fill enqueued back to back, outputs preallocated "
+                         "at their upper bound); twophase: plan (host learns nnz) then fill, as a caller that sizes its outputs does")
     return ap.parse_args()
 
 
@@ -147,10 +148,16 @@ def main():
             ctx = asm.ctx
 
             def step(self):
-                asm.step(umo, vmo, fill, onepass=(args.protocol == "onepass"))
+                if args.protocol == "async":
+                    asm.step_async(umo, vmo, fill)  # no host round trip inside a step; errors surface in sync()
+                else:
+                    asm.step(umo, vmo, fill, onepass=False)
 
             def sync(self):
-                asm.ctx.synchronize()
+                if args.protocol == "async":
+                    asm.finish()
+                else:
+                    asm.ctx.synchronize()
 
             @property
             def nnz(self):

@@ -166,11 +166,12 @@ typedef struct {
 int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                       double *const nzval[5]);
-/* One-pass variant for device-resident callers that know an upper bound of the output sizes (a column
- * holds at most 7, 7, 5, 3, 3 entries of T, Tadv, TκH, TκVML, TκVdeep): inputs are read once and the five
- * matrices written once (tile offsets by decoupled look-back instead of a count pass).  Asynchronous;
- * capacity[m] = entries rowval[m]/nzval[m] can hold; colptr[m] holds n_wet+1.  otmb_transportmatrix_result
- * synchronises, raises the reference's errors / OTMB_ERR_CAPACITY and returns the five nnz.           */
+/* Asynchronous variant for device-resident callers that preallocate the outputs at an upper bound (a column
+ * holds at most 7, 7, 5, 3, 3 entries of T, Tadv, TκH, TκVML, TκVdeep): count -> scan -> fill are enqueued back
+ * to back with no host round trip.  capacity[m] = entries rowval[m]/nzval[m] can hold; colptr[m] holds
+ * n_wet+1.  otmb_transportmatrix_result synchronises, raises the reference's errors / OTMB_ERR_CAPACITY,
+ * compacts T if entries cancelled and returns the five nnz.  (Environment OTMB_LOOKBACK=1 selects an
+ * experimental single-kernel variant whose tile offsets come from a decoupled look-back.)             */
 int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t *const colptr[5],
                                  int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
 int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);

@@ -67,8 +67,10 @@ struct KernelTimer {
 #define OTMB_NFLAGS 16
 enum {
     FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
-    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_U_VALID, FLAG_V_VALID, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY,
-    FLAG_T_CANCEL  // some T entry summed to exactly zero: T was written with gaps and needs compaction
+    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY,
+    FLAG_T_CANCEL,  // some T entry summed to exactly zero: T was written with gaps and needs compaction
+    OTMB_NFLAGS_TM = 12,            // words [0, OTMB_NFLAGS_TM) belong to transportmatrix and are reset by it
+    FLAG_U_VALID = 12, FLAG_V_VALID = 13  // owned by facefluxes: untouched by a transportmatrix call in between
 };
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);

@@ -14,6 +14,8 @@
 //                                   written once -- the algorithmic HBM traffic;
 //   4. entries are staged through LDS and streamed out with fully coalesced 8-byte-per-lane stores
 //      (a column's entries are contiguous, a tile's columns are contiguous).
+#include <cstdlib>
+
 #include "otmb_tm_column.h"
 
 #ifndef TM_THREADS
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const unsigned cnt = wc[m];
         bool room = true;
-        if (MODE == MODE_ONEPASS) {
+        if (p.cap[m] > 0) {  // callers that preallocate at an upper bound (0 = sized exactly by a plan)
             room = g0[m] + wb[m] + cnt <= p.cap[m];
             if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
         }
@@ -381,6 +383,14 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
     if (threadIdx.x == 0) {
         c0[N] = t0 + 1; c1[N] = t1 + 1; c2[N] = t2 + 1; c3[N] = t3 + 1; c4[N] = t4 + 1;
+    }
+}
+
+// same, with the totals still on the device (asynchronous count -> scan -> fill)
+__global__ void tm_finish_colptr_dev(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, const i64 *tot, i64 b0, i64 b1, i64 b2,
+                                     i64 b3, i64 b4) {
+    if (threadIdx.x == 0) {
+        c0[N] = b0 + tot[0] + 1; c1[N] = b1 + tot[1] + 1; c2[N] = b2 + tot[2] + 1; c3[N] = b3 + tot[3] + 1; c4[N] = b4 + tot[4] + 1;
     }
 }
 
@@ -560,7 +570,8 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     fill_params(p, *a, ctx, &pl);
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
-    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS_TM * sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dtot, 0, 8 * sizeof(i64), ctx->stream));
     if (ntiles > 0) {
         {
             KernelTimer kt(ctx, K_TM_COUNT);
@@ -573,7 +584,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = check_flags(ctx))) return rc;
@@ -625,7 +636,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
                            p.nnz_base[2] + pl.nnz[2], p.nnz_base[3] + pl.nnz[3], p.nnz_base[4] + pl.nnz[4]);
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     // the values exist only now: raise the reference's errors, and repair T if entries cancelled
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = check_flags(ctx))) { pl.valid = false; return rc; }
@@ -652,9 +663,17 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     if ((rc = validate_args(ctx, a))) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
-    // look-back words [ntiles][5] + the ticket, zeroed on the stream before every launch
-    const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);
-    if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
+    // Default: COUNT -> tile scan -> FILL enqueued back to back with no host round trip (the totals stay on the
+    // device).  OTMB_LOOKBACK=1 selects the single-kernel decoupled look-back variant instead (read-once, but
+    // currently slower: the look-back depth is about the number of tiles in flight).
+    static const bool use_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e && e[0] == '1'; }();
+    const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);  // look-back words + prefixes (+ ticket)
+    if (use_lookback) {
+        if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
+    } else {
+        if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
+        if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
+    }
     if (!ctx->plan) ctx->plan = new TmPlan();
     TmPlan &pl = *ctx->plan;
     pl.valid = false;
@@ -664,31 +683,53 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     fill_params(p, *a, ctx, &pl);
     for (int m = 0; m < 5; ++m) {
         if (!colptr[m] || !rowval[m] || !nzval[m]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        if (capacity[m] <= 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "capacity");
         p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
         p.cap[m] = capacity[m];
     }
     if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)a->n_wet + 16))) return rc;
     p.tcount = (uint8_t *)ctx->tcount.p;
     pl.outT[0] = p.colptr[0]; pl.outT[1] = p.rowval[0]; pl.outT[2] = p.nzval[0];
-    p.status = (u64 *)ctx->lookback.p;
-    p.n_tiles = ntiles + 1;
-    p.ticket = (int *)((char *)ctx->lookback.p + stbytes);
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     p.totals = dtot;
-    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->lookback.p, 0, stbytes + 64, ctx->stream));
-    if (ntiles > 0) {
-        KernelTimer kt(ctx, K_TM_ONEPASS);
-        hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
-    } else {
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS_TM * sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dtot, 0, 8 * sizeof(i64), ctx->stream));
+    if (ntiles == 0) {
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
                            p.colptr[3], p.colptr[4], (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2], p.nnz_base[3],
                            p.nnz_base[4]);
+    } else if (use_lookback) {
+        p.status = (u64 *)ctx->lookback.p;
+        p.n_tiles = ntiles + 1;
+        p.ticket = (int *)((char *)ctx->lookback.p + stbytes);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->lookback.p, 0, stbytes + 64, ctx->stream));
+        KernelTimer kt(ctx, K_TM_ONEPASS);
+        hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+    } else {
+        {
+            KernelTimer kt(ctx, K_TM_COUNT);
+            hipLaunchKernelGGL(tm_kernel<MODE_COUNT>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+        }
+        {
+            KernelTimer kt(ctx, K_TILESCAN);
+            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, ntiles, TM_NF,
+                                 (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF);
+        }
+        {
+            KernelTimer kt(ctx, K_TM_FILL);
+            hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+        }
+        {
+            KernelTimer kt(ctx, K_TM_FINISH);
+            hipLaunchKernelGGL(tm_finish_colptr_dev, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
+                               p.colptr[3], p.colptr[4], (i64)a->n_wet, (const i64 *)dtot, p.nnz_base[0], p.nnz_base[1],
+                               p.nnz_base[2], p.nnz_base[3], p.nnz_base[4]);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     pl.onepass_pending = true;
     return OTMB_OK;

@@ -297,3 +297,32 @@ def test_plan_survives_other_calls_before_fill(oracle):
     got = asm.result_to_host()
     for m in MATS:
         assert_csc_equal(got[m], rtm[m], m)
+
+
+def test_async_pipeline_of_steps(oracle):
+    """step_async x3 without host synchronisation, then finish(): same result, errors still surface."""
+    import torch
+
+    from otmb_amd.capi import OtmbError
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case("small_rho3d")
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    for _ in range(3):
+        asm.step_async(umo, vmo, _fill(g))
+    asm.finish()
+    got = asm.result_to_host()
+    for m in MATS:
+        assert_csc_equal(got[m], rtm[m], m)
+    bad = torch.full_like(umo, float("nan"))
+    asm.wet3d.fill_(1)  # all wet + all NaN -> the reference's assertion
+    asm.facefluxes_async(bad, vmo, _fill(g))
+    asm.transportmatrix_onepass(asm.phi, sync=False)
+    with pytest.raises(OtmbError, match="AssertionError"):
+        asm.finish()
