@@ -206,6 +206,15 @@ def main():
         dom = max(kavg, key=kavg.get)
         bytes_alg = runner.algorithmic_bytes() if dom.startswith("tm_kernel") else runner.facefluxes_bytes()
         achieved = bytes_alg / (kavg[dom] * 1e-3) / 1e9
+        # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same
+        # command (profiles/traffic.json; bytes do not depend on the box, unlike times)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("workload") == args.workload and world == 1 and args.rho == "array":
+                traffic = tj["kernels"].get(dom, {}).get("traffic_bytes")
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "wet-cells/s assembled into T", "value": value, "unit": "wet-cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -219,7 +228,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": kavg[dom],
             },
             "kernels_ms": {k: round(v, 5) for k, v in kavg.items()},
