@@ -37,7 +37,10 @@ def parse():
     ap.add_argument("--protocol", default="async", choices=["async", "twophase"],
                     help="async: otmb_transportmatrix_dev (count -> scan -> fill enqueued back to back, outputs preallocated "
                          "at their upper bound); twophase: plan (host learns nnz) then fill, as a caller that sizes its outputs does")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.steps = max(1, args.steps)
+    args.warmup = max(0, args.warmup)
+    return args
 
 
 def cpu_baseline(g, gm, workload):
@@ -115,10 +118,19 @@ def main():
             n_wet_total = srun.n_global
             ctx = be.ctx
 
+            pending = False
+
             def step(self):
-                srun.step(umo, vmo, fill)
+                if args.protocol == "async":
+                    srun.step_async(umo, vmo, fill)  # only the facefluxes chain's planes couple the ranks
+                    self.pending = True
+                else:
+                    srun.step(umo, vmo, fill)
 
             def sync(self):
+                if self.pending:
+                    srun.finish()
+                    self.pending = False
                 be.sync()
 
             @property
@@ -147,17 +159,20 @@ def main():
             n_wet_total = asm.N
             ctx = asm.ctx
 
+            pending = False
+
             def step(self):
                 if args.protocol == "async":
                     asm.step_async(umo, vmo, fill)  # no host round trip inside a step; errors surface in sync()
+                    self.pending = True
                 else:
                     asm.step(umo, vmo, fill, onepass=False)
 
             def sync(self):
-                if args.protocol == "async":
+                if self.pending:
                     asm.finish()
-                else:
-                    asm.ctx.synchronize()
+                    self.pending = False
+                asm.ctx.synchronize()
 
             @property
             def nnz(self):
@@ -195,6 +210,7 @@ def main():
     runner.ctx.timing_enable(True)
     for _ in range(args.steps):
         runner.step()
+    runner.sync()
     ktimes = runner.ctx.timing_collect()
     runner.ctx.timing_enable(False)
 

@@ -222,6 +222,34 @@ class SlabRunner:
         self.nnz_global[0] = int(t_all.sum())
         return out
 
+    # ---- asynchronous pipeline ----------------------------------------------------------------------------
+    # step() above synchronises all ranks twice per field (the two all_gathers), so every rank waits for the
+    # whole facefluxes chain: (W-1) x (one slab's facefluxes + one hop) per field.  step_async() keeps only the
+    # chain's point-to-point planes: each rank's columns are written with LOCAL colptr offsets, nothing is
+    # gathered, no host waits for the device.  Ranks then run skewed by one chain hop but all stay busy, and a
+    # stream of fields (the TMIP workflow: one matrix per month/year) flows at the speed of the slowest slab.
+    # finish() synchronises, combines the validity flags and the nnz of the LAST field and turns the local
+    # colptrs into global ones (+ per-matrix base), after which the pieces concatenate as usual.
+    def step_async(self, umo, vmo, fill):
+        cm = self.comm
+        if self.has_below:
+            cm.recv(self.top_below, self.rank + 1)
+        top_first = self.be.facefluxes(umo, vmo, fill, self.top_below)
+        if self.has_above:
+            cm.send(top_first, self.rank - 1)
+        self.be.assemble_async()
+
+    def finish(self):
+        cm = self.comm
+        nnz, uv = self.be.result()
+        allv = cm.allgather_i64(list(nnz) + [int(uv[0]), int(uv[1])], self.device)
+        if not (allv[:, 5].any() and allv[:, 6].any()):
+            raise AssertionError("all umo or vmo values are NaN or _FillValue")  # velocities.jl:199-200
+        self.nnz_base = allv[: self.rank, :5].sum(axis=0) if self.rank > 0 else np.zeros(5, dtype=np.int64)
+        self.nnz_global = allv[:, :5].sum(axis=0)
+        self.be.shift_colptr(self.nnz_base)
+        return self.be.out
+
     def sync(self):
         self.be.sync()
 
@@ -283,7 +311,7 @@ class HipSlabBackend:
             top[self.G - self.P:self.G].copy_(top_below)
         return top_first
 
-    def plan(self):
+    def _tm_args(self):
         a = self.capi.TmArgs()
         a.nx, a.ny, a.nz = self.nx, self.ny, self.nz
         a.topology, a.upwind, a.n_wet = self.s["topology"], int(self.s["upwind"]), self.n_own
@@ -299,6 +327,11 @@ class HipSlabBackend:
             a.dist_nbr[k] = self.dist_[k].data_ptr()
         a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.ml.data_ptr()
         a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.s["kappa"]
+        return a
+
+    def plan(self):
+        a = self._tm_args()
+        self._cap = None
         u, v = C.c_int32(0), C.c_int32(0)
         self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
         self.ctx.check(self.lib.otmb_transportmatrix_set_slab(self.ctx.handle, self.s["wet_base"]))
@@ -326,6 +359,38 @@ class HipSlabBackend:
 
     def shift_T_colptr(self, delta):
         self.out[MATS[0]][0].add_(int(delta))
+
+    PER_COLUMN_MAX = (7, 7, 5, 3, 3)
+
+    def assemble_async(self):
+        """otmb_transportmatrix_dev on this slab: count -> scan -> fill enqueued with local colptr offsets."""
+        if self.out is None or getattr(self, "_cap", None) is None:
+            cap = [self.n_own * k + 1 for k in self.PER_COLUMN_MAX]
+            self.out = {m: (torch.empty(self.n_own + 1, dtype=torch.int64, device=self.device),
+                            torch.empty(cap[k], dtype=torch.int64, device=self.device),
+                            torch.empty(cap[k], dtype=torch.float64, device=self.device)) for k, m in enumerate(MATS)}
+            self._cap = cap
+        a = self._tm_args()
+        self.ctx.check(self.lib.otmb_transportmatrix_set_slab(self.ctx.handle, self.s["wet_base"]))
+        cp = self.capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
+        rv = self.capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
+        nz = self.capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
+        caps = (C.c_int64 * 5)(*self._cap)
+        self.ctx.check(self.lib.otmb_transportmatrix_dev(self.ctx.handle, C.byref(a), C.byref(cp), C.byref(rv), C.byref(nz),
+                                                         C.byref(caps)))
+
+    def result(self):
+        u, v = C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
+        nnz = (C.c_int64 * 5)()
+        self.ctx.check(self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz)))
+        self.nnz = [int(x) for x in nnz]
+        return self.nnz, (u.value, v.value)
+
+    def shift_colptr(self, bases):
+        for k, m in enumerate(MATS):
+            if int(bases[k]):
+                self.out[m][0].add_(int(bases[k]))
 
     def sync(self):
         self.ctx.synchronize()

@@ -36,8 +36,13 @@ def run(rank, world, port, backend_kind, case, outdir):
     dev = be.device
     umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
     vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
-    for _ in range(2):  # twice: buffers are reused between fields
-        out = runner.step(umo, vmo, 1e20)
+    if os.environ.get("OTMB_TEST_ASYNC") == "1":
+        for _ in range(3):  # a stream of fields with no collective in between
+            runner.step_async(umo, vmo, 1e20)
+        out = runner.finish()
+    else:
+        for _ in range(2):  # twice: buffers are reused between fields
+            out = runner.step(umo, vmo, 1e20)
     runner.sync()
     host = be.result_to_host() if backend_kind == "hip" else out
     glob = od.gather_global_csc(comm, host, runner.n_own, be.nnz, dev)

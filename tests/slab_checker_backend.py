@@ -71,6 +71,16 @@ class OracleSlabBackend:
         self.out = {m: (self.cols[m][0] + int(nnz_base[k]) + 1, self.cols[m][1], self.cols[m][2]) for k, m in enumerate(MATS)}
         return self.out
 
+    def assemble_async(self):
+        self.plan()
+        self.fill(np.zeros(5, dtype=np.int64))
+
+    def result(self):
+        return self.nnz, self.uv
+
+    def shift_colptr(self, bases):
+        self.out = {m: (self.out[m][0] + int(bases[k]), self.out[m][1], self.out[m][2]) for k, m in enumerate(MATS)}
+
     def shift_T_colptr(self, delta):
         cp, rv, nz = self.out[MATS[0]]
         self.out[MATS[0]] = (cp + int(delta), rv, nz)

@@ -34,9 +34,9 @@ def whole_grid_reference(oracle, nx, ny, nz, seed, rho, topo):
     return idx, oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
 
 
-def run_ranks(world, kind, case, outdir, timeout=300):
+def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False):
     port = free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTMB_TEST_ASYNC="1" if async_mode else "0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), kind,
                                *[str(x) for x in case], str(outdir)], env=env) for r in range(world)]
     rcs = [p.wait(timeout=timeout) for p in procs]
@@ -67,4 +67,11 @@ def test_balanced_partition_properties():
 def test_slab_orchestration_gloo(oracle, tmp_path, world, rho):
     case = (12, 10, 9, 21, rho, "tripolar")
     z = run_ranks(world, "oracle", case, tmp_path)
+    check_against_whole_grid(oracle, z, case)
+
+
+def test_slab_async_pipeline_gloo(oracle, tmp_path):
+    """step_async x3 + finish: no collective per field, local colptrs shifted to global ones at the end."""
+    case = (12, 10, 9, 22, "array", "tripolar")
+    z = run_ranks(3, "oracle", case, tmp_path, async_mode=True)
     check_against_whole_grid(oracle, z, case)

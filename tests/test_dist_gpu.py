@@ -13,3 +13,9 @@ def test_hip_slabs_match_whole_grid_oracle(oracle, tmp_path, world, rho):
     case = (24, 18, 11, 33, rho, "tripolar")
     z = run_ranks(world, "hip", case, tmp_path)
     check_against_whole_grid(oracle, z, case)
+
+
+def test_hip_slabs_async_pipeline(oracle, tmp_path):
+    case = (24, 18, 11, 34, "array", "tripolar")
+    z = run_ranks(3, "hip", case, tmp_path, async_mode=True)
+    check_against_whole_grid(oracle, z, case)
