@@ -326,3 +326,51 @@ def test_async_pipeline_of_steps(oracle):
     asm.transportmatrix_onepass(asm.phi, sync=False)
     with pytest.raises(OtmbError, match="AssertionError"):
         asm.finish()
+
+
+# ---- randomised sweep: many small grids, both topologies, odd/even nx, zero and missing fluxes --------------
+@pytest.mark.parametrize("seed", range(24))
+def test_random_small_grids(api, oracle, seed):
+    from helpers import gridmetrics_of, randomize_metrics
+    from otmb_amd import synthetic
+
+    rng = np.random.default_rng(1000 + seed)
+    nx, ny, nz = int(rng.integers(3, 11)), int(rng.integers(2, 8)), int(rng.integers(1, 7))
+    topo = "tripolar" if rng.random() < 0.7 else "bipolar"
+    rho = "array" if rng.random() < 0.5 else "scalar"
+    g = synthetic.make_grid(nx, ny, nz, seed=int(rng.integers(1 << 30)), land_fraction=float(rng.uniform(0.0, 0.6)), topology=topo, rho=rho)
+    gm = randomize_metrics(gridmetrics_of(g), seed=seed)
+    umo, vmo = g.umo.data.copy(order="F"), g.vmo.data.copy(order="F")
+    wet = ~np.isnan(gm.v3D)
+    z = rng.random(umo.shape) < 0.15  # exact zeros: faces without any flux
+    umo[z & wet] = 0.0
+    vmo[(rng.random(umo.shape) < 0.15) & wet] = 0.0
+    umo[(rng.random(umo.shape) < 0.05) & wet] = np.nan  # missing inside the ocean
+    if not np.any(wet):
+        pytest.skip("all land")
+    ref = oracle.makeindices(gm.v3D)
+    idx = api.makeindices(gm.v3D)
+    assert np.array_equal(idx.Lwet3D, ref["Lwet3D"])
+    try:
+        rphi = oracle.facefluxes(umo, vmo, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    except oracle.OracleError:
+        with pytest.raises(Exception):
+            api.facefluxes(umo, vmo, gm, idx, FillValue=1e20)
+        return
+    phi = api.facefluxes(umo, vmo, gm, idx, FillValue=1e20)
+    for k in rphi:
+        assert np.array_equal(phi[k], rphi[k]), k
+    upwind = bool(rng.random() < 0.6)
+    kw = dict(mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=float(rng.choice([0.0, 500.0])), κVML=0.1, κVdeep=1e-5, upwind=upwind)
+    try:
+        rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, kw["κH"], 0.1, 1e-5, upwind)
+    except oracle.OracleError as e:
+        from otmb_amd.capi import OtmbError
+
+        with pytest.raises(OtmbError) as ei:
+            api.transportmatrix(ϕ=rphi, **kw)
+        assert {-1: 1, -2: 2, -3: 3, -4: 4, -5: 5, -6: 6}[e.code] == ei.value.status
+        return
+    tm = api.transportmatrix(ϕ=rphi, **kw)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], f"seed {seed} {nx}x{ny}x{nz} {topo} {m}")
