@@ -312,6 +312,9 @@ __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return 
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
 #define NEG0 (-0.0)
 
+// CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
+// The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
+template <bool CHECKS>
 __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
                                             i64 c, Column &col) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
@@ -330,8 +333,11 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
               lB = ldi(tb.lw, oB);
     const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
                  gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
-    const double qW0 = ldd(tb.pw, oC), qE0 = ldd(tb.pe, oC), qS0 = ldd(tb.ps, oC), qN0 = ldd(tb.pn, oC),
-                 qB0 = ldd(tb.pb, oC), qT0 = ldd(tb.pt, oC);  // own fluxes, for the outgoing check
+    double qW0 = 0, qE0 = 0, qS0 = 0, qN0 = 0, qB0 = 0, qT0 = 0;
+    if (CHECKS) {  // own fluxes, for the outgoing check
+        qW0 = ldd(tb.pw, oC); qE0 = ldd(tb.pe, oC); qS0 = ldd(tb.ps, oC); qN0 = ldd(tb.pn, oC); qB0 = ldd(tb.pb, oC);
+        qT0 = ldd(tb.pt, oC);
+    }
     const double vC = ldd(tb.v, oC), vE = ldd(tb.v, oE), vW = ldd(tb.v, oW), vS = ldd(tb.v, oS), vN = ldd(tb.v, oN),
                  vA = ldd(tb.v, oA), vB = ldd(tb.v, oB);
     double rC, rE, rW, rS, rN, rA, rB;
@@ -367,14 +373,14 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
     const double fA = wA ? sel_pos(gA0, up) : 0.0;  // cell above pushes its bottom flux
     const double fB = wB ? sel_neg(gB0, up) : 0.0;  // cell below pushes its top flux (its k > 1, :290)
     const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
-    {   // own pushes must land in a wet cell (see build_column)
+    if (CHECKS) {  // own pushes must land in a wet cell (see build_column)
         const double ow = sel_pos(qW0, up), oe = sel_neg(qE0, up), os = sel_pos(qS0, up), on = sel_neg(qN0, up);
         const double ob = sel_pos(qB0, up), ot = hA ? sel_neg(qT0, up) : 0.0;
         const bool bad = (nonzero(ow) & !wW) | (nonzero(oe) & !wE) | (nonzero(os) & !wS) | (nonzero(on) & !wN) |
                          (nonzero(ob) & !wB) | (nonzero(ot) & !wA);
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+        if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
     }
-    if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
 
     // row order of the column: A, S, row-mates by i, N, B.  Row-mates: W, SELF, E -- except at the
     // periodic wrap (i == 0: SELF, E, W(nx-1);  i == nx-1: E(0), W, SELF)
@@ -496,6 +502,17 @@ __device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase 
     const double mld = ldd((const char *)p.ml, s2);
     const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
     const bool wE = lE != 0, wW = lW != 0, wS = hS && lS != 0, wN = hN && lN != 0, wA = hA && lA != 0, wB = hB && lB != 0;
+#ifndef OTMB_CHECKS_IN_FILL
+    {   // the two input checks that need no arithmetic: own pushes land in wet cells (the reference indexes
+        // Lwet3D[C𝑗] unconditionally, :247 etc.) and ρ is not NaN on wet cells (:233)
+        const double ow = sel_pos(ldd(tb.pw, oC), up), oe = sel_neg(ldd(tb.pe, oC), up), os = sel_pos(ldd(tb.ps, oC), up),
+                     on = sel_neg(ldd(tb.pn, oC), up), ob = sel_pos(ldd(tb.pb, oC), up), ot = hA ? sel_neg(ldd(tb.pt, oC), up) : 0.0;
+        const bool bad = (nonzero(ow) & !wW) | (nonzero(oe) & !wE) | (nonzero(os) & !wS) | (nonzero(on) & !wN) |
+                         (nonzero(ob) & !wB) | (nonzero(ot) & !wA);
+        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+        if (tb.rho && isnan(ldd(tb.rho, oC))) raise_flag(p.flags, FLAG_RHO_NAN);
+    }
+#endif
     const bool aE = wE && nonzero(sel_pos(gE0, up)), aW = wW && nonzero(sel_neg(gW0, up));
     const bool aS = wS && nonzero(sel_neg(gS0, up)), aN = wN && nonzero(sel_pos(gN0, up));
     const bool aA = wA && nonzero(sel_pos(gA0, up)), aB = wB && nonzero(sel_neg(gB0, up));

@@ -133,8 +133,16 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 if (MODE == MODE_COUNT && regular) {
                     fast_presence(p, tb, oC, cell.i, cell.j, cell.k, col.padv, col.phh, col.pml, col.pdp);
                 } else {
-                    if (regular) fast_column(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+                    #ifdef OTMB_CHECKS_IN_FILL
+                    if (regular) fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+#else
+                    if (regular) fast_column<MODE == MODE_ONEPASS>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+#endif
+#ifdef OTMB_DBG_NOGENERIC  // timing experiment only (wrong on the seam row)
+                    else { col.padv = col.phh = col.pml = col.pdp = 0; }
+#else
                     else build_column(p, cell, c, col);
+#endif
                 }
                 live = true;
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
