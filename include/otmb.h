@@ -113,6 +113,13 @@ int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_v
  * u/v (or phi_i/phi_j): (nx,ny,nz) Float64 or Float32 (src_is_f32); rho: (nx,ny,nz) or NULL with rho_scalar;
  * edge_east/edge_north: gridmetrics.edge_length_2D[:east], [:north] (nx,ny).  Every cell is computed, as in
  * the reference.  A bipolar topology is an error (the reference indexes thkcello[nothing] at j == ny).    */
+/* B-grid (u, v on the NE corner, e.g. ACCESS-ESM1-5 uo/vo) -> default C-grid:
+ * interpolateontodefaultCgrid(…, ::BGridCell), src/gridcellgeometry.jl:106-140: _FillValue -> 0, then
+ * u2 = 0.5 (u + u one row south), v2 = 0.5 (v + v one cell west), zero shifted in at j == 1 / i == 1.    */
+int32_t otmb_bgrid_to_cgrid_dev(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, double fill,
+                                int64_t nx, int64_t ny, int64_t nz, double *u2, double *v2);
+int32_t otmb_bgrid_to_cgrid(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, double fill,
+                            int64_t nx, int64_t ny, int64_t nz, double *u2, double *v2);
 int32_t otmb_velocity2fluxes_dev(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, const double *rho,
                                  double rho_scalar, const double *thkcello, const double *edge_east,
                                  const double *edge_north, int64_t nx, int64_t ny, int64_t nz, int32_t topology,

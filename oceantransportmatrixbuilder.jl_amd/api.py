@@ -145,22 +145,42 @@ def _velocity_flux(which, a_i, a_j, gridmetrics, rho, device):
     return oi, oj
 
 
-def interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics):
-    """src/gridcellgeometry.jl:103-105: C-grid fields pass through; A-grid raises as in the reference.
-    B-grid interpolation (:106-140) is outside this round's scope."""
-    from .gridmetrics import getarakawagrid
+def interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics, *, device=0):
+    """src/gridcellgeometry.jl:103-140: C-grid fields pass through; B-grid fields whose velocity points sit on the NE
+    corner are averaged onto the east/north faces (on the device); A-grid raises as in the reference."""
+    from .gridmetrics import getarakawagrid, midpointonsphere
 
     kind, u_pos, v_pos = getarakawagrid(u_lon, u_lat, v_lon, v_lat, gridmetrics)
     if kind == "C":
         return u, u_lon, u_lat, v, v_lon, v_lat
     if kind == "A":
         raise RuntimeError("Interpolation not implemented for A-grid type")
-    raise NotImplementedError(f"B-grid({u_pos},{v_pos}) interpolation is not part of the MI355X path yet")
+    if not (u_pos == v_pos == "NE"):
+        raise RuntimeError(f"Interpolation not implemented for this B-grid({u_pos},{v_pos}) type")  # :109
+    ud, up = data_and_props(u)
+    vd, _ = data_and_props(v)
+    fill = up["_FillValue"]  # :111
+    x = np.asarray(ud)
+    y = np.asarray(vd)
+    is32 = x.dtype == np.float32 and y.dtype == np.float32
+    dt = np.float32 if is32 else np.float64
+    x = np.asfortranarray(x, dtype=dt)
+    y = np.asfortranarray(y, dtype=dt)
+    nx, ny, nz = x.shape
+    u2 = np.empty(x.shape, dtype=np.float64, order="F")
+    v2 = np.empty(x.shape, dtype=np.float64, order="F")
+    ctx = context(device)
+    ctx.check(capi.lib().otmb_bgrid_to_cgrid(ctx.handle, x.ctypes.data, y.ctypes.data, int(is32), float(fill), nx, ny, nz,
+                                             u2.ctypes.data, v2.ctypes.data))
+    lv, tv = gridmetrics["lon_vertices"], gridmetrics["lat_vertices"]
+    u2_lon, u2_lat = midpointonsphere(lv[2], tv[2], lv[1], tv[1])  # :132  (NE, SE)
+    v2_lon, v2_lat = midpointonsphere(lv[3], tv[3], lv[2], tv[2])  # :133  (NW, NE)
+    return u2, u2_lon, u2_lat, v2, v2_lon, v2_lat
 
 
 def velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics, ρ, *, device=0):
     """src/velocities.jl:10-39 -> (ϕᵢ, ϕⱼ)."""
-    u, _, _, v, _, _ = interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics)
+    u, _, _, v, _, _ = interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics, device=device)
     return _velocity_flux("otmb_velocity2fluxes", u, v, gridmetrics, ρ, device)
 
 
@@ -271,3 +291,19 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
     return NT(**{name: SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]])
                  for m, name in enumerate(MATS)})
+
+
+def as2D(x, wet3D):
+    """src/extratools.jl:111-115: scatter a surface vector back onto the (nx,ny) grid, NaN on land."""
+    wet = np.asfortranarray(wet3D).astype(bool)
+    out = np.full(wet.shape[:2], np.nan, order="F")
+    out.T[wet[:, :, 0].T] = np.asarray(x, dtype=np.float64)  # column-major order of the wet cells
+    return out
+
+
+def as3D(x, wet3D):
+    """src/extratools.jl:122-126: scatter a wet-cell vector back onto the (nx,ny,nz) grid, NaN on land."""
+    wet = np.asfortranarray(wet3D).astype(bool)
+    out = np.full(wet.shape, np.nan, order="F")
+    out.ravel(order="K")[np.flatnonzero(wet.ravel(order="K"))] = np.asarray(x, dtype=np.float64)
+    return out

@@ -128,6 +128,25 @@ int32_t otmb_bolus_gm_velocity(otmb_ctx *ctx, const double *rho, const double *z
     return OTMB_OK;
 }
 
+int32_t otmb_bgrid_to_cgrid(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, double fill, int64_t nx, int64_t ny,
+                            int64_t nz, double *u2, double *v2) {
+    if (!ctx || !u || !v || !u2 || !v2) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = (size_t)(nx * ny * nz), es = src_is_f32 ? 4 : 8;
+    const void *du, *dv;
+    TRY(upload(ctx, ST_UMO, u, G * es, &du));
+    TRY(upload(ctx, ST_VMO, v, G * es, &dv));
+    void *o1, *o2;
+    TRY(stage(ctx, ST_PHI0, G * 8, &o1));
+    TRY(stage(ctx, ST_PHI0 + 1, G * 8, &o2));
+    TRY(otmb_bgrid_to_cgrid_dev(ctx, du, dv, src_is_f32, fill, nx, ny, nz, (double *)o1, (double *)o2));
+    HIP_TRY(ctx, hipMemcpyAsync(u2, o1, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v2, o2, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
 int32_t otmb_velocity2fluxes(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, const double *rho, double rho_scalar,
                              const double *thkcello, const double *edge_east, const double *edge_north, int64_t nx, int64_t ny,
                              int64_t nz, int32_t topology, double *phi_i, double *phi_j) {

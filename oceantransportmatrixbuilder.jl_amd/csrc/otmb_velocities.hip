@@ -41,6 +41,42 @@ __global__ __launch_bounds__(256) void velocity_flux_kernel(const T *__restrict_
     }
 }
 
+// B-grid (velocities on the NE corner) -> default C-grid: interpolateontodefaultCgrid(…, ::BGridCell),
+// src/gridcellgeometry.jl:106-140.  u2 = 0.5 (u + u shifted by one row in j), v2 = 0.5 (v + v shifted by one cell
+// in i), with _FillValue replaced by 0 first (:125-128); the shifted-in row/column is zero (no periodic wrap).
+template <typename T>
+__global__ __launch_bounds__(256) void bgrid_to_cgrid_kernel(const T *__restrict__ u, const T *__restrict__ v, double fill, int nx,
+                                                              int ny, i64 P, i64 G, double *__restrict__ u2, double *__restrict__ v2) {
+    const i64 L = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (L >= G) return;
+    const i64 r = L % P;
+    const int j = (int)(r / nx), i = (int)(r - (i64)j * nx);
+    auto rep = [fill](double x) { return (__double_as_longlong(x) == __double_as_longlong(fill)) ? 0.0 : x; };  // replace(u, fill => 0.0)
+    const double uc = rep((double)u[L]), vc = rep((double)v[L]);
+    const double us = (j > 0) ? rep((double)u[L - nx]) : 0.0;  // [zeros(nx,1,nz);; u2[:, 1:end-1, :]]  (:127)
+    const double vw = (i > 0) ? rep((double)v[L - 1]) : 0.0;   // [zeros(1,ny,nz); v2[1:end-1, :, :]]   (:128)
+    u2[L] = 0.5 * (uc + us);
+    v2[L] = 0.5 * (vc + vw);
+}
+
+extern "C" int32_t otmb_bgrid_to_cgrid_dev(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, double fill, int64_t nx,
+                                           int64_t ny, int64_t nz, double *u2, double *v2) {
+    if (!ctx || !u || !v || !u2 || !v2) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1 || nx * ny * nz >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 P = nx * ny, G = P * nz;
+    const unsigned nb = (unsigned)((G + 255) / 256);
+    KernelTimer kt(ctx, K_VELFLUX);
+    if (src_is_f32)
+        hipLaunchKernelGGL(bgrid_to_cgrid_kernel<float>, dim3(nb), dim3(256), 0, ctx->stream, (const float *)u, (const float *)v, fill,
+                           (int)nx, (int)ny, P, G, u2, v2);
+    else
+        hipLaunchKernelGGL(bgrid_to_cgrid_kernel<double>, dim3(nb), dim3(256), 0, ctx->stream, (const double *)u, (const double *)v,
+                           fill, (int)nx, (int)ny, P, G, u2, v2);
+    HIP_TRY(ctx, hipGetLastError());
+    return OTMB_OK;
+}
+
 static int32_t vf_launch(otmb_ctx *ctx, const void *in_i, const void *in_j, int32_t src_is_f32, const double *rho,
                          double rho_scalar, const double *thk, const double *edge_e, const double *edge_n, int64_t nx,
                          int64_t ny, int64_t nz, int32_t topology, bool to_velocity, double *out_i, double *out_j) {

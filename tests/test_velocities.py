@@ -91,3 +91,34 @@ def test_hip_velocity2fluxes_bipolar_is_an_error():
     u, u_lon, u_lat, v, v_lon, v_lat = _velocities(g, gm)
     with pytest.raises(OtmbError):
         api.velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gm, 1035.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_hip_bgrid_interpolation(oracle, dtype):
+    """interpolateontodefaultCgrid(…, ::BGridCell) (gridcellgeometry.jl:106-140) against its array expression."""
+    import otmb_amd.api as api
+    from otmb_amd import Cube
+
+    g, gm = make_case("small_rho3d")
+    rng = np.random.default_rng(8)
+    wet = ~np.isnan(gm.v3D)
+    fill = float(dtype(1e20))
+    u = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, fill).astype(dtype))
+    v = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, fill).astype(dtype))
+    ne_lon, ne_lat = gm.lon_vertices[2], gm.lat_vertices[2]  # B-grid: both velocity points on the NE corner
+    u2, u2_lon, u2_lat, v2, v2_lon, v2_lat = api.interpolateontodefaultCgrid(Cube(u, _FillValue=fill), ne_lon, ne_lat,
+                                                                              Cube(v, _FillValue=fill), ne_lon, ne_lat, gm)
+    ur = np.where(u.astype(np.float64) == fill, 0.0, u.astype(np.float64))
+    vr = np.where(v.astype(np.float64) == fill, 0.0, v.astype(np.float64))
+    us = np.zeros_like(ur); us[:, 1:, :] = ur[:, :-1, :]
+    vw = np.zeros_like(vr); vw[1:, :, :] = vr[:-1, :, :]
+    assert np.array_equal(u2, 0.5 * (ur + us)) and np.array_equal(v2, 0.5 * (vr + vw))
+    # the interpolated points are the east / north face midpoints: a C-grid as far as getarakawagrid is concerned
+    from otmb_amd.gridmetrics import getarakawagrid
+
+    assert getarakawagrid(u2_lon, u2_lat, v2_lon, v2_lat, gm) == ("C", "E", "N")
+    # and the whole chain runs: B-grid velocities -> fluxes, same as feeding the interpolated fields directly
+    fi, fj = api.velocity2fluxes(Cube(u, _FillValue=fill), ne_lon, ne_lat, Cube(v, _FillValue=fill), ne_lon, ne_lat, gm, g.rho)
+    ri, rj = oracle.velocity_flux(u2, v2, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], gm.gridtopology.kind)
+    assert np.array_equal(fi, ri, equal_nan=True) and np.array_equal(fj, rj, equal_nan=True)
