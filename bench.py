@@ -43,27 +43,34 @@ def parse():
     return args
 
 
-def cpu_baseline(g, gm, workload):
+def cpu_baseline(g, gm, workload, reps=5):
     """The oracle (single-thread C restatement of the reference algorithm: push COO -> sparse() x4 ->
-    3 sparse adds) timed on this box's host cores, one pass over the same workload.  kind = "port":
-    the Julia reference cannot run here (no julia binary)."""
+    3 sparse adds) timed on this box's host cores over the same workload: 1 warm-up + median of `reps`
+    passes.  kind = "port": the Julia reference cannot run here (no julia binary; SURVEY.md
+    section 8c)."""
     from oracle import oracle as orc
 
     orc.build()
-    t0 = time.perf_counter()
     idx = orc.makeindices(gm.v3D)
-    t1 = time.perf_counter()
-    phi = orc.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], g.umo.properties["_FillValue"], gm.gridtopology.kind)
-    t2 = time.perf_counter()
-    orc.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True, tight=True)
-    t3 = time.perf_counter()
+    fill = g.umo.properties["_FillValue"]
     N = idx["N"]
+    t_ff, t_tm = [], []
+    for rep in range(reps + 1):
+        t1 = time.perf_counter()
+        phi = orc.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], fill, gm.gridtopology.kind)
+        t2 = time.perf_counter()
+        orc.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True, tight=True)
+        t3 = time.perf_counter()
+        if rep:  # the first pass is the warm-up
+            t_ff.append(t2 - t1)
+            t_tm.append(t3 - t2)
+    ff, tm = float(np.median(t_ff)), float(np.median(t_tm))
     return {
-        "value": N / (t3 - t1), "unit": "wet-cells/s", "cores": 1, "kind": "port",
-        "sample": f"1 pass of facefluxes+transportmatrix on the full {workload} grid (N={N}); "
-                  f"facefluxes {t2 - t1:.2f} s, transportmatrix {t3 - t2:.2f} s; "
+        "value": N / (ff + tm), "unit": "wet-cells/s", "cores": 1, "kind": "port",
+        "sample": f"facefluxes+transportmatrix on the full {workload} grid (N={N}), 1 warm-up + median of {reps} passes; "
+                  f"facefluxes {ff:.3f} s, transportmatrix {tm:.3f} s (COO generation + sparse() x4 + 3 adds); "
                   f"host {os.cpu_count()} logical cores, 1 used",
-        "seconds": t3 - t1,
+        "seconds": ff + tm,
     }
 
 
