@@ -224,6 +224,20 @@ int32_t otmb_bolus_gm_velocity(otmb_ctx *ctx, const double *rho, const double *z
                                const double *dist_east, const double *dist_north, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double kappa_gm, double maxslope, double *u, double *v);
 
+/* ---- the reference's two-step formulation as a general (non-fused) device path -------------------------
+ * otmb_sparse_entries_*: the COO generators in the reference's emission order -- which = 0
+ *   advection_operator_sparse_entries (src/matrixbuilding.jl:221-299), 1 horizontal_diffusion_… (:337-418),
+ *   2 vertical_diffusion_… with the mixed-layer mask (:438-479, Ω of :85), 3 the same with Ω = all (:109).
+ *   plan -> number of triplets (and the reference's errors), fill -> I, J, V (device arrays of that length).
+ * otmb_sparse_*: SparseArrays.sparse(I, J, V, m, n) as called at :41,63,92,116 -- duplicates summed in input
+ *   order, explicit zeros kept, rows ascending per column.  plan -> nnz, fill -> colptr (n+1), rowval, nzval.
+ * Device pointers; one plan/fill pair at a time per context.                                             */
+int32_t otmb_sparse_entries_plan_dev(otmb_ctx *ctx, int32_t which, const otmb_tm_args *args, int64_t *len);
+int32_t otmb_sparse_entries_fill_dev(otmb_ctx *ctx, int64_t *I, int64_t *J, double *V);
+int32_t otmb_sparse_plan_dev(otmb_ctx *ctx, const int64_t *I, const int64_t *J, const double *V, int64_t len, int64_t m,
+                             int64_t n, int64_t *nnz);
+int32_t otmb_sparse_fill_dev(otmb_ctx *ctx, int64_t *colptr, int64_t *rowval, double *nzval);
+
 /* ---- A + B for SparseMatrixCSC{Float64,Int64} -- SparseArrays' map(+, A, B), the `+` of
  *      src/matrixbuilding.jl:147 used when the caller passes precomputed operators (:133-143): per column a
  *      sorted merge, a missing operand counts as +0.0, results that are exactly zero are not stored.

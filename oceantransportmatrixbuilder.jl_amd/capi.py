@@ -76,6 +76,10 @@ SYMBOLS = {
                                               C.POINTER(_vp * 4), C.POINTER(_vp * 4), C.POINTER(_vp * 4)]),
     "otmb_bolus_gm_velocity_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
     "otmb_bolus_gm_velocity": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
+    "otmb_sparse_entries_plan_dev": (C.c_int32, [_vp, C.c_int32, C.POINTER(TmArgs), _ip]),
+    "otmb_sparse_entries_fill_dev": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "otmb_sparse_plan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _ip]),
+    "otmb_sparse_fill_dev": (C.c_int32, [_vp, _vp, _vp, _vp]),
     "otmb_spadd_plan_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),
     "otmb_spadd_fill_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "otmb_spadd": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),

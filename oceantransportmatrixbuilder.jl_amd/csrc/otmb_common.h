@@ -21,6 +21,10 @@ struct DevBuf {
 
 struct TmPlan;  // otmb_transportmatrix.hip
 
+// pending plan of the general path (otmb_coo.hip): COO generator and sparse()
+struct CooPlan { int which = -1; otmb_tm_args args; int64_t ntiles = 0, len = 0; };
+struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = nullptr; int64_t len = 0, m = 0, n = 0, nnz = 0; };
+
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
     K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_NKERNELS
@@ -34,10 +38,13 @@ struct otmb_ctx {
     std::string err;
     // scratch for the scans / flags
     DevBuf blocksums, blockoffs, flags, lookback, tcount, tfix[3];
+    DevBuf sort[5];            // radix-sort keys/values/temporary of the general sparse() path
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     int *h_flags = nullptr;  // pinned host mirror of the flag words
     i64 *h_tot = nullptr;    // pinned host mirror of scan totals
     TmPlan *plan = nullptr;
+    CooPlan coo;
+    SpPlan sp;
     // staging for the host-pointer entry points
     std::vector<DevBuf> stage;
     // optional per-kernel timing with HIP events recorded on the launch stream

@@ -234,6 +234,36 @@ class DeviceAssembler:
             res[m] = (cp.cpu().numpy(), rv[: self.nnz[k]].cpu().numpy(), nz[: self.nnz[k]].cpu().numpy())
         return res
 
+    # ---- the reference's two-step formulation (general path) ----------------------------------------------------
+    def sparse_entries(self, which, phi=None):
+        """COO triplets (I, J, V device tensors) of one operator in the reference's push order
+        (advection/horizontal/vertical *_operator_sparse_entries, src/matrixbuilding.jl:221-479).
+        which: "Tadv" | "TκH" | "TκVML" | "TκVdeep"."""
+        code = {"Tadv": 0, "TκH": 1, "TκVML": 2, "TκVdeep": 3}[which]
+        a = self._args(phi if phi is not None else self.phi)
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.otmb_sparse_entries_plan_dev(self.ctx.handle, code, C.byref(a), C.byref(n)))
+        ln = int(n.value)
+        I = torch.empty(max(ln, 1), dtype=torch.int64, device=self.device)
+        J = torch.empty(max(ln, 1), dtype=torch.int64, device=self.device)
+        V = torch.empty(max(ln, 1), dtype=torch.float64, device=self.device)
+        self.ctx.check(self.lib.otmb_sparse_entries_fill_dev(self.ctx.handle, I.data_ptr(), J.data_ptr(), V.data_ptr()))
+        return I[:ln], J[:ln], V[:ln]
+
+    def sparse(self, I, J, V, m, n):
+        """SparseArrays.sparse(I, J, V, m, n) on the device -> (colptr, rowval, nzval) tensors."""
+        I, J, V = I.contiguous(), J.contiguous(), V.contiguous()
+        nnz = C.c_int64(0)
+        self.ctx.check(self.lib.otmb_sparse_plan_dev(self.ctx.handle, I.data_ptr(), J.data_ptr(), V.data_ptr(), I.numel(), m, n,
+                                                     C.byref(nnz)))
+        k = int(nnz.value)
+        cp = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        rv = torch.empty(max(k, 1), dtype=torch.int64, device=self.device)
+        nz = torch.empty(max(k, 1), dtype=torch.float64, device=self.device)
+        self.ctx.check(self.lib.otmb_sparse_fill_dev(self.ctx.handle, cp.data_ptr(), rv.data_ptr(), nz.data_ptr()))
+        self.ctx.synchronize()
+        return cp, rv[:k], nz[:k]
+
     # ---- accounting ---------------------------------------------------------------------------
     def algorithmic_bytes(self):
         """bytes the assembly must move with all five matrices returned

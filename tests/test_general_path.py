@@ -1,0 +1,71 @@
+"""The reference's own two-step formulation on the device: COO generators in emission order, then
+sparse(I,J,V,N,N) -- bit-exact against the oracle's generators / sparse(), and equal to the fused kernel."""
+import numpy as np
+import pytest
+
+from helpers import MATS, assert_csc_equal, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(oracle, name):
+    import torch
+
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case(name)
+    ref = oracle.makeindices(gm.v3D)
+    fill = g.umo.properties["_FillValue"]
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], fill, gm.gridtopology.kind)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    asm.facefluxes(umo, vmo, fill)
+    return g, gm, ref, rphi, asm
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_rho3d", "odd_nx_fold", "nx2", "tiny_bipolar", "small_rho3d"])
+def test_coo_generators_and_sparse_match_oracle(oracle, name):
+    g, gm, ref, rphi, asm = _setup(oracle, name)
+    kind, N = gm.gridtopology.kind, ref["N"]
+    Om = oracle.ml_mask(gm.zt, g.mlotst, ref["Lwet"], gm.v3D.shape)
+    want = {
+        "Tadv": oracle.advection_entries(rphi, gm.v3D, g.rho, ref["Lwet"], ref["Lwet3D"], kind, True),
+        "TκH": oracle.hdiff_entries(gm.v3D, gm.thkcello, gm.edge_length_2D, gm.distance_to_neighbour_2D, ref["Lwet"], ref["Lwet3D"], kind, g.kappaH),
+        "TκVML": oracle.vdiff_entries(gm.v3D, gm.area2D, gm.zt, ref["Lwet"], ref["Lwet3D"], kind, g.kappaVML, Om),
+        "TκVdeep": oracle.vdiff_entries(gm.v3D, gm.area2D, gm.zt, ref["Lwet"], ref["Lwet3D"], kind, g.kappaVdeep, None),
+    }
+    asm.step(None, None, None) if False else None
+    fused = None
+    for m in ("Tadv", "TκH", "TκVML", "TκVdeep"):
+        I, J, V = asm.sparse_entries(m)
+        wi, wj, wv = want[m]
+        assert np.array_equal(I.cpu().numpy(), wi) and np.array_equal(J.cpu().numpy(), wj), m  # emission order
+        assert np.array_equal(V.cpu().numpy(), wv), m
+        cp, rv, nz = asm.sparse(I, J, V, N, N)
+        got = (cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy())
+        assert_csc_equal(got, oracle.sparse(wi, wj, wv, N, N), f"{name}/{m} sparse()")
+        if fused is None:
+            asm.transportmatrix(asm.phi)
+            fused = asm.result_to_host()
+        assert_csc_equal(got, fused[m], f"{name}/{m} general path == fused kernel")
+
+
+def test_device_sparse_on_arbitrary_triplets(oracle):
+    import torch
+
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm, ref, rphi, asm = _setup(oracle, "tiny_tripolar")
+    rng = np.random.default_rng(5)
+    m, n, ln = 300, 257, 20000
+    I = rng.integers(1, m + 1, ln); J = rng.integers(1, n + 1, ln); V = rng.standard_normal(ln)
+    V[::11] = 0.0
+    J[J == 17] = 18  # an empty column in the middle; the last columns may be empty as well
+    J[J > 250] = 250
+    cp, rv, nz = asm.sparse(torch.from_numpy(I).cuda(), torch.from_numpy(J).cuda(), torch.from_numpy(V).cuda(), m, n)
+    assert_csc_equal((cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy()), oracle.sparse(I, J, V, m, n), "random COO")
+    e = torch.empty(0, dtype=torch.int64, device="cuda")
+    cp, rv, nz = asm.sparse(e, e, torch.empty(0, dtype=torch.float64, device="cuda"), 5, 5)
+    assert cp.cpu().tolist() == [1] * 6 and rv.numel() == 0
