@@ -53,6 +53,7 @@ struct Column {
     double hh[NSLOT];    // TκH values   (slots SELF, EC, WC, FQ, S, N)
     double ml[NSLOT];    // TκVML values (slots SELF, A, B)
     double dp[NSLOT];    // TκVdeep values
+    double tv[NSLOT];    // T values (filled by the kernel once the four operators are known)
     unsigned padv, phh, pml, pdp;  // presence masks (bit = slot)
     unsigned bef[NSLOT];  // bef[X]: slots ordered before X in the column
 };
