@@ -86,7 +86,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # OTMB_FORCE_SLAB=1: take the depth-slab (distributed) code path even with one rank, e.g. under
+    # `torchrun --nproc-per-node 1`, to exercise RCCL initialisation and collectives on a one-GPU box
+    force_slab = os.environ.get("OTMB_FORCE_SLAB") == "1" and "RANK" in os.environ
+    if world > 1 or force_slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # OTMB_DIST_BACKEND=gloo + OTMB_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
@@ -102,7 +105,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     nx, ny, nz, lf = synthetic.PRESETS[args.workload]
-    if world > 1:
+    if world > 1 or force_slab:
         # weak scaling: the global grid is nx x ny x (nz*world) (levels stretched over the same depth), cut
         # into `world` depth slabs with balanced wet counts; every rank generates only its own levels
         from otmb_amd import dist as odist
@@ -194,7 +197,7 @@ def main():
         runner = _Single()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -208,7 +211,7 @@ def main():
     runner.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -262,7 +265,7 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
