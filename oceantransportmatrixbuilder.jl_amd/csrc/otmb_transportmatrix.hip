@@ -47,7 +47,6 @@ struct TmPlan {
 // data and tag travel together, so no fence is needed and nothing depends on workgroup placement.
 #define ST_AGG (1ull << 62)
 #define ST_PFX (2ull << 62)
-#define ST_VAL(x) ((x) & ((1ull << 62) - 1))
 #define LOOKBACK_SPIN_LIMIT (1 << 22)
 
 __device__ __forceinline__ void st_store(u64 *p, u64 v) {
