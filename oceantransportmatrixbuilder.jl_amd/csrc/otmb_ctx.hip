@@ -145,7 +145,7 @@ int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, i
 }
 
 const char *otmb_kernel_name(int32_t k) {
-    static const char *names[K_NKERNELS] = {"tm_kernel<count>", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
+    static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
                                             "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";

@@ -29,7 +29,7 @@
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
 
-enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_ONEPASS = 2 };
+enum { MODE_FILL = 1, MODE_ONEPASS = 2 };
 
 struct TmPlan {
     otmb_tm_args args;  // device pointers
@@ -54,6 +54,89 @@ __device__ __forceinline__ void st_store(u64 *p, u64 v) {
 }
 __device__ __forceinline__ u64 st_load(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- COUNT pass as its own kernel: presence only, TPB tiles per workgroup -------------------------------
+// The pass is a chain of dependent loads (Lwet -> neighbours' Lwet3D / fluxes) with almost no arithmetic, i.e.
+// latency bound; giving every thread one cell of each of TPB tiles puts TPB independent chains in flight.
+__device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) {
+    const i64 w0 = tile * TM_THREADS, w = w0 + tid;
+    if (w0 >= p.n_own) return 0;
+    const i64 Lmin = p.lwet[w0] - 1;
+    const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
+    const i64 Lmax = p.lwet[wlast] - 1;
+    const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
+    const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
+    if (!span_ok) {
+        if (tid == 0) raise_flag(p.flags, FLAG_NONCANONICAL);
+        return 0;
+    }
+    if (w >= p.n_own) return 0;
+    const i64 L = p.lwet[w] - 1;
+    const i64 Lnext = (w + 1 < p.n_own) ? p.lwet[w + 1] - 1 : p.G;
+    const i64 c = p.wet_base + w + 1;
+    if (L < Lmin || L > Lmax || Lnext <= L) {
+        raise_flag(p.flags, FLAG_NONCANONICAL);
+        return 0;
+    }
+    TileBase tb;
+    tb.lw = (const char *)(p.lw + base_elem);
+    tb.v = nullptr; tb.thk = nullptr;
+    tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
+    tb.pe = (const char *)(p.phi[OTMB_EAST] + base_elem);
+    tb.pw = (const char *)(p.phi[OTMB_WEST] + base_elem);
+    tb.pn = (const char *)(p.phi[OTMB_NORTH] + base_elem);
+    tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
+    tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
+    tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
+    const Cell cell = cell_of(L, p.nx, p.ny, p.P);
+    const unsigned oC = (unsigned)(L - base_elem) * 8u;
+    if (ldi(tb.lw, oC) != c) {
+        raise_flag(p.flags, FLAG_NONCANONICAL);
+        return 0;
+    }
+    unsigned padv, phh, pml, pdp;
+    const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
+    if (regular) {
+        fast_presence(p, tb, oC, cell.i, cell.j, cell.k, padv, phh, pml, pdp);
+    } else {
+        Column col;
+        build_column(p, cell, c, col);
+        padv = col.padv; phh = col.phh; pml = col.pml; pdp = col.pdp;
+    }
+    return (u64)__popc(padv | phh | pml | pdp) | ((u64)__popc(padv) << 11) | ((u64)__popc(phh) << 22) | ((u64)__popc(pml) << 33) |
+           ((u64)__popc(pdp) << 43);
+}
+
+#ifndef TM_COUNT_TPB
+#define TM_COUNT_TPB 1  // measured at 1 deg: 1 -> 0.099 ms, 2 -> 0.109 ms, 4 -> 0.115 ms (count as a mode of tm_kernel: 0.116 ms)
+#endif
+template <int TPB>
+__global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, i64 ntiles) {
+    __shared__ u64 wave_tot[TPB][TM_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    u64 mine[TPB];
+#pragma unroll
+    for (int q = 0; q < TPB; ++q) mine[q] = count_cell(p, (i64)blockIdx.x * TPB + q, tid);
+#pragma unroll
+    for (int q = 0; q < TPB; ++q) {  // wave totals (the in-tile offsets are recomputed by the fill pass)
+        u64 x = mine[q];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+        if (lane == 0) wave_tot[q][wid] = x;
+    }
+    __syncthreads();
+    if (tid < TPB * TM_NF) {
+        const int q = tid / TM_NF, m = tid - q * TM_NF;
+        const i64 tile = (i64)blockIdx.x * TPB + q;
+        if (tile < ntiles) {
+            u64 all = 0;
+#pragma unroll
+            for (int w = 0; w < TM_THREADS / 64; ++w) all += wave_tot[q][w];
+            const unsigned sh = (m == 0) ? 0 : (m == 1) ? 11 : (m == 2) ? 22 : (m == 3) ? 33 : 43;
+            p.tilesums[tile * TM_NF + m] = (unsigned)((all >> sh) & ((m < 3) ? 0x7ffu : 0x3ffu));
+        }
+    }
 }
 
 template <int MODE>
@@ -129,10 +212,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 raise_flag(p.flags, FLAG_NONCANONICAL);
             } else {
                 const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
-                if (MODE == MODE_COUNT && regular) {
-                    fast_presence(p, tb, oC, cell.i, cell.j, cell.k, col.padv, col.phh, col.pml, col.pdp);
-                } else {
-                    #ifdef OTMB_CHECKS_IN_FILL
+                {
+#ifdef OTMB_CHECKS_IN_FILL
                     if (regular) fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
 #else
                     if (regular) fast_column<MODE == MODE_ONEPASS>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
@@ -146,7 +227,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 live = true;
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
                 nU = __popc(uni); nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
-                if (MODE != MODE_COUNT) {
+                {
 #pragma unroll
                     for (int s = 0; s < NSLOT; ++s)
                     {   // T's values are kept: recomputing them in the write phase measured 4 % slower
@@ -182,17 +263,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                             (unsigned)((excl >> 33) & 0x3ff), (unsigned)((excl >> 43) & 0x3ff)};
     const unsigned agg[5] = {(unsigned)(all & 0x7ff), (unsigned)((all >> 11) & 0x7ff), (unsigned)((all >> 22) & 0x7ff),
                              (unsigned)((all >> 33) & 0x3ff), (unsigned)((all >> 43) & 0x3ff)};
-
-    if (MODE == MODE_COUNT) {
-        if (tid < TM_NF) {
-            unsigned a = 0;
-#pragma unroll
-            for (int m = 0; m < TM_NF; ++m)
-                if (m == tid) a = agg[m];
-            p.tilesums[tile * TM_NF + tid] = a;
-        }
-        return;
-    }
 
     // ---- 3. the tile's global offsets ----
     if (MODE == MODE_FILL) {
@@ -585,7 +655,8 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     if (ntiles > 0) {
         {
             KernelTimer kt(ctx, K_TM_COUNT);
-            hipLaunchKernelGGL(tm_kernel<MODE_COUNT>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+            hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
+                               dim3(TM_THREADS), 0, ctx->stream, p, (i64)ntiles);
         }
         {
             KernelTimer kt(ctx, K_TILESCAN);
@@ -720,7 +791,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     } else {
         {
             KernelTimer kt(ctx, K_TM_COUNT);
-            hipLaunchKernelGGL(tm_kernel<MODE_COUNT>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+            hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
+                               dim3(TM_THREADS), 0, ctx->stream, p, (i64)ntiles);
         }
         {
             KernelTimer kt(ctx, K_TILESCAN);
