@@ -45,7 +45,8 @@ typedef enum {
     OTMB_ERR_INVALID_ARG = 11,
     OTMB_ERR_NO_PLAN = 12,         /* fill/fetch without a successful plan */
     OTMB_ERR_NONCANONICAL_INDICES = 13, /* Lwet3D is not what makeindices(v3D) returns */
-    OTMB_ERR_CAPACITY = 14
+    OTMB_ERR_CAPACITY = 14,
+    OTMB_ERR_PUSH_MASK = 15        /* args.push_mask does not describe args.phi / args.lwet3d (nothing was written) */
 } otmb_status;
 
 /* gridmetrics.gridtopology (src/gridtopology.jl:1-16) */
@@ -104,8 +105,19 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
  * and OR-ed across slabs by the caller.                                                             */
 int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                  const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
-                                 int32_t topology, double *const phi[6], const double *top_below);
+                                 int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask);
 int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid);
+
+/* Push mask: what the pattern of the advection operator needs to know about a cell's six fluxes, 16 bits per
+ * cell.  Bits 0-5: the cell sends mass through its west, east, south, north, bottom, top face under upwind
+ * weighting, i.e. max(ϕwest,0), min(ϕeast,0), max(ϕsouth,0), min(ϕnorth,0), max(ϕbottom,0), min(ϕtop,0) is
+ * non-zero (src/matrixbuilding.jl:244,253,262,271,280,289); bit 6: the cell is wet; bits 8-14: the same for
+ * centred weighting (ϕ/2 non-zero).  otmb_facefluxes_slab_dev writes it for the cells it computes when
+ * push_mask is not NULL (the fluxes are in registers there); otmb_push_mask_dev derives it from existing ϕ
+ * arrays for the cells [first, first+count) (0-based linear indices; halo planes of a depth slab, or fluxes
+ * that were modified after facefluxes).  Asynchronous.                                                  */
+int32_t otmb_push_mask_dev(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first,
+                           int64_t count, uint16_t *push_mask);
 
 /* ---- velocity2fluxes / fluxes2velocity -- src/velocities.jl:10-39, :50-74 (nanmean2 :89-93, nanmin2 :108);
  *      with facefluxes they make facefluxesfromvelocities (:140-151).  Default C-grid (u on east faces, v on
@@ -160,6 +172,11 @@ typedef struct {
     const double *zt;            /* gridmetrics.zt (nz) */
     const double *mlotst;        /* mlotst (nx,ny), NaN = missing */
     double kappa_h, kappa_vml, kappa_vdeep;
+    const uint16_t *push_mask;   /* optional (device pointer, NULL = derived from phi and lwet3d by the library): the
+                                  * per-cell push mask written by otmb_facefluxes_slab_dev / otmb_push_mask_dev for
+                                  * exactly these phi and this wet mask; lets the counting pass read 2 bytes per
+                                  * neighbour instead of re-reading the six ϕ arrays.  Host-pointer entry points
+                                  * ignore it.                                                                   */
 } otmb_tm_args;
 
 /* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).

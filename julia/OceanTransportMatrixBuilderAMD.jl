@@ -112,6 +112,7 @@ struct TmArgs
     dist_nbr::NTuple{4,Ptr{Float64}}
     area2d::Ptr{Float64}; zt::Ptr{Float64}; mlotst::Ptr{Float64}
     kappa_h::Float64; kappa_vml::Float64; kappa_vdeep::Float64
+    push_mask::Ptr{UInt16}        # device-resident callers only; C_NULL here (host arrays)
 end
 
 const HDIRS = (:west, :east, :south, :north)      # OTMB_DIR_*
@@ -148,7 +149,7 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
             ntuple(i -> pointer(ph[i]), 6), pointer(v), pointer(thk),
             ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0,
             pointer(lw3), pointer(lw), ntuple(i -> pointer(el[i]), 4), ntuple(i -> pointer(dn[i]), 4),
-            pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep)))
+            pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep), Ptr{UInt16}(C_NULL)))
         check(ccall(sym(:otmb_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), ctx[], a, nnz))
     end
     colptr = [Vector{Int64}(undef, N + 1) for _ in 1:5]

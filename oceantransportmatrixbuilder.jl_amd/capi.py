@@ -9,7 +9,7 @@ OK = 0
 STATUS_NAMES = {
     1: "RHO_NAN", 2: "TADV_NAN", 3: "TKH_NAN", 4: "TKVML_NAN", 5: "TKVDEEP_NAN", 6: "FLUX_INTO_LAND",
     7: "UNKNOWN_TOPOLOGY", 8: "ALL_MISSING", 9: "ALLOC", 10: "HIP", 11: "INVALID_ARG", 12: "NO_PLAN",
-    13: "NONCANONICAL_INDICES", 14: "CAPACITY",
+    13: "NONCANONICAL_INDICES", 14: "CAPACITY", 15: "PUSH_MASK",
 }
 PHI_ORDER = ("east", "west", "north", "south", "top", "bottom")  # OTMB_EAST..OTMB_BOTTOM
 HDIRS = ("west", "east", "south", "north")  # OTMB_DIR_*
@@ -39,6 +39,7 @@ class TmArgs(C.Structure):
         ("edge_length", C.c_void_p * 4), ("dist_nbr", C.c_void_p * 4),
         ("area2d", C.c_void_p), ("zt", C.c_void_p), ("mlotst", C.c_void_p),
         ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
+        ("push_mask", C.c_void_p),
     ]
 
 
@@ -65,7 +66,8 @@ SYMBOLS = {
     "otmb_fluxes2velocity_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_velocity2fluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_fluxes2velocity": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
-    "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp]),
+    "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
+    "otmb_push_mask_dev": (C.c_int32, [_vp, C.POINTER(_vp * 6), _vp, C.c_int64, C.c_int64, _vp]),
     "otmb_facefluxes_slab_flags": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64]),
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
@@ -113,10 +115,15 @@ def _preload_hip_runtime():
                 pass
 
 
-def use_library(path):
-    """Switch the process to another build of the library (perf A/B of variants; contexts are per library)."""
-    global _lib, LIB_PATH
+_lenient = False
+
+
+def use_library(path, lenient=False):
+    """Switch the process to another build of the library (perf A/B of variants; contexts are per library).
+    lenient: tolerate symbols the build lacks (timing an older commit with tools/ab_variants.py only)."""
+    global _lib, LIB_PATH, _lenient
     LIB_PATH = path
+    _lenient = lenient
     _lib = None
 
 
@@ -130,6 +137,8 @@ def lib():
         _preload_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if _lenient and not hasattr(l, name):
+                continue
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
@@ -175,7 +184,7 @@ class Context:
     def timing_enable(self, on=True):
         self.check(lib().otmb_ctx_timing_enable(self._h, int(on)))
 
-    def timing_collect(self, n=11):
+    def timing_collect(self, n=12):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()

@@ -27,7 +27,7 @@ struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = null
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 
@@ -40,6 +40,7 @@ struct otmb_ctx {
     DevBuf blocksums, blockoffs, flags, lookback, tcount, tfix[3];
     DevBuf sort[5];            // radix-sort keys/values/temporary of the general sparse() path
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
+    DevBuf mask;              // push mask derived by the library when the caller passes none
     int *h_flags = nullptr;  // pinned host mirror of the flag words
     i64 *h_tot = nullptr;    // pinned host mirror of scan totals
     TmPlan *plan = nullptr;
@@ -76,12 +77,15 @@ enum {
     FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
     FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY,
     FLAG_T_CANCEL,  // some T entry summed to exactly zero: T was written with gaps and needs compaction
+    FLAG_COUNT_MISMATCH,  // a tile's fill pass found other counts than its counting pass: push_mask does not describe ϕ
     OTMB_NFLAGS_TM = 12,            // words [0, OTMB_NFLAGS_TM) belong to transportmatrix and are reset by it
     FLAG_U_VALID = 12, FLAG_V_VALID = 13  // owned by facefluxes: untouched by a transportmatrix call in between
 };
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
 int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);
+int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
+                              uint16_t *push_mask);  // otmb_facefluxes.hip
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
 
@@ -100,3 +104,16 @@ int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_tr
 // gsum: scratch of (ntiles / 1024 + 1) * nf i64 (see otmb_scan_scratch)
 void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *tot, i64 ntiles, int nf, i64 *gsum);
 static inline size_t otmb_scan_scratch(i64 ntiles, int nf) { return (size_t)(ntiles / 1024 + 2) * nf * sizeof(i64); }
+
+// ---- push mask (include/otmb.h, otmb_push_mask_dev): bits 0-5 west, east, south, north, bottom, top;
+// bit 6 wet; the centred-weighting variant in the high byte.  x / 2 is the reference's ϕ / 2 (:244-289).
+enum { PM_W = 1u << 0, PM_E = 1u << 1, PM_S = 1u << 2, PM_N = 1u << 3, PM_B = 1u << 4, PM_T = 1u << 5, PM_WET = 1u << 6 };
+__device__ __forceinline__ unsigned otmb_push_bits(double w, double e, double s, double n, double b, double t, bool wet) {
+    const double hw = w / 2, he = e / 2, hs = s / 2, hn = n / 2, hb = b / 2, ht = t / 2;
+    const unsigned lo = (w > 0.0 ? PM_W : 0u) | (e < 0.0 ? PM_E : 0u) | (s > 0.0 ? PM_S : 0u) | (n < 0.0 ? PM_N : 0u) |
+                        (b > 0.0 ? PM_B : 0u) | (t < 0.0 ? PM_T : 0u) | (wet ? PM_WET : 0u);
+    const unsigned hi = ((hw > 0.0) | (hw < 0.0) ? PM_W : 0u) | ((he > 0.0) | (he < 0.0) ? PM_E : 0u) |
+                        ((hs > 0.0) | (hs < 0.0) ? PM_S : 0u) | ((hn > 0.0) | (hn < 0.0) ? PM_N : 0u) |
+                        ((hb > 0.0) | (hb < 0.0) ? PM_B : 0u) | ((ht > 0.0) | (ht < 0.0) ? PM_T : 0u) | (wet ? PM_WET : 0u);
+    return lo | (hi << 8);
+}

@@ -50,6 +50,7 @@ const char *otmb_status_string(int32_t s) {
         case OTMB_ERR_NO_PLAN: return "no transportmatrix plan";
         case OTMB_ERR_NONCANONICAL_INDICES: return "Lwet3D is not the wet rank in linear-index order (makeindices)";
         case OTMB_ERR_CAPACITY: return "output capacity too small";
+        case OTMB_ERR_PUSH_MASK: return "push_mask does not describe these face fluxes and wet mask";
         default: return "unknown status";
     }
 }
@@ -147,7 +148,8 @@ int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, i
 const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
-                                            "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d"};
+                                            "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
+                                            "push_mask_kernel"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    const double *__restrict__ top_below, int *flags) {
+    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *flags) {
     const i64 s = (i64)blockIdx.x * FF_THREADS + threadIdx.x;
     bool uvalid = false, vvalid = false;
     if (s < P) {
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
                     const double b = topbelow;                  // :238-240
                     const double t = (((b + w) + so) - e) - n;  // :242
                     east[o + s] = e; west[o + s] = w; north[o + s] = n; south[o + s] = so; top[o + s] = t; bottom[o + s] = b;
+                    if (push_mask) push_mask[o + s] = (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc);
                     topbelow = t;
                 }
             }
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
 
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
-                               int32_t topology, double *const phi[6], const double *top_below, bool check_missing) {
+                               int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
+                               bool check_missing) {
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -100,12 +102,12 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
         hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
                            (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], top_below, dflags);
+                           phi[OTMB_BOTTOM], top_below, push_mask, dflags);
     else
         hipLaunchKernelGGL(facefluxes_kernel<double>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const double *)umo,
                            (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], top_below, dflags);
+                           phi[OTMB_BOTTOM], top_below, push_mask, dflags);
     }
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
@@ -120,7 +122,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
 extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                        const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                        int32_t topology, double *const phi[6]) {
-    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, nullptr, true);
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, nullptr, nullptr, true);
 }
 
 // Depth-slab variant: the levels handed in are levels [k0,k1) of a deeper grid.  top_below (nx*ny, may
@@ -129,8 +131,44 @@ extern "C" int32_t otmb_facefluxes_dev(otmb_ctx *ctx, const void *umo, const voi
 // returned through otmb_facefluxes_slab_flags after a synchronize and combined by the caller.
 extern "C" int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                             const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
-                                            int32_t topology, double *const phi[6], const double *top_below) {
-    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, false);
+                                            int32_t topology, double *const phi[6], const double *top_below,
+                                            uint16_t *push_mask) {
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, push_mask, false);
+}
+
+// Push mask of existing ϕ arrays (include/otmb.h): one thread per cell of [first, first + count).
+__global__ __launch_bounds__(256) void push_mask_kernel(const double *__restrict__ pe, const double *__restrict__ pw,
+                                                        const double *__restrict__ pn, const double *__restrict__ ps,
+                                                        const double *__restrict__ pt, const double *__restrict__ pb,
+                                                        const i64 *__restrict__ lw, i64 first, i64 count,
+                                                        uint16_t *__restrict__ mask) {
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    const i64 L = first + q;
+    mask[L] = (uint16_t)otmb_push_bits(pw[L], pe[L], ps[L], pn[L], pb[L], pt[L], lw[L] != 0);
+}
+
+int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
+                              uint16_t *push_mask) {
+    if (count <= 0) return OTMB_OK;
+    KernelTimer kt(ctx, K_PUSHMASK);
+    hipLaunchKernelGGL(push_mask_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, phi[OTMB_EAST],
+                       phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], (const i64 *)lwet3d,
+                       (i64)first, (i64)count, push_mask);
+    return OTMB_OK;
+}
+
+extern "C" int32_t otmb_push_mask_dev(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first,
+                                      int64_t count, uint16_t *push_mask) {
+    if (!ctx || !phi || !lwet3d || !push_mask) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    for (int f = 0; f < 6; ++f)
+        if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
+    if (first < 0 || count < 0 || count >= (1ll << 39)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t rc = otmb_launch_push_mask(ctx, phi, lwet3d, first, count, push_mask);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    return OTMB_OK;
 }
 
 extern "C" int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid) {

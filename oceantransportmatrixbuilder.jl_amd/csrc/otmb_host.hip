@@ -171,6 +171,7 @@ int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)(a->nx * a->ny), G = P * (size_t)a->nz;
     otmb_tm_args d = *a;
+    d.push_mask = nullptr;  // host entry point: a caller's mask pointer would be host memory; derive it on the device
     const void *p;
     for (int f = 0; f < 6; ++f) { TRY(upload(ctx, ST_PHI0 + f, a->phi[f], G * 8, &p)); d.phi[f] = (const double *)p; }
     TRY(upload(ctx, ST_V, a->v3d, G * 8, &p)); d.v3d = (const double *)p;

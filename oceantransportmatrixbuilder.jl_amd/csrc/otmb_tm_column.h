@@ -21,6 +21,7 @@ struct TmParams {
     double rho_s;
     const i64 *lw;    // Lwet3D (global wet ranks in a slab run), 0 = missing
     const i64 *lwet;  // Lwet: 1-based linear indices (in this grid) of the wet cells this launch owns
+    const uint16_t *mask;  // push mask of every cell of the grid (counting pass; otmb_push_bits)
     const double *edge[4], *dist[4];
     const double *area, *zt, *ml;
     double kH, kML, kDeep;
@@ -307,7 +308,7 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
 //  * accumulators start at -0.0: (-0.0) + x == x bit for bit for every x, which is exactly
 //    sparse()'s "first touch copies, later ones add" without tracking the first touch.
 struct TileBase {  // array pointers advanced to the tile's lowest neighbour (uniform per workgroup)
-    const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb;
+    const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb, *mk;
 };
 __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
@@ -484,47 +485,46 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
 }
 
 // Presence only (regular cells): which rows the four operator matrices hold in this column -- a function
-// of the wet mask, the sign tests on the six incoming fluxes and the mixed-layer mask, no arithmetic.
-// The union is an upper bound of T's rows (map(+) drops only exact-zero sums).
+// of the wet mask, the sign tests on the six incoming fluxes and the mixed-layer mask, no arithmetic.  The
+// wet bits and the sign tests come from the push mask (2 bytes per neighbour, see otmb_push_bits) instead
+// of Lwet3D and the six ϕ arrays.  The union is an upper bound of T's rows (map(+) drops only exact-zero sums).
+__device__ __forceinline__ unsigned ldm(const char *b, unsigned byteoff) { return *(const uint16_t *)(b + byteoff); }
 __device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
                                               unsigned &padv, unsigned &phh, unsigned &pml, unsigned &pdp) {
-    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
     const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
-    const unsigned nx8 = (unsigned)nx * 8u, P8 = (unsigned)p.P * 8u;
-    const unsigned oE = oC + (unsigned)(di_e * 8), oW = oC + (unsigned)(di_w * 8);
-    const unsigned oS = hS ? oC - nx8 : oC, oN = hN ? oC + nx8 : oC;
-    const unsigned oA = hA ? oC - P8 : oC, oB = hB ? oC + P8 : oC;
+    const unsigned mC_o = oC >> 2, nx2 = (unsigned)nx * 2u, P2 = (unsigned)p.P * 2u;  // mask elements are 2 bytes
+    const unsigned sh = p.upwind ? 0u : 8u;
+    const unsigned mC = ldm(tb.mk, mC_o) >> sh, mE = ldm(tb.mk, mC_o + (unsigned)(di_e * 2)) >> sh,
+                   mW = ldm(tb.mk, mC_o + (unsigned)(di_w * 2)) >> sh, mS = ldm(tb.mk, hS ? mC_o - nx2 : mC_o) >> sh,
+                   mN = ldm(tb.mk, hN ? mC_o + nx2 : mC_o) >> sh, mA = ldm(tb.mk, hA ? mC_o - P2 : mC_o) >> sh,
+                   mB = ldm(tb.mk, hB ? mC_o + P2 : mC_o) >> sh;
     const unsigned s2 = ((unsigned)j * (unsigned)nx + (unsigned)i) * 8u;
-    const i64 lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN), lA = ldi(tb.lw, oA),
-              lB = ldi(tb.lw, oB);
-    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
-                 gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
     const double mld = ldd((const char *)p.ml, s2);
     const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
-    const bool wE = lE != 0, wW = lW != 0, wS = hS && lS != 0, wN = hN && lN != 0, wA = hA && lA != 0, wB = hB && lB != 0;
+    const bool wE = mE & PM_WET, wW = mW & PM_WET, wS = hS && (mS & PM_WET), wN = hN && (mN & PM_WET), wA = hA && (mA & PM_WET),
+               wB = hB && (mB & PM_WET);
 #ifndef OTMB_CHECKS_IN_FILL
     {   // the two input checks that need no arithmetic: own pushes land in wet cells (the reference indexes
         // Lwet3D[C𝑗] unconditionally, :247 etc.) and ρ is not NaN on wet cells (:233)
-        const double ow = sel_pos(ldd(tb.pw, oC), up), oe = sel_neg(ldd(tb.pe, oC), up), os = sel_pos(ldd(tb.ps, oC), up),
-                     on = sel_neg(ldd(tb.pn, oC), up), ob = sel_pos(ldd(tb.pb, oC), up), ot = hA ? sel_neg(ldd(tb.pt, oC), up) : 0.0;
-        const bool bad = (nonzero(ow) & !wW) | (nonzero(oe) & !wE) | (nonzero(os) & !wS) | (nonzero(on) & !wN) |
-                         (nonzero(ob) & !wB) | (nonzero(ot) & !wA);
+        const bool bad = ((mC & PM_W) && !wW) | ((mC & PM_E) && !wE) | ((mC & PM_S) && !wS) | ((mC & PM_N) && !wN) |
+                         ((mC & PM_B) && !wB) | (hA && (mC & PM_T) && !wA);
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
         if (tb.rho && isnan(ldd(tb.rho, oC))) raise_flag(p.flags, FLAG_RHO_NAN);
     }
 #endif
-    const bool aE = wE && nonzero(sel_pos(gE0, up)), aW = wW && nonzero(sel_neg(gW0, up));
-    const bool aS = wS && nonzero(sel_neg(gS0, up)), aN = wN && nonzero(sel_pos(gN0, up));
-    const bool aA = wA && nonzero(sel_pos(gA0, up)), aB = wB && nonzero(sel_neg(gB0, up));
+    // the east cell pushes through its west face, the cell above through its bottom face, ... (:244-296)
+    const bool aE = wE && (mE & PM_W), aW = wW && (mW & PM_E), aS = wS && (mS & PM_N), aN = wN && (mN & PM_S);
+    const bool aA = wA && (mA & PM_B), aB = wB && (mB & PM_T);
     padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
            ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
     phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
           ((unsigned)(wW | wE | wS | wN) << S_SELF);
     pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
     const bool omC = ztk < mld;
-    const bool mB = wB & omC & (ztb < mld), mA = wA & omC & (zta < mld);
-    pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
+    const bool mlB = wB & omC & (ztb < mld), mlA = wA & omC & (zta < mld);
+    pml = ((unsigned)mlB << S_B) | ((unsigned)mlA << S_A) | ((unsigned)(mlA | mlB) << S_SELF);
 }
 
 // T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)

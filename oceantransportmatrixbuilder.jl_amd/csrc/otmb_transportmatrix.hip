@@ -56,6 +56,13 @@ __device__ __forceinline__ u64 st_load(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A value every lane of the wave holds identically, moved to scalar registers.
+__device__ __forceinline__ i64 wave_uniform(i64 x) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(u64)x);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((u64)x >> 32));
+    return (i64)(((u64)hi << 32) | lo);
+}
+
 // ---- COUNT pass as its own kernel: presence only, TPB tiles per workgroup -------------------------------
 // The pass is a chain of dependent loads (Lwet -> neighbours' Lwet3D / fluxes) with almost no arithmetic, i.e.
 // latency bound; giving every thread one cell of each of TPB tiles puts TPB independent chains in flight.
@@ -81,20 +88,12 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
     }
     TileBase tb;
     tb.lw = (const char *)(p.lw + base_elem);
-    tb.v = nullptr; tb.thk = nullptr;
     tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
-    tb.pe = (const char *)(p.phi[OTMB_EAST] + base_elem);
-    tb.pw = (const char *)(p.phi[OTMB_WEST] + base_elem);
-    tb.pn = (const char *)(p.phi[OTMB_NORTH] + base_elem);
-    tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
-    tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
-    tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
+    tb.mk = (const char *)(p.mask + base_elem);
+    tb.v = tb.thk = tb.pe = tb.pw = tb.pn = tb.ps = tb.pt = tb.pb = nullptr;  // not read by the presence pass
     const Cell cell = cell_of(L, p.nx, p.ny, p.P);
     const unsigned oC = (unsigned)(L - base_elem) * 8u;
-    if (ldi(tb.lw, oC) != c) {
-        raise_flag(p.flags, FLAG_NONCANONICAL);
-        return 0;
-    }
+    // (Lwet3D[Lwet[w]] == w + 1 is verified by the fill pass, which loads Lwet3D anyway)
     unsigned padv, phh, pml, pdp;
     const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
     if (regular) {
@@ -144,8 +143,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
     __shared__ int s_tile;
-    __shared__ __attribute__((aligned(16))) i64 s_row[TM_STAGE];
-    __shared__ __attribute__((aligned(16))) double s_val[TM_STAGE];
+    typedef i64 ent_t __attribute__((ext_vector_type(2)));
+    __shared__ ent_t s_ent[TM_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
@@ -189,6 +188,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
     tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
     tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
+    tb.mk = nullptr;  // the push mask is read by the counting pass only
 
     // ---- 1. the column ----
     // T's rows are RESERVED as the union of the four operators' rows (known without arithmetic); the rows
@@ -266,7 +266,16 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 
     // ---- 3. the tile's global offsets ----
     if (MODE == MODE_FILL) {
-        if (tid < TM_NF) s_prefix[tid] = p.tileoffs[tile * TM_NF + tid];
+        // The space of this tile was reserved by the counting pass from the push mask.  A mask that does not
+        // describe these ϕ / Lwet3D (stale, or not a makeindices result) would make the two passes disagree:
+        // compare the tile's counts and write nothing on a mismatch (-1 = poisoned offset).
+        if (tid < TM_NF) {
+            unsigned mine_agg = 0;
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m)
+                if (m == tid) mine_agg = agg[m];
+            s_prefix[tid] = (p.tilesums[tile * TM_NF + tid] == mine_agg) ? p.tileoffs[tile * TM_NF + tid] : -1;
+        }
     } else {
 #ifdef OTMB_DBG_NOLOOKBACK  // timing experiment only: fake, in-bounds offsets
         if (tid < TM_NF) s_prefix[tid] = tile * (tid < 2 ? 1792 : (tid == 2 ? 1280 : 768));
@@ -359,6 +368,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     i64 g0[5];
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) g0[m] = s_prefix[m];  // entries of matrix m before this tile (this launch)
+    if (MODE == MODE_FILL && (g0[0] | g0[1] | g0[2] | g0[3] | g0[4]) < 0) {
+        if (tid == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
+        return;
+    }
 
     if (MODE == MODE_ONEPASS && w0 + TM_THREADS >= p.n_own) {  // last tile: totals and the closing colptr entry
         if (tid < TM_NF) {
@@ -382,23 +395,27 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         for (int m = 0; m < TM_NF; ++m) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
     }
     const unsigned pm[5] = {pT, col.padv, col.phh, col.pml, col.pdp};
-    const unsigned wb[5] = {(unsigned)(before & 0x7ff), (unsigned)((before >> 11) & 0x7ff), (unsigned)((before >> 22) & 0x7ff),
-                            (unsigned)((before >> 33) & 0x3ff), (unsigned)((before >> 43) & 0x3ff)};
-    const u64 wtot = __shfl(incl, 63);  // this wave's totals (packed)
+    // wave-uniform quantities go to scalar registers: the run's base pointers are then SGPR pairs, the stores
+    // take the `global_store vaddr32, vdata, sbase` form and the copy loop is a scalar loop
+    const u64 ubefore = (u64)wave_uniform((i64)before);
+    const u64 wtot = ((u64)__builtin_amdgcn_readlane((unsigned)(incl >> 32), 63) << 32) | __builtin_amdgcn_readlane((unsigned)incl, 63);
+    const unsigned wb[5] = {(unsigned)(ubefore & 0x7ff), (unsigned)((ubefore >> 11) & 0x7ff), (unsigned)((ubefore >> 22) & 0x7ff),
+                            (unsigned)((ubefore >> 33) & 0x3ff), (unsigned)((ubefore >> 43) & 0x3ff)};
     const unsigned wc[5] = {(unsigned)(wtot & 0x7ff), (unsigned)((wtot >> 11) & 0x7ff), (unsigned)((wtot >> 22) & 0x7ff),
                             (unsigned)((wtot >> 33) & 0x3ff), (unsigned)((wtot >> 43) & 0x3ff)};
-    i64 *my_row = s_row + wid * TM_WSTAGE;
-    double *my_val = s_val + wid * TM_WSTAGE;
     typedef i64 i64x2 __attribute__((ext_vector_type(2)));
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    // staging is interleaved {row, value bits}: one 16-byte LDS write per entry
+    i64x2 *my_ent = s_ent + wid * TM_WSTAGE;
+    const i64 *my_q = (const i64 *)my_ent;
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) {
         // The run is streamed out with 16-byte stores (two entries per lane): 8-byte-per-lane stores are
         // store-issue bound per CU (measured: the write phase cost as much as loads + arithmetic).  The
         // run starts at an arbitrary 8-byte position, so entries are staged at LDS index q + par where par
-        // is the run's parity: LDS pairs and global pairs are then both 16-byte aligned.
-        i64 *rv = p.rowval[m] + g0[m] + wb[m];
-        double *nz = p.nzval[m] + g0[m] + wb[m];
+        // is the run's parity: entry pairs (u, u+1), u even, are then 16-byte aligned in global memory.
+        const i64 run0 = wave_uniform(g0[m]) + wb[m];
+        i64 *rv = p.rowval[m] + run0;
+        double *nz = p.nzval[m] + run0;
         const unsigned par = (unsigned)(((unsigned long long)rv >> 3) & 1ull);
         const bool wide = ((((unsigned long long)rv) ^ ((unsigned long long)nz)) & 15ull) == 0;  // same parity for both arrays
 #ifdef OTMB_DBG_NOLDS
@@ -406,12 +423,16 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #else
         if (live) {
 #endif
+            const unsigned q0 = par + ex[m] - wb[m];
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 if ((pm[m] >> s) & 1u) {
-                    const unsigned q = par + ex[m] - wb[m] + __popc(pm[m] & col.bef[s]);  // position inside the wave's run
-                    my_row[q] = col.idx[s];
-                    my_val[q] = (m == 0) ? col.tv[s] : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
+                    const unsigned q = q0 + __popc(pm[m] & col.bef[s]);  // position inside the wave's run
+                    const double v = (m == 0) ? col.tv[s] : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
+                    i64x2 e;
+                    e.x = col.idx[s];
+                    e.y = __double_as_longlong(v);
+                    my_ent[q] = e;
                 }
             }
         }
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         const unsigned cnt = wc[m];
         bool room = true;
         if (p.cap[m] > 0) {  // callers that preallocate at an upper bound (0 = sized exactly by a plan)
-            room = g0[m] + wb[m] + cnt <= p.cap[m];
+            room = run0 + cnt <= p.cap[m];
             if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
         }
 #ifdef OTMB_DBG_NOSTORE
@@ -429,28 +450,29 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         if (room) {
             const unsigned end = par + cnt;  // staged entries occupy LDS indices [par, end)
             if (wide) {
-                for (unsigned u = 2 * lane; u < end; u += 128) {
-                    const bool lo = u >= par, hi = u + 1 < end;
-                    if (lo & hi) {
-#ifdef OTMB_NT_STORES
-                        __builtin_nontemporal_store(*(const i64x2 *)(my_row + u), (i64x2 *)(rv - par + u));
-                        __builtin_nontemporal_store(*(const f64x2 *)(my_val + u), (f64x2 *)(nz - par + u));
-#else
-                        *(i64x2 *)(rv - par + u) = *(const i64x2 *)(my_row + u);
-                        *(f64x2 *)(nz - par + u) = *(const f64x2 *)(my_val + u);
-#endif
-                    } else if (lo) {
-                        rv[u - par] = my_row[u];
-                        nz[u - par] = my_val[u];
-                    } else if (hi) {
-                        rv[u + 1 - par] = my_row[u + 1];
-                        nz[u + 1 - par] = my_val[u + 1];
+                char *rvb = (char *)(rv - par);
+                char *nzb = (char *)(nz - par);
+                for (unsigned base = 0; base < end; base += 128) {  // full pairs
+                    const unsigned u = base + 2 * lane;
+                    if ((u >= par) & (u + 1 < end)) {
+                        i64x2 r, v;
+                        r.x = my_q[2 * u]; v.x = my_q[2 * u + 1]; r.y = my_q[2 * u + 2]; v.y = my_q[2 * u + 3];
+                        *(i64x2 *)(rvb + u * 8u) = r;
+                        *(i64x2 *)(nzb + u * 8u) = v;
                     }
+                }
+                // the (at most two) entries without a partner: index 1 of an odd-parity run, and the last one if
+                // it sits at an even index
+                const unsigned e = (lane == 0) ? 1u : end - 1;
+                const bool single = (lane == 0) ? ((par == 1) & (end > 1)) : ((lane == 1) & ((end & 1u) == 1u) & (end > par));
+                if (single) {
+                    *(i64 *)(rvb + e * 8u) = my_q[2 * e];
+                    *(i64 *)(nzb + e * 8u) = my_q[2 * e + 1];
                 }
             } else {
                 for (unsigned e = lane; e < cnt; e += 64) {
-                    rv[e] = my_row[par + e];
-                    nz[e] = my_val[par + e];
+                    rv[e] = my_q[2 * (par + e)];
+                    ((i64 *)nz)[e] = my_q[2 * (par + e) + 1];
                 }
             }
         }
@@ -551,10 +573,24 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.flags = (int *)ctx->flags.p;
 }
 
+// The counting pass reads the push mask: the caller's (written by facefluxes for exactly these ϕ), or one derived
+// here from ϕ and Lwet3D.
+static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &p) {
+    if (a.push_mask) {
+        p.mask = a.push_mask;
+        return OTMB_OK;
+    }
+    int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->mask, (size_t)p.G * sizeof(uint16_t) + 16))) return rc;
+    p.mask = (const uint16_t *)ctx->mask.p;
+    return otmb_launch_push_mask(ctx, a.phi, a.lwet3d, 0, p.G, (uint16_t *)ctx->mask.p);
+}
+
 static int32_t check_flags(otmb_ctx *ctx) {
     const int *f = ctx->h_flags;
     if (f[FLAG_NONCANONICAL]) return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
     if (f[FLAG_LOOKBACK_TIMEOUT]) return otmb_fail(ctx, OTMB_ERR_HIP, "look-back spin limit reached");
+    if (f[FLAG_COUNT_MISMATCH]) return otmb_fail(ctx, OTMB_ERR_PUSH_MASK);
     if (f[FLAG_RHO_NAN]) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // reference order: :233, loop, :39, :61, :90, :114
     if (f[FLAG_FLUX_INTO_LAND]) return otmb_fail(ctx, OTMB_ERR_FLUX_INTO_LAND);
     if (f[FLAG_TADV_NAN]) return otmb_fail(ctx, OTMB_ERR_TADV_NAN);
@@ -653,6 +689,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS_TM * sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dtot, 0, 8 * sizeof(i64), ctx->stream));
     if (ntiles > 0) {
+        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
@@ -789,6 +826,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         KernelTimer kt(ctx, K_TM_ONEPASS);
         hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     } else {
+        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),

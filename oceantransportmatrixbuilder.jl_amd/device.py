@@ -112,26 +112,38 @@ class DeviceAssembler:
 
     # ---- per time slice -----------------------------------------------------------------------
     def facefluxes(self, umo, vmo, fill):
-        """umo/vmo: flat device tensors (float64 or float32).  Returns the six ϕ tensors (reused)."""
-        if getattr(self, "phi", None) is None:
-            self.phi = [torch.empty(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
-        is32 = umo.dtype == torch.float32
-        ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
-        self.ctx.check(self.lib.otmb_facefluxes_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(is32),
-                                                    self.wet3d.data_ptr(), float(fill), self.nx, self.ny, self.nz,
-                                                    self.topology, C.byref(ptrs)))
-        return self.phi
+        """umo/vmo: flat device tensors (float64 or float32).  Returns the six ϕ tensors (reused).  Raises the
+        reference's "all values missing" assertion (velocities.jl:199-200) like otmb_facefluxes_dev."""
+        phi = self.facefluxes_async(umo, vmo, fill)
+        self._check_missing()
+        return phi
 
     def facefluxes_async(self, umo, vmo, fill):
-        """Same kernel, no host round trip: the reference's "all values missing" assertion (velocities.jl:199-200)
-        is evaluated by finish()."""
+        """Same kernel, no host round trip: the "all values missing" assertion is evaluated by finish().  The
+        kernel also writes the push mask of these fluxes (include/otmb.h), which lets the counting pass of the
+        following transportmatrix skip the six ϕ arrays."""
         if getattr(self, "phi", None) is None:
             self.phi = [torch.empty(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
+            self.push_mask = torch.empty(self.G, dtype=torch.int16, device=self.device)
         ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
+        self._mask_key = None
         self.ctx.check(self.lib.otmb_facefluxes_slab_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
                                                          int(umo.dtype == torch.float32), self.wet3d.data_ptr(), float(fill),
-                                                         self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None))
+                                                         self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
+                                                         self.push_mask.data_ptr()))
+        self._mask_key = self._phi_key(self.phi)
         return self.phi
+
+    @staticmethod
+    def _phi_key(phi):
+        # the mask describes exactly the values facefluxes wrote: any later in-place torch op bumps _version
+        return tuple((p.data_ptr(), p._version) for p in phi)
+
+    def _check_missing(self):
+        u, v = C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
+        if not (u.value and v.value):
+            raise capi.OtmbError(8, self.lib.otmb_status_string(8).decode())
 
     def step_async(self, umo, vmo, fill):
         """Enqueue one pass of the hot path (facefluxes -> count -> scan -> fill) without any host synchronisation;
@@ -139,10 +151,7 @@ class DeviceAssembler:
         return self.transportmatrix_onepass(self.facefluxes_async(umo, vmo, fill), sync=False)
 
     def finish(self):
-        u, v = C.c_int32(0), C.c_int32(0)
-        self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
-        if not (u.value and v.value):
-            raise capi.OtmbError(8, self.lib.otmb_status_string(8).decode())
+        self._check_missing()
         return self.result()
 
     def _args(self, phi):
@@ -161,6 +170,9 @@ class DeviceAssembler:
             a.dist_nbr[k] = self.dist[k].data_ptr()
         a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.mlotst.data_ptr()
         a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.kappa
+        # ϕ straight from this object's facefluxes and untouched since: hand over its push mask
+        fresh = getattr(self, "_mask_key", None) is not None and self._mask_key == self._phi_key(phi)
+        a.push_mask = self.push_mask.data_ptr() if fresh else None
         return a
 
     def plan(self, phi):

@@ -287,6 +287,7 @@ class HipSlabBackend:
         self.area, self.zt, self.ml = self._t(s["area2D"]), self._t(s["zt"]), self._t(s["mlotst"])
         self.wet_own = self._t(s["wet_own"], np.uint8)
         self.phi = [torch.zeros(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
+        self.push_mask = torch.zeros(self.G, dtype=torch.int16, device=self.device)
         self.own0 = s["k_own0"] * self.P
         self.nown_lev = s["k_own1"] - s["k_own0"]
         # Lwet of the owned cells: local linear indices (1-based) inside the extended grid, ascending
@@ -302,13 +303,19 @@ class HipSlabBackend:
         self.ctx.check(self.lib.otmb_facefluxes_slab_dev(
             self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), self.wet_own.data_ptr(),
             float(fill), self.nx, self.ny, self.nown_lev, self.s["topology"], C.byref(ptrs),
-            top_below.data_ptr() if top_below is not None else None))
+            top_below.data_ptr() if top_below is not None else None, self.push_mask[o:o + n].data_ptr()))
         top, bottom = self.phi[4], self.phi[5]  # OTMB_TOP, OTMB_BOTTOM
         top_first = top[o:o + self.P]
+        allphi = self.capi.ptr_array(6, [p.data_ptr() for p in self.phi])
+        # halo levels act as neighbours only: the one flux each of them pushes into an owned cell, and its push mask
         if self.s["k_own0"] > 0:  # halo above: its ϕbottom is my first level's ϕtop (velocities.jl:240)
             bottom[0:self.P].copy_(top_first)
+            self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), 0, self.P,
+                                                       self.push_mask.data_ptr()))
         if top_below is not None:  # halo below: its ϕtop is the plane received from the slab below
             top[self.G - self.P:self.G].copy_(top_below)
+            self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), self.G - self.P,
+                                                       self.P, self.push_mask.data_ptr()))
         return top_first
 
     def _tm_args(self):
@@ -327,6 +334,7 @@ class HipSlabBackend:
             a.dist_nbr[k] = self.dist_[k].data_ptr()
         a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.ml.data_ptr()
         a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.s["kappa"]
+        a.push_mask = self.push_mask.data_ptr()  # written by facefluxes() for exactly self.phi
         return a
 
     def plan(self):

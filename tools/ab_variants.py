@@ -11,7 +11,10 @@ b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 variants = {}
 for arg in sys.argv[1:]:
     name, flags = arg.split("=", 1)
-    variants[name] = b.build(force=True, extra=flags.split(), name=name)
+    if flags.startswith("@"):  # a prebuilt library (e.g. an older commit built with tools/build_ref_variant.sh)
+        variants[name] = os.path.join(ROOT, flags[1:])
+    else:
+        variants[name] = b.build(force=True, extra=flags.split(), name=name)
 import torch
 import otmb_amd
 from otmb_amd import capi, synthetic
@@ -25,7 +28,7 @@ umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
 vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
 asms = {}
 for name, path in variants.items():
-    capi.use_library(path)
+    capi.use_library(path, lenient=True)
     a = DeviceAssembler(0)
     a.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
     a.step(umo, vmo, 1e20)
