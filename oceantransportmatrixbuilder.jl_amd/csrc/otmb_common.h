@@ -112,8 +112,8 @@ __device__ __forceinline__ unsigned otmb_push_bits(double w, double e, double s,
     const double hw = w / 2, he = e / 2, hs = s / 2, hn = n / 2, hb = b / 2, ht = t / 2;
     const unsigned lo = (w > 0.0 ? PM_W : 0u) | (e < 0.0 ? PM_E : 0u) | (s > 0.0 ? PM_S : 0u) | (n < 0.0 ? PM_N : 0u) |
                         (b > 0.0 ? PM_B : 0u) | (t < 0.0 ? PM_T : 0u) | (wet ? PM_WET : 0u);
-    const unsigned hi = ((hw > 0.0) | (hw < 0.0) ? PM_W : 0u) | ((he > 0.0) | (he < 0.0) ? PM_E : 0u) |
-                        ((hs > 0.0) | (hs < 0.0) ? PM_S : 0u) | ((hn > 0.0) | (hn < 0.0) ? PM_N : 0u) |
-                        ((hb > 0.0) | (hb < 0.0) ? PM_B : 0u) | ((ht > 0.0) | (ht < 0.0) ? PM_T : 0u) | (wet ? PM_WET : 0u);
+    const unsigned hi = (((hw > 0.0) | (hw < 0.0)) ? PM_W : 0u) | (((he > 0.0) | (he < 0.0)) ? PM_E : 0u) |
+                        (((hs > 0.0) | (hs < 0.0)) ? PM_S : 0u) | (((hn > 0.0) | (hn < 0.0)) ? PM_N : 0u) |
+                        (((hb > 0.0) | (hb < 0.0)) ? PM_B : 0u) | (((ht > 0.0) | (ht < 0.0)) ? PM_T : 0u) | (wet ? PM_WET : 0u);
     return lo | (hi << 8);
 }

@@ -143,8 +143,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
     __shared__ int s_tile;
-    typedef i64 ent_t __attribute__((ext_vector_type(2)));
-    __shared__ ent_t s_ent[TM_STAGE];
+    __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // rows, then value bits
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
@@ -394,7 +393,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #pragma unroll
         for (int m = 0; m < TM_NF; ++m) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
     }
-    const unsigned pm[5] = {pT, col.padv, col.phh, col.pml, col.pdp};
+    // the vertical operators only ever hold the rows above, self and below (:438-479): lets the compiler drop
+    // the other five slot tests of their staging loops
+    const unsigned vslots = (1u << S_A) | (1u << S_SELF) | (1u << S_B);
+    const unsigned pm[5] = {pT, col.padv, col.phh, col.pml & vslots, col.pdp & vslots};
     // wave-uniform quantities go to scalar registers: the run's base pointers are then SGPR pairs, the stores
     // take the `global_store vaddr32, vdata, sbase` form and the copy loop is a scalar loop
     const u64 ubefore = (u64)wave_uniform((i64)before);
@@ -404,9 +406,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const unsigned wc[5] = {(unsigned)(wtot & 0x7ff), (unsigned)((wtot >> 11) & 0x7ff), (unsigned)((wtot >> 22) & 0x7ff),
                             (unsigned)((wtot >> 33) & 0x3ff), (unsigned)((wtot >> 43) & 0x3ff)};
     typedef i64 i64x2 __attribute__((ext_vector_type(2)));
-    // staging is interleaved {row, value bits}: one 16-byte LDS write per entry
-    i64x2 *my_ent = s_ent + wid * TM_WSTAGE;
-    const i64 *my_q = (const i64 *)my_ent;
+    // rows and value bits are staged in two arrays: an entry is two 8-byte LDS writes straight from the registers
+    // that hold it, a pair of entries one 16-byte LDS read per array
+    i64 *my_row = s_stage + wid * TM_WSTAGE;
+    i64 *my_val = my_row + TM_STAGE;  // a constant distance: one address register, the LDS offset field does the rest
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) {
         // The run is streamed out with 16-byte stores (two entries per lane): 8-byte-per-lane stores are
@@ -429,10 +432,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 if ((pm[m] >> s) & 1u) {
                     const unsigned q = q0 + __popc(pm[m] & col.bef[s]);  // position inside the wave's run
                     const double v = (m == 0) ? col.tv[s] : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
-                    i64x2 e;
-                    e.x = col.idx[s];
-                    e.y = __double_as_longlong(v);
-                    my_ent[q] = e;
+                    my_row[q] = col.idx[s];
+                    my_val[q] = __double_as_longlong(v);
                 }
             }
         }
@@ -455,10 +456,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 for (unsigned base = 0; base < end; base += 128) {  // full pairs
                     const unsigned u = base + 2 * lane;
                     if ((u >= par) & (u + 1 < end)) {
-                        i64x2 r, v;
-                        r.x = my_q[2 * u]; v.x = my_q[2 * u + 1]; r.y = my_q[2 * u + 2]; v.y = my_q[2 * u + 3];
-                        *(i64x2 *)(rvb + u * 8u) = r;
-                        *(i64x2 *)(nzb + u * 8u) = v;
+                        *(i64x2 *)(rvb + u * 8u) = *(const i64x2 *)(my_row + u);
+                        *(i64x2 *)(nzb + u * 8u) = *(const i64x2 *)(my_val + u);
                     }
                 }
                 // the (at most two) entries without a partner: index 1 of an odd-parity run, and the last one if
@@ -466,13 +465,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 const unsigned e = (lane == 0) ? 1u : end - 1;
                 const bool single = (lane == 0) ? ((par == 1) & (end > 1)) : ((lane == 1) & ((end & 1u) == 1u) & (end > par));
                 if (single) {
-                    *(i64 *)(rvb + e * 8u) = my_q[2 * e];
-                    *(i64 *)(nzb + e * 8u) = my_q[2 * e + 1];
+                    *(i64 *)(rvb + e * 8u) = my_row[e];
+                    *(i64 *)(nzb + e * 8u) = my_val[e];
                 }
             } else {
                 for (unsigned e = lane; e < cnt; e += 64) {
-                    rv[e] = my_q[2 * (par + e)];
-                    ((i64 *)nz)[e] = my_q[2 * (par + e) + 1];
+                    rv[e] = my_row[par + e];
+                    ((i64 *)nz)[e] = my_val[par + e];
                 }
             }
         }
