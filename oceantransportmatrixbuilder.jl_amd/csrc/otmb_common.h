@@ -103,6 +103,8 @@ int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_tr
 // sums: [ntiles][nf] u32 ; offs: [ntiles][nf] i64 exclusive prefix ; tot: [nf] i64 (device)
 // gsum: scratch of (ntiles / 1024 + 1) * nf i64 (see otmb_scan_scratch)
 void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *tot, i64 ntiles, int nf, i64 *gsum);
+#define OTMB_SCAN_GROUP 1024  // tiles per first-level scan group (SCAN_THREADS of otmb_scan.hip)
+void otmb_launch_tilescan_groups(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *gsum, i64 ntiles, int nf);
 static inline size_t otmb_scan_scratch(i64 ntiles, int nf) { return (size_t)(ntiles / 1024 + 2) * nf * sizeof(i64); }
 
 // ---- push mask (include/otmb.h, otmb_push_mask_dev): bits 0-5 west, east, south, north, bottom, top;

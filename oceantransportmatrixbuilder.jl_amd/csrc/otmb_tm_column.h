@@ -39,6 +39,7 @@ struct TmParams {
     // scan state
     uint32_t *tilesums;    // [ntiles][5]  (COUNT writes)
     const i64 *tileoffs;   // [ntiles][5]  (FILL reads)
+    const i64 *gsum;       // [groups][5] totals of the scan groups, when tileoffs are group-relative (else NULL)
     u64 *status;           // [n_tiles] status words, then [n_tiles][5] inclusive prefixes (ONEPASS)
     i64 n_tiles;
     int *ticket;           // dynamic tile id (ONEPASS)

@@ -26,6 +26,7 @@
 #define TM_WAVES_PER_SIMD 3  // measured: capping at 128 VGPRs (4 waves/SIMD) spills and is 8 % slower
 #endif
 #define TM_MAXROWS 7  // rows per column: A, S, W, SELF, E, N|fold, B
+#define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
 
@@ -273,7 +274,12 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #pragma unroll
             for (int m = 0; m < TM_NF; ++m)
                 if (m == tid) mine_agg = agg[m];
-            s_prefix[tid] = (p.tilesums[tile * TM_NF + tid] == mine_agg) ? p.tileoffs[tile * TM_NF + tid] : -1;
+            i64 base = 0;
+            if (p.gsum) {  // offsets are relative to the tile's scan group: add the totals of the groups before it
+                const i64 g = tile / OTMB_SCAN_GROUP;
+                for (i64 q = 0; q < g; ++q) base += p.gsum[q * TM_NF + tid];
+            }
+            s_prefix[tid] = (p.tilesums[tile * TM_NF + tid] == mine_agg) ? p.tileoffs[tile * TM_NF + tid] + base : -1;
         }
     } else {
 #ifdef OTMB_DBG_NOLOOKBACK  // timing experiment only: fake, in-bounds offsets
@@ -372,13 +378,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         return;
     }
 
-    if (MODE == MODE_ONEPASS && w0 + TM_THREADS >= p.n_own) {  // last tile: totals and the closing colptr entry
+    if (w0 + TM_THREADS >= p.n_own) {  // last tile: the closing colptr entry (and the totals, if no scan produced them)
         if (tid < TM_NF) {
             i64 tot = 0;
 #pragma unroll
             for (int m = 0; m < TM_NF; ++m)
                 if (m == tid) tot = g0[m] + agg[m];
-            p.totals[tid] = tot;
+            if (MODE == MODE_ONEPASS || p.gsum) p.totals[tid] = tot;
             i64 *cp = (tid == 0) ? p.colptr[0] : (tid == 1) ? p.colptr[1] : (tid == 2) ? p.colptr[2] : (tid == 3) ? p.colptr[3] : p.colptr[4];
             const i64 nb = (tid == 0) ? p.nnz_base[0] : (tid == 1) ? p.nnz_base[1] : (tid == 2) ? p.nnz_base[2] : (tid == 3) ? p.nnz_base[3] : p.nnz_base[4];
             cp[p.n_own] = nb + tot + 1;
@@ -484,14 +490,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
     if (threadIdx.x == 0) {
         c0[N] = t0 + 1; c1[N] = t1 + 1; c2[N] = t2 + 1; c3[N] = t3 + 1; c4[N] = t4 + 1;
-    }
-}
-
-// same, with the totals still on the device (asynchronous count -> scan -> fill)
-__global__ void tm_finish_colptr_dev(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, const i64 *tot, i64 b0, i64 b1, i64 b2,
-                                     i64 b3, i64 b4) {
-    if (threadIdx.x == 0) {
-        c0[N] = b0 + tot[0] + 1; c1[N] = b1 + tot[1] + 1; c2[N] = b2 + tot[2] + 1; c3[N] = b3 + tot[3] + 1; c4[N] = b4 + tot[4] + 1;
     }
 }
 
@@ -746,7 +744,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
         KernelTimer kt(ctx, K_TM_FILL);
         hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     }
-    {
+    if (pl.ntiles == 0) {  // (otherwise the fill kernel's last tile writes the closing colptr entries)
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
                            p.colptr[3], p.colptr[4], (i64)pl.args.n_wet, p.nnz_base[0] + pl.nnz[0], p.nnz_base[1] + pl.nnz[1],
@@ -833,18 +831,17 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         }
         {
             KernelTimer kt(ctx, K_TILESCAN);
-            otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, ntiles, TM_NF,
-                                 (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF);
+            i64 *gsum = (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF;
+            if (ntiles <= TM_INFILL_GROUPS * OTMB_SCAN_GROUP) {  // first level only; the fill pass adds the group bases
+                otmb_launch_tilescan_groups(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, gsum, ntiles, TM_NF);
+                p.gsum = gsum;
+            } else {
+                otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, ntiles, TM_NF, gsum);
+            }
         }
         {
             KernelTimer kt(ctx, K_TM_FILL);
             hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
-        }
-        {
-            KernelTimer kt(ctx, K_TM_FINISH);
-            hipLaunchKernelGGL(tm_finish_colptr_dev, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
-                               p.colptr[3], p.colptr[4], (i64)a->n_wet, (const i64 *)dtot, p.nnz_base[0], p.nnz_base[1],
-                               p.nnz_base[2], p.nnz_base[3], p.nnz_base[4]);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -374,3 +374,31 @@ def test_random_small_grids(api, oracle, seed):
     tm = api.transportmatrix(ϕ=rphi, **kw)
     for m in MATS:
         assert_csc_equal(tuple(tm[m]), rtm[m], f"seed {seed} {nx}x{ny}x{nz} {topo} {m}")
+
+
+def test_three_launch_tile_scan_path(oracle, monkeypatch):
+    """Grids of up to 1024 tiles take the single-launch tile scan; force the three-launch path of the larger grids
+    (otmb_scan.hip) on a test-sized grid."""
+    import torch
+
+    from helpers import gridmetrics_of
+    from otmb_amd import synthetic
+    from otmb_amd.device import DeviceAssembler
+
+    monkeypatch.setenv("OTMB_SCAN_SINGLE_MAX", "0")
+    g = synthetic.make_grid(90, 80, 20, seed=78, rho="array")
+    gm = gridmetrics_of(g)
+    ref = oracle.makeindices(gm.v3D)
+    assert 256 < ref["N"] < 1024 * 256  # several tiles, one scan group: the single-launch path would be taken
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True, tight=True)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    assert asm.N == ref["N"]
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    for onepass in (True, False):
+        asm.step(umo, vmo, 1e20, onepass=onepass)
+        got = asm.result_to_host()
+        for m in MATS:
+            assert_csc_equal(got[m], rtm[m], f"{m}/onepass={onepass}")
