@@ -7,74 +7,123 @@
 #include "otmb_common.h"
 
 #define FF_THREADS 64
-#define FF_KB 8  // levels whose loads are issued together
+#ifndef FF_KB
+#define FF_KB 6  // levels per chunk (two chunks are live: the one being processed and the one in flight)
+#endif
 
 // replace(x, NaN => 0.0, FillValue => 0.0) -- isequal semantics (:203, :215)
 __device__ __forceinline__ double ff_replace(double x, double fill) {
     return (isnan(x) || __double_as_longlong(x) == __double_as_longlong(fill)) ? 0.0 : x;
 }
 
+// The inputs of FF_KB consecutive levels of one water column (registers; every index is a compile-time constant)
+template <typename T>
+struct FfChunk {
+    T u[FF_KB], v[FF_KB], uw[FF_KB], vs[FF_KB];
+    unsigned char wc[FF_KB], wE[FF_KB], wW[FF_KB], wS[FF_KB], wN[FF_KB];
+};
+
+// lane offsets are 32-bit BYTE offsets (8*nx*ny < 2^31, checked on the host) from level bases that are uniform:
+// scalar base + vector offset addressing, no 64-bit address arithmetic per access
+template <typename T> __device__ __forceinline__ T ff_ld(const T *base, unsigned idx) {
+    return *(const T *)((const char *)base + idx * (unsigned)sizeof(T));
+}
+template <typename T> __device__ __forceinline__ void ff_st(T *base, unsigned idx, T x) {
+    *(T *)((char *)base + idx * (unsigned)sizeof(T)) = x;
+}
+struct FfCol {
+    unsigned s, sE, sW, cS, cN;  // this column and its (clamped) neighbour columns inside a level
+    bool hS, hN;
+};
+
+template <typename T>
+__device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo, const T *__restrict__ vmo,
+                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0) {
+#pragma unroll
+    for (int q = 0; q < FF_KB; ++q) {
+        const int k = (k0 - q >= 0) ? k0 - q : 0;  // clamped: loads are unconditional, the level is skipped later
+        const T *ul = umo + (i64)k * P, *vl = vmo + (i64)k * P;
+        const uint8_t *wl = wet + (i64)k * P;
+        c.u[q] = ff_ld(ul, col.s); c.v[q] = ff_ld(vl, col.s);
+        c.uw[q] = ff_ld(ul, col.sW); c.vs[q] = ff_ld(vl, col.cS);
+        c.wc[q] = ff_ld(wl, col.s); c.wE[q] = ff_ld(wl, col.sE); c.wW[q] = ff_ld(wl, col.sW); c.wS[q] = ff_ld(wl, col.cS);
+        c.wN[q] = ff_ld(wl, col.cN);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
+                                          bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
+                                          double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
+                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask) {
+#pragma unroll
+    for (int q = 0; q < FF_KB; ++q) {
+        const int k = k0 - q;
+        if (k >= 0) {
+            const i64 o = (i64)k * P;
+            const bool wc = c.wc[q] != 0, wE = c.wE[q] != 0, wW = c.wW[q] != 0;
+            const bool wS = col.hS && c.wS[q] != 0, wN = col.hN && c.wN[q] != 0;
+            double u = (double)c.u[q], v = (double)c.v[q];  // Array{Float64}(umo), :125-126
+            // nofluxboundaries!, :167-173
+            if (!wc || !wE) u = 0.0;
+            if (!wc || !wN) v = 0.0;
+            uvalid |= !(isnan(u) || u == fill);  // :199
+            vvalid |= !(isnan(v) || v == fill);  // :200
+            const double e = ff_replace(u, fill), n = ff_replace(v, fill);
+            // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
+            double uw = (double)c.uw[q];
+            if (!wW || !wc) uw = 0.0;
+            const double w = ff_replace(uw, fill);
+            // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
+            double vs = (double)c.vs[q];
+            if (!wS || !wc) vs = 0.0;
+            const double so = col.hS ? ff_replace(vs, fill) : 0.0;
+            const double b = topbelow;                  // :238-240
+            const double t = (((b + w) + so) - e) - n;  // :242
+            ff_st(east + o, col.s, e); ff_st(west + o, col.s, w); ff_st(north + o, col.s, n); ff_st(south + o, col.s, so);
+            ff_st(top + o, col.s, t); ff_st(bottom + o, col.s, b);
+            if (push_mask) ff_st(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
+            topbelow = t;
+        }
+    }
+}
+
+// Software pipeline over chunks of FF_KB levels: while chunk A is turned into fluxes and stored, the loads of the
+// next chunk B are already in flight.  A column is one thread and the grid has few columns (1.7 waves per SIMD at
+// 1 degree), so nothing else hides the memory latency of a chunk.
 template <typename T>
 __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
     const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *flags) {
-    const i64 s = (i64)blockIdx.x * FF_THREADS + threadIdx.x;
+    const unsigned s = blockIdx.x * FF_THREADS + threadIdx.x;
     bool uvalid = false, vvalid = false;
-    if (s < P) {
-        const int j = (int)(s / nx), i = (int)(s - (i64)j * nx);
-        const i64 sE = (i64)j * nx + ((i + 1 < nx) ? i + 1 : 0);        // i₊₁, gridtopology.jl:57
-        const i64 sW = (i64)j * nx + ((i > 0) ? i - 1 : nx - 1);        // i₋₁, :58
-        const i64 sS = (j > 0) ? s - nx : -1;                            // j₋₁, :63
-        const i64 sN = (j + 1 < ny) ? s + nx : ((topo == OTMB_TRIPOLAR) ? (i64)j * nx + (nx - 1 - i) : -1);  // :62, :94
+    if (s < (unsigned)P) {
+        const unsigned j = s / (unsigned)nx, i = s - j * (unsigned)nx, row = j * (unsigned)nx;
+        FfCol col;
+        col.s = s;
+        col.sE = row + ((i + 1 < (unsigned)nx) ? i + 1 : 0);  // i₊₁, gridtopology.jl:57
+        col.sW = row + ((i > 0) ? i - 1 : nx - 1);            // i₋₁, :58
+        col.hS = j > 0;                                        // j₋₁, :63
+        const bool fold = (j + 1 >= (unsigned)ny) && (topo == OTMB_TRIPOLAR);
+        col.hN = (j + 1 < (unsigned)ny) || fold;               // j₊₁, :62; tripolar fold :94
+        col.cS = col.hS ? s - nx : s;                          // clamped neighbour columns: loads stay unconditional
+        col.cN = (j + 1 < (unsigned)ny) ? s + nx : (fold ? row + (nx - 1 - i) : s);
         // seafloor ϕbottom is zero (:238); for a depth slab that is not the deepest, the plane handed up
         // by the slab below (its ϕtop at its first level) continues the chain without re-association
         double topbelow = top_below ? top_below[s] : 0.0;
-        // clamped neighbour columns: every load below is unconditional so that the loads of FF_KB levels
-        // are all in flight together (one memory round trip per chunk instead of several per level)
-        const bool hS = sS >= 0, hN = sN >= 0;
-        const i64 cS = hS ? sS : s, cN = hN ? sN : s;
-        for (int k0 = nz - 1; k0 >= 0; k0 -= FF_KB) {
-            double u_[FF_KB], v_[FF_KB], uw_[FF_KB], vs_[FF_KB];
-            unsigned char wc_[FF_KB], wE_[FF_KB], wW_[FF_KB], wS_[FF_KB], wN_[FF_KB];
-#pragma unroll
-            for (int q = 0; q < FF_KB; ++q) {
-                const int k = (k0 - q >= 0) ? k0 - q : 0;
-                const i64 o = (i64)k * P;
-                u_[q] = (double)umo[o + s]; v_[q] = (double)vmo[o + s];  // Array{Float64}(umo), :125-126
-                uw_[q] = (double)umo[o + sW]; vs_[q] = (double)vmo[o + cS];
-                wc_[q] = wet[o + s]; wE_[q] = wet[o + sE]; wW_[q] = wet[o + sW]; wS_[q] = wet[o + cS]; wN_[q] = wet[o + cN];
-            }
-#pragma unroll
-            for (int q = 0; q < FF_KB; ++q) {
-                const int k = k0 - q;
-                if (k >= 0) {
-                    const i64 o = (i64)k * P;
-                    const bool wc = wc_[q] != 0, wE = wE_[q] != 0, wW = wW_[q] != 0;
-                    const bool wS = hS && wS_[q] != 0, wN = hN && wN_[q] != 0;
-                    double u = u_[q], v = v_[q];
-                    // nofluxboundaries!, :167-173
-                    if (!wc || !wE) u = 0.0;
-                    if (!wc || !wN) v = 0.0;
-                    uvalid |= !(isnan(u) || u == fill);  // :199
-                    vvalid |= !(isnan(v) || v == fill);  // :200
-                    const double e = ff_replace(u, fill), n = ff_replace(v, fill);
-                    // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
-                    double uw = uw_[q];
-                    if (!wW || !wc) uw = 0.0;
-                    const double w = ff_replace(uw, fill);
-                    // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
-                    double vs = vs_[q];
-                    if (!wS || !wc) vs = 0.0;
-                    const double so = hS ? ff_replace(vs, fill) : 0.0;
-                    const double b = topbelow;                  // :238-240
-                    const double t = (((b + w) + so) - e) - n;  // :242
-                    east[o + s] = e; west[o + s] = w; north[o + s] = n; south[o + s] = so; top[o + s] = t; bottom[o + s] = b;
-                    if (push_mask) push_mask[o + s] = (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc);
-                    topbelow = t;
-                }
-            }
+        FfChunk<T> A, B;
+        int k0 = nz - 1;
+        ff_load(A, umo, vmo, wet, col, P, k0);
+        while (k0 >= 0) {
+            ff_load(B, umo, vmo, wet, col, P, k0 - FF_KB);
+            ff_levels(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            k0 -= FF_KB;
+            if (k0 < 0) break;
+            ff_load(A, umo, vmo, wet, col, P, k0 - FF_KB);
+            ff_levels(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            k0 -= FF_KB;
         }
     }
     if (__any(uvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_U_VALID] == 0) atomicExch(&flags[FLAG_U_VALID], 1);
@@ -88,7 +137,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
-    if (nx < 1 || ny < 1 || nz < 1 || nx * ny >= (1ll << 31)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (nx < 1 || ny < 1 || nz < 1 || nx * ny >= (1ll << 28)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
     if (topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);  // :163 -> gridtopology.jl:111
     if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
