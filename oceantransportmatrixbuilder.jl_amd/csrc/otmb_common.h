@@ -41,8 +41,9 @@ struct otmb_ctx {
     DevBuf sort[5];            // radix-sort keys/values/temporary of the general sparse() path
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     DevBuf mask;              // push mask derived by the library when the caller passes none
-    int *h_flags = nullptr;  // pinned host mirror of the flag words
-    i64 *h_tot = nullptr;    // pinned host mirror of scan totals
+    int *h_flags = nullptr;  // pinned host mirror of the state block (flag words first)
+    i64 *h_tot = nullptr;    // the totals inside it (h_flags + OTMB_NFLAGS)
+    int ff_gen = 0;          // facefluxes call counter: a validity flag is set by writing the current value (no reset pass)
     TmPlan *plan = nullptr;
     CooPlan coo;
     SpPlan sp;
@@ -79,8 +80,13 @@ enum {
     FLAG_T_CANCEL,  // some T entry summed to exactly zero: T was written with gaps and needs compaction
     FLAG_COUNT_MISMATCH,  // a tile's fill pass found other counts than its counting pass: push_mask does not describe ϕ
     OTMB_NFLAGS_TM = 12,            // words [0, OTMB_NFLAGS_TM) belong to transportmatrix and are reset by it
-    FLAG_U_VALID = 12, FLAG_V_VALID = 13  // owned by facefluxes: untouched by a transportmatrix call in between
+    // owned by facefluxes, behind the 16 scan totals: untouched by transportmatrix, which resets and fetches the
+    // flag words and its totals as ONE block (one fill and one copy kernel per call instead of two of each)
+    FLAG_U_VALID = 16 + 2 * 16, FLAG_V_VALID = FLAG_U_VALID + 1
 };
+// device state block (ctx->flags) and its pinned host mirror (ctx->h_flags): 16 flag words | 16 i64 totals | 4 words
+#define OTMB_STATE_BYTES (OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64) + 4 * sizeof(int))
+#define OTMB_TM_STATE_BYTES (OTMB_NFLAGS * sizeof(int) + 8 * sizeof(i64))  // flags + the totals transportmatrix uses
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
 int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);

@@ -69,12 +69,13 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
         return OTMB_ERR_HIP;
     }
     c->stream = c->own_stream;
-    if (hipHostMalloc((void **)&c->h_flags, OTMB_NFLAGS * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_tot, 16 * sizeof(i64)) != hipSuccess) {
+    if (hipHostMalloc((void **)&c->h_flags, OTMB_STATE_BYTES) != hipSuccess) {
         otmb_ctx_destroy(c);
         return OTMB_ERR_ALLOC;
     }
-    if (otmb_reserve(c, c->flags, OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64)) != OTMB_OK) {
+    memset(c->h_flags, 0, OTMB_STATE_BYTES);
+    c->h_tot = (i64 *)(c->h_flags + OTMB_NFLAGS);
+    if (otmb_reserve(c, c->flags, OTMB_STATE_BYTES) != OTMB_OK || hipMemset(c->flags.p, 0, OTMB_STATE_BYTES) != hipSuccess) {
         otmb_ctx_destroy(c);
         return OTMB_ERR_ALLOC;
     }
@@ -93,7 +94,6 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
-    if (ctx->h_tot) (void)hipHostFree(ctx->h_tot);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

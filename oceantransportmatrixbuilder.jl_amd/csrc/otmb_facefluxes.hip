@@ -96,7 +96,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *flags) {
+    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *flags, int gen) {
     const unsigned s = blockIdx.x * FF_THREADS + threadIdx.x;
     bool uvalid = false, vvalid = false;
     if (s < (unsigned)P) {
@@ -126,8 +126,9 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
             k0 -= FF_KB;
         }
     }
-    if (__any(uvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_U_VALID] == 0) atomicExch(&flags[FLAG_U_VALID], 1);
-    if (__any(vvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_V_VALID] == 0) atomicExch(&flags[FLAG_V_VALID], 1);
+    // "some value is valid" = the flag holds this call's number (no reset pass between calls)
+    if (__any(uvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_U_VALID] != gen) atomicExch(&flags[FLAG_U_VALID], gen);
+    if (__any(vvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_V_VALID] != gen) atomicExch(&flags[FLAG_V_VALID], gen);
 }
 
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
@@ -143,7 +144,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 P = nx * ny;
     int *dflags = (int *)ctx->flags.p;
-    HIP_TRY(ctx, hipMemsetAsync(dflags + FLAG_U_VALID, 0, 2 * sizeof(int), ctx->stream));
+    ctx->ff_gen = (ctx->ff_gen == 0x7fffffff) ? 1 : ctx->ff_gen + 1;
     const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
@@ -151,20 +152,19 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
         hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
                            (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], top_below, push_mask, dflags);
+                           phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen);
     else
         hipLaunchKernelGGL(facefluxes_kernel<double>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const double *)umo,
                            (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
                            phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], top_below, push_mask, dflags);
+                           phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen);
     }
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + FLAG_U_VALID, dflags + FLAG_U_VALID, 2 * sizeof(int),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    if (!check_missing) return OTMB_OK;  // slab: the caller combines the flags of all slabs
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ctx->h_flags[FLAG_U_VALID] || !ctx->h_flags[FLAG_V_VALID]) return otmb_fail(ctx, OTMB_ERR_ALL_MISSING);
+    if (!check_missing) return OTMB_OK;  // slab / asynchronous: otmb_facefluxes_slab_flags fetches the flags when asked
+    int32_t u = 0, v = 0, rc;
+    if ((rc = otmb_facefluxes_slab_flags(ctx, &u, &v))) return rc;
+    if (!u || !v) return otmb_fail(ctx, OTMB_ERR_ALL_MISSING);
     return OTMB_OK;
 }
 
@@ -222,8 +222,11 @@ extern "C" int32_t otmb_push_mask_dev(otmb_ctx *ctx, const double *const phi[6],
 
 extern "C" int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid) {
     if (!ctx || !u_valid || !v_valid) return OTMB_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + FLAG_U_VALID, (int *)ctx->flags.p + FLAG_U_VALID, 2 * sizeof(int),
+                                hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *u_valid = ctx->h_flags[FLAG_U_VALID];
-    *v_valid = ctx->h_flags[FLAG_V_VALID];
+    *u_valid = ctx->h_flags[FLAG_U_VALID] == ctx->ff_gen;
+    *v_valid = ctx->h_flags[FLAG_V_VALID] == ctx->ff_gen;
     return OTMB_OK;
 }

@@ -683,8 +683,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     fill_params(p, *a, ctx, &pl);
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
-    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS_TM * sizeof(int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dtot, 0, 8 * sizeof(i64), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
     if (ntiles > 0) {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         {
@@ -699,8 +698,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = check_flags(ctx))) return rc;
     for (int m = 0; m < 5; ++m) nnz[m] = pl.nnz[m] = ctx->h_tot[m];
@@ -808,8 +806,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     p.totals = dtot;
-    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_NFLAGS_TM * sizeof(int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dtot, 0, 8 * sizeof(i64), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
     if (ntiles == 0) {
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
@@ -845,8 +842,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, TM_NF * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     pl.onepass_pending = true;
     return OTMB_OK;
 }

@@ -8,7 +8,7 @@ for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
-    if "tm_kernel" not in k and "facefluxes" not in k and "tilescan" not in k: continue
+    if not any(t in k for t in ("tm_kernel", "tm_count", "facefluxes", "tilescan", "push_mask")): continue
     print(k)
     for c in sorted(agg[k]):
         v = agg[k][c]
