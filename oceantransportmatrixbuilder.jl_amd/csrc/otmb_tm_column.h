@@ -26,6 +26,8 @@ struct TmParams {
     const double *area, *zt, *ml;
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
+    int rho_in_fill;   // the ρ-NaN check (:233) is done by the fill pass (which loads ρ anyway) instead of the counting pass:
+                       // set when both passes run before the flags are read (otmb_transportmatrix_dev)
     i64 P, G;
     i64 n_own;         // number of entries of lwet = columns produced
     i64 wet_base;      // wet rank of column 0 is wet_base + 1 (depth slabs; 0 otherwise)
@@ -417,7 +419,14 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
 #undef ADV1
         const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
                          (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
-        if (bad) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
+        // the ρ check of the asynchronous protocol shares this (rarely taken) branch: a separate one right after the
+        // loads splits the scheduling region and cost 6 % of the kernel (collecting ALL error checks into one branch
+        // at the end measured 2 % slower than this)
+        const bool badrho = !CHECKS && p.rho_in_fill && isnan(rC);
+        if (bad | badrho) {
+            if (badrho) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+            if (bad) raise_flag(p.flags, FLAG_TADV_NAN);    // :39
+        }
         // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
         double d = NEG0;
         d += aA ? dA_ : NEG0;
@@ -512,7 +521,7 @@ __device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase 
         const bool bad = ((mC & PM_W) && !wW) | ((mC & PM_E) && !wE) | ((mC & PM_S) && !wS) | ((mC & PM_N) && !wN) |
                          ((mC & PM_B) && !wB) | (hA && (mC & PM_T) && !wA);
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-        if (tb.rho && isnan(ldd(tb.rho, oC))) raise_flag(p.flags, FLAG_RHO_NAN);
+        if (!p.rho_in_fill && tb.rho && isnan(ldd(tb.rho, oC))) raise_flag(p.flags, FLAG_RHO_NAN);
     }
 #endif
     // the east cell pushes through its west face, the cell above through its bottom face, ... (:244-296)

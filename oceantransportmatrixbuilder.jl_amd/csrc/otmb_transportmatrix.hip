@@ -821,6 +821,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     } else {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
+        p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),

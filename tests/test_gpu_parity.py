@@ -402,3 +402,34 @@ def test_three_launch_tile_scan_path(oracle, monkeypatch):
         got = asm.result_to_host()
         for m in MATS:
             assert_csc_equal(got[m], rtm[m], f"{m}/onepass={onepass}")
+
+
+def test_rho_nan_is_reported_by_both_device_protocols(oracle):
+    """The asynchronous protocol checks ρ in the fill pass (which loads it anyway), the two-phase protocol in the
+    counting pass (plan must already report it): same error, and it wins over a flux into land (reference order:
+    src/matrixbuilding.jl:233 comes before the loop)."""
+    import torch
+
+    from otmb_amd.capi import OtmbError
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case("small_rho3d")
+    ref = oracle.makeindices(gm.v3D)
+    rho = g.rho.copy(order="F")
+    rho.ravel(order="F")[ref["Lwet"][ref["N"] // 2] - 1] = np.nan
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    for onepass in (True, False):
+        with pytest.raises(OtmbError, match="ρ contains NaNs"):
+            asm.step(umo, vmo, _fill(g), onepass=onepass)
+    # double fault: also push a flux into land
+    phi = asm.facefluxes(umo, vmo, _fill(g))
+    wet = ref["wet3D"].astype(bool)
+    i, j, k = np.argwhere(wet & ~np.roll(wet, 1, axis=0))[0]
+    L = i + wet.shape[0] * (j + wet.shape[1] * k)
+    phi[1][L] = 5.0  # OTMB_WEST; in place through torch, so the assembler drops its push mask
+    for twophase in (False, True):
+        with pytest.raises(OtmbError, match="ρ contains NaNs"):
+            asm.transportmatrix(phi) if twophase else asm.transportmatrix_onepass(phi)
