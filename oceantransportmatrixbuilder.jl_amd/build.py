@@ -12,8 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libotmb_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
-
+# (LLVM's alternative machine-scheduler strategies -- max-memory-clause, max-ilp, iterative-* -- were compared with
+# tools/ab_variants.py over several array placements each: none beats the default on the fill pass.)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-Wno-bitwise-instead-of-logical"]
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
@@ -40,7 +42,9 @@ def build(force=False, verbose=False, extra=(), name=None):
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ("" if name is None else "_" + name) + ".o")
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
+        drop = {e[len("-REMOVE:"):] for e in extra if e.startswith("-REMOVE:")}  # A/B variants: strip a default flag
+        flags = [f for f in FLAGS if f not in drop] + [e for e in extra if not e.startswith("-REMOVE:")]
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

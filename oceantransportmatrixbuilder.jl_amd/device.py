@@ -5,6 +5,7 @@ caller with device-resident data (AMDGPU.jl ROCArrays) would call the same `_dev
 All arrays are flat torch tensors whose memory is Julia's column-major (nx,ny,nz) layout.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,7 +33,24 @@ class DeviceAssembler:
         self.out = None
 
     def _t(self, a, dtype=np.float64):
-        return torch.from_numpy(_flat(a, dtype)).to(self.device)
+        h = torch.from_numpy(_flat(a, dtype))
+        d = self._empty(h.numel(), h.dtype)
+        d.copy_(h)
+        return d
+
+    def _empty(self, n, dtype):
+        """Device array of n elements.  OTMB_STAGGER=<bytes> (experiment, tools/placement_study.py) starts the k-th
+        array k*stagger bytes into its allocation, so that equal offsets in different arrays do not share the low
+        address bits."""
+        stagger = int(os.environ.get("OTMB_STAGGER", "0"))
+        if stagger <= 0:
+            return torch.empty(n, dtype=dtype, device=self.device)
+        item = torch.empty(0, dtype=dtype).element_size()
+        self._nalloc = getattr(self, "_nalloc", 0) + 1
+        pad = (self._nalloc * stagger) % (1 << 21)
+        pad -= pad % 256
+        raw = torch.empty(n * item + pad, dtype=torch.uint8, device=self.device)
+        return raw[pad:pad + n * item].view(dtype)
 
     # ---- grid ---------------------------------------------------------------------------------
     def set_grid(self, gridmetrics, mlotst, rho, kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True):
@@ -100,8 +118,8 @@ class DeviceAssembler:
 
     def makeindices(self):
         """otmb_makeindices_dev on the resident v3D (src/matrixbuilding.jl:10-24)."""
-        self.lwet3d = torch.empty(self.G, dtype=torch.int64, device=self.device)
-        self.lwet = torch.empty(self.G, dtype=torch.int64, device=self.device)
+        self.lwet3d = self._empty(self.G, torch.int64)
+        self.lwet = self._empty(self.G, torch.int64)
         self.wet3d = torch.empty(self.G, dtype=torch.uint8, device=self.device)
         n = C.c_int64(0)
         self.ctx.check(self.lib.otmb_makeindices_dev(self.ctx.handle, self.v3d.data_ptr(), self.nx, self.ny, self.nz,
@@ -123,8 +141,8 @@ class DeviceAssembler:
         kernel also writes the push mask of these fluxes (include/otmb.h), which lets the counting pass of the
         following transportmatrix skip the six ϕ arrays."""
         if getattr(self, "phi", None) is None:
-            self.phi = [torch.empty(self.G, dtype=torch.float64, device=self.device) for _ in range(6)]
-            self.push_mask = torch.empty(self.G, dtype=torch.int16, device=self.device)
+            self.phi = [self._empty(self.G, torch.float64) for _ in range(6)]
+            self.push_mask = self._empty(self.G, torch.int16)
         ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
         self._mask_key = None
         self.ctx.check(self.lib.otmb_facefluxes_slab_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
@@ -212,9 +230,8 @@ class DeviceAssembler:
         result()."""
         if self.out is None or getattr(self, "_out_cap", None) is None:
             cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
-            self.out = {m: (torch.empty(self.N + 1, dtype=torch.int64, device=self.device),
-                            torch.empty(cap[k], dtype=torch.int64, device=self.device),
-                            torch.empty(cap[k], dtype=torch.float64, device=self.device)) for k, m in enumerate(MATS)}
+            self.out = {m: (self._empty(self.N + 1, torch.int64), self._empty(cap[k], torch.int64),
+                            self._empty(cap[k], torch.float64)) for k, m in enumerate(MATS)}
             self._out_cap = cap
         a = self._args(phi)
         cp = capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
