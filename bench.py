@@ -65,12 +65,30 @@ def cpu_baseline(g, gm, workload, reps=5):
             t_ff.append(t2 - t1)
             t_tm.append(t3 - t2)
     ff, tm = float(np.median(t_ff)), float(np.median(t_tm))
+    # second figure: the same algorithm on several host threads -- the four operator builds run
+    # concurrently and the three adds are column-parallel (oracle/otmb_oracle.c, orc_transportmatrix_omp); the
+    # scatter-then-sort formulation of the reference offers no more parallelism without being changed
+    t_par = []
+    for rep in range(4):
+        t1 = time.perf_counter()
+        orc.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True, tight=True, parallel=True)
+        if rep:
+            t_par.append(time.perf_counter() - t1)
+    tmp = float(np.median(t_par))
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        model = "unknown CPU"
     return {
         "value": N / (ff + tm), "unit": "wet-cells/s", "cores": 1, "kind": "port",
         "sample": f"facefluxes+transportmatrix on the full {workload} grid (N={N}), 1 warm-up + median of {reps} passes; "
                   f"facefluxes {ff:.3f} s, transportmatrix {tm:.3f} s (COO generation + sparse() x4 + 3 adds); "
-                  f"host {os.cpu_count()} logical cores, 1 used",
+                  f"host {os.cpu_count()} logical cores ({model}), 1 used",
         "seconds": ff + tm,
+        "multithread": {"value": N / (ff + tmp), "unit": "wet-cells/s", "cores": min(orc.omp_threads(), os.cpu_count() or 1),
+                        "seconds": ff + tmp,
+                        "sample": f"same workload, OpenMP: 4 concurrent operator builds + column-parallel adds "
+                                  f"({orc.omp_threads()} threads), transportmatrix {tmp:.3f} s, median of 3; facefluxes as above"},
     }
 
 

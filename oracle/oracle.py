@@ -211,10 +211,16 @@ def spadd(A, B, n):
     return Cp, Ci[:nnz].copy(), Cx[:nnz].copy()
 
 
+def omp_threads():
+    """Host threads the multi-threaded variant uses for the column-parallel adds (OMP_NUM_THREADS / all cores)."""
+    return int(lib().orc_omp_threads())
+
+
 def transportmatrix(phi, gm, idx, rho, mlotst, kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True,
-                    tight=False):
+                    tight=False, parallel=False):
     """Whole reference path (matrixbuilding.jl:128-150).  gm: gridmetrics NT/dict; idx: makeindices dict.
-    Returns {name: (colptr, rowval, nzval)} for T, Tadv, TκH, TκVML, TκVdeep (1-based Int64)."""
+    Returns {name: (colptr, rowval, nzval)} for T, Tadv, TκH, TκVML, TκVdeep (1-based Int64).
+    parallel=True: orc_transportmatrix_omp (four concurrent operator builds, column-parallel adds; same bits)."""
     v3D = _f(gm["v3D"]); thk = _f(gm["thkcello"])
     ph = [_f(phi[k]) for k in PHI_ORDER]
     e = [_f(gm["edge_length_2D"][d]) for d in HDIRS]; dd = [_f(gm["distance_to_neighbour_2D"][d]) for d in HDIRS]
@@ -236,8 +242,9 @@ def transportmatrix(phi, gm, idx, rho, mlotst, kappaH=500.0, kappaVML=0.1, kappa
     rv = [np.empty(c, np.int64) for c in caps]
     nz = [np.empty(c, np.float64) for c in caps]
     nnz = (C.c_int64 * 5)()
-    rc = lib().orc_transportmatrix(C.byref(a), (_ip * 5)(*[_i(x) for x in cp]), (_ip * 5)(*[_i(x) for x in rv]),
-                                   (_dp * 5)(*[_d(x) for x in nz]), nnz)
+    fn = lib().orc_transportmatrix_omp if parallel else lib().orc_transportmatrix
+    rc = fn(C.byref(a), (_ip * 5)(*[_i(x) for x in cp]), (_ip * 5)(*[_i(x) for x in rv]),
+            (_dp * 5)(*[_d(x) for x in nz]), nnz)
     if rc:
         raise OracleError(rc)
     return {m: (cp[k], rv[k][: nnz[k]].copy(), nz[k][: nnz[k]].copy()) for k, m in enumerate(MATS)}

@@ -546,6 +546,106 @@ done:
 }
 
 
+/* ---- the same algorithm on several host threads (bench.py's second CPU figure) ---------------------------
+ * The reference's formulation (scatter triplets, then sparse() = two counting sorts, then three adds) has little
+ * parallelism to offer without changing it: what IS independent are the four operator builds (:140-143), and the
+ * adds are independent per column.  So: four concurrent operator builds (triplets + NaN check + sparse()), then
+ * the three adds column-parallel in two passes (count, prefix, write).  Output is bit-identical to
+ * orc_transportmatrix (tests/test_oracle.py). */
+#ifdef _OPENMP
+#include <omp.h>
+
+/* one column of map(+): writes into Ci/Cx when they are not NULL; returns the number of stored entries */
+static inline int64_t spadd_col(int64_t j, const int64_t *Ap, const int64_t *Ai, const double *Ax, const int64_t *Bp,
+                                const int64_t *Bi, const double *Bx, int64_t *Ci, double *Cx) {
+    int64_t Ak = Ap[j], stopA = Ap[j + 1], Bk = Bp[j], stopB = Bp[j + 1], n = 0;
+    while (Ak < stopA || Bk < stopB) {
+        double x;
+        int64_t r;
+        if (Ak < stopA && Bk < stopB && Ai[Ak - 1] == Bi[Bk - 1]) {
+            x = Ax[Ak - 1] + Bx[Bk - 1]; r = Ai[Ak - 1]; ++Ak; ++Bk;
+        } else if (Bk >= stopB || (Ak < stopA && Ai[Ak - 1] < Bi[Bk - 1])) {
+            x = Ax[Ak - 1] + 0.0; r = Ai[Ak - 1]; ++Ak;
+        } else {
+            x = 0.0 + Bx[Bk - 1]; r = Bi[Bk - 1]; ++Bk;
+        }
+        if (x != 0.0) {
+            if (Ci) { Ci[n] = r; Cx[n] = x; }
+            ++n;
+        }
+    }
+    return n;
+}
+
+int64_t orc_spadd_omp(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, const int64_t *Bp,
+                      const int64_t *Bi, const double *Bx, int64_t *Cp, int64_t *Ci, double *Cx) {
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) Cp[j + 1] = spadd_col(j, Ap, Ai, Ax, Bp, Bi, Bx, NULL, NULL);
+    Cp[0] = 1;
+    for (int64_t j = 0; j < n; ++j) Cp[j + 1] += Cp[j]; /* serial prefix: n adds */
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) spadd_col(j, Ap, Ai, Ax, Bp, Bi, Bx, Ci + Cp[j] - 1, Cx + Cp[j] - 1);
+    return Cp[n] - 1;
+}
+
+int32_t orc_omp_threads(void) { return omp_get_max_threads(); }
+
+int32_t orc_transportmatrix_omp(const orc_tm_args *a, int64_t *const colptr[5], int64_t *const rowval[5],
+                                double *const nzval[5], int64_t nnz[5]) {
+    const int64_t N = a->N;
+    int32_t rcs[4] = {ORC_OK, ORC_OK, ORC_OK, ORC_OK};
+#pragma omp parallel for schedule(static, 1) num_threads(4)
+    for (int m = 1; m <= 4; ++m) {
+        /* triplet capacity per cell: 12 advective, 8 horizontal, 4 vertical (sizehints :235, :346, :447) */
+        const int64_t cap = (m == 1 ? 12 : (m == 2 ? 8 : 4)) * (N > 0 ? N : 1);
+        int64_t *I = (int64_t *)malloc((size_t)cap * 8), *J = (int64_t *)malloc((size_t)cap * 8);
+        double *V = (double *)malloc((size_t)cap * 8);
+        uint8_t *Om = (m == 3) ? (uint8_t *)malloc((size_t)(N > 0 ? N : 1)) : NULL;
+        int64_t len = ORC_ERR_ALLOC;
+        if (I && J && V && (m != 3 || Om)) {
+            if (m == 1)
+                len = orc_advection_entries(a->phi, a->v3D, a->rho, a->rho_scalar, a->Lwet, a->Lwet3D, N, &a->g,
+                                            a->upwind, I, J, V);
+            else if (m == 2)
+                len = orc_hdiff_entries(a->v3D, a->thk, a->edge, a->dist, a->Lwet, a->Lwet3D, N, &a->g, a->kappaH,
+                                        NULL, I, J, V);
+            else if (m == 3) {
+                orc_ml_mask(a->zt, a->mlotst, a->Lwet, N, &a->g, Om);
+                len = orc_vdiff_entries(a->v3D, a->area2D, a->zt, a->Lwet, a->Lwet3D, N, &a->g, a->kappaVML, Om, I, J, V);
+            } else
+                len = orc_vdiff_entries(a->v3D, a->area2D, a->zt, a->Lwet, a->Lwet3D, N, &a->g, a->kappaVdeep, NULL, I,
+                                        J, V);
+        }
+        if (len < 0)
+            rcs[m - 1] = (int32_t)len;
+        else if (has_nan(V, len))
+            rcs[m - 1] = (m == 1) ? ORC_ERR_TADV_NAN : (m == 2) ? ORC_ERR_TKH_NAN : (m == 3) ? ORC_ERR_TKVML_NAN : ORC_ERR_TKVDEEP_NAN;
+        else {
+            nnz[m] = orc_sparse(I, J, V, len, N, N, colptr[m], rowval[m], nzval[m]);
+            if (nnz[m] < 0) rcs[m - 1] = ORC_ERR_ALLOC;
+        }
+        free(I); free(J); free(V); free(Om);
+    }
+    for (int m = 0; m < 4; ++m) /* the serial order of the reference decides which error is reported */
+        if (rcs[m] != ORC_OK) return rcs[m];
+    int64_t c1 = nnz[1] + nnz[2] + 1, c2 = c1 + nnz[3];
+    int64_t *p1 = (int64_t *)malloc((size_t)(N + 1) * 8), *i1 = (int64_t *)malloc((size_t)c1 * 8);
+    double *x1 = (double *)malloc((size_t)c1 * 8);
+    int64_t *p2 = (int64_t *)malloc((size_t)(N + 1) * 8), *i2 = (int64_t *)malloc((size_t)c2 * 8);
+    double *x2 = (double *)malloc((size_t)c2 * 8);
+    int32_t rc = ORC_OK;
+    if (!p1 || !i1 || !x1 || !p2 || !i2 || !x2) {
+        rc = ORC_ERR_ALLOC;
+    } else {
+        orc_spadd_omp(N, colptr[1], rowval[1], nzval[1], colptr[2], rowval[2], nzval[2], p1, i1, x1);
+        orc_spadd_omp(N, p1, i1, x1, colptr[3], rowval[3], nzval[3], p2, i2, x2);
+        nnz[0] = orc_spadd_omp(N, p2, i2, x2, colptr[4], rowval[4], nzval[4], colptr[0], rowval[0], nzval[0]);
+    }
+    free(p1); free(i1); free(x1); free(p2); free(i2); free(x2);
+    return rc;
+}
+#endif /* _OPENMP */
+
 /* ---- velocity2fluxes / fluxes2velocity: velocities.jl:10-39, :50-74, nanmean2 :89-93, nanmin2 :108 -----
  * Default C-grid only (interpolateontodefaultCgrid passes C-grid fields through, gridcellgeometry.jl:104).
  * rho: 3-D array or NULL with rho_scalar (twocellnanmean(x::Number) = x, :81).  Loops over ALL cells.

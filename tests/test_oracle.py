@@ -222,3 +222,26 @@ def test_oracle_reproduces_golden_fixtures(oracle, name):
         tm = oracle.transportmatrix(gd["phi"], gd["gm"], idx, gd["rho"], gd["mlotst"], kH, kML, kD, upwind)
         for q, m in enumerate(MATS):
             assert_csc_equal(tm[m], gd["tm"](upwind)[q], f"{name}/{m}")
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold"])
+def test_multithreaded_oracle_variant_is_bit_identical(oracle, name):
+    """orc_transportmatrix_omp (bench.py's multi-thread CPU figure): concurrent operator builds and column-parallel adds
+    must not change a bit, and errors keep the reference's order."""
+    from helpers import MATS, assert_csc_equal, make_case
+
+    g, gm = make_case(name)
+    idx = oracle.makeindices(gm.v3D)
+    phi = oracle.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], g.umo.properties["_FillValue"], gm.gridtopology.kind)
+    for upwind in (True, False):
+        a = oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind)
+        b = oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind, parallel=True)
+        for m in MATS:
+            assert_csc_equal(b[m], a[m], f"{name}/{m}/upwind={upwind}")
+    assert oracle.omp_threads() >= 1
+    rho = np.full(gm.v3D.shape, np.nan)
+    with pytest.raises(oracle.OracleError) as e1:
+        oracle.transportmatrix(phi, gm, idx, rho, g.mlotst, parallel=False)
+    with pytest.raises(oracle.OracleError) as e2:
+        oracle.transportmatrix(phi, gm, idx, rho, g.mlotst, parallel=True)
+    assert e1.value.args == e2.value.args
