@@ -73,6 +73,29 @@ class DeviceAssembler:
         self.upwind = bool(upwind)
         self.makeindices()
 
+    def set_grid_tensors(self, *, shape, topology, v3d, thkcello, edge_length, dist_nbr, area2d, zt, mlotst, rho,
+                         kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True):
+        """Grid whose arrays already live on this GPU (flat float64 tensors in Julia's column-major order; edge_length /
+        dist_nbr: four (nx*ny) tensors in OTMB_DIR_* order west, east, south, north; rho: tensor or number).  Nothing
+        is copied: the caller keeps the tensors alive through this object."""
+        self.shape = tuple(int(x) for x in shape)
+        self.nx, self.ny, self.nz = self.shape
+        self.G = self.nx * self.ny * self.nz
+        self.topology = int(topology)
+        self.v3d, self.thk = v3d, thkcello
+        self.edge, self.dist = list(edge_length), list(dist_nbr)
+        self.area, self.zt, self.mlotst = area2d, zt, mlotst
+        self.rho = rho if torch.is_tensor(rho) else None
+        self.rho_scalar = 0.0 if torch.is_tensor(rho) else float(rho)
+        for t in (self.v3d, self.thk, *self.edge, *self.dist, self.area, self.zt, self.mlotst) + ((self.rho,) if self.rho is not None else ()):
+            if t.device != self.device or t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("set_grid_tensors: contiguous float64 tensors on this assembler's device are required")
+        if self.v3d.numel() != self.G or self.thk.numel() != self.G or self.zt.numel() != self.nz:
+            raise ValueError("set_grid_tensors: array sizes do not match shape")
+        self.kappa = (float(kappaH), float(kappaVML), float(kappaVdeep))
+        self.upwind = bool(upwind)
+        self.makeindices()
+
     def set_grid_from_raw(self, *, areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices, mlotst, rho,
                           kappaH=500.0, kappaVML=0.1, kappaVdeep=1.0e-5, upwind=True):
         """makegridmetrics on the device (otmb_makegridmetrics_dev): the raw CMIP arrays go up once, every derived
