@@ -433,3 +433,37 @@ def test_rho_nan_is_reported_by_both_device_protocols(oracle):
     for twophase in (False, True):
         with pytest.raises(OtmbError, match="ρ contains NaNs"):
             asm.transportmatrix(phi) if twophase else asm.transportmatrix_onepass(phi)
+
+
+def test_set_grid_tensors_equals_set_grid(oracle):
+    """Device-resident callers hand over tensors (tools/large_run_device.py does, for the 0.1 degree grid): same result
+    as uploading the host arrays."""
+    import torch
+
+    from otmb_amd.capi import HDIRS
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case("small_rho3d")
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+
+    def dev(a):
+        return torch.from_numpy(np.asfortranarray(a, dtype=np.float64).ravel(order="F").copy()).cuda()
+
+    asm = DeviceAssembler(0)
+    asm.set_grid_tensors(shape=gm.v3D.shape, topology=gm.gridtopology.kind, v3d=dev(gm.v3D), thkcello=dev(gm.thkcello),
+                         edge_length=[dev(gm.edge_length_2D[d]) for d in HDIRS],
+                         dist_nbr=[dev(gm.distance_to_neighbour_2D[d]) for d in HDIRS], area2d=dev(gm.area2D),
+                         zt=dev(gm.zt), mlotst=dev(g.mlotst), rho=dev(g.rho), kappaH=g.kappaH, kappaVML=g.kappaVML,
+                         kappaVdeep=g.kappaVdeep)
+    assert asm.N == ref["N"]
+    asm.step(dev(g.umo.data), dev(g.vmo.data), _fill(g))
+    got = asm.result_to_host()
+    for m in MATS:
+        assert_csc_equal(got[m], rtm[m], m)
+    with pytest.raises(ValueError):
+        asm.set_grid_tensors(shape=gm.v3D.shape, topology=1, v3d=dev(gm.v3D).float(), thkcello=dev(gm.thkcello),
+                             edge_length=[dev(gm.edge_length_2D[d]) for d in HDIRS],
+                             dist_nbr=[dev(gm.distance_to_neighbour_2D[d]) for d in HDIRS], area2d=dev(gm.area2D),
+                             zt=dev(gm.zt), mlotst=dev(g.mlotst), rho=1035.0)
