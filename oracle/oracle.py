@@ -16,6 +16,7 @@ ERRORS = {
     -1: "ρ contains NaNs", -2: "Tadv contains NaNs.", -3: "TκH contains NaNs.", -4: "TκVML contains NaNs.",
     -5: "TκVdeep contains NaNs.", -6: "flux into land or outside the grid", -7: "Unknown grid type",
     -8: "AssertionError: all fluxes missing", -9: "allocation failed",
+    -20: "ArgumentError: Adjacency / distance matrices must be symmetric",
 }
 
 
@@ -248,6 +249,30 @@ def transportmatrix(phi, gm, idx, rho, mlotst, kappaH=500.0, kappaVML=0.1, kappa
     if rc:
         raise OracleError(rc)
     return {m: (cp[k], rv[k][: nnz[k]].copy(), nz[k][: nnz[k]].copy()) for k, m in enumerate(MATS)}
+
+
+def lump_and_spray(wet3D, vol, T, mask=None, di=2, dj=2, dk=1):
+    """extratools.jl:38-119.  T = (colptr, rowval, nzval) 1-based.  Returns LUMP, SPRAY as (colptr, rowval, nzval) and vol_c."""
+    wet = np.asfortranarray(np.asarray(wet3D) != 0).astype(np.uint8)
+    nx, ny, nz = wet.shape
+    m = None if mask is None else np.asfortranarray(np.asarray(mask) != 0).astype(np.uint8)
+    vol = np.ascontiguousarray(vol, dtype=np.float64)
+    N = len(vol)
+    Tp = np.ascontiguousarray(T[0], dtype=np.int64); Ti = np.ascontiguousarray(T[1], dtype=np.int64)
+    lrow = np.empty(max(N, 1), np.int64); lval = np.empty(max(N, 1), np.float64)
+    scp = np.empty(N + 2, np.int64); srow = np.empty(max(N, 1), np.int64); vc = np.empty(max(N, 1), np.float64)
+    Nc = C.c_int64(0)
+    fn = lib().orc_lump_and_spray
+    fn.restype = C.c_int32
+    rc = fn(wet.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p), C.c_int64(nx), C.c_int64(ny),
+            C.c_int64(nz), _d(vol), _i(Tp), _i(Ti), C.c_int64(di), C.c_int64(dj), C.c_int64(dk), _i(lrow), _d(lval), _i(scp),
+            _i(srow), _d(vc), C.byref(Nc))
+    if rc:
+        raise OracleError(rc)
+    n = Nc.value
+    LUMP = (np.arange(1, N + 2, dtype=np.int64), lrow[:N].copy(), lval[:N].copy())
+    SPRAY = (scp[: n + 1].copy(), srow[:N].copy(), np.ones(N))
+    return LUMP, SPRAY, vc[:n].copy()
 
 
 def haversine(lon1, lat1, lon2, lat2):

@@ -646,6 +646,143 @@ int32_t orc_transportmatrix_omp(const orc_tm_args *a, int64_t *const colptr[5], 
 }
 #endif /* _OPENMP */
 
+/* ---- lump_and_spray: src/extratools.jl:38-119 ---------------------------------------------------------------
+ * wet3D, mask (NULL = trues, :38): nx*ny*nz bytes; vol: N volumes of the wet cells; Tp/Ti: colptr/rowval of T
+ * (1-based; only the pattern is used, findnz(T) :45).  Outputs: LUMP is Nc x N with exactly one entry per column
+ * (lump_row[N] 1-based, lump_val[N]); SPRAY is its transposed pattern filled with ones (spray_colptr[Nc+1],
+ * spray_row[N] 1-based); vol_c[Nc].  Capacities N (+1).  Third-party semantics restated: Graphs.SimpleGraph(adjmx)
+ * requires a symmetric matrix (ArgumentError otherwise -> ORC_ERR_ASYMMETRIC); Graphs.connected_components lists
+ * the components by ascending smallest vertex; SparseArrays products as cited inline. */
+#define ORC_ERR_ASYMMETRIC (-20)
+static int col_has_row(const int64_t *Tp, const int64_t *Ti, int64_t col, int64_t row) { /* T[row,col] stored? */
+    for (int64_t q = Tp[col - 1]; q < Tp[col]; ++q)
+        if (Ti[q - 1] == row) return 1;
+    return 0;
+}
+int32_t orc_lump_and_spray(const uint8_t *wet3D, const uint8_t *mask, int64_t nx, int64_t ny, int64_t nz,
+                           const double *vol, const int64_t *Tp, const int64_t *Ti, int64_t di, int64_t dj,
+                           int64_t dk, int64_t *lump_row, double *lump_val, int64_t *spray_colptr,
+                           int64_t *spray_row, double *vol_c, int64_t *Nc_out) {
+    const int64_t ex = nx + di - 1, ey = ny + dj - 1, ez = nz + dk - 1; /* :41-43 */
+    const int64_t G = nx * ny * nz, Gext = ex * ey * ez, bv = di * dj * dk;
+    int64_t *LUMPidx = (int64_t *)calloc((size_t)Gext, 8);
+    int64_t *rank = (int64_t *)calloc((size_t)G, 8); /* wet rank (1-based) of an original cell, 0 = dry */
+    int64_t *cellof = (int64_t *)malloc((size_t)(G > 0 ? G : 1) * 8); /* original linear index (0-based) of wet rank r */
+    int64_t *loc = (int64_t *)malloc((size_t)bv * 8), *lab = (int64_t *)malloc((size_t)bv * 8), *queue = (int64_t *)malloc((size_t)bv * 8);
+    int32_t rc = ORC_OK;
+    if (!LUMPidx || !rank || !cellof || !loc || !lab || !queue) { rc = ORC_ERR_ALLOC; goto done; }
+    int64_t N = 0;
+    for (int64_t L = 0; L < G; ++L)
+        if (wet3D[L]) { cellof[N] = L; rank[L] = ++N; }
+#define EXT(i, j, k) ((i) + ex * ((j) + ey * (k))) /* 0-based coordinates -> 0-based extended linear index, :47 */
+    int64_t c = 2; /* :55 */
+    for (int64_t k = 0; k < nz; ++k)
+        for (int64_t j = 0; j < ny; ++j)
+            for (int64_t i = 0; i < nx; ++i) { /* eachindex(C), :57 */
+                const int64_t L = i + nx * (j + ny * k);
+                const int inmask = mask ? (mask[L] != 0) : 1;
+                if (LUMPidx[EXT(i, j, k)] > 0 && inmask) continue; /* :61 */
+                if (!inmask) { /* :78-81 */
+                    LUMPidx[EXT(i, j, k)] = c++;
+                    continue;
+                }
+                /* the block C𝑖 .+ neighbours in vec order (i fastest), :64; wet members become the graph's vertices */
+                int64_t nv = 0;
+                for (int64_t d = 0; d < dk; ++d)
+                    for (int64_t b = 0; b < dj; ++b)
+                        for (int64_t a = 0; a < di; ++a) {
+                            const int64_t ii = i + a, jj = j + b, kk = k + d;
+                            const int inside = ii < nx && jj < ny && kk < nz;
+                            if (inside && wet3D[ii + nx * (jj + ny * kk)])
+                                loc[nv++] = ii + nx * (jj + ny * kk); /* original linear index of vertex nv */
+                            else
+                                LUMPidx[EXT(ii, jj, kk)] = 1; /* :66-68 (ghost cells of the extension are dry) */
+                        }
+                /* vertex of an original cell inside this block, or -1 */
+#define VERTEX_OF(Lc, out)                                                                      \
+    do {                                                                                        \
+        const int64_t Lc_ = (Lc);                                                               \
+        const int64_t ci = Lc_ % nx, cj = (Lc_ / nx) % ny, ck = Lc_ / (nx * ny);                \
+        (out) = -1;                                                                             \
+        if (ci >= i && ci < i + di && cj >= j && cj < j + dj && ck >= k && ck < k + dk)         \
+            for (int64_t q_ = 0; q_ < nv; ++q_)                                                 \
+                if (loc[q_] == Lc_) { (out) = q_; break; }                                      \
+    } while (0)
+                /* SimpleGraph(view(connectivitymatrix, wetidx, wetidx)): symmetric or ArgumentError, :71-72.  Every
+                 * asymmetric pair has one direction stored, so walking the stored entries finds it. */
+                for (int64_t v = 0; v < nv && rc == ORC_OK; ++v) {
+                    const int64_t col = rank[loc[v]];
+                    for (int64_t q = Tp[col - 1]; q < Tp[col]; ++q) {
+                        const int64_t row = Ti[q - 1];
+                        int64_t u;
+                        VERTEX_OF(cellof[row - 1], u);
+                        if (u >= 0 && !col_has_row(Tp, Ti, row, col)) { rc = ORC_ERR_ASYMMETRIC; break; }
+                    }
+                }
+                if (rc != ORC_OK) goto done;
+                /* connected_components: vertices ascending; a search from an unlabelled vertex labels its component */
+                for (int64_t v = 0; v < nv; ++v) lab[v] = -1;
+                for (int64_t u0 = 0; u0 < nv; ++u0) {
+                    if (lab[u0] >= 0) continue;
+                    int64_t head = 0, tail = 0;
+                    lab[u0] = u0;
+                    queue[tail++] = u0;
+                    while (head < tail) {
+                        const int64_t src = queue[head++], col = rank[loc[src]];
+                        for (int64_t q = Tp[col - 1]; q < Tp[col]; ++q) {
+                            int64_t u;
+                            VERTEX_OF(cellof[Ti[q - 1] - 1], u);
+                            if (u >= 0 && lab[u] < 0) { lab[u] = u0; queue[tail++] = u; }
+                        }
+                    }
+                    for (int64_t v = 0; v < nv; ++v) /* LUMPidx[wetidx[comp]] .= c, :75 */
+                        if (lab[v] == u0) {
+                            const int64_t Lc = loc[v];
+                            LUMPidx[EXT(Lc % nx, (Lc / nx) % ny, Lc / (nx * ny))] = c;
+                        }
+                    ++c; /* :76 */
+                }
+#undef VERTEX_OF
+            }
+    /* LUMP = sparse(LUMPidx[C][:], 1:length(C), 1) :85; wet_c = LUMP * wet .> 0 :88; LUMP = LUMP[wet_c, wet] :91 */
+    {
+        int64_t *newrow = (int64_t *)calloc((size_t)c + 1, 8);
+        if (!newrow) { rc = ORC_ERR_ALLOC; goto done; }
+        for (int64_t w = 0; w < N; ++w) {
+            const int64_t Lc = cellof[w];
+            newrow[LUMPidx[EXT(Lc % nx, (Lc / nx) % ny, Lc / (nx * ny))]] = 1;
+        }
+        int64_t Nc = 0;
+        for (int64_t r = 1; r <= c; ++r)
+            if (newrow[r]) newrow[r] = ++Nc;
+        for (int64_t w = 0; w < N; ++w) {
+            const int64_t Lc = cellof[w];
+            lump_row[w] = newrow[LUMPidx[EXT(Lc % nx, (Lc / nx) % ny, Lc / (nx * ny))]];
+        }
+        free(newrow);
+        *Nc_out = Nc;
+        /* vol_c = LUMP * vol :96 -- mul!: for every column j ascending, y[row] += 1 * vol[j] */
+        for (int64_t I = 0; I < Nc; ++I) vol_c[I] = 0.0;
+        for (int64_t w = 0; w < N; ++w) vol_c[lump_row[w] - 1] = vol_c[lump_row[w] - 1] + 1 * vol[w];
+        /* LUMP = sparse(Diagonal(1 ./ vol_c)) * LUMP * sparse(Diagonal(vol)) :97, evaluated left to right */
+        for (int64_t w = 0; w < N; ++w) lump_val[w] = ((1.0 / vol_c[lump_row[w] - 1]) * 1) * vol[w];
+        /* SPRAY = copy(LUMP'); SPRAY.nzval .= 1 :101-102 -- transposition = stable counting sort by row */
+        for (int64_t I = 0; I <= Nc; ++I) spray_colptr[I] = 0;
+        for (int64_t w = 0; w < N; ++w) spray_colptr[lump_row[w]] += 1;
+        spray_colptr[0] = 1;
+        for (int64_t I = 1; I <= Nc; ++I) spray_colptr[I] += spray_colptr[I - 1];
+        int64_t *cur = (int64_t *)malloc((size_t)(Nc > 0 ? Nc : 1) * 8);
+        if (!cur) { rc = ORC_ERR_ALLOC; goto done; }
+        for (int64_t I = 0; I < Nc; ++I) cur[I] = spray_colptr[I];
+        for (int64_t w = 0; w < N; ++w) spray_row[cur[lump_row[w] - 1]++ - 1] = w + 1;
+        free(cur);
+    }
+#undef EXT
+done:
+    free(LUMPidx); free(rank); free(cellof); free(loc); free(lab); free(queue);
+    return rc;
+}
+
 /* ---- velocity2fluxes / fluxes2velocity: velocities.jl:10-39, :50-74, nanmean2 :89-93, nanmin2 :108 -----
  * Default C-grid only (interpolateontodefaultCgrid passes C-grid fields through, gridcellgeometry.jl:104).
  * rho: 3-D array or NULL with rho_scalar (twocellnanmean(x::Number) = x, :81).  Loops over ALL cells.

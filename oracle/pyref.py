@@ -449,3 +449,131 @@ def bolus_gm_velocity(rho, gm, idx, topo, kappaGM=600.0, maxslope=0.01):
         u[C[0] - 1, C[1] - 1, C[2] - 1] = dyad_deriv(Ki, Z, topo, C)
         v[C[0] - 1, C[1] - 1, C[2] - 1] = dyad_deriv(Kj, Z, topo, C)
     return u, v
+
+
+# ---- lump_and_spray: src/extratools.jl:38-119 (literal transliteration, small grids only) -------------------------
+class AsymmetricConnectivity(Exception):
+    """Graphs.SimpleGraph(adjmx) throws ArgumentError("Adjacency / distance matrices must be symmetric")."""
+
+
+def _connected_components(nv, adj):
+    """Graphs.connected_components: label = smallest vertex of the component (vertices are visited in ascending
+    order and a search labels everything reachable); components are listed in the order their label first appears
+    while scanning the vertices, i.e. by ascending smallest vertex, members ascending."""
+    label = [0] * (nv + 1)
+    for u in range(1, nv + 1):
+        if label[u]:
+            continue
+        label[u] = u
+        queue = [u]
+        while queue:
+            src = queue.pop(0)
+            for v in sorted(adj[src]):
+                if not label[v]:
+                    label[v] = u
+                    queue.append(v)
+    comps, seen = [], {}
+    for v in range(1, nv + 1):
+        if label[v] not in seen:
+            seen[label[v]] = len(comps)
+            comps.append([])
+        comps[seen[label[v]]].append(v)
+    return comps
+
+
+def lump_and_spray(wet3D, vol, T, mask=None, di=2, dj=2, dk=1):
+    """wet3D (nx,ny,nz) bool; vol (N,) volumes of the wet cells; T = (colptr, rowval, nzval) 1-based N x N;
+    mask (nx,ny,nz) bool or None.  Returns LUMP (Nc x N), SPRAY (N x Nc) as (colptr, rowval, nzval) and vol_c."""
+    wet3D = np.asarray(wet3D, dtype=bool)
+    nx, ny, nz = wet3D.shape
+    if mask is None:
+        mask = np.ones(wet3D.shape, dtype=bool)  # trues(size(wet3D)), :38
+    ex, ey, ez = nx + di - 1, ny + dj - 1, nz + dk - 1  # :41-43
+    LUMPidx = np.zeros((ex, ey, ez), dtype=np.int64, order="F")
+
+    def Lext(i, j, k):  # 1-based linear index in the extended grid, :47
+        return i + ex * ((j - 1) + ey * (k - 1))
+
+    wet3Dext = np.zeros((ex, ey, ez), dtype=bool)  # :48-49
+    wet3Dext[:nx, :ny, :nz] = wet3D
+    Lwet = [Lext(i + 1, j + 1, k + 1) for k in range(ez) for j in range(ey) for i in range(ex) if wet3Dext[i, j, k]]  # :50
+    colptr, rowval, _ = T
+    N = len(colptr) - 1
+    conn = set()  # connectivitymatrix = sparse(Lwet[i], Lwet[j], true, ...), :46, :52
+    for c in range(N):
+        for q in range(int(colptr[c]), int(colptr[c + 1])):
+            conn.add((Lwet[int(rowval[q - 1]) - 1], Lwet[c]))
+    flat = LUMPidx.reshape(-1, order="F")  # a view: flat[L-1] is LUMPidx at extended linear index L
+    wetext = wet3Dext.reshape(-1, order="F")
+    c = 2  # :55
+    for k in range(1, nz + 1):  # for 𝑖 in eachindex(C), :57: i fastest
+        for j in range(1, ny + 1):
+            for i in range(1, nx + 1):
+                if LUMPidx[i - 1, j - 1, k - 1] > 0 and mask[i - 1, j - 1, k - 1]:  # :61
+                    continue
+                if mask[i - 1, j - 1, k - 1]:  # :62
+                    Li = [Lext(i + a, j + b, k + d) for d in range(dk) for b in range(dj) for a in range(di)]  # :64
+                    for L in Li:  # :66-68
+                        if not wetext[L - 1]:
+                            flat[L - 1] = 1
+                    wetidx = [L for L in Li if wetext[L - 1]]  # :70
+                    nv = len(wetidx)
+                    adj = {u: set() for u in range(1, nv + 1)}
+                    for a in range(nv):  # view(connectivitymatrix, wetidx, wetidx) -> SimpleGraph, :71-72
+                        for b in range(nv):
+                            ab, ba = (wetidx[a], wetidx[b]) in conn, (wetidx[b], wetidx[a]) in conn
+                            if ab != ba:
+                                raise AsymmetricConnectivity()
+                            if ab and a != b:
+                                adj[a + 1].add(b + 1)
+                    for comp in _connected_components(nv, adj):  # :74-77
+                        for v in comp:
+                            flat[wetidx[v - 1] - 1] = c
+                        c += 1
+                else:  # :78-81
+                    LUMPidx[i - 1, j - 1, k - 1] = c
+                    c += 1
+    # LUMP = sparse(LUMPidx[C][:], 1:length(C), 1), :85
+    rows = [int(LUMPidx[i, j, k]) for k in range(nz) for j in range(ny) for i in range(nx)]
+    G = nx * ny * nz
+    wet = wet3D.reshape(-1, order="F")
+    m = max(rows)
+    has_wet = [False] * (m + 1)  # wet_c = LUMP * wet .> 0, :88
+    for L in range(G):
+        if wet[L]:
+            has_wet[rows[L]] = True
+    newrow = {}
+    for r in range(1, m + 1):
+        if has_wet[r]:
+            newrow[r] = len(newrow) + 1
+    Nc = len(newrow)
+    lump_rows = [newrow[rows[L]] for L in range(G) if wet[L]]  # LUMP[wet_c, wet], :91
+    vol = np.asarray(vol, dtype=np.float64)
+    vol_c = np.zeros(Nc)  # vol_c = LUMP * vol, :96: y[I] += 1 * vol[j] for j ascending
+    for w, I in enumerate(lump_rows):
+        vol_c[I - 1] = vol_c[I - 1] + 1 * vol[w]
+    # LUMP = sparse(Diagonal(1 ./ vol_c)) * LUMP * sparse(Diagonal(vol)), :97 -- left to right
+    lump_vals = [((1.0 / vol_c[I - 1]) * 1) * vol[w] for w, I in enumerate(lump_rows)]
+    LUMP = (np.arange(1, N + 2, dtype=np.int64), np.array(lump_rows, dtype=np.int64), np.array(lump_vals, dtype=np.float64))
+    # SPRAY = copy(LUMP'); SPRAY.nzval .= 1, :101-102
+    members = [[] for _ in range(Nc)]
+    for w, I in enumerate(lump_rows):
+        members[I - 1].append(w + 1)
+    scp, srv = [1], []
+    for I in range(Nc):
+        srv.extend(members[I])
+        scp.append(len(srv) + 1)
+    SPRAY = (np.array(scp, dtype=np.int64), np.array(srv, dtype=np.int64), np.ones(len(srv)))
+    return LUMP, SPRAY, vol_c
+
+
+def as2D(x, wet3D):  # :127-131
+    out = np.full(wet3D.shape[:2], np.nan, order="F")
+    out.T[np.asarray(wet3D)[:, :, 0].T] = x
+    return out
+
+
+def as3D(x, wet3D):  # :138-142
+    out = np.full(wet3D.shape, np.nan, order="F")
+    out.reshape(-1, order="F")[np.asarray(wet3D).reshape(-1, order="F")] = x
+    return out

@@ -245,3 +245,65 @@ def test_multithreaded_oracle_variant_is_bit_identical(oracle, name):
     with pytest.raises(oracle.OracleError) as e2:
         oracle.transportmatrix(phi, gm, idx, rho, g.mlotst, parallel=True)
     assert e1.value.args == e2.value.args
+
+
+# ---- lump_and_spray (src/extratools.jl:38-119) -------------------------------------------------------------------
+LUMP_SETTINGS = [(2, 2, 1, False), (3, 2, 2, True), (1, 1, 1, False), (4, 5, 1, True), (2, 3, 3, True), (10, 10, 1, False)]
+
+
+def lump_inputs(oracle, name):
+    from helpers import make_case
+
+    g, gm = make_case(name)
+    idx = oracle.makeindices(gm.v3D)
+    phi = oracle.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], g.umo.properties["_FillValue"], gm.gridtopology.kind)
+    tm = oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst)
+    wet = idx["wet3D"].astype(bool)
+    vol = gm.v3D.reshape(-1, order="F")[wet.reshape(-1, order="F")]
+    return wet, vol, tm, idx["N"]
+
+
+def lump_mask(wet, seed):
+    rng = np.random.default_rng(seed)
+    mask = rng.random(wet.shape) < 0.6
+    mask[:, : wet.shape[1] // 3, :] = False
+    return mask
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_bipolar", "odd_nx_fold"])
+def test_lump_and_spray_oracle_matches_transliteration(oracle, name):
+    wet, vol, tm, N = lump_inputs(oracle, name)
+    for q, (di, dj, dk, usemask) in enumerate(LUMP_SETTINGS):
+        mask = lump_mask(wet, q) if usemask else None
+        a = oracle.lump_and_spray(wet, vol, tm["T"], mask, di, dj, dk)
+        b = pyref.lump_and_spray(wet, vol, tm["T"], mask, di, dj, dk)
+        for x, y in zip(a[0] + a[1] + (a[2],), b[0] + b[1] + (b[2],)):
+            assert np.array_equal(x, y), (name, di, dj, dk, usemask)
+        # what the reference's docstring promises: LUMP is volume conserving and LUMP * SPRAY = I
+        LUMP, SPRAY, vol_c = a
+        Nc = len(vol_c)
+        Lm = sp.csc_matrix((LUMP[2], LUMP[1] - 1, LUMP[0] - 1), shape=(Nc, N))
+        Sm = sp.csc_matrix((SPRAY[2], SPRAY[1] - 1, SPRAY[0] - 1), shape=(N, Nc))
+        assert abs(Lm @ Sm - sp.identity(Nc)).max() < 1e-14
+        assert np.allclose(Lm.T @ vol_c, vol, rtol=1e-14)
+        if (di, dj, dk) == (1, 1, 1) and mask is None:
+            assert Nc == N
+
+
+def test_lump_and_spray_rejects_asymmetric_connectivity(oracle):
+    """An advection-only (upwind) matrix has a one-directional pattern: Graphs.SimpleGraph throws ArgumentError."""
+    wet, vol, tm, N = lump_inputs(oracle, "tiny_tripolar")
+    with pytest.raises(oracle.OracleError, match="symmetric"):
+        oracle.lump_and_spray(wet, vol, tm["Tadv"], None, 2, 2, 1)
+    with pytest.raises(pyref.AsymmetricConnectivity):
+        pyref.lump_and_spray(wet, vol, tm["Tadv"], None, 2, 2, 1)
+
+
+def test_as2d_as3d(oracle):
+    wet, vol, tm, N = lump_inputs(oracle, "tiny_tripolar")
+    x = np.arange(1.0, N + 1)
+    x3 = pyref.as3D(x, wet)
+    assert np.array_equal(x3.reshape(-1, order="F")[wet.reshape(-1, order="F")], x) and np.isnan(x3[~wet]).all()
+    n2 = int(wet[:, :, 0].sum())
+    x2 = pyref.as2D(np.arange(1.0, n2 + 1), wet)
+    assert np.array_equal(x2.reshape(-1, order="F")[wet[:, :, 0].reshape(-1, order="F")], np.arange(1.0, n2 + 1))
