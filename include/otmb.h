@@ -46,7 +46,8 @@ typedef enum {
     OTMB_ERR_NO_PLAN = 12,         /* fill/fetch without a successful plan */
     OTMB_ERR_NONCANONICAL_INDICES = 13, /* Lwet3D is not what makeindices(v3D) returns */
     OTMB_ERR_CAPACITY = 14,
-    OTMB_ERR_PUSH_MASK = 15        /* args.push_mask does not describe args.phi / args.lwet3d (nothing was written) */
+    OTMB_ERR_PUSH_MASK = 15,       /* args.push_mask does not describe args.phi / args.lwet3d (nothing was written) */
+    OTMB_ERR_ASYMMETRIC_PATTERN = 16 /* lump_and_spray: Graphs.SimpleGraph's ArgumentError for a one-directional T pattern */
 } otmb_status;
 
 /* gridmetrics.gridtopology (src/gridtopology.jl:1-16) */
@@ -265,6 +266,29 @@ int32_t otmb_spadd_fill_dev(otmb_ctx *ctx, int64_t n, const int64_t *Ap, const i
                             const int64_t *Bp, const int64_t *Bi, const double *Bx, int64_t *Cp, int64_t *Ci, double *Cx);
 int32_t otmb_spadd(otmb_ctx *ctx, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, const int64_t *Bp,
                    const int64_t *Bi, const double *Bx, int64_t *Cp, int64_t *Ci, double *Cx, int64_t *nnz_out);
+
+/* ---- lump_and_spray(wet3D, vol, T, mask = trues(size(wet3D)); di = 2, dj = 2, dk = 1) -- src/extratools.jl:38-119:
+ *      the coarsening operators LUMP (Nc x N, volume weighted: LUMP * x is the coarse vector), SPRAY (N x Nc, ones:
+ *      LUMP * T * SPRAY is the coarse operator) and the coarse volumes vol_c.  Cells are lumped in di x dj x dk blocks,
+ *      inside `mask` only, never across cells that T's pattern does not connect (connected components of the block,
+ *      Graphs.connected_components; T's pattern must be symmetric inside every block like Graphs.SimpleGraph demands:
+ *      OTMB_ERR_ASYMMETRIC_PATTERN otherwise -- e.g. an advection-only operator).  Only the PATTERN of T is read.
+ * _dev (device pointers, two-phase): plan takes wet3d / lwet3d / lwet / n_wet as makeindices returns them, mask (bytes,
+ *   NULL = all true) and T's colptr / rowval; it returns Nc.  fill writes LUMP (colptr N+1 = 1..N+1: one entry per column,
+ *   rowval N, nzval N), SPRAY (colptr Nc+1, rowval N, nzval N) and vol_c (Nc).  Limits: nx <= 4900, di*dj*dk <= 4096.
+ * otmb_lump_and_spray (host pointers, what the Julia shim calls): outputs with capacity N (N+1 for spray_colptr); the
+ *   trivial arrays (LUMP's colptr, SPRAY's ones) are left to the caller.                                            */
+int32_t otmb_lump_and_spray_plan_dev(otmb_ctx *ctx, const uint8_t *wet3d, const uint8_t *mask, const int64_t *lwet3d,
+                                     const int64_t *lwet, int64_t n_wet, int64_t nx, int64_t ny, int64_t nz,
+                                     const int64_t *t_colptr, const int64_t *t_rowval, int64_t di, int64_t dj, int64_t dk,
+                                     int64_t *n_coarse);
+int32_t otmb_lump_and_spray_fill_dev(otmb_ctx *ctx, const double *vol, int64_t *lump_colptr, int64_t *lump_rowval,
+                                     double *lump_nzval, int64_t *spray_colptr, int64_t *spray_rowval, double *spray_nzval,
+                                     double *vol_c);
+int32_t otmb_lump_and_spray(otmb_ctx *ctx, const uint8_t *wet3d, const uint8_t *mask, int64_t nx, int64_t ny, int64_t nz,
+                            const double *vol, int64_t n_wet, const int64_t *t_colptr, const int64_t *t_rowval, int64_t di,
+                            int64_t dj, int64_t dk, int64_t *lump_rowval, double *lump_nzval, int64_t *spray_colptr,
+                            int64_t *spray_rowval, double *vol_c, int64_t *n_coarse);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,8 @@ from . import gridtopology, synthetic  # noqa: F401
 def __getattr__(name):
     # api/capi import the HIP library lazily so that host-only helpers work without it
     if name in ("makeindices", "facefluxesfrommasstransport", "facefluxes", "transportmatrix", "velocity2fluxes",
-                "fluxes2velocity", "facefluxesfromvelocities", "interpolateontodefaultCgrid",
+                "fluxes2velocity", "facefluxesfromvelocities", "interpolateontodefaultCgrid", "lump_and_spray", "as2D", "as3D",
+                "spadd", "bolus_GM_velocity",
                 "buildTadv", "buildTκH", "buildTκVML", "buildTκVdeep", "buildTkH", "buildTkVML", "buildTkVdeep"):
         from . import api
         return getattr(api, name)

@@ -293,6 +293,35 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
                  for m, name in enumerate(MATS)})
 
 
+def lump_and_spray(wet3D, vol, T, mask=None, *, di=2, dj=2, dk=1, device=0):
+    """LUMP, SPRAY, vol_c = lump_and_spray(wet3D, vol, T, mask; di, dj, dk) (src/extratools.jl:38-119): coarsening in
+    di x dj x dk blocks inside `mask`, never across cells that T's pattern does not connect.  `LUMP * x` is the coarse
+    vector, `LUMP * T * SPRAY` the coarse operator.  T: SparseMatrixCSC (only its pattern is read)."""
+    ctx = context(device)
+    wet = np.asfortranarray(np.asarray(wet3D) != 0).astype(np.uint8)
+    nx, ny, nz = wet.shape
+    m = None if mask is None else np.asfortranarray(np.asarray(mask) != 0).astype(np.uint8)
+    if m is not None and m.shape != wet.shape:
+        raise ValueError("mask must have the shape of wet3D")
+    v = np.ascontiguousarray(vol, dtype=np.float64)
+    N = v.size
+    if T.n != N or T.m != N:
+        raise ValueError("T must be N x N with N = length(vol)")
+    Tp = np.ascontiguousarray(T.colptr, dtype=np.int64)
+    Ti = np.ascontiguousarray(T.rowval, dtype=np.int64)
+    lrow, lval = np.empty(max(N, 1), np.int64), np.empty(max(N, 1), np.float64)
+    scp, srow, vc = np.empty(N + 2, np.int64), np.empty(max(N, 1), np.int64), np.empty(max(N, 1), np.float64)
+    nc = C.c_int64(0)
+    ctx.check(capi.lib().otmb_lump_and_spray(ctx.handle, wet.ctypes.data, None if m is None else m.ctypes.data, nx, ny, nz,
+                                            v.ctypes.data, N, Tp.ctypes.data, Ti.ctypes.data, int(di), int(dj), int(dk),
+                                            lrow.ctypes.data, lval.ctypes.data, scp.ctypes.data, srow.ctypes.data,
+                                            vc.ctypes.data, C.byref(nc)))
+    Nc = int(nc.value)
+    LUMP = SparseMatrixCSC(Nc, N, np.arange(1, N + 2, dtype=np.int64), lrow[:N].copy(), lval[:N].copy())
+    SPRAY = SparseMatrixCSC(N, Nc, scp[: Nc + 1].copy(), srow[:N].copy(), np.ones(N))
+    return LUMP, SPRAY, vc[:Nc].copy()
+
+
 def as2D(x, wet3D):
     """src/extratools.jl:111-115: scatter a surface vector back onto the (nx,ny) grid, NaN on land."""
     wet = np.asfortranarray(wet3D).astype(bool)

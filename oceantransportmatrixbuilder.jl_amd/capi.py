@@ -9,7 +9,7 @@ OK = 0
 STATUS_NAMES = {
     1: "RHO_NAN", 2: "TADV_NAN", 3: "TKH_NAN", 4: "TKVML_NAN", 5: "TKVDEEP_NAN", 6: "FLUX_INTO_LAND",
     7: "UNKNOWN_TOPOLOGY", 8: "ALL_MISSING", 9: "ALLOC", 10: "HIP", 11: "INVALID_ARG", 12: "NO_PLAN",
-    13: "NONCANONICAL_INDICES", 14: "CAPACITY", 15: "PUSH_MASK",
+    13: "NONCANONICAL_INDICES", 14: "CAPACITY", 15: "PUSH_MASK", 16: "ASYMMETRIC_PATTERN",
 }
 PHI_ORDER = ("east", "west", "north", "south", "top", "bottom")  # OTMB_EAST..OTMB_BOTTOM
 HDIRS = ("west", "east", "south", "north")  # OTMB_DIR_*
@@ -68,6 +68,11 @@ SYMBOLS = {
     "otmb_fluxes2velocity": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
     "otmb_push_mask_dev": (C.c_int32, [_vp, C.POINTER(_vp * 6), _vp, C.c_int64, C.c_int64, _vp]),
+    "otmb_lump_and_spray_plan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp,
+                                                  C.c_int64, C.c_int64, C.c_int64, _ip]),
+    "otmb_lump_and_spray_fill_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "otmb_lump_and_spray": (C.c_int32, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64,
+                                         C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _ip]),
     "otmb_facefluxes_slab_flags": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64]),
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),

@@ -41,6 +41,10 @@ struct otmb_ctx {
     DevBuf sort[5];            // radix-sort keys/values/temporary of the general sparse() path
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     DevBuf mask;              // push mask derived by the library when the caller passes none
+    DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)
+    DevBuf lump_host;         // staging of the host-pointer entry point
+    bool lump_valid = false;
+    i64 lump_N = 0, lump_Nc = 0;
     int *h_flags = nullptr;  // pinned host mirror of the state block (flag words first)
     i64 *h_tot = nullptr;    // the totals inside it (h_flags + OTMB_NFLAGS)
     int ff_gen = 0;          // facefluxes call counter: a validity flag is set by writing the current value (no reset pass)

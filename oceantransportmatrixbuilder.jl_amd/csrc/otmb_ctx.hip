@@ -51,6 +51,7 @@ const char *otmb_status_string(int32_t s) {
         case OTMB_ERR_NONCANONICAL_INDICES: return "Lwet3D is not the wet rank in linear-index order (makeindices)";
         case OTMB_ERR_CAPACITY: return "output capacity too small";
         case OTMB_ERR_PUSH_MASK: return "push_mask does not describe these face fluxes and wet mask";
+        case OTMB_ERR_ASYMMETRIC_PATTERN: return "ArgumentError: Adjacency / distance matrices must be symmetric";
         default: return "unknown status";
     }
 }
@@ -92,6 +93,10 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
+    for (DevBuf &b : ctx->lump)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->mask.p) (void)hipFree(ctx->mask.p);
+    if (ctx->lump_host.p) (void)hipFree(ctx->lump_host.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

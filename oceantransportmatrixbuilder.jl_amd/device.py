@@ -276,6 +276,34 @@ class DeviceAssembler:
         phi = self.facefluxes(umo, vmo, fill)
         return self.transportmatrix_onepass(phi) if onepass else self.transportmatrix(phi)
 
+    def lump_and_spray(self, mask=None, di=2, dj=2, dk=1, matrix="T"):
+        """lump_and_spray (src/extratools.jl:38-119) on the resident grid and the resident result `matrix` (only its
+        pattern is read; the volumes are v3D on the wet cells).  mask: flat uint8/bool device tensor or None.
+        Returns device tensors: LUMP (colptr, rowval, nzval), SPRAY (colptr, rowval, nzval), vol_c."""
+        k = MATS.index(matrix)
+        cp, rv, _ = self.out[matrix]
+        m = None
+        if mask is not None:
+            m = mask.to(self.device).reshape(-1).to(torch.uint8).contiguous()
+            if m.numel() != self.G:
+                raise ValueError("mask must have one entry per grid cell")
+        nc = C.c_int64(0)
+        self.ctx.check(self.lib.otmb_lump_and_spray_plan_dev(
+            self.ctx.handle, self.wet3d.data_ptr(), None if m is None else m.data_ptr(), self.lwet3d.data_ptr(),
+            self.lwet.data_ptr(), self.N, self.nx, self.ny, self.nz, cp.data_ptr(), rv.data_ptr(), int(di), int(dj), int(dk),
+            C.byref(nc)))
+        Nc, N = int(nc.value), self.N
+        vol = self.v3d[self.lwet[:N] - 1].contiguous()
+        i64 = lambda n: torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        f64 = lambda n: torch.empty(max(n, 1), dtype=torch.float64, device=self.device)
+        L = (i64(N + 1), i64(N), f64(N))
+        S = (i64(Nc + 1), i64(N), f64(N))
+        vc = f64(Nc)
+        self.ctx.check(self.lib.otmb_lump_and_spray_fill_dev(self.ctx.handle, vol.data_ptr(), L[0].data_ptr(), L[1].data_ptr(),
+                                                             L[2].data_ptr(), S[0].data_ptr(), S[1].data_ptr(), S[2].data_ptr(),
+                                                             vc.data_ptr()))
+        return (L[0], L[1][:N], L[2][:N]), (S[0], S[1][:N], S[2][:N]), vc[:Nc]
+
     def result_to_host(self):
         self.ctx.synchronize()
         if any(self.out[m][1].numel() < self.nnz[k] for k, m in enumerate(MATS)):
