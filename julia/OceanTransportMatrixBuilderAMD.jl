@@ -5,7 +5,7 @@
 #   makeindices                 src/matrixbuilding.jl:10-24
 #   facefluxesfrommasstransport src/velocities.jl:118-130   (facefluxes :190-255, nofluxboundaries! :154-179)
 #   transportmatrix             src/matrixbuilding.jl:128-150
-# Everything else (makegridmetrics, velocity2fluxes, lump_and_spray, ...) is re-exported from the
+# lump_and_spray (src/extratools.jl:38-119) is bound too; everything else (makegridmetrics, velocity2fluxes, ...) is re-exported from the
 # reference package unchanged, so `using OceanTransportMatrixBuilderAMD` replaces
 # `using OceanTransportMatrixBuilder` in a TMIP script.
 #
@@ -22,7 +22,7 @@ import OceanTransportMatrixBuilder as OTMB
 # re-export the untouched part of the reference API
 using OceanTransportMatrixBuilder: makegridmetrics, velocity2fluxes, fluxes2velocity, facefluxesfromvelocities
 export makegridmetrics, velocity2fluxes, fluxes2velocity, facefluxesfromvelocities
-export makeindices, facefluxesfrommasstransport, facefluxes, transportmatrix
+export makeindices, facefluxesfrommasstransport, facefluxes, transportmatrix, lump_and_spray
 
 const LIBPATH = get(ENV, "OTMB_HIP_LIB", joinpath(@__DIR__, "..", "oceantransportmatrixbuilder.jl_amd", "lib", "libotmb_hip.so"))
 const lib = Ref{Ptr{Cvoid}}(C_NULL)
@@ -47,6 +47,7 @@ function check(rc::Int32)
     msg = unsafe_string(ccall(sym(:otmb_last_error), Cstring, (Ptr{Cvoid},), ctx[]))
     rc == 8 && throw(AssertionError(msg))      # velocities.jl:199-200
     rc == 11 && throw(ArgumentError(msg))
+    rc == 16 && throw(ArgumentError("Adjacency / distance matrices must be symmetric"))  # Graphs.SimpleGraph, extratools.jl:72
     error(msg)                                 # ErrorException: "Tadv contains NaNs." etc.
 end
 
@@ -164,6 +165,29 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
     end
     mats = [SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], rowval[m], nzval[m]) for m in 1:5]
     return (; T = mats[1], Tadv = mats[2], TκH = mats[3], TκVML = mats[4], TκVdeep = mats[5])
+end
+
+"""
+    LUMP, SPRAY, vol_c = lump_and_spray(wet3D, vol, T, mask = trues(size(wet3D)); di = 2, dj = 2, dk = 1)
+
+extratools.jl:38-119.  Only the pattern of `T` is read.
+"""
+function lump_and_spray(wet3D, vol, T, mask = trues(size(wet3D)); di = 2, dj = 2, dk = 1)
+    wet = Array{UInt8,3}(wet3D); msk = Array{UInt8,3}(mask)
+    nx, ny, nz = size(wet)
+    v = Vector{Float64}(vol); N = length(v)
+    Tp = Vector{Int64}(T.colptr); Ti = Vector{Int64}(T.rowval)
+    lrow = Vector{Int64}(undef, N); lval = Vector{Float64}(undef, N)
+    scp = Vector{Int64}(undef, N + 1); srow = Vector{Int64}(undef, N); vc = Vector{Float64}(undef, N)
+    Nc = Ref{Int64}(0)
+    check(ccall(sym(:otmb_lump_and_spray), Int32,
+        (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Int64,
+         Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+        ctx[], wet, msk, nx, ny, nz, v, N, Tp, Ti, di, dj, dk, lrow, lval, scp, srow, vc, Nc))
+    resize!(scp, Nc[] + 1); resize!(vc, Nc[])
+    LUMP = SparseMatrixCSC{Float64,Int64}(Nc[], N, collect(Int64, 1:(N + 1)), lrow, lval)
+    SPRAY = SparseMatrixCSC{Float64,Int64}(N, Nc[], scp, srow, ones(N))
+    return LUMP, SPRAY, vc
 end
 
 end # module
