@@ -99,3 +99,52 @@ def test_device_lump_and_spray_on_resident_result(oracle):
         assert np.array_equal(L[0].cpu().numpy(), want[0][0])
         assert np.array_equal(S[0].cpu().numpy(), want[1][0]) and np.array_equal(S[1].cpu().numpy(), want[1][1])
         assert np.array_equal(S[2].cpu().numpy(), want[1][2]) and np.array_equal(vc.cpu().numpy(), want[2])
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_lump_and_spray_random_sweep(oracle, seed):
+    """Random small grids, masks, block sizes (including blocks larger than the grid and dk > 1) and synthetic symmetric
+    connectivity patterns: the device result must equal the oracle's, or both must refuse an asymmetric pattern."""
+    import otmb_amd.api as api
+    from otmb_amd.capi import OtmbError
+
+    rng = np.random.default_rng(7000 + seed)
+    nx, ny, nz = int(rng.integers(1, 14)), int(rng.integers(1, 9)), int(rng.integers(1, 6))
+    wet = rng.random((nx, ny, nz)) < rng.uniform(0.3, 1.0)
+    if not wet.any():
+        wet[0, 0, 0] = True
+    N = int(wet.sum())
+    rank = np.zeros(wet.shape, dtype=np.int64)
+    rank.reshape(-1, order="F")[wet.reshape(-1, order="F")] = np.arange(1, N + 1)
+    # pattern: diagonal + a random subset of the 6-neighbour links (periodic in i), symmetric unless `broken`
+    broken = seed % 7 == 3
+    cols = [set([c]) for c in range(N + 1)]
+    for (a, b, c) in np.argwhere(wet):
+        for (da, db, dc) in ((1, 0, 0), (0, 1, 0), (0, 0, 1)):
+            a2, b2, c2 = (a + da) % nx, b + db, c + dc
+            if b2 < ny and c2 < nz and wet[a2, b2, c2] and rng.random() < 0.7:
+                r1, r2 = int(rank[a, b, c]), int(rank[a2, b2, c2])
+                cols[r1].add(r2)
+                if not (broken and rng.random() < 0.3):
+                    cols[r2].add(r1)
+    colptr = np.ones(N + 1, dtype=np.int64)
+    rowval = []
+    for c in range(1, N + 1):
+        rows = sorted(cols[c])
+        rowval.extend(rows)
+        colptr[c] = colptr[c - 1] + len(rows)
+    rowval = np.array(rowval, dtype=np.int64)
+    T = (colptr, rowval, np.ones(len(rowval)))
+    vol = rng.uniform(1.0, 1e6, N)
+    di, dj, dk = int(rng.integers(1, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    mask = None if rng.random() < 0.3 else (rng.random(wet.shape) < rng.uniform(0.2, 1.0))
+    Tm = api.SparseMatrixCSC(N, N, *T)
+    try:
+        want = oracle.lump_and_spray(wet, vol, T, mask, di, dj, dk)
+    except oracle.OracleError:
+        with pytest.raises(OtmbError) as e:
+            api.lump_and_spray(wet, vol, Tm, mask, di=di, dj=dj, dk=dk)
+        assert e.value.name == "ASYMMETRIC_PATTERN"
+        return
+    got = api.lump_and_spray(wet, vol, Tm, mask, di=di, dj=dj, dk=dk)
+    _same(got, want, (seed, nx, ny, nz, di, dj, dk))
