@@ -148,3 +148,39 @@ def test_lump_and_spray_random_sweep(oracle, seed):
         return
     got = api.lump_and_spray(wet, vol, Tm, mask, di=di, dj=dj, dk=dk)
     _same(got, want, (seed, nx, ny, nz, di, dj, dk))
+
+
+def test_lump_and_spray_edge_grids(oracle):
+    import otmb_amd.api as api
+
+    # one wet cell; a single column; blocks larger than the grid; everything dry except one level
+    cases = []
+    w = np.zeros((4, 3, 2), dtype=bool); w[1, 1, 0] = True
+    cases.append((w, (2, 2, 1)))
+    w = np.zeros((1, 1, 5), dtype=bool); w[0, 0, :3] = True
+    cases.append((w, (1, 1, 2)))
+    w = np.ones((3, 2, 2), dtype=bool)
+    cases.append((w, (8, 8, 4)))
+    w = np.zeros((6, 5, 3), dtype=bool); w[:, :, 1] = True
+    cases.append((w, (2, 3, 3)))
+    for wet, (di, dj, dk) in cases:
+        N = int(wet.sum())
+        rank = np.zeros(wet.shape, dtype=np.int64)
+        rank.reshape(-1, order="F")[wet.reshape(-1, order="F")] = np.arange(1, N + 1)
+        cols = [set([c]) for c in range(N + 1)]
+        for (a, b, c) in np.argwhere(wet):
+            for (da, db, dc) in ((1, 0, 0), (0, 1, 0), (0, 0, 1)):
+                a2, b2, c2 = a + da, b + db, c + dc
+                if a2 < wet.shape[0] and b2 < wet.shape[1] and c2 < wet.shape[2] and wet[a2, b2, c2]:
+                    cols[int(rank[a, b, c])].add(int(rank[a2, b2, c2])); cols[int(rank[a2, b2, c2])].add(int(rank[a, b, c]))
+        colptr = np.ones(N + 1, dtype=np.int64); rowval = []
+        for c in range(1, N + 1):
+            rowval.extend(sorted(cols[c])); colptr[c] = colptr[c - 1] + len(cols[c])
+        T = (colptr, np.array(rowval, dtype=np.int64), np.ones(len(rowval)))
+        vol = np.linspace(1.0, 2.0, N)
+        for mask in (None, np.zeros(wet.shape, dtype=bool)):
+            want = oracle.lump_and_spray(wet, vol, T, mask, di, dj, dk)
+            got = api.lump_and_spray(wet, vol, api.SparseMatrixCSC(N, N, *T), mask, di=di, dj=dj, dk=dk)
+            _same(got, want, (wet.shape, di, dj, dk, mask is None))
+            if mask is not None:
+                assert len(got[2]) == N  # nothing is lumped outside the mask
