@@ -107,6 +107,7 @@ def main():
     # OTMB_FORCE_SLAB=1: take the depth-slab (distributed) code path even with one rank, e.g. under
     # `torchrun --nproc-per-node 1`, to exercise RCCL initialisation and collectives on a one-GPU box
     force_slab = os.environ.get("OTMB_FORCE_SLAB") == "1" and "RANK" in os.environ
+    saved_stdout_fd = None
     if world > 1 or force_slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -115,6 +116,11 @@ def main():
         if os.environ.get("OTMB_SHARE_GPU") == "1":
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        # RCCL prints a version banner on the process's stdout when its first communicator comes up; stdout must carry
+        # exactly one JSON line, so file descriptor 1 points at stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -282,7 +288,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g, gm, args.workload)
         elif world == 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        if saved_stdout_fd is not None:
+            os.dup2(saved_stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        if saved_stdout_fd is not None:
+            os.dup2(2, 1)  # anything the communicator says while shutting down goes to stderr too
     if dist.is_initialized():
         dist.destroy_process_group()
 
