@@ -63,7 +63,7 @@ def test_balanced_partition_properties():
         assert all(a < b for a, b in parts) and all(parts[r][1] == parts[r + 1][0] for r in range(world - 1))
 
 
-@pytest.mark.parametrize("world,rho", [(2, "array"), (3, "scalar")])
+@pytest.mark.parametrize("world,rho", [(2, "array"), (3, "scalar"), (4, "array")])
 def test_slab_orchestration_gloo(oracle, tmp_path, world, rho):
     case = (12, 10, 9, 21, rho, "tripolar")
     z = run_ranks(world, "oracle", case, tmp_path)
