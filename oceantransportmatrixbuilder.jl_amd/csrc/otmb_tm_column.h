@@ -314,8 +314,18 @@ struct TileBase {  // array pointers advanced to the tile's lowest neighbour (un
     const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb, *mk;
 };
 __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
+#ifdef OTMB_DBG_NOVALLOAD  // timing experiment only (wrong values): value-only inputs are not loaded, the pattern inputs are
+__device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return 1.0 + (double)byteoff * 1e-9 + (double)((size_t)b & 0xfff) * 1e-7; }
+#else
+__device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return ldd(b, byteoff); }
+#endif
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
 #define NEG0 (-0.0)
+#ifdef OTMB_DBG_MULDIV  // timing experiment only: what the 28 divisions of a column cost (wrong values)
+#define FDIV(a, b) ((a) * (b))
+#else
+#define FDIV(a, b) ((a) / (b))
+#endif
 
 // CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
 // The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
@@ -343,28 +353,44 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
         qW0 = ldd(tb.pw, oC); qE0 = ldd(tb.pe, oC); qS0 = ldd(tb.ps, oC); qN0 = ldd(tb.pn, oC); qB0 = ldd(tb.pb, oC);
         qT0 = ldd(tb.pt, oC);
     }
-    const double vC = ldd(tb.v, oC), vE = ldd(tb.v, oE), vW = ldd(tb.v, oW), vS = ldd(tb.v, oS), vN = ldd(tb.v, oN),
-                 vA = ldd(tb.v, oA), vB = ldd(tb.v, oB);
+#ifdef OTMB_DBG_NOEW  // timing experiment only (wrong values): no second load instruction into lines that are in flight
+    const double vC = ldv(tb.v, oC), vE = vC, vW = vC, vS = ldv(tb.v, oS), vN = ldv(tb.v, oN), vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
+#else
+    const double vC = ldv(tb.v, oC), vE = ldv(tb.v, oE), vW = ldv(tb.v, oW), vS = ldv(tb.v, oS), vN = ldv(tb.v, oN),
+                 vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
+#endif
     double rC, rE, rW, rS, rN, rA, rB;
     if (tb.rho) {
-        rC = ldd(tb.rho, oC); rE = ldd(tb.rho, oE); rW = ldd(tb.rho, oW); rS = ldd(tb.rho, oS); rN = ldd(tb.rho, oN);
-        rA = ldd(tb.rho, oA); rB = ldd(tb.rho, oB);
+        rC = ldv(tb.rho, oC); rS = ldv(tb.rho, oS); rN = ldv(tb.rho, oN); rA = ldv(tb.rho, oA); rB = ldv(tb.rho, oB);
+#ifdef OTMB_DBG_NOEW
+        rE = rC; rW = rC;
+#else
+        rE = ldv(tb.rho, oE); rW = ldv(tb.rho, oW);
+#endif
     } else {
         rC = rE = rW = rS = rN = rA = rB = p.rho_s;
     }
-    const double tC = ldd(tb.thk, oC), tE = ldd(tb.thk, oE), tW = ldd(tb.thk, oW), tS = ldd(tb.thk, oS),
-                 tN = ldd(tb.thk, oN);
+#ifdef OTMB_DBG_NOEW
+    const double tC = ldv(tb.thk, oC), tE = tC, tW = tC, tS = ldv(tb.thk, oS), tN = ldv(tb.thk, oN);
+#else
+    const double tC = ldv(tb.thk, oC), tE = ldv(tb.thk, oE), tW = ldv(tb.thk, oW), tS = ldv(tb.thk, oS),
+                 tN = ldv(tb.thk, oN);
+#endif
     const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
                *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
     const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
                *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
-    const double eW_c = ldd(eWp, s2), eE_c = ldd(eEp, s2), eS_c = ldd(eSp, s2), eN_c = ldd(eNp, s2);
-    const double dW_c = ldd(dWp, s2), dE_c = ldd(dEp, s2), dS_c = ldd(dSp, s2), dN_c = ldd(dNp, s2);
-    const double eE_w = ldd(eEp, sW), dE_w = ldd(dEp, sW);  // west cell's east edge / distance to its east nbr
-    const double eW_e = ldd(eWp, sE), dW_e = ldd(dWp, sE);
-    const double eN_s = ldd(eNp, sS), dN_s = ldd(dNp, sS);
-    const double eS_n = ldd(eSp, sN), dS_n = ldd(dSp, sN);  // oppdir = south away from the seam row (:407)
-    const double ar = ldd((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
+    const double eW_c = ldv(eWp, s2), eE_c = ldv(eEp, s2), eS_c = ldv(eSp, s2), eN_c = ldv(eNp, s2);
+    const double dW_c = ldv(dWp, s2), dE_c = ldv(dEp, s2), dS_c = ldv(dSp, s2), dN_c = ldv(dNp, s2);
+#ifdef OTMB_DBG_NOEW
+    const double eE_w = eE_c, dE_w = dE_c, eW_e = eW_c, dW_e = dW_c;
+#else
+    const double eE_w = ldv(eEp, sW), dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
+    const double eW_e = ldv(eWp, sE), dW_e = ldv(dWp, sE);
+#endif
+    const double eN_s = ldv(eNp, sS), dN_s = ldv(dNp, sS);
+    const double eS_n = ldv(eSp, sN), dS_n = ldv(dSp, sN);  // oppdir = south away from the seam row (:407)
+    const double ar = ldv((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
     const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
 
     const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
@@ -408,8 +434,8 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
     {
 #define ADV1(PHI, RX, VX, OFF, DG)                \
     const double rb##OFF = ((RX) + rC) / 2;       \
-    const double OFF = -(PHI) / (rb##OFF * (VX)); \
-    const double DG = (PHI) / (rb##OFF * vC);
+    const double OFF = FDIV(-(PHI), (rb##OFF * (VX))); \
+    const double DG = FDIV((PHI), (rb##OFF * vC));
         ADV1(fA, rA, vA, oA_, dA_)
         ADV1(-fS, rS, vS, oS_, dS_)
         ADV1(-fW, rW, vW, oW_, dW_)
@@ -446,8 +472,8 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
     {
 #define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
     const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
-    const double OWN = (p.kH * a##OWN) / ((D_C) * vC);       \
-    const double IN = (p.kH * a##OWN) / ((D_X) * (VX));
+    const double OWN = FDIV((p.kH * a##OWN), ((D_C) * vC));       \
+    const double IN = FDIV((p.kH * a##OWN), ((D_X) * (VX)));
         H1(tW, eW_c, eE_w, dW_c, dE_w, vW, ownW, inW)
         H1(tE, eE_c, eW_e, dE_c, dW_e, vE, ownE, inE)
         H1(tS, eS_c, eN_s, dS_c, dN_s, vS, ownS, inS)
@@ -470,7 +496,7 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
     {
         const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
         const double nD = p.kDeep * ar;
-        const double ownB = nD / (dB * vC), inB = nD / (dB * vB), ownA = nD / (dA * vC), inA = nD / (dA * vA);
+        const double ownB = FDIV(nD, (dB * vC)), inB = FDIV(nD, (dB * vB)), ownA = FDIV(nD, (dA * vC)), inA = FDIV(nD, (dA * vA));
         if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
         double d = NEG0;  // own pushes: bottom then top
         d += wB ? ownB : NEG0;
@@ -483,7 +509,7 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
         col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
         if (mA | mB) {
             const double nM = p.kML * ar;
-            const double mownB = nM / (dB * vC), minB = nM / (dB * vB), mownA = nM / (dA * vC), minA = nM / (dA * vA);
+            const double mownB = FDIV(nM, (dB * vC)), minB = FDIV(nM, (dB * vB)), mownA = FDIV(nM, (dA * vC)), minA = FDIV(nM, (dA * vA));
             if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
             double m = NEG0;
             m += mB ? mownB : NEG0;
