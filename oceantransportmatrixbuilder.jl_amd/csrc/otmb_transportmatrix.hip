@@ -139,6 +139,90 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
     }
 }
 
+// ---- decoupled look-back (one-pass mode) ---------------------------------------------------------------------
+// One status word per tile: flag | the tile's five aggregates packed as in the block scan (55 bits).  A predecessor
+// therefore costs ONE load, whatever the number of matrices.  A tile whose inclusive prefixes are known stores them to
+// prefix[tile][0..4] with agent-scope (write-through) stores, drains them (s_waitcnt vmcnt(0)) and only then flips its
+// status word to ST_PFX; readers take the five prefixes with agent-scope loads after seeing the flag.  Called by ONE
+// wave of the tile; the exclusive prefixes land in s_prefix[0..4].
+__device__ __forceinline__ void tm_lookback(const TmParams &p, i64 tile, int lane, u64 all, i64 *s_prefix) {
+    const unsigned agg[5] = {(unsigned)(all & 0x7ff), (unsigned)((all >> 11) & 0x7ff), (unsigned)((all >> 22) & 0x7ff),
+                             (unsigned)((all >> 33) & 0x3ff), (unsigned)((all >> 43) & 0x3ff)};
+    u64 *status = p.status;
+    i64 *prefix = (i64 *)(p.status + p.n_tiles);
+    if (tile == 0) {
+        if (lane < TM_NF) {
+            i64 v = 0;
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m)
+                if (m == lane) v = agg[m];
+            st_store((u64 *)&prefix[lane], (u64)v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_store(&status[0], ST_PFX | all);
+        if (lane < TM_NF) s_prefix[lane] = 0;
+        return;
+    }
+    if (lane == 0) st_store(&status[tile], ST_AGG | all);
+    i64 acc[TM_NF] = {0, 0, 0, 0, 0};
+    i64 look = tile - 1;  // nearest predecessor not yet accounted for
+    int spins = 0;
+    bool ok = true;
+    while (true) {
+        const i64 t = look - lane;  // lane 0 inspects the nearest predecessor
+        u64 sw = ST_AGG;             // positions before tile 0: empty aggregate (tile 0 always ends the walk)
+        if (t >= 0) {
+            sw = st_load(&status[t]);
+            while ((sw >> 62) == 0 && spins < LOOKBACK_SPIN_LIMIT) {
+                __builtin_amdgcn_s_sleep(1);
+                sw = st_load(&status[t]);
+                ++spins;
+            }
+        }
+        if (__any((sw >> 62) == 0)) {  // bounded spin expired: report, never hang
+            if (lane == 0) raise_flag(p.flags, FLAG_LOOKBACK_TIMEOUT);
+            ok = false;
+            break;
+        }
+        const u64 is_pfx = __ballot((sw >> 62) == 2);
+        const int first = is_pfx ? __builtin_ctzll(is_pfx) : 64;
+        // tiles nearer than the first prefix holder contribute their aggregates
+        const u64 mineagg = (lane < first) ? sw : 0;
+        int part[TM_NF] = {(int)(mineagg & 0x7ff), (int)((mineagg >> 11) & 0x7ff), (int)((mineagg >> 22) & 0x7ff),
+                           (int)((mineagg >> 33) & 0x3ff), (int)((mineagg >> 43) & 0x3ff)};
+#pragma unroll
+        for (int m = 0; m < TM_NF; ++m) {
+            int x = part[m];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+            acc[m] += x;
+        }
+        if (is_pfx) {  // the holder's inclusive prefixes end the walk
+            const i64 th = look - first;
+            i64 pv = 0;
+            if (lane < TM_NF) pv = (i64)st_load((const u64 *)&prefix[th * TM_NF + lane]);
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m) acc[m] += __shfl(pv, m);
+            break;
+        }
+        look -= 64;
+    }
+    if (ok) {
+        if (lane < TM_NF) {
+            i64 e = 0, v = 0;
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m)
+                if (m == lane) { e = acc[m]; v = acc[m] + agg[m]; }
+            st_store((u64 *)&prefix[tile * TM_NF + lane], (u64)v);
+            s_prefix[lane] = e;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_store(&status[tile], ST_PFX | all);
+    } else if (lane < TM_NF) {
+        s_prefix[lane] = 0;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
@@ -164,6 +248,21 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         __syncthreads();
         tile = s_tile;
 #endif
+    }
+    // One-pass mode: the tile's five counts follow from the push mask alone (count_cell), so they are published
+    // FIRST and the look-back runs now, while the predecessors are still busy with their columns: nobody ever waits
+    // for anybody's arithmetic, and prefixes propagate within a few microseconds of a tile's start.
+    u64 early_all = 0;
+    if (MODE == MODE_ONEPASS) {
+        u64 x = count_cell(p, tile, tid);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+        if (lane == 0) wave_tot[wid] = x;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < TM_THREADS / 64; ++q) early_all += wave_tot[q];
+        __syncthreads();  // wave_tot is reused by the block scan below
+        if (wid == 0) tm_lookback(p, tile, lane, early_all, s_prefix);
     }
     const i64 w0 = tile * TM_THREADS;
     const i64 w = w0 + tid;
@@ -216,7 +315,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #ifdef OTMB_CHECKS_IN_FILL
                     if (regular) fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
 #else
-                    if (regular) fast_column<MODE == MODE_ONEPASS>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+                    if (regular) fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col);  // the input checks ran with the counts
 #endif
 #ifdef OTMB_DBG_NOGENERIC  // timing experiment only (wrong on the seam row)
                     else { col.padv = col.phh = col.pml = col.pdp = 0; }
@@ -265,6 +364,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                              (unsigned)((all >> 33) & 0x3ff), (unsigned)((all >> 43) & 0x3ff)};
 
     // ---- 3. the tile's global offsets ----
+    if (MODE == MODE_ONEPASS && all != early_all) {  // the columns disagree with the mask-derived counts (see MODE_FILL)
+        if (tid == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
+        return;
+    }
     if (MODE == MODE_FILL) {
         // The space of this tile was reserved by the counting pass from the push mask.  A mask that does not
         // describe these ϕ / Lwet3D (stale, or not a makeindices result) would make the two passes disagree:
@@ -280,93 +383,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 for (i64 q = 0; q < g; ++q) base += p.gsum[q * TM_NF + tid];
             }
             s_prefix[tid] = (p.tilesums[tile * TM_NF + tid] == mine_agg) ? p.tileoffs[tile * TM_NF + tid] + base : -1;
-        }
-    } else {
-#ifdef OTMB_DBG_NOLOOKBACK  // timing experiment only: fake, in-bounds offsets
-        if (tid < TM_NF) s_prefix[tid] = tile * (tid < 2 ? 1792 : (tid == 2 ? 1280 : 768));
-        if (false)
-#else
-        if (wid == 0)
-#endif
-        {
-            // One status word per tile: flag | the tile's five aggregates packed as in the block scan (55
-            // bits).  A predecessor therefore costs ONE load, whatever the number of matrices.  A tile
-            // whose inclusive prefixes are known stores them to prefix[tile][0..4] with agent-scope
-            // (write-through) stores, drains them (s_waitcnt vmcnt(0)) and only then flips its status word
-            // to ST_PFX; readers take the five prefixes with agent-scope loads after seeing the flag.
-            u64 *status = p.status;
-            i64 *prefix = (i64 *)(p.status + p.n_tiles);
-            if (tile == 0) {
-                if (lane < TM_NF) {
-                    i64 v = 0;
-#pragma unroll
-                    for (int m = 0; m < TM_NF; ++m)
-                        if (m == lane) v = agg[m];
-                    st_store((u64 *)&prefix[lane], (u64)v);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) st_store(&status[0], ST_PFX | all);
-                if (lane < TM_NF) s_prefix[lane] = 0;
-            } else {
-                if (lane == 0) st_store(&status[tile], ST_AGG | all);
-                i64 acc[TM_NF] = {0, 0, 0, 0, 0};
-                i64 look = tile - 1;  // nearest predecessor not yet accounted for
-                int spins = 0;
-                bool ok = true;
-                while (true) {
-                    const i64 t = look - lane;  // lane 0 inspects the nearest predecessor
-                    u64 sw = ST_AGG;             // positions before tile 0: empty aggregate (tile 0 always ends the walk)
-                    if (t >= 0) {
-                        sw = st_load(&status[t]);
-                        while ((sw >> 62) == 0 && spins < LOOKBACK_SPIN_LIMIT) {
-                            __builtin_amdgcn_s_sleep(1);
-                            sw = st_load(&status[t]);
-                            ++spins;
-                        }
-                    }
-                    if (__any((sw >> 62) == 0)) {  // bounded spin expired: report, never hang
-                        if (lane == 0) raise_flag(p.flags, FLAG_LOOKBACK_TIMEOUT);
-                        ok = false;
-                        break;
-                    }
-                    const u64 is_pfx = __ballot((sw >> 62) == 2);
-                    const int first = is_pfx ? __builtin_ctzll(is_pfx) : 64;
-                    // tiles nearer than the first prefix holder contribute their aggregates
-                    const u64 mineagg = (lane < first) ? sw : 0;
-                    int part[TM_NF] = {(int)(mineagg & 0x7ff), (int)((mineagg >> 11) & 0x7ff), (int)((mineagg >> 22) & 0x7ff),
-                                       (int)((mineagg >> 33) & 0x3ff), (int)((mineagg >> 43) & 0x3ff)};
-#pragma unroll
-                    for (int m = 0; m < TM_NF; ++m) {
-                        int x = part[m];
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-                        acc[m] += x;
-                    }
-                    if (is_pfx) {  // the holder's inclusive prefixes end the walk
-                        const i64 th = look - first;
-                        i64 pv = 0;
-                        if (lane < TM_NF) pv = (i64)st_load((const u64 *)&prefix[th * TM_NF + lane]);
-#pragma unroll
-                        for (int m = 0; m < TM_NF; ++m) acc[m] += __shfl(pv, m);
-                        break;
-                    }
-                    look -= 64;
-                }
-                if (ok) {
-                    if (lane < TM_NF) {
-                        i64 e = 0, v = 0;
-#pragma unroll
-                        for (int m = 0; m < TM_NF; ++m)
-                            if (m == lane) { e = acc[m]; v = acc[m] + agg[m]; }
-                        st_store((u64 *)&prefix[tile * TM_NF + lane], (u64)v);
-                        s_prefix[lane] = e;
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) st_store(&status[tile], ST_PFX | all);
-                } else if (lane < TM_NF) {
-                    s_prefix[lane] = 0;
-                }
-            }
         }
     }
     __syncthreads();
@@ -777,9 +793,11 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
     // Default: COUNT -> tile scan -> FILL enqueued back to back with no host round trip (the totals stay on the
-    // device).  OTMB_LOOKBACK=1 selects the single-kernel decoupled look-back variant instead (read-once, but
-    // currently slower: the look-back depth is about the number of tiles in flight).
-    static const bool use_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e && e[0] == '1'; }();
+    // device).  OTMB_LOOKBACK=1 selects the single-kernel decoupled look-back variant instead.
+#ifndef OTMB_DEFAULT_LOOKBACK
+#define OTMB_DEFAULT_LOOKBACK 0
+#endif
+    static const bool use_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e ? e[0] == '1' : (OTMB_DEFAULT_LOOKBACK != 0); }();
     const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);  // look-back words + prefixes (+ ticket)
     if (use_lookback) {
         if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
@@ -813,6 +831,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
                            p.colptr[3], p.colptr[4], (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2], p.nnz_base[3],
                            p.nnz_base[4]);
     } else if (use_lookback) {
+        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
+        p.rho_in_fill = 1;  // the one-pass kernel checks ρ where it loads it
         p.status = (u64 *)ctx->lookback.p;
         p.n_tiles = ntiles + 1;
         p.ticket = (int *)((char *)ctx->lookback.p + stbytes);

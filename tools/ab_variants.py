@@ -58,7 +58,7 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
 for name in variants:
     out = {}
     for k, d in res[name].items():
-        if "finish" in k or "onepass" in k or "mask" in k:
+        if "finish" in k or "mask" in k:
             continue
         per = [float(np.median(v)) for v in d.values()]
         out[k.replace("_kernel", "").replace("tm_kernel", "tm")] = f"{np.mean(per):.4f} [{min(per):.4f}-{max(per):.4f}]"
