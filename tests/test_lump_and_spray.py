@@ -184,3 +184,23 @@ def test_lump_and_spray_edge_grids(oracle):
             _same(got, want, (wet.shape, di, dj, dk, mask is None))
             if mask is not None:
                 assert len(got[2]) == N  # nothing is lumped outside the mask
+
+
+def _lump_fixture_paths():
+    from test_oracle import lump_fixtures
+
+    return lump_fixtures()
+
+
+@pytest.mark.parametrize("path", _lump_fixture_paths(), ids=lambda p: p.split("/")[-1][:-4])
+def test_hip_reproduces_lump_fixtures(path):
+    import otmb_amd.api as api
+
+    z = np.load(path)
+    di, dj, dk = (int(x) for x in z["block"])
+    N = len(z["vol"])
+    T = api.SparseMatrixCSC(N, N, z["T_colptr"], z["T_rowval"], np.ones(len(z["T_rowval"])))
+    LUMP, SPRAY, vol_c = api.lump_and_spray(z["wet3D"], z["vol"], T, z["mask"], di=di, dj=dj, dk=dk)
+    assert np.array_equal(LUMP.rowval, z["lump_rowval"]) and np.array_equal(LUMP.nzval, z["lump_nzval"])
+    assert np.array_equal(SPRAY.colptr, z["spray_colptr"]) and np.array_equal(SPRAY.rowval, z["spray_rowval"])
+    assert np.array_equal(vol_c, z["vol_c"])

@@ -307,3 +307,22 @@ def test_as2d_as3d(oracle):
     n2 = int(wet[:, :, 0].sum())
     x2 = pyref.as2D(np.arange(1.0, n2 + 1), wet)
     assert np.array_equal(x2.reshape(-1, order="F")[wet[:, :, 0].reshape(-1, order="F")], np.arange(1.0, n2 + 1))
+
+
+def lump_fixtures():
+    import glob
+    import os
+
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lump", "*.npz")))
+
+
+@pytest.mark.parametrize("path", lump_fixtures(), ids=lambda p: p.split("/")[-1][:-4])
+def test_oracle_reproduces_lump_fixtures(oracle, path):
+    z = np.load(path)
+    di, dj, dk = (int(x) for x in z["block"])
+    N = len(z["vol"])
+    T = (z["T_colptr"], z["T_rowval"], np.ones(len(z["T_rowval"])))
+    LUMP, SPRAY, vol_c = oracle.lump_and_spray(z["wet3D"], z["vol"], T, z["mask"], di, dj, dk)
+    assert np.array_equal(LUMP[1], z["lump_rowval"]) and np.array_equal(LUMP[2], z["lump_nzval"])
+    assert np.array_equal(SPRAY[0], z["spray_colptr"]) and np.array_equal(SPRAY[1], z["spray_rowval"])
+    assert np.array_equal(vol_c, z["vol_c"]) and np.array_equal(LUMP[0], np.arange(1, N + 2))
