@@ -85,6 +85,17 @@ class Comm:
     def send(self, t, dst):
         dist.send(self._stage(t).contiguous(), dst)
 
+    def isend(self, t, dst):
+        """Non-blocking send; returns a handle for wait_send.  The tensor must stay unmodified until then (with gloo it
+        is snapshotted to the host right here)."""
+        b = self._stage(t).contiguous()
+        return (dist.isend(b, dst), b)
+
+    @staticmethod
+    def wait_send(handle):
+        if handle is not None:
+            handle[0].wait()
+
     def recv(self, t, src):
         if self.backend == "gloo" and t.is_cuda:
             b = torch.empty(t.shape, dtype=t.dtype)
@@ -232,15 +243,24 @@ class SlabRunner:
     # colptrs into global ones (+ per-matrix base), after which the pieces concatenate as usual.
     def step_async(self, umo, vmo, fill):
         cm = self.comm
+        cm.wait_send(getattr(self, "_pending_send", None))  # the plane handed up by the previous field has left
+        self._pending_send = None
         if self.has_below:
             cm.recv(self.top_below, self.rank + 1)
         top_first = self.be.facefluxes(umo, vmo, fill, self.top_below)
         if self.has_above:
-            cm.send(top_first, self.rank - 1)
+            # the plane goes up from its own buffer without holding back this rank's count/fill kernels: nothing waits
+            # for the send until the next field is about to reuse the buffer
+            if getattr(self, "_send_buf", None) is None:
+                self._send_buf = torch.empty_like(top_first)
+            self._send_buf.copy_(top_first)
+            self._pending_send = cm.isend(self._send_buf, self.rank - 1)
         self.be.assemble_async()
 
     def finish(self):
         cm = self.comm
+        cm.wait_send(getattr(self, "_pending_send", None))
+        self._pending_send = None
         nnz, uv = self.be.result()
         allv = cm.allgather_i64(list(nnz) + [int(uv[0]), int(uv[1])], self.device)
         if not (allv[:, 5].any() and allv[:, 6].any()):
