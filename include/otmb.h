@@ -178,6 +178,9 @@ typedef struct {
                                   * exactly these phi and this wet mask; lets the counting pass read 2 bytes per
                                   * neighbour instead of re-reading the six ϕ arrays.  Host-pointer entry points
                                   * ignore it.                                                                   */
+    int32_t only_t;              /* extension (0 = the reference's behaviour): non-zero builds T alone -- the four operator
+                                  * matrices are still evaluated (T is their sum) but neither counted nor written: their
+                                  * nnz come out 0 and their output pointers may be NULL.  Halves the bytes written.      */
 } otmb_tm_args;
 
 /* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).

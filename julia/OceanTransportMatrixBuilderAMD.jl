@@ -114,6 +114,7 @@ struct TmArgs
     area2d::Ptr{Float64}; zt::Ptr{Float64}; mlotst::Ptr{Float64}
     kappa_h::Float64; kappa_vml::Float64; kappa_vdeep::Float64
     push_mask::Ptr{UInt16}        # device-resident callers only; C_NULL here (host arrays)
+    only_t::Int32                 # extension: 1 = materialise T alone
 end
 
 const HDIRS = (:west, :east, :south, :north)      # OTMB_DIR_*
@@ -127,7 +128,8 @@ the library writes colptr/rowval/nzval straight into the Julia-owned vectors.
 """
 function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
         κH = 500.0, κVML = 0.1, κVdeep = 1.0e-5,
-        Tadv = nothing, TκH = nothing, TκVML = nothing, TκVdeep = nothing, upwind = true)
+        Tadv = nothing, TκH = nothing, TκVML = nothing, TκVdeep = nothing, upwind = true, operators = true)
+    # operators = false (extension, not in the reference): only T is materialised, the four operators return `nothing`
     if !(isnothing(Tadv) && isnothing(TκH) && isnothing(TκVML) && isnothing(TκVdeep))
         # precomputed operators (matrixbuilding.jl:140-143): build the missing ones here, add on the host
         r = transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind)
@@ -150,7 +152,8 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
             ntuple(i -> pointer(ph[i]), 6), pointer(v), pointer(thk),
             ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0,
             pointer(lw3), pointer(lw), ntuple(i -> pointer(el[i]), 4), ntuple(i -> pointer(dn[i]), 4),
-            pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep), Ptr{UInt16}(C_NULL)))
+            pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep), Ptr{UInt16}(C_NULL),
+            Int32(operators ? 0 : 1)))
         check(ccall(sym(:otmb_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), ctx[], a, nnz))
     end
     colptr = [Vector{Int64}(undef, N + 1) for _ in 1:5]
@@ -163,7 +166,7 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
     for m in 1:5   # plan's count for T is the union-pattern bound; exact-zero sums are dropped (:147)
         resize!(rowval[m], final[m]); resize!(nzval[m], final[m])
     end
-    mats = [SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], rowval[m], nzval[m]) for m in 1:5]
+    mats = Any[(operators || m == 1) ? SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], rowval[m], nzval[m]) : nothing for m in 1:5]
     return (; T = mats[1], Tadv = mats[2], TκH = mats[3], TκVML = mats[4], TκVdeep = mats[5])
 end
 

@@ -257,9 +257,11 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
 
 def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None, rho=None, κH=500.0, κVML=0.1,
                     κVdeep=1.0e-5, kappaH=None, kappaVML=None, kappaVdeep=None, Tadv=None, TκH=None, TκVML=None,
-                    TκVdeep=None, upwind=True, device=0):
+                    TκVdeep=None, upwind=True, operators=True, device=0):
     """matrixbuilding.jl:128-150 -> NT(T, Tadv, TκH, TκVML, TκVdeep), each a SparseMatrixCSC.
-    ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords."""
+    ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords.
+    operators=False (extension; the reference always returns all five): only T is materialised, the other four come
+    back as None -- the same T, half the bytes written and a third of the bytes copied back to the host."""
     phi = ϕ if ϕ is not None else phi
     rho = ρ if ρ is not None else rho
     kH = κH if kappaH is None else kappaH
@@ -277,6 +279,7 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     ctx = context(device)
     keep = []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep)
+    a.only_t = 0 if operators else 1
     nnz = (C.c_int64 * 5)()
     ctx.check(capi.lib().otmb_transportmatrix_plan(ctx.handle, C.byref(a), C.byref(nnz)))
     N = int(indices["N"])
@@ -289,7 +292,7 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     final = (C.c_int64 * 5)()
     ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
-    return NT(**{name: SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]])
+    return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
                  for m, name in enumerate(MATS)})
 
 

@@ -40,6 +40,7 @@ class TmArgs(C.Structure):
         ("area2d", C.c_void_p), ("zt", C.c_void_p), ("mlotst", C.c_void_p),
         ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
         ("push_mask", C.c_void_p),
+        ("only_t", C.c_int32),
     ]
 
 

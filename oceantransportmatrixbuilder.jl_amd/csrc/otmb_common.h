@@ -98,6 +98,7 @@ int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const i
                               uint16_t *push_mask);  // otmb_facefluxes.hip
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
+bool otmb_tm_plan_only_t(otmb_ctx *ctx);                              // otmb_transportmatrix.hip
 
 #define HIP_TRY(ctx, call)                                                              \
     do {                                                                                \

@@ -199,7 +199,9 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t *dcp[5], *drv[5];
     double *dnz[5];
-    for (int m = 0; m < 5; ++m) {
+    const int nm = otmb_tm_plan_only_t(ctx) ? 1 : 5;  // T alone (otmb_tm_args.only_t): the operators' outputs may be NULL
+    for (int m = 0; m < 5; ++m) { dcp[m] = nullptr; drv[m] = nullptr; dnz[m] = nullptr; }
+    for (int m = 0; m < nm; ++m) {
         if (!colptr[m] || (nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         void *d;
         TRY(stage(ctx, ST_COLPTR0 + m, (size_t)(N + 1) * 8, &d)); dcp[m] = (int64_t *)d;
@@ -209,7 +211,7 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     TRY(otmb_transportmatrix_fill_dev(ctx, dcp, drv, dnz));
     TRY(otmb_transportmatrix_nnz(ctx, nnz));  // T's count can only shrink (entries that summed to exactly zero)
     for (int m = 0; m < 5; ++m) nnz_out[m] = nnz[m];
-    for (int m = 0; m < 5; ++m) {
+    for (int m = 0; m < nm; ++m) {
         HIP_TRY(ctx, hipMemcpyAsync(colptr[m], dcp[m], (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (nnz[m] > 0) {
             HIP_TRY(ctx, hipMemcpyAsync(rowval[m], drv[m], (size_t)nnz[m] * 8, hipMemcpyDeviceToHost, ctx->stream));

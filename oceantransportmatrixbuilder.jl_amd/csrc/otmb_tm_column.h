@@ -26,6 +26,7 @@ struct TmParams {
     const double *area, *zt, *ml;
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
+    int only_t;        // build T alone: the operators are evaluated but neither counted nor written (otmb_tm_args.only_t)
     int rho_in_fill;   // the ρ-NaN check (:233) is done by the fill pass (which loads ρ anyway) instead of the counting pass:
                        // set when both passes run before the flags are read (otmb_transportmatrix_dev)
     i64 P, G;

@@ -104,6 +104,7 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
         build_column(p, cell, c, col);
         padv = col.padv; phh = col.phh; pml = col.pml; pdp = col.pdp;
     }
+    if (p.only_t) return (u64)__popc(padv | phh | pml | pdp);
     return (u64)__popc(padv | phh | pml | pdp) | ((u64)__popc(padv) << 11) | ((u64)__popc(phh) << 22) | ((u64)__popc(pml) << 33) |
            ((u64)__popc(pdp) << 43);
 }
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 }
                 live = true;
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
-                nU = __popc(uni); nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
+                nU = __popc(uni);
+                if (!p.only_t) { nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp); }
                 {
 #pragma unroll
                     for (int s = 0; s < NSLOT; ++s)
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             if (MODE == MODE_ONEPASS || p.gsum) p.totals[tid] = tot;
             i64 *cp = (tid == 0) ? p.colptr[0] : (tid == 1) ? p.colptr[1] : (tid == 2) ? p.colptr[2] : (tid == 3) ? p.colptr[3] : p.colptr[4];
             const i64 nb = (tid == 0) ? p.nnz_base[0] : (tid == 1) ? p.nnz_base[1] : (tid == 2) ? p.nnz_base[2] : (tid == 3) ? p.nnz_base[3] : p.nnz_base[4];
-            cp[p.n_own] = nb + tot + 1;
+            if (tid == 0 || !p.only_t) cp[p.n_own] = nb + tot + 1;
         }
     }
 
@@ -413,12 +415,14 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     // g0[m] + (entries of the tile's earlier waves).  No workgroup barrier is needed in this phase.
     if (live) {
 #pragma unroll
-        for (int m = 0; m < TM_NF; ++m) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
+        for (int m = 0; m < TM_NF; ++m)
+            if (m == 0 || !p.only_t) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
     }
     // the vertical operators only ever hold the rows above, self and below (:438-479): lets the compiler drop
     // the other five slot tests of their staging loops
     const unsigned vslots = (1u << S_A) | (1u << S_SELF) | (1u << S_B);
-    const unsigned pm[5] = {pT, col.padv, col.phh, col.pml & vslots, col.pdp & vslots};
+    const unsigned ops = p.only_t ? 0u : ~0u;  // T alone: nothing of the operators is staged or stored
+    const unsigned pm[5] = {pT, col.padv & ops, col.phh & ops, col.pml & vslots & ops, col.pdp & vslots & ops};
     // wave-uniform quantities go to scalar registers: the run's base pointers are then SGPR pairs, the stores
     // take the `global_store vaddr32, vdata, sbase` form and the copy loop is a scalar loop
     const u64 ubefore = (u64)wave_uniform((i64)before);
@@ -505,7 +509,11 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 // closing colptr entry of each matrix: nnz_base + nnz + 1 (values known on the host since the plan)
 __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
     if (threadIdx.x == 0) {
-        c0[N] = t0 + 1; c1[N] = t1 + 1; c2[N] = t2 + 1; c3[N] = t3 + 1; c4[N] = t4 + 1;
+        c0[N] = t0 + 1;
+        if (c1) c1[N] = t1 + 1;
+        if (c2) c2[N] = t2 + 1;
+        if (c3) c3[N] = t3 + 1;
+        if (c4) c4[N] = t4 + 1;
     }
 }
 
@@ -575,6 +583,7 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.area = a.area2d; p.zt = a.zt; p.ml = a.mlotst;
     p.kH = a.kappa_h; p.kML = a.kappa_vml; p.kDeep = a.kappa_vdeep;
     p.nx = (int)a.nx; p.ny = (int)a.ny; p.nz = (int)a.nz; p.topo = a.topology; p.upwind = a.upwind;
+    p.only_t = a.only_t != 0;
     p.P = a.nx * a.ny; p.G = p.P * a.nz;
     p.n_own = a.n_wet;
     if (pl) {
@@ -673,6 +682,8 @@ void otmb_tm_plan_free(otmb_ctx *ctx) {
     ctx->plan = nullptr;
 }
 
+bool otmb_tm_plan_only_t(otmb_ctx *ctx) { return ctx->plan && ctx->plan->args.only_t != 0; }
+
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N) {
     if (!ctx->plan || !ctx->plan->valid) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
     for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m];
@@ -747,8 +758,10 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     TmParams p;
     fill_params(p, pl.args, ctx, &pl);
     for (int m = 0; m < 5; ++m) {
-        if (!colptr[m] || (pl.nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
-        p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
+        const bool wanted = (m == 0) || !pl.args.only_t;
+        if (wanted && (!colptr[m] || (pl.nnz[m] > 0 && (!rowval[m] || !nzval[m])))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        p.colptr[m] = wanted ? (i64 *)colptr[m] : nullptr; p.rowval[m] = wanted ? (i64 *)rowval[m] : nullptr;
+        p.nzval[m] = wanted ? nzval[m] : nullptr;
     }
     int32_t rc;
     if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)pl.args.n_wet + 16))) return rc;
@@ -813,10 +826,12 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     TmParams p;
     fill_params(p, *a, ctx, &pl);
     for (int m = 0; m < 5; ++m) {
-        if (!colptr[m] || !rowval[m] || !nzval[m]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
-        if (capacity[m] <= 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "capacity");
-        p.colptr[m] = (i64 *)colptr[m]; p.rowval[m] = (i64 *)rowval[m]; p.nzval[m] = nzval[m];
-        p.cap[m] = capacity[m];
+        const bool wanted = (m == 0) || !a->only_t;
+        if (wanted && (!colptr[m] || !rowval[m] || !nzval[m])) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        if (wanted && capacity[m] <= 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "capacity");
+        p.colptr[m] = wanted ? (i64 *)colptr[m] : nullptr; p.rowval[m] = wanted ? (i64 *)rowval[m] : nullptr;
+        p.nzval[m] = wanted ? nzval[m] : nullptr;
+        p.cap[m] = wanted ? capacity[m] : 0;
     }
     if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)a->n_wet + 16))) return rc;
     p.tcount = (uint8_t *)ctx->tcount.p;

@@ -214,6 +214,7 @@ class DeviceAssembler:
         # ϕ straight from this object's facefluxes and untouched since: hand over its push mask
         fresh = getattr(self, "_mask_key", None) is not None and self._mask_key == self._phi_key(phi)
         a.push_mask = self.push_mask.data_ptr() if fresh else None
+        a.only_t = 1 if getattr(self, "only_T", False) else 0  # extension: materialise T alone (outputs of the operators unused)
         return a
 
     def plan(self, phi):

@@ -480,3 +480,37 @@ def test_single_kernel_lookback_variant():
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lookback_worker.py")
     r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LOOKBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold"])
+def test_t_only_extension_gives_the_same_T(api, oracle, name):
+    """operators=False / otmb_tm_args.only_t: the four operators are evaluated but not materialised; T is unchanged."""
+    import torch
+
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = make_case(name)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], _fill(g), gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    idx = api.makeindices(gm.v3D)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML,
+                             κVdeep=g.kappaVdeep, operators=False)
+    assert_csc_equal(tuple(tm["T"]), rtm["T"], name)
+    assert all(tm[m] is None for m in MATS[1:])
+    asm = DeviceAssembler(0)
+    asm.only_T = True
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    for onepass in (True, False):
+        asm.step(umo, vmo, _fill(g), onepass=onepass)
+        assert asm.nnz[1:] == [0, 0, 0, 0]
+        cp, rv, nz = asm.out["T"]
+        n = asm.nnz[0]
+        assert_csc_equal((cp.cpu().numpy(), rv[:n].cpu().numpy(), nz[:n].cpu().numpy()), rtm["T"], f"{name}/onepass={onepass}")
+    asm.only_T = False
+    asm.step(umo, vmo, _fill(g))
+    got = asm.result_to_host()
+    for m in MATS:
+        assert_csc_equal(got[m], rtm[m], m)
