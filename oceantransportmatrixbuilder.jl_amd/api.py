@@ -296,6 +296,57 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
                  for m, name in enumerate(MATS)})
 
 
+# ---- buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120) -----------------------------
+# One operator at a time, in the reference's own two-step formulation on the device: the COO generator in its emission
+# order, the NaN check, then sparse(𝑖s, 𝑗s, Tvals, N, N) (csrc/otmb_coo.hip).
+def _build_operator(which, *, gridmetrics, indices, phi=None, rho=1035.0, mlotst=None, kappa=(500.0, 0.1, 1.0e-5), upwind=True,
+                    device=0):
+    import torch
+
+    from .device import DeviceAssembler
+
+    asm = DeviceAssembler(device)
+    shape = np.asarray(gridmetrics["v3D"]).shape
+    ml = np.full(shape[:2], np.nan) if mlotst is None else mlotst
+    asm.set_grid(gridmetrics, ml, rho, *kappa, upwind=upwind)
+    if asm.N != int(indices["N"]):
+        raise ValueError("indices do not belong to gridmetrics.v3D")
+    if phi is None:
+        dphi = [torch.zeros(asm.G, dtype=torch.float64, device=asm.device) for _ in range(6)]
+    else:
+        dphi = [asm._t(np.asarray(phi[k])) for k in PHI_ORDER]
+    I, J, V = asm.sparse_entries(which, dphi)
+    cp, rv, nz = asm.sparse(I, J, V, asm.N, asm.N)
+    return SparseMatrixCSC(asm.N, asm.N, cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy())
+
+
+def buildTadv(*, ϕ=None, phi=None, gridmetrics, indices, ρ=None, rho=None, upwind=True, device=0):
+    """matrixbuilding.jl:31-44."""
+    return _build_operator("Tadv", gridmetrics=gridmetrics, indices=indices, phi=ϕ if ϕ is not None else phi,
+                           rho=ρ if ρ is not None else rho, upwind=upwind, device=device)
+
+
+def buildTκH(*, gridmetrics, indices, ρ=None, rho=None, κH=None, kappaH=None, device=0):
+    """matrixbuilding.jl:51-66 (ρ is accepted and unused, as in the reference)."""
+    k = κH if κH is not None else kappaH
+    return _build_operator("TκH", gridmetrics=gridmetrics, indices=indices, kappa=(float(k), 0.1, 1.0e-5), device=device)
+
+
+def buildTκVML(*, mlotst, gridmetrics, indices, κVML=None, kappaVML=None, device=0):
+    """matrixbuilding.jl:74-95."""
+    k = κVML if κVML is not None else kappaVML
+    return _build_operator("TκVML", gridmetrics=gridmetrics, indices=indices, mlotst=mlotst, kappa=(500.0, float(k), 1.0e-5), device=device)
+
+
+def buildTκVdeep(*, mlotst=None, gridmetrics, indices, κVdeep=None, kappaVdeep=None, device=0):
+    """matrixbuilding.jl:103-120 (mlotst is accepted and unused, as in the reference)."""
+    k = κVdeep if κVdeep is not None else kappaVdeep
+    return _build_operator("TκVdeep", gridmetrics=gridmetrics, indices=indices, kappa=(500.0, 0.1, float(k)), device=device)
+
+
+buildTkH, buildTkVML, buildTkVdeep = buildTκH, buildTκVML, buildTκVdeep  # ASCII aliases
+
+
 def lump_and_spray(wet3D, vol, T, mask=None, *, di=2, dj=2, dk=1, device=0):
     """LUMP, SPRAY, vol_c = lump_and_spray(wet3D, vol, T, mask; di, dj, dk) (src/extratools.jl:38-119): coarsening in
     di x dj x dk blocks inside `mask`, never across cells that T's pattern does not connect.  `LUMP * x` is the coarse

@@ -69,3 +69,26 @@ def test_device_sparse_on_arbitrary_triplets(oracle):
     e = torch.empty(0, dtype=torch.int64, device="cuda")
     cp, rv, nz = asm.sparse(e, e, torch.empty(0, dtype=torch.float64, device="cuda"), 5, 5)
     assert cp.cpu().tolist() == [1] * 6 and rv.numel() == 0
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold"])
+def test_build_single_operators_like_the_reference(oracle, name):
+    """buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120) one at a time equal the operators
+    transportmatrix returns."""
+    import otmb_amd
+    from helpers import MATS, assert_csc_equal, make_case
+
+    g, gm = make_case(name)
+    ref = oracle.makeindices(gm.v3D)
+    fill = g.umo.properties["_FillValue"]
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], fill, gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    idx = otmb_amd.makeindices(gm.v3D)
+    got = {
+        "Tadv": otmb_amd.buildTadv(ϕ=rphi, gridmetrics=gm, indices=idx, ρ=g.rho),
+        "TκH": otmb_amd.buildTκH(gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH),
+        "TκVML": otmb_amd.buildTκVML(mlotst=g.mlotst, gridmetrics=gm, indices=idx, κVML=g.kappaVML),
+        "TκVdeep": otmb_amd.buildTκVdeep(mlotst=g.mlotst, gridmetrics=gm, indices=idx, κVdeep=g.kappaVdeep),
+    }
+    for m in MATS[1:]:
+        assert_csc_equal(tuple(got[m]), rtm[m], f"{name}/{m}")
