@@ -14,4 +14,6 @@ for rep in range(3):
     t0 = time.perf_counter(); idx = api.makeindices(gm.v3D); t1 = time.perf_counter()
     phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx); t2 = time.perf_counter()
     tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho); t3 = time.perf_counter()
-    print(f"makeindices {1e3*(t1-t0):.1f} ms, facefluxes {1e3*(t2-t1):.1f} ms, transportmatrix {1e3*(t3-t2):.1f} ms  (N={idx.N}, nnz(T)={tm.T.nnz})")
+    tt = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, operators=False); t4 = time.perf_counter()
+    print(f"makeindices {1e3*(t1-t0):.1f} ms, facefluxes {1e3*(t2-t1):.1f} ms, transportmatrix {1e3*(t3-t2):.1f} ms, "
+          f"transportmatrix(operators=false) {1e3*(t4-t3):.1f} ms  (N={idx.N}, nnz(T)={tm.T.nnz})")
