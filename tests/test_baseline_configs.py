@@ -1,0 +1,177 @@
+"""BASELINE.json's configurations at their stated sizes (run with -m gpu on the MI355X box).
+
+configs[0]/[1]  ACCESS-ESM1-5-like 1 degree grid 360x300x50: the HIP path (device-resident, through the C ABI) against the
+                oracle on the WHOLE grid, bit for bit, all five matrices and the six face fluxes -- scalar ρ (config 1),
+                3-D ρ (config 2 as the reference has it: bolus_GM_velocity never enters T, src/RediGM.jl:44), upwind and
+                centred.
+configs[2]      0.25 degree grid 1440x1080x75 on one GPU and
+configs[4]      0.1 degree grid 3600x2700x75 on one GPU (it fits: 220 GB of the 288 GB): the 3-D inputs are generated on
+                the device (synthetic_device.py); checked through the size-independent properties the reference's tests
+                assert (test/online.jl:93-123; tests/properties.py) AND against the oracle on a depth sub-slab copied back
+                to the host: levels [k0-1, k1+1] of the device's own inputs and ϕ go through tests/slab_checker_backend.py
+                (the oracle on the extended sub-grid), and the owned columns must match bit for bit.
+configs[3]      (the 0.25 degree grid cut in depth across 8 GPUs) needs 8 GPUs: its orchestration is covered by
+                tests/test_dist_cpu.py (gloo, up to 8 ranks) and tests/test_dist_gpu.py.
+"""
+import numpy as np
+import pytest
+
+from helpers import MATS, assert_csc_equal, gridmetrics_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat(a):
+    import torch
+
+    return torch.from_numpy(np.asfortranarray(a).ravel(order="F")).cuda()
+
+
+# ---- 1 degree: whole-grid oracle parity ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def access1deg():
+    from otmb_amd import synthetic
+
+    g = synthetic.preset("access1deg", rho="array")
+    gm = gridmetrics_of(g)
+    return g, gm
+
+
+@pytest.fixture(scope="module")
+def access1deg_ref(access1deg, oracle):
+    g, gm = access1deg
+    idx = oracle.makeindices(gm.v3D)
+    phi = oracle.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], 1e20, gm.gridtopology.kind)
+    return idx, phi
+
+
+@pytest.mark.parametrize("rho_kind,upwind", [("scalar", True), ("array", True), ("array", False)])
+def test_access1deg_matches_oracle_bit_for_bit(access1deg, access1deg_ref, oracle, rho_kind, upwind):
+    import torch
+
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = access1deg
+    idx, rphi = access1deg_ref
+    rho = g.rho if rho_kind == "array" else 1035.0
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, rho, g.kappaH, g.kappaVML, g.kappaVdeep, upwind=upwind)
+    assert asm.N == idx["N"] == 3051515
+    assert np.array_equal(asm.lwet[: asm.N].cpu().numpy(), idx["Lwet"])
+    assert np.array_equal(asm.lwet3d.cpu().numpy(), idx["Lwet3D"].ravel(order="F"))
+    umo, vmo = _flat(g.umo.data), _flat(g.vmo.data)
+    for protocol in ("async", "twophase"):
+        if protocol == "async":
+            asm.step_async(umo, vmo, 1e20)
+            asm.finish()
+        else:
+            asm.step(umo, vmo, 1e20, onepass=False)
+        if protocol == "async":
+            for q, name in enumerate(oracle.PHI_ORDER):
+                got = asm.phi[q].cpu().numpy()
+                want = rphi[name].ravel(order="F")
+                same = (got == want) & (np.signbit(got) == np.signbit(want))
+                assert same.all(), (name, np.flatnonzero(~same)[:3])
+            rtm = oracle.transportmatrix(rphi, gm, idx, rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind, tight=True)
+        got = asm.result_to_host()
+        for m in MATS:
+            assert_csc_equal(got[m], rtm[m], f"access1deg/{rho_kind}/upwind={upwind}/{protocol}/{m}")
+    # the reference's own assertions on this grid (test/online.jl:93-123)
+    from properties import check_facefluxes, check_matrices, failed
+
+    checks = check_facefluxes(asm.phi, asm.nx, asm.ny, asm.nz)
+    checks.update(check_matrices(asm.out, asm.nnz, asm.N, asm.v3d[asm.lwet[: asm.N] - 1], upwind=upwind, nchunks=4))
+    assert not failed(checks), checks
+    del asm
+    torch.cuda.empty_cache()
+
+
+# ---- 0.25 and 0.1 degree: properties + oracle parity on a depth sub-slab -------------------------------------------
+def _subslab_oracle_check(oracle, dg, asm, k0, k1, upwind=True):
+    """Oracle on levels [k0-1, k1+1) of the device's own inputs (halo levels act as neighbours only); the columns of the
+    cells of levels [k0, k1) must equal the device's, and so must the six fluxes of those levels given the chain's
+    input plane ϕtop[k1]."""
+    import torch
+
+    from slab_checker_backend import OracleSlabBackend
+
+    nx, ny, nz = dg.nx, dg.ny, dg.nz
+    P = nx * ny
+    ha, hb = int(k0 > 0), int(k1 < nz)
+    ka, kb = k0 - ha, k1 + hb
+    nze = kb - ka
+
+    def host3(t, a, b, dtype=np.float64):
+        return np.asfortranarray(t[a * P:b * P].cpu().numpy().astype(dtype, copy=False).reshape(nx, ny, b - a, order="F"))
+
+    def host2(t):
+        return np.asfortranarray(t.cpu().numpy().reshape(nx, ny, order="F"))
+
+    from otmb_amd.capi import HDIRS
+
+    lw = host3(asm.lwet3d, ka, kb, np.int64)
+    own_lw = lw[:, :, ha:ha + (k1 - k0)]
+    n_own = int((own_lw != 0).sum())
+    assert n_own > 0
+    wet_base = int(own_lw[own_lw != 0].min()) - 1
+    s = dict(nx=nx, ny=ny, nz=nze, topology=dg.topology, k_own0=ha, k_own1=ha + (k1 - k0), wet_base=wet_base, n_own=n_own,
+             v3D=host3(asm.v3d, ka, kb), thkcello=host3(asm.thk, ka, kb),
+             rho=host3(asm.rho, ka, kb) if asm.rho is not None else asm.rho_scalar, lwet3d=lw,
+             wet_own=own_lw != 0, zt=dg.zt_host[ka:kb],
+             edge_length_2D={d: host2(asm.edge[q]) for q, d in enumerate(HDIRS)},
+             distance_to_neighbour_2D={d: host2(asm.dist[q]) for q, d in enumerate(HDIRS)},
+             area2D=host2(asm.area), mlotst=host2(asm.mlotst), kappa=asm.kappa, upwind=upwind)
+    be = OracleSlabBackend()
+    be.setup(s)
+    top_below = asm.phi[4][k1 * P:(k1 + 1) * P].cpu() if hb else None  # OTMB_TOP of the level below the slab
+    be.facefluxes(dg.umo[k0 * P:k1 * P].cpu(), dg.vmo[k0 * P:k1 * P].cpu(), dg.fill, top_below)
+    for q, name in enumerate(oracle.PHI_ORDER):
+        got = host3(asm.phi[q], k0, k1)
+        want = be.phi[name][:, :, ha:ha + (k1 - k0)]
+        same = (got == want) & (np.signbit(got) == np.signbit(want))
+        assert same.all(), (name, np.argwhere(~same)[:3])
+    be.plan()
+    c0, c1 = wet_base, wet_base + n_own
+    for kk, m in enumerate(MATS):
+        cp, rv, nzv = asm.out[m]
+        cph = cp[c0:c1 + 1].cpu().numpy()
+        a, b = int(cph[0]) - 1, int(cph[-1]) - 1
+        got = (cph - cph[0], rv[a:b].cpu().numpy(), nzv[a:b].cpu().numpy())
+        assert_csc_equal(got, be.cols[m], f"levels [{k0},{k1}) {m}")
+    return n_own
+
+
+@pytest.mark.parametrize("workload,slab,protocol", [("quarterdeg", (36, 38), "async"), ("tenthdeg", (11, 12), "twophase")])
+def test_large_grid_properties_and_subslab_oracle(oracle, workload, slab, protocol):
+    import torch
+
+    from otmb_amd import synthetic_device
+    from properties import check_facefluxes, check_matrices, failed
+
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    need = {"quarterdeg": 60e9, "tenthdeg": 245e9}[workload]
+    if free < need:
+        pytest.skip(f"{workload} needs {need / 1e9:.0f} GB of free HBM, {free / 1e9:.0f} GB available")
+    dev = torch.device("cuda", 0)
+    dg = synthetic_device.make_device_grid(workload, dev)
+    asm = synthetic_device.assembler_for(dg)
+    assert asm.G == dg.nx * dg.ny * dg.nz
+    if protocol == "async":
+        asm.step_async(dg.umo, dg.vmo, dg.fill)
+        asm.finish()
+    else:  # outputs sized exactly by plan -> fill (the upper-bound buffers of the async protocol would not fit at 0.1 degree)
+        asm.step(dg.umo, dg.vmo, dg.fill, onepass=False)
+    N = asm.N
+    assert 0.5 < N / asm.G < 0.6  # ~70 M wet cells at 0.25 degree in BASELINE.json's words; 63.5 M / 397 M here
+    checks = check_facefluxes(asm.phi, dg.nx, dg.ny, dg.nz)
+    checks.update(check_matrices(asm.out, asm.nnz, N, asm.v3d[asm.lwet[:N] - 1], upwind=True, nchunks=64))
+    assert not failed(checks), checks
+    n_checked = _subslab_oracle_check(oracle, dg, asm, *slab)
+    assert n_checked > 100000
+    # the surface and the deepest level as well (one halo only) on the smaller grid
+    if workload == "quarterdeg":
+        _subslab_oracle_check(oracle, dg, asm, 0, 1)
+        _subslab_oracle_check(oracle, dg, asm, dg.nz - 1, dg.nz)
+    del asm, dg
+    torch.cuda.empty_cache()
