@@ -108,6 +108,12 @@ int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo
                                  const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                  int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask);
 int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid);
+/* The same two flags for EVERY facefluxes call on this context since the previous call of this function, oldest
+ * first (a pipeline of asynchronous steps: the reference asserts per call, src/velocities.jl:199-200, so a field
+ * without a single valid value in step 3 of 12 must not be hidden by steps 4-12).  Synchronises.  At most the 64
+ * most recent calls are remembered: drain the pipeline at least that often.                                  */
+int32_t otmb_facefluxes_pending_flags(otmb_ctx *ctx, int32_t capacity, int32_t *u_valid, int32_t *v_valid,
+                                      int32_t *n_calls);
 
 /* Push mask: what the pattern of the advection operator needs to know about a cell's six fluxes, 16 bits per
  * cell.  Bits 0-5: the cell sends mass through its west, east, south, north, bottom, top face under upwind
@@ -203,6 +209,12 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
 int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t *const colptr[5],
                                  int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
 int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);
+/* Several otmb_transportmatrix_dev calls may be enqueued before one otmb_transportmatrix_result (a pipeline over time
+ * slices).  Every call keeps its own error flags; result reports the FIRST call that failed -- where the reference
+ * would have thrown (src/matrixbuilding.jl:39,61,90,114,233) -- with "(asynchronous step k of n)" appended to
+ * otmb_last_error, and the nnz of the last call when none failed.  failed_step: 0-based index of that call among
+ * the calls since the previous result, -1 if the last result found no failure.                               */
+int32_t otmb_transportmatrix_failed_step(otmb_ctx *ctx, int64_t *step);
 
 /* Depth-slab partition (multi-GPU).  The wet index is k-slowest (src/matrixbuilding.jl:14-15), so a slab
  * of levels owns a contiguous column range of every matrix.  set_slab (before plan / _dev): the local

@@ -24,10 +24,11 @@ class OtmbError(RuntimeError):
     (ErrorException / AssertionError texts of src/matrixbuilding.jl:39,61,90,114,233,
     src/gridtopology.jl:111-116, src/velocities.jl:199-200)."""
 
-    def __init__(self, status, message):
+    def __init__(self, status, message, step=None):
         super().__init__(message)
         self.status = status
         self.name = STATUS_NAMES.get(status, str(status))
+        self.step = step  # asynchronous pipelines: 0-based index of the first step that failed
 
 
 class TmArgs(C.Structure):
@@ -75,6 +76,8 @@ SYMBOLS = {
     "otmb_lump_and_spray": (C.c_int32, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64,
                                          C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _ip]),
     "otmb_facefluxes_slab_flags": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "otmb_facefluxes_pending_flags": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "otmb_transportmatrix_failed_step": (C.c_int32, [_vp, _ip]),
     "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64]),
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_result": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),

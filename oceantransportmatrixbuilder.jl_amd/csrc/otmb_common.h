@@ -23,7 +23,7 @@ struct TmPlan;  // otmb_transportmatrix.hip
 
 // pending plan of the general path (otmb_coo.hip): COO generator and sparse()
 struct CooPlan { int which = -1; otmb_tm_args args; int64_t ntiles = 0, len = 0; };
-struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = nullptr; int64_t len = 0, m = 0, n = 0, nnz = 0; };
+struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = nullptr; int64_t len = -1, m = 0, n = 0, nnz = 0; };
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
@@ -48,6 +48,17 @@ struct otmb_ctx {
     int *h_flags = nullptr;  // pinned host mirror of the state block (flag words first)
     i64 *h_tot = nullptr;    // the totals inside it (h_flags + OTMB_NFLAGS)
     int ff_gen = 0;          // facefluxes call counter: a validity flag is set by writing the current value (no reset pass)
+    int ff_first = 1;        // oldest facefluxes call whose validity flags have not been handed out (otmb_facefluxes_pending_flags)
+    // asynchronous pipeline: every otmb_transportmatrix_dev call gets its own state block (flags + totals) and every
+    // facefluxes call its own pair of validity words, in rings of OTMB_RING slots (device) mirrored in pinned host
+    // memory, so that a failure in step 3 of 12 is still there when the host finally looks (otmb_transportmatrix_result)
+    DevBuf ring;
+    int *h_ring = nullptr;
+    i64 tm_first = 0, tm_next = 0;   // pending asynchronous transportmatrix steps [tm_first, tm_next)
+    int32_t tm_sticky = 0;           // first failure folded out of the ring when it wrapped (status, step index)
+    i64 tm_sticky_step = -1;
+    std::string tm_sticky_msg;
+    i64 tm_failed_step = -1;         // what the last otmb_transportmatrix_result found
     TmPlan *plan = nullptr;
     CooPlan coo;
     SpPlan sp;
@@ -91,6 +102,10 @@ enum {
 // device state block (ctx->flags) and its pinned host mirror (ctx->h_flags): 16 flag words | 16 i64 totals | 4 words
 #define OTMB_STATE_BYTES (OTMB_NFLAGS * sizeof(int) + 16 * sizeof(i64) + 4 * sizeof(int))
 #define OTMB_TM_STATE_BYTES (OTMB_NFLAGS * sizeof(int) + 8 * sizeof(i64))  // flags + the totals transportmatrix uses
+#define OTMB_RING 64
+#define OTMB_RING_BYTES (OTMB_RING * OTMB_TM_STATE_BYTES + OTMB_RING * 2 * sizeof(int))
+static inline int *otmb_ring_tm(int *ring, i64 step) { return (int *)((char *)ring + (size_t)(step % OTMB_RING) * OTMB_TM_STATE_BYTES); }
+static inline int *otmb_ring_ff(int *ring, int gen) { return (int *)((char *)ring + OTMB_RING * OTMB_TM_STATE_BYTES) + 2 * (gen % OTMB_RING); }
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
 int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);

@@ -128,9 +128,18 @@ __global__ __launch_bounds__(COO_THREADS) void coo_kernel(const TmParams p, uint
 }
 
 // ---- sparse(): after the stable sort by (col,row) --------------------------------------------------------
-__global__ __launch_bounds__(256) void sp_keys_kernel(const i64 *__restrict__ I, const i64 *__restrict__ J, i64 len, u64 *keys, u64 *idx) {
+// sparse(I, J, V, m, n) demands 1 <= I <= m and 1 <= J <= n (SparseArrays throws an ArgumentError otherwise): checked here,
+// before anything is packed into 32+32-bit keys or used as a colptr position; *bad counts the offending triplets.
+__global__ __launch_bounds__(256) void sp_keys_kernel(const i64 *__restrict__ I, const i64 *__restrict__ J, i64 len, i64 m, i64 n, u64 *keys,
+                                                      u64 *idx, i64 *bad) {
     const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (e < len) { keys[e] = ((u64)J[e] << 32) | (u64)I[e]; idx[e] = (u64)e; }
+    if (e < len) {
+        const i64 i = I[e], j = J[e];
+        const bool ok = i >= 1 && i <= m && j >= 1 && j <= n;
+        keys[e] = ok ? (((u64)j << 32) | (u64)i) : ~0ull;
+        idx[e] = (u64)e;
+        if (!ok && *bad == 0) atomicAdd((unsigned long long *)bad, 1ull);
+    }
 }
 template <bool WRITE>
 __global__ __launch_bounds__(256) void sp_heads_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ idx, const double *__restrict__ V,
@@ -269,10 +278,16 @@ int32_t otmb_sparse_plan_dev(otmb_ctx *ctx, const int64_t *I, const int64_t *J, 
     const i64 nt = (len + 255) / 256;
     if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)(nt + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(nt + 1) * sizeof(i64) + otmb_scan_scratch(nt, 1)))) return rc;
-    i64 *dtot = (i64 *)((int *)ctx->flags.p + OTMB_NFLAGS) + 11;
-    HIP_TRY(ctx, hipMemsetAsync(dtot, 0, sizeof(i64), ctx->stream));
+    i64 *dtot = (i64 *)((int *)ctx->flags.p + OTMB_NFLAGS) + 11;  // [11] nnz, [12] triplets with an index out of range
+    ctx->sp.len = -1;                                               // no valid plan until this one succeeds
+    HIP_TRY(ctx, hipMemsetAsync(dtot, 0, 2 * sizeof(i64), ctx->stream));
     if (len > 0) {
-        hipLaunchKernelGGL(sp_keys_kernel, dim3((unsigned)nt), dim3(256), 0, ctx->stream, (const i64 *)I, (const i64 *)J, (i64)len, k0, v0);
+        hipLaunchKernelGGL(sp_keys_kernel, dim3((unsigned)nt), dim3(256), 0, ctx->stream, (const i64 *)I, (const i64 *)J, (i64)len, (i64)m, (i64)n,
+                           k0, v0, dtot + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot + 12, dtot + 1, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_tot[12] != 0)
+            return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "ArgumentError: row indices I[k] must satisfy 1 <= I[k] <= m and column indices J[k] 1 <= J[k] <= n");
         size_t tmp = 0;
         if (rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, v0, v1, (size_t)len, 0, 64, ctx->stream) != hipSuccess) return otmb_fail(ctx, OTMB_ERR_HIP, "radix_sort_pairs (size)");
         if ((rc = otmb_reserve(ctx, ctx->sort[4], tmp + 16))) return rc;
@@ -291,6 +306,7 @@ int32_t otmb_sparse_plan_dev(otmb_ctx *ctx, const int64_t *I, const int64_t *J, 
 
 int32_t otmb_sparse_fill_dev(otmb_ctx *ctx, int64_t *colptr, int64_t *rowval, double *nzval) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
+    if (ctx->sp.len < 0) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
     if (!colptr || (ctx->sp.nnz > 0 && (!rowval || !nzval))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 len = ctx->sp.len, nt = (len + 255) / 256;

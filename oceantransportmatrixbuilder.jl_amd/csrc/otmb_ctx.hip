@@ -80,6 +80,15 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
         otmb_ctx_destroy(c);
         return OTMB_ERR_ALLOC;
     }
+    if (hipHostMalloc((void **)&c->h_ring, OTMB_RING_BYTES) != hipSuccess) {
+        otmb_ctx_destroy(c);
+        return OTMB_ERR_ALLOC;
+    }
+    memset(c->h_ring, 0, OTMB_RING_BYTES);
+    if (otmb_reserve(c, c->ring, OTMB_RING_BYTES) != OTMB_OK || hipMemset(c->ring.p, 0, OTMB_RING_BYTES) != hipSuccess) {
+        otmb_ctx_destroy(c);
+        return OTMB_ERR_ALLOC;
+    }
     *out = c;
     return OTMB_OK;
 }
@@ -89,7 +98,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     otmb_tm_plan_free(ctx);
-    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->lookback, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4]})
+    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->lookback, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4]})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
@@ -99,6 +108,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     if (ctx->lump_host.p) (void)hipFree(ctx->lump_host.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

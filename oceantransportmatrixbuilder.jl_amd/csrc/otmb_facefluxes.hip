@@ -96,7 +96,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *flags, int gen) {
+    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen) {
     const unsigned s = blockIdx.x * FF_THREADS + threadIdx.x;
     bool uvalid = false, vvalid = false;
     if (s < (unsigned)P) {
@@ -126,9 +126,10 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
             k0 -= FF_KB;
         }
     }
-    // "some value is valid" = the flag holds this call's number (no reset pass between calls)
-    if (__any(uvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_U_VALID] != gen) atomicExch(&flags[FLAG_U_VALID], gen);
-    if (__any(vvalid) && (threadIdx.x & 63) == 0 && flags[FLAG_V_VALID] != gen) atomicExch(&flags[FLAG_V_VALID], gen);
+    // "some value is valid" = the call's pair of words (ring slot gen % OTMB_RING) holds this call's number: no reset
+    // pass between calls, and the verdict on call g survives the next OTMB_RING - 1 calls
+    if (__any(uvalid) && (threadIdx.x & 63) == 0 && uv[0] != gen) atomicExch(&uv[0], gen);
+    if (__any(vvalid) && (threadIdx.x & 63) == 0 && uv[1] != gen) atomicExch(&uv[1], gen);
 }
 
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
@@ -143,8 +144,9 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 P = nx * ny;
-    int *dflags = (int *)ctx->flags.p;
-    ctx->ff_gen = (ctx->ff_gen == 0x7fffffff) ? 1 : ctx->ff_gen + 1;
+    if (ctx->ff_gen == 0x7fffffff) { ctx->ff_gen = 0; ctx->ff_first = 1; }
+    ctx->ff_gen += 1;
+    int *dflags = otmb_ring_ff((int *)ctx->ring.p, ctx->ff_gen);
     const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
@@ -220,13 +222,40 @@ extern "C" int32_t otmb_push_mask_dev(otmb_ctx *ctx, const double *const phi[6],
     return OTMB_OK;
 }
 
-extern "C" int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid) {
-    if (!ctx || !u_valid || !v_valid) return OTMB_ERR_INVALID_ARG;
+static int32_t fetch_ff_ring(otmb_ctx *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + FLAG_U_VALID, (int *)ctx->flags.p + FLAG_U_VALID, 2 * sizeof(int),
+    HIP_TRY(ctx, hipMemcpyAsync(otmb_ring_ff(ctx->h_ring, 0), otmb_ring_ff((int *)ctx->ring.p, 0), OTMB_RING * 2 * sizeof(int),
                                 hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *u_valid = ctx->h_flags[FLAG_U_VALID] == ctx->ff_gen;
-    *v_valid = ctx->h_flags[FLAG_V_VALID] == ctx->ff_gen;
+    return OTMB_OK;
+}
+
+extern "C" int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid) {
+    if (!ctx || !u_valid || !v_valid) return OTMB_ERR_INVALID_ARG;
+    int32_t rc;
+    if ((rc = fetch_ff_ring(ctx))) return rc;
+    const int *uv = otmb_ring_ff(ctx->h_ring, ctx->ff_gen);
+    *u_valid = ctx->ff_gen > 0 && uv[0] == ctx->ff_gen;
+    *v_valid = ctx->ff_gen > 0 && uv[1] == ctx->ff_gen;
+    return OTMB_OK;
+}
+
+// Validity flags of EVERY facefluxes call since the previous call of this function, oldest first (at most the
+// OTMB_RING most recent ones: older verdicts have been overwritten, callers drain the pipeline before that).
+extern "C" int32_t otmb_facefluxes_pending_flags(otmb_ctx *ctx, int32_t capacity, int32_t *u_valid, int32_t *v_valid,
+                                                 int32_t *n_calls) {
+    if (!ctx || !u_valid || !v_valid || !n_calls || capacity < 0) return OTMB_ERR_INVALID_ARG;
+    int32_t rc;
+    if ((rc = fetch_ff_ring(ctx))) return rc;
+    int first = ctx->ff_first;
+    if (ctx->ff_gen - first + 1 > OTMB_RING) first = ctx->ff_gen - OTMB_RING + 1;
+    int n = 0;
+    for (int g = first; g <= ctx->ff_gen && n < capacity; ++g, ++n) {
+        const int *uv = otmb_ring_ff(ctx->h_ring, g);
+        u_valid[n] = uv[0] == g;
+        v_valid[n] = uv[1] == g;
+    }
+    *n_calls = n;
+    ctx->ff_first = first + n;
     return OTMB_OK;
 }

@@ -608,8 +608,8 @@ static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &
     return otmb_launch_push_mask(ctx, a.phi, a.lwet3d, 0, p.G, (uint16_t *)ctx->mask.p);
 }
 
-static int32_t check_flags(otmb_ctx *ctx) {
-    const int *f = ctx->h_flags;
+static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr) {
+    if (!f) f = ctx->h_flags;
     if (f[FLAG_NONCANONICAL]) return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
     if (f[FLAG_LOOKBACK_TIMEOUT]) return otmb_fail(ctx, OTMB_ERR_HIP, "look-back spin limit reached");
     if (f[FLAG_COUNT_MISMATCH]) return otmb_fail(ctx, OTMB_ERR_PUSH_MASK);
@@ -675,6 +675,18 @@ static int32_t t_fixup(otmb_ctx *ctx, TmPlan &pl, i64 *colptrT, i64 *rowvalT, do
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     pl.nnz[0] = actual;
     return OTMB_OK;
+}
+
+// Fold the completed pending steps [tm_first, tm_next) of the asynchronous protocol into the sticky (status, step) pair:
+// the first failing step wins.  The stream is idle on entry (the steps' state blocks have landed in h_ring).
+static void fold_pending(otmb_ctx *ctx) {
+    for (i64 s = ctx->tm_first; s < ctx->tm_next; ++s) {
+        if (ctx->tm_sticky) break;
+        const int32_t rc = check_flags(ctx, otmb_ring_tm(ctx->h_ring, s));  // sets ctx->err
+        if (rc) { ctx->tm_sticky = rc; ctx->tm_sticky_step = s; ctx->tm_sticky_msg = ctx->err; }
+    }
+    if (ctx->tm_sticky) ctx->err = ctx->tm_sticky_msg;
+    ctx->tm_first = ctx->tm_next;
 }
 
 void otmb_tm_plan_free(otmb_ctx *ctx) {
@@ -788,6 +800,12 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     return OTMB_OK;
 }
 
+int32_t otmb_transportmatrix_failed_step(otmb_ctx *ctx, int64_t *step) {
+    if (!ctx || !step) return OTMB_ERR_INVALID_ARG;
+    *step = ctx->tm_failed_step;
+    return OTMB_OK;
+}
+
 int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]) {
     if (!ctx || !nnz) return OTMB_ERR_INVALID_ARG;
     if (!ctx->plan) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
@@ -836,8 +854,17 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)a->n_wet + 16))) return rc;
     p.tcount = (uint8_t *)ctx->tcount.p;
     pl.outT[0] = p.colptr[0]; pl.outT[1] = p.rowval[0]; pl.outT[2] = p.nzval[0];
-    int *dflags = (int *)ctx->flags.p;
+    // this step's own state block (flag words + totals): a ring slot, so that the verdict on every step of a pipeline
+    // of asynchronous calls is still there when otmb_transportmatrix_result finally looks.  A full ring is folded
+    // into the sticky (status, step) pair first -- one host synchronisation per OTMB_RING steps.
+    if (ctx->tm_next - ctx->tm_first >= OTMB_RING) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        fold_pending(ctx);
+    }
+    int *dflags = otmb_ring_tm((int *)ctx->ring.p, ctx->tm_next);
+    int *hflags = otmb_ring_tm(ctx->h_ring, ctx->tm_next);
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
+    p.flags = dflags;
     p.totals = dtot;
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
     if (ntiles == 0) {
@@ -878,7 +905,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(hflags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->tm_next += 1;
     pl.onepass_pending = true;
     return OTMB_OK;
 }
@@ -888,11 +916,28 @@ int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]) {
     if (!ctx->plan || !ctx->plan->onepass_pending) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->plan->onepass_pending = false;
-    int32_t rc;
-    if ((rc = check_flags(ctx))) return rc;
-    for (int m = 0; m < 5; ++m) ctx->plan->nnz[m] = ctx->h_tot[m];
-    if (ctx->h_flags[FLAG_T_CANCEL]) {
+    // every step enqueued since the previous result: the FIRST one that failed is reported (the reference would have
+    // thrown there, src/matrixbuilding.jl:39,61,90,114,233), with its position in the error text
+    const i64 n_steps = ctx->tm_next, last = ctx->tm_next - 1;
+    const int *lastf = otmb_ring_tm(ctx->h_ring, last);
+    fold_pending(ctx);
+    const int32_t st = ctx->tm_sticky;
+    ctx->tm_failed_step = ctx->tm_sticky_step;
+    ctx->tm_sticky = 0; ctx->tm_sticky_step = -1;
+    ctx->tm_first = ctx->tm_next = 0;
+    if (st) {
+        if (n_steps > 1) {
+            char where[96];
+            snprintf(where, sizeof where, " (asynchronous step %lld of %lld)", (long long)ctx->tm_failed_step + 1, (long long)n_steps);
+            ctx->err += where;
+        }
+        return st;
+    }
+    const i64 *lasttot = (const i64 *)(lastf + OTMB_NFLAGS);
+    for (int m = 0; m < 5; ++m) ctx->plan->nnz[m] = lasttot[m];
+    if (lastf[FLAG_T_CANCEL]) {
         TmPlan &pl = *ctx->plan;
+        int32_t rc;
         if ((rc = t_fixup(ctx, pl, (i64 *)pl.outT[0], (i64 *)pl.outT[1], (double *)pl.outT[2]))) return rc;
     }
     for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m];

@@ -180,20 +180,57 @@ class DeviceAssembler:
         # the mask describes exactly the values facefluxes wrote: any later in-place torch op bumps _version
         return tuple((p.data_ptr(), p._version) for p in phi)
 
+    PIPELINE_DEPTH = 60  # the library remembers the verdicts of its 64 most recent asynchronous calls: drain before that
+
+    def _first_missing(self):
+        """Index (among the facefluxes calls since the previous check) of the first call whose umo or vmo held no valid
+        value at all (the reference asserts per call, velocities.jl:199-200), or None; n = number of calls examined."""
+        cap = 64
+        u, v, n = (C.c_int32 * cap)(), (C.c_int32 * cap)(), C.c_int32(0)
+        self.ctx.check(self.lib.otmb_facefluxes_pending_flags(self.ctx.handle, cap, u, v, C.byref(n)))
+        self._ff_pending = 0
+        for q in range(n.value):
+            if not (u[q] and v[q]):
+                return q, n.value
+        return None, n.value
+
     def _check_missing(self):
-        u, v = C.c_int32(0), C.c_int32(0)
-        self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
-        if not (u.value and v.value):
-            raise capi.OtmbError(8, self.lib.otmb_status_string(8).decode())
+        bad, n = self._first_missing()
+        if bad is not None:
+            where = f" (asynchronous step {bad + 1} of {n})" if n > 1 else ""
+            raise capi.OtmbError(8, self.lib.otmb_status_string(8).decode() + where, step=bad)
+
+    def finish_facefluxes(self):
+        """Drain a pipeline of facefluxes_async calls (no transportmatrix): raises the assertion of the first field
+        without any valid value."""
+        self._check_missing()
+        return self.phi
 
     def step_async(self, umo, vmo, fill):
         """Enqueue one pass of the hot path (facefluxes -> count -> scan -> fill) without any host synchronisation;
-        successive calls pipeline on the stream.  finish() synchronises and raises what the last pass found."""
-        return self.transportmatrix_onepass(self.facefluxes_async(umo, vmo, fill), sync=False)
+        successive calls pipeline on the stream.  finish() synchronises and raises what the FIRST failing pass found
+        (every pass keeps its own error flags on the device; OtmbError.step is its index)."""
+        if getattr(self, "_ff_pending", 0) >= self.PIPELINE_DEPTH:
+            self.finish()
+        out = self.transportmatrix_onepass(self.facefluxes_async(umo, vmo, fill), sync=False)
+        self._ff_pending = getattr(self, "_ff_pending", 0) + 1
+        return out
 
     def finish(self):
-        self._check_missing()
-        return self.result()
+        """Drain the pipeline: the earliest failing step wins; within a step facefluxes' assertion comes first, as in
+        the reference (facefluxes runs before transportmatrix)."""
+        bad, n = self._first_missing()
+        err = None
+        try:
+            out = self.result()
+        except capi.OtmbError as e:
+            err = e
+        if bad is not None and (err is None or err.step is None or bad <= err.step):
+            where = f" (asynchronous step {bad + 1} of {n})" if n > 1 else ""
+            raise capi.OtmbError(8, self.lib.otmb_status_string(8).decode() + where, step=bad)
+        if err is not None:
+            raise err
+        return out
 
     def _args(self, phi):
         a = capi.TmArgs()
@@ -268,7 +305,12 @@ class DeviceAssembler:
 
     def result(self):
         nnz = (C.c_int64 * 5)()
-        self.ctx.check(self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz)))
+        rc = self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz))
+        if rc != capi.OK:
+            step = C.c_int64(-1)
+            self.lib.otmb_transportmatrix_failed_step(self.ctx.handle, C.byref(step))
+            raise capi.OtmbError(rc, self.lib.otmb_last_error(self.ctx.handle).decode("utf-8"),
+                                 step=int(step.value) if step.value >= 0 else None)
         self.nnz = [int(x) for x in nnz]
         return self.out
 

@@ -243,6 +243,9 @@ class SlabRunner:
     # colptrs into global ones (+ per-matrix base), after which the pieces concatenate as usual.
     def step_async(self, umo, vmo, fill):
         cm = self.comm
+        if getattr(self, "_n_async", 0) >= self.PIPELINE_DEPTH:  # same count on every rank: the drain is collective
+            self.finish()
+        self._n_async = getattr(self, "_n_async", 0) + 1
         cm.wait_send(getattr(self, "_pending_send", None))  # the plane handed up by the previous field has left
         self._pending_send = None
         if self.has_below:
@@ -257,14 +260,40 @@ class SlabRunner:
             self._pending_send = cm.isend(self._send_buf, self.rank - 1)
         self.be.assemble_async()
 
+    PIPELINE_DEPTH = 60  # the library keeps the verdicts of its 64 most recent asynchronous calls
+
+    # reference order of the checks inside one transportmatrix call (src/matrixbuilding.jl:233, the loop, :39, :61, :90, :114)
+    _STATUS_ORDER = (13, 10, 15, 1, 6, 2, 3, 4, 5, 14)
+
     def finish(self):
+        """Drain the pipeline on every rank.  Each rank reports, per pending step, its slab's two facefluxes validity flags
+        and the first step its transportmatrix failed in; ONE all_gather later every rank knows the same thing and raises
+        the same error -- that of the earliest failing step (facefluxes' assertion first within a step, as in the
+        reference), so no rank is left waiting in a collective for one that has raised."""
         cm = self.comm
         cm.wait_send(getattr(self, "_pending_send", None))
         self._pending_send = None
-        nnz, uv = self.be.result()
-        allv = cm.allgather_i64(list(nnz) + [int(uv[0]), int(uv[1])], self.device)
-        if not (allv[:, 5].any() and allv[:, 6].any()):
-            raise AssertionError("all umo or vmo values are NaN or _FillValue")  # velocities.jl:199-200
+        r = self.be.result()  # never raises for the reference's own errors: dict(nnz, u, v, status, step, message)
+        D = self.PIPELINE_DEPTH + 4
+        n_steps = len(r["u"])
+        vec = list(r["nnz"]) + [int(r["status"]), int(r["step"]), n_steps]
+        vec += [int(x) for x in r["u"]] + [0] * (D - n_steps) + [int(x) for x in r["v"]] + [0] * (D - n_steps)
+        allv = cm.allgather_i64(vec, self.device)
+        self._n_async = 0
+        n_steps = int(allv[:, 7].min())
+        u_any, v_any = allv[:, 8:8 + D].any(axis=0), allv[:, 8 + D:8 + 2 * D].any(axis=0)
+        missing = [q for q in range(n_steps) if not (u_any[q] and v_any[q])]  # velocities.jl:199-200, over the whole grid
+        failed = [(int(row[6]), self._STATUS_ORDER.index(int(row[5])) if int(row[5]) in self._STATUS_ORDER else 99, int(row[5]), rk)
+                  for rk, row in enumerate(allv) if int(row[5]) != 0]
+        first_tm = min(failed) if failed else None
+        where = lambda q: f" (asynchronous step {q + 1} of {n_steps})" if n_steps > 1 else ""
+        if missing and (first_tm is None or missing[0] <= first_tm[0]):
+            raise AssertionError("all umo or vmo values are NaN or _FillValue" + where(missing[0]))
+        if first_tm is not None:
+            from .capi import OtmbError, lib
+
+            step, _, status, rk = first_tm
+            raise OtmbError(status, lib().otmb_status_string(status).decode() + where(step) + f" [slab of rank {rk}]", step=step)
         self.nnz_base = allv[: self.rank, :5].sum(axis=0) if self.rank > 0 else np.zeros(5, dtype=np.int64)
         self.nnz_global = allv[:, :5].sum(axis=0)
         self.be.shift_colptr(self.nnz_base)
@@ -406,14 +435,30 @@ class HipSlabBackend:
         caps = (C.c_int64 * 5)(*self._cap)
         self.ctx.check(self.lib.otmb_transportmatrix_dev(self.ctx.handle, C.byref(a), C.byref(cp), C.byref(rv), C.byref(nz),
                                                          C.byref(caps)))
+        self._n_async = getattr(self, "_n_async", 0) + 1
 
     def result(self):
-        u, v = C.c_int32(0), C.c_int32(0)
-        self.ctx.check(self.lib.otmb_facefluxes_slab_flags(self.ctx.handle, C.byref(u), C.byref(v)))
+        """Verdicts of every asynchronous step since the previous call.  The reference's own failures are RETURNED
+        (status, step, message), not raised: SlabRunner.finish lets every rank raise the same one after its all_gather."""
+        cap = 64
+        u, v, n = (C.c_int32 * cap)(), (C.c_int32 * cap)(), C.c_int32(0)
+        self.ctx.check(self.lib.otmb_facefluxes_pending_flags(self.ctx.handle, cap, u, v, C.byref(n)))
         nnz = (C.c_int64 * 5)()
-        self.ctx.check(self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz)))
-        self.nnz = [int(x) for x in nnz]
-        return self.nnz, (u.value, v.value)
+        rc = self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz))
+        step, msg = C.c_int64(-1), ""
+        if rc != self.capi.OK:
+            msg = self.lib.otmb_last_error(self.ctx.handle).decode("utf-8")
+            if rc in (9, 10, 11, 12):  # allocation / HIP / usage errors are not the reference's: fail here and now
+                raise self.capi.OtmbError(rc, msg)
+            self.lib.otmb_transportmatrix_failed_step(self.ctx.handle, C.byref(step))
+        else:
+            self.nnz = [int(x) for x in nnz]
+        # the verdicts of the asynchronous steps are the LAST _n_async facefluxes calls (synchronous steps before them
+        # were checked when they ran)
+        first = max(0, n.value - getattr(self, "_n_async", 0))
+        self._n_async = 0
+        return dict(nnz=list(self.nnz) if rc == self.capi.OK else [0] * 5, u=[u[q] for q in range(first, n.value)],
+                    v=[v[q] for q in range(first, n.value)], status=int(rc), step=int(step.value), message=msg)
 
     def shift_colptr(self, bases):
         for k, m in enumerate(MATS):

@@ -36,7 +36,45 @@ def run(rank, world, port, backend_kind, case, outdir):
     dev = be.device
     umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
     vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
-    if os.environ.get("OTMB_TEST_ASYNC") == "1":
+    fault = os.environ.get("OTMB_TEST_FAULT")  # "rank:step:kind" -- a failure injected into one step of an asynchronous pipeline
+    if fault:
+        from otmb_amd.capi import OtmbError
+
+        frank, fstep, kind = fault.split(":")
+        frank, fstep = int(frank), int(fstep)
+        lw = np.asfortranarray(be.s["lwet3d"]).ravel(order="F")
+        P = nx * ny
+        own = np.flatnonzero(lw[be.s["k_own0"] * P:be.s["k_own1"] * P]) + be.s["k_own0"] * P
+        L = int(own[len(own) // 2])
+        caught = None
+        try:
+            for sidx in range(5):
+                u, restore = umo, None
+                if sidx == fstep and kind == "rho" and rank == frank:  # NaN in ρ on ONE wet cell of ONE slab, this step only
+                    if backend_kind == "hip":
+                        old = be.rho[L].clone()
+                        be.rho[L] = float("nan")
+                        restore = lambda: be.rho.__setitem__(L, old)
+                    else:
+                        flat = be.s["rho"].reshape(-1, order="F")
+                        assert np.shares_memory(flat, be.s["rho"])
+                        old = float(flat[L])
+                        flat[L] = np.nan
+                        restore = lambda: flat.__setitem__(L, old)
+                if sidx == fstep and kind == "missing":  # no valid umo anywhere (every rank): velocities.jl:199
+                    u = torch.full_like(umo, float("nan"))
+                runner.step_async(u, vmo, 1e20)
+                if restore:
+                    restore()
+            runner.finish()
+        except (OtmbError, AssertionError) as e:
+            caught = e
+        with open(os.path.join(outdir, f"fault_{rank}.txt"), "w") as f:
+            f.write("none" if caught is None else f"{type(caught).__name__}|{getattr(caught, 'step', None)}|{caught}")
+        # the pipeline is usable again after the failure
+        runner.step_async(umo, vmo, 1e20)
+        out = runner.finish()
+    elif os.environ.get("OTMB_TEST_ASYNC") == "1":
         for _ in range(3):  # a stream of fields with no collective in between
             runner.step_async(umo, vmo, 1e20)
         out = runner.finish()

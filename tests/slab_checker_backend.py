@@ -72,11 +72,21 @@ class OracleSlabBackend:
         return self.out
 
     def assemble_async(self):
-        self.plan()
-        self.fill(np.zeros(5, dtype=np.int64))
+        """One asynchronous step: like the product backend, a failure is remembered per step and reported by result()."""
+        if not hasattr(self, "_steps"):
+            self._steps = []
+        try:
+            self.plan()
+            self.fill(np.zeros(5, dtype=np.int64))
+            self._steps.append((0, self.uv))
+        except orc.OracleError as e:
+            self._steps.append(({-1: 1, -2: 2, -3: 3, -4: 4, -5: 5, -6: 6}.get(e.code, 10), self.uv))
 
     def result(self):
-        return self.nnz, self.uv
+        steps, self._steps = self._steps, []
+        bad = [q for q, (st, _) in enumerate(steps) if st]
+        return dict(nnz=[0] * 5 if bad else list(self.nnz), u=[int(uv[0]) for _, uv in steps], v=[int(uv[1]) for _, uv in steps],
+                    status=steps[bad[0]][0] if bad else 0, step=bad[0] if bad else -1, message="")
 
     def shift_colptr(self, bases):
         self.out = {m: (self.out[m][0] + int(bases[k]), self.out[m][1], self.out[m][2]) for k, m in enumerate(MATS)}

@@ -34,9 +34,11 @@ def whole_grid_reference(oracle, nx, ny, nz, seed, rho, topo):
     return idx, oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
 
 
-def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False):
+def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None):
     port = free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTMB_TEST_ASYNC="1" if async_mode else "0")
+    if fault:
+        env["OTMB_TEST_FAULT"] = fault
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), kind,
                                *[str(x) for x in case], str(outdir)], env=env) for r in range(world)]
     rcs = [p.wait(timeout=timeout) for p in procs]
@@ -74,4 +76,32 @@ def test_slab_async_pipeline_gloo(oracle, tmp_path):
     """step_async x3 + finish: no collective per field, local colptrs shifted to global ones at the end."""
     case = (12, 10, 9, 22, "array", "tripolar")
     z = run_ranks(3, "oracle", case, tmp_path, async_mode=True)
+    check_against_whole_grid(oracle, z, case)
+
+
+def check_fault_reports(outdir, world, exc, step, text):
+    for r in range(world):
+        name, st, msg = open(os.path.join(outdir, f"fault_{r}.txt")).read().split("|", 2)
+        assert name == exc and text in msg and f"step {step + 1} of 5" in msg, (r, name, st, msg)
+        if exc == "OtmbError":
+            assert int(st) == step
+
+
+@pytest.mark.parametrize("fault,exc,text", [("1:1:rho", "OtmbError", "ρ contains NaNs"), ("2:4:rho", "OtmbError", "ρ contains NaNs"),
+                                            ("0:0:rho", "OtmbError", "ρ contains NaNs")])
+def test_slab_pipeline_reports_first_failing_step_on_every_rank(oracle, tmp_path, fault, exc, text):
+    """A failure in step k of 5 asynchronous steps (a NaN in ρ in ONE slab) is raised by finish() on EVERY rank with the
+    step's index -- nobody hangs in a collective -- and the result afterwards is right.  (The facefluxes assertion,
+    velocities.jl:199-200, cannot fire on a grid with land: nofluxboundaries! zeroes those faces first; its per-step
+    bookkeeping is tested on an all-wet grid in tests/test_pipeline_errors.py.)"""
+    case = (12, 10, 9, 23, "array", "tripolar")
+    z = run_ranks(3, "oracle", case, tmp_path, fault=fault)
+    check_fault_reports(tmp_path, 3, exc, int(fault.split(":")[1]), text)
+    check_against_whole_grid(oracle, z, case)
+
+
+def test_slab_orchestration_gloo_world8_on_75_levels(oracle, tmp_path):
+    """BASELINE.json configs[3]'s shape in small: 75 levels cut into 8 depth slabs."""
+    case = (10, 8, 75, 24, "array", "tripolar")
+    z = run_ranks(8, "oracle", case, tmp_path, async_mode=True)
     check_against_whole_grid(oracle, z, case)

@@ -69,6 +69,17 @@ def test_device_sparse_on_arbitrary_triplets(oracle):
     e = torch.empty(0, dtype=torch.int64, device="cuda")
     cp, rv, nz = asm.sparse(e, e, torch.empty(0, dtype=torch.float64, device="cuda"), 5, 5)
     assert cp.cpu().tolist() == [1] * 6 and rv.numel() == 0
+    # indices outside 1..m / 1..n: SparseArrays throws an ArgumentError; nothing may be written out of bounds
+    from otmb_amd.capi import OtmbError
+
+    for bi, bj in [(0, 3), (m + 1, 3), (5, 0), (5, n + 1), (-7, 3), (5, 1 << 40)]:
+        I2, J2 = I.copy(), J.copy()
+        I2[123], J2[123] = bi, bj
+        with pytest.raises(OtmbError, match="ArgumentError") as ei:
+            asm.sparse(torch.from_numpy(I2).cuda(), torch.from_numpy(J2).cuda(), torch.from_numpy(V).cuda(), m, n)
+        assert ei.value.name == "INVALID_ARG"
+    cp, rv, nz = asm.sparse(torch.from_numpy(I).cuda(), torch.from_numpy(J).cuda(), torch.from_numpy(V).cuda(), m, n)
+    assert_csc_equal((cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy()), oracle.sparse(I, J, V, m, n), "after the failures")
 
 
 @pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold"])
