@@ -65,6 +65,10 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out);
 void otmb_ctx_destroy(otmb_ctx *ctx);
 /* Borrow a hipStream_t (e.g. torch's current stream) for every _dev call; NULL = the ctx's own. */
 int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *hip_stream);
+/* Enqueue on the device's DEFAULT (null) stream instead -- the stream a framework uses when it has not been given
+ * another one (torch's default stream has handle 0, which otmb_ctx_set_stream reads as "the ctx's own"): the
+ * library's kernels are then ordered with the caller's own kernels and copies on that stream.                  */
+int32_t otmb_ctx_use_default_stream(otmb_ctx *ctx);
 int32_t otmb_ctx_synchronize(otmb_ctx *ctx);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */

@@ -51,6 +51,7 @@ SYMBOLS = {
     "otmb_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(_vp)]),
     "otmb_ctx_destroy": (None, [_vp]),
     "otmb_ctx_set_stream": (C.c_int32, [_vp, _vp]),
+    "otmb_ctx_use_default_stream": (C.c_int32, [_vp]),
     "otmb_ctx_synchronize": (C.c_int32, [_vp]),
     "otmb_last_error": (C.c_char_p, [_vp]),
     "otmb_status_string": (C.c_char_p, [C.c_int32]),
@@ -185,7 +186,15 @@ class Context:
             raise OtmbError(rc, lib().otmb_last_error(self._h).decode("utf-8"))
 
     def set_stream(self, stream_ptr):
-        self.check(lib().otmb_ctx_set_stream(self._h, _vp(stream_ptr or 0)))
+        """Borrow a HIP stream for every _dev call.  Handle 0 is the device's default (null) stream -- torch's default
+        stream -- so that the library's kernels are ordered with the caller's torch operations."""
+        if not stream_ptr:
+            self.check(lib().otmb_ctx_use_default_stream(self._h))
+        else:
+            self.check(lib().otmb_ctx_set_stream(self._h, _vp(stream_ptr)))
+
+    def use_own_stream(self):
+        self.check(lib().otmb_ctx_set_stream(self._h, _vp(0)))
 
     def synchronize(self):
         self.check(lib().otmb_ctx_synchronize(self._h))

@@ -119,6 +119,12 @@ int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *s) {
     return OTMB_OK;
 }
 
+int32_t otmb_ctx_use_default_stream(otmb_ctx *ctx) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    ctx->stream = nullptr;  // HIP's null stream: what torch calls its default stream
+    return OTMB_OK;
+}
+
 int32_t otmb_ctx_synchronize(otmb_ctx *ctx) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

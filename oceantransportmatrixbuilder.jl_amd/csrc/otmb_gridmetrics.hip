@@ -69,12 +69,13 @@ __global__ __launch_bounds__(64) void gridmetrics3d_kernel(const double *__restr
     const i64 s = (i64)blockIdx.x * 64 + threadIdx.x;
     if (s >= P) return;
     double a = area_in[s];
-    if (a == 0.0 || a == f0 || a == f1) a = __builtin_nan("");  // :269-280 (missing already arrives as NaN)
+    // :269-280 (missing already arrives as NaN); replace() matches with isequal: -0.0 is not isequal to 0
+    if ((a == 0.0 && !signbit(a)) || a == f0 || a == f1) a = __builtin_nan("");
     area2d[s] = a;
     double zbot = 0.0;
     for (int k = 0; k < nz; ++k) {
         double v = vol[(i64)k * P + s];
-        if (v == 0.0 || v == f0 || v == f1) v = __builtin_nan("");
+        if ((v == 0.0 && !signbit(v)) || v == f0 || v == f1) v = __builtin_nan("");
         const double t = v / a;                       // :283
         zbot = (k == 0) ? t : zbot + t;               // cumsum(thkcello, dims = 3), :284
         v3d[(i64)k * P + s] = v;

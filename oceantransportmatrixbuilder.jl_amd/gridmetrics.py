@@ -98,8 +98,8 @@ def makegridmetrics(*, areacello, volcello, lon, lat, lev, lon_vertices, lat_ver
 
     def clean(a):
         a = np.array(a, dtype=np.float64, order="F")
-        for f in fills:
-            a[a == f] = np.nan
+        for f in fills:  # replace() matches with isequal: -0.0 is not isequal to 0 and stays what it is
+            a[(a == f) & (np.signbit(a) == np.signbit(f))] = np.nan
         return a
 
     v3D = clean(vol_raw)  # :275-276

@@ -17,6 +17,7 @@ ERRORS = {
     -5: "TκVdeep contains NaNs.", -6: "flux into land or outside the grid", -7: "Unknown grid type",
     -8: "AssertionError: all fluxes missing", -9: "allocation failed",
     -20: "ArgumentError: Adjacency / distance matrices must be symmetric",
+    -21: "ArgumentError: Collection must contain exactly 1 element (vertexpermutation)", -22: "Unknown Arakawa grid type",
 }
 
 
@@ -313,3 +314,94 @@ def bolus_gm_velocity(rho, Z3D, wet3D, dist_east, dist_north, topo, kappaGM=600.
     if rc:
         raise OracleError(rc)
     return u, v
+
+
+# ---- makegridmetrics / topology detection / Arakawa detection / B-grid interpolation (src/gridcellgeometry.jl) ----------
+ARAKAWA_POS = ("C", "SW", "SE", "NE", "NW", "S", "N", "W", "E")  # field order of the reference's `cell` NamedTuple (:65)
+
+
+def _data_and_fill(x):
+    """(array, _FillValue or None) of a plain array or of an object with .data/.properties like the package's Cube."""
+    props = getattr(x, "properties", None) or {}
+    data = getattr(x, "data", x)
+    return np.asarray(data), (float(props["_FillValue"]) if "_FillValue" in props else None)
+
+
+def makegridmetrics(*, areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices):
+    """makegridmetrics (gridcellgeometry.jl:265-311) -> dict with the reference's field names; per-direction dicts keyed by
+    direction name; gridtopology = dict(kind=0|1).  Raises OracleError(-7) for an unknown topology."""
+    area, fa = _data_and_fill(areacello)
+    vol, fv = _data_and_fill(volcello)
+    area = np.asfortranarray(np.where(np.isnan(area.astype(np.float64)), np.nan, area), dtype=np.float64)
+    vol = np.asfortranarray(vol, dtype=np.float64)
+    nx, ny, nz = vol.shape
+    lon = _f(np.asarray(getattr(lon, "data", lon)))
+    lat = _f(np.asarray(getattr(lat, "data", lat)))
+    lonv_in = _f(np.asarray(getattr(lon_vertices, "data", lon_vertices)))
+    latv_in = _f(np.asarray(getattr(lat_vertices, "data", lat_vertices)))
+    f2 = lambda: np.empty((nx, ny), order="F")
+    f3 = lambda: np.empty((nx, ny, nz), order="F")
+    area2D, v3D, thk, Z3D = f2(), f3(), f3(), f3()
+    lonv, latv = np.empty((4, nx, ny), order="F"), np.empty((4, nx, ny), order="F")
+    edge, dedge, dnbr = [f2() for _ in range(4)], [f2() for _ in range(4)], [f2() for _ in range(4)]
+    pa = lambda arrs: (_dp * 4)(*[_d(a) for a in arrs])
+    fn = lib().orc_makegridmetrics
+    fn.restype = C.c_int32
+    rc = fn(_d(vol), _d(area), C.c_double(fa if fa is not None else 0.0), C.c_int32(fa is not None),
+            C.c_double(fv if fv is not None else 0.0), C.c_int32(fv is not None), _d(lon), _d(lat), _d(lonv_in), _d(latv_in),
+            C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), _d(area2D), _d(v3D), _d(thk), _d(Z3D), _d(lonv), _d(latv), pa(edge),
+            pa(dedge), pa(dnbr))
+    if rc < 0:
+        raise OracleError(rc)
+    return dict(area2D=area2D, v3D=v3D, thkcello=thk, lon_vertices=lonv, lat_vertices=latv, lon=lon, lat=lat, Z3D=Z3D,
+                zt=np.asarray(getattr(lev, "data", lev), dtype=np.float64),
+                edge_length_2D=dict(zip(HDIRS, edge)), distance_to_edge_2D=dict(zip(HDIRS, dedge)),
+                distance_to_neighbour_2D=dict(zip(HDIRS, dnbr)), gridtopology=dict(kind=int(rc)))
+
+
+def getgridtopology(lon_vertices, lat_vertices):
+    """gridtopology.jl:33-53 on vertices in the default order: 0 bipolar, 1 tripolar, 2 unknown."""
+    lonv, latv = _f(lon_vertices), _f(lat_vertices)
+    fn = lib().orc_getgridtopology
+    fn.restype = C.c_int32
+    return int(fn(_d(lonv), _d(latv), C.c_int64(lonv.shape[1]), C.c_int64(lonv.shape[2])))
+
+
+def vertexpermutation(lon_vertices, lat_vertices):
+    lonv, latv = _f(lon_vertices), _f(lat_vertices)
+    perm = (C.c_int32 * 4)()
+    fn = lib().orc_vertexpermutation
+    fn.restype = C.c_int32
+    if fn(_d(lonv), _d(latv), C.c_int64(lonv.shape[1]), C.c_int64(lonv.shape[2]), perm):
+        raise OracleError(-21)
+    return [int(x) for x in perm]
+
+
+def getarakawagrid(u_lon, u_lat, v_lon, v_lat, gridmetrics):
+    """gridcellgeometry.jl:50-95 -> ("A"|"B"|"C", u_pos, v_pos, relerr)."""
+    lon, lat = _f(gridmetrics["lon"]), _f(gridmetrics["lat"])
+    lonv, latv = _f(gridmetrics["lon_vertices"]), _f(gridmetrics["lat_vertices"])
+    kind, up, vp, rel = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_double(0)
+    fn = lib().orc_getarakawagrid
+    fn.restype = C.c_int32
+    rc = fn(C.c_double(float(np.asarray(u_lon)[0, 0])), C.c_double(float(np.asarray(u_lat)[0, 0])),
+            C.c_double(float(np.asarray(v_lon)[0, 0])), C.c_double(float(np.asarray(v_lat)[0, 0])), _d(lon), _d(lat), _d(lonv), _d(latv),
+            C.byref(kind), C.byref(up), C.byref(vp), C.byref(rel))
+    if rc:
+        raise OracleError(-22)  # "Unknown Arakawa grid type"
+    return "ABC"[kind.value], ARAKAWA_POS[up.value], ARAKAWA_POS[vp.value], rel.value
+
+
+def bgrid_to_cgrid(u, v, fill, gridmetrics):
+    """interpolateontodefaultCgrid(…, ::BGridCell) (:106-140) -> u2, u2_lon, u2_lat, v2, v2_lon, v2_lat."""
+    u = np.asfortranarray(np.asarray(u), dtype=np.float64)
+    v = np.asfortranarray(np.asarray(v), dtype=np.float64)
+    nx, ny, nz = u.shape
+    lonv, latv = _f(gridmetrics["lon_vertices"]), _f(gridmetrics["lat_vertices"])
+    u2, v2 = np.empty(u.shape, order="F"), np.empty(u.shape, order="F")
+    pts = [np.empty((nx, ny), order="F") for _ in range(4)]
+    fn = lib().orc_bgrid_to_cgrid
+    fn.restype = None
+    fn(_d(u), _d(v), C.c_double(float(fill)), C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), _d(lonv), _d(latv), _d(u2), _d(v2),
+       _d(pts[0]), _d(pts[1]), _d(pts[2]), _d(pts[3]))
+    return u2, pts[0], pts[1], v2, pts[2], pts[3]

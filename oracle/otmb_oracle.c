@@ -903,3 +903,194 @@ double orc_haversine(double lon1, double lat1, double lon2, double lat2) {
     if (r > 1.0) r = 1.0; /* min(√a, 1) */
     return 2 * (6371000.0 * asin(r));
 }
+
+/* ==== makegridmetrics and the velocity-grid helpers: src/gridcellgeometry.jl (rows a14, f2, f4 of SURVEY.md §8) ====
+ * Scalar restatement, one cell at a time like the reference's comprehensions.  Distances.haversine is a third-party
+ * dependency (Distances.jl 0.10, not on disk): orc_haversine above states its published formula with sin/cos of
+ * deg2rad(x); newer Distances releases evaluate the same formula with sind/cosd, whose results can differ in the last
+ * ulps -- the north star's tolerance for floating point (1e-12 relative) covers that, and the tests that compare
+ * transcendental results use it.  Everything else here (replace, divisions, cumsum, midpoints, index pairing) is
+ * exact arithmetic and compared bit for bit.                                                                    */
+
+/* midpointonsphere, :249-255 */
+void orc_midpointonsphere(double lonA, double latA, double lonB, double latB, double *lon, double *lat) {
+    if (fabs(lonA - lonB) < 180) {
+        *lon = (lonA + lonB) / 2;
+        *lat = (latA + latB) / 2;
+    } else { /* the edge crosses the longitudinal edge of the map */
+        *lon = (lonA + lonB) / 2 + 180;
+        *lat = (latA + latB) / 2 + 0;
+    }
+}
+
+#define VTX(a, v, i, j) ((a)[(v) + 4 * ((i) + nx * (j))]) /* (4,nx,ny) column-major */
+
+/* vertexpermutation, :158-178: 0-based permutation that sorts the vertices of cell (1,1) into SW, SE, NE, NW using the
+ * vertices it shares with its east and north neighbours.  -1: some `only(...)` would throw.                       */
+int32_t orc_vertexpermutation(const double *lonv, const double *latv, int64_t nx, int64_t ny, int32_t perm[4]) {
+    if (nx < 2 || ny < 2) return -1;
+    int in_e[4], in_n[4];
+    for (int v = 0; v < 4; ++v) {
+        in_e[v] = in_n[v] = 0;
+        for (int w = 0; w < 4; ++w) { /* Set(points) ∩ Set(points_east): tuple equality (==; -0.0 == 0.0, NaN never) */
+            if (VTX(lonv, v, 0, 0) == VTX(lonv, w, 1, 0) && VTX(latv, v, 0, 0) == VTX(latv, w, 1, 0)) in_e[v] = 1;
+            if (VTX(lonv, v, 0, 0) == VTX(lonv, w, 0, 1) && VTX(latv, v, 0, 0) == VTX(latv, w, 0, 1)) in_n[v] = 1;
+        }
+    }
+    int idx3 = -1, idx2 = -1, idx4 = -1, idx1 = -1, c;
+    c = 0; for (int v = 0; v < 4; ++v) if (in_e[v] && in_n[v]) { idx3 = v; ++c; }          /* common to all 3 cells */
+    if (c != 1) return -1;
+    c = 0; for (int v = 0; v < 4; ++v) if (in_e[v] && v != idx3) { idx2 = v; ++c; }        /* (i,j) and (i+1,j) only */
+    if (c != 1) return -1;
+    c = 0; for (int v = 0; v < 4; ++v) if (in_n[v] && v != idx3) { idx4 = v; ++c; }        /* (i,j) and (i,j+1) only */
+    if (c != 1) return -1;
+    c = 0; for (int v = 0; v < 4; ++v) if (v != idx2 && v != idx3 && v != idx4) { idx1 = v; ++c; }
+    if (c != 1) return -1;
+    perm[0] = idx1; perm[1] = idx2; perm[2] = idx3; perm[3] = idx4;
+    return 0;
+}
+
+/* getgridtopology, gridtopology.jl:33-53 with isapprox_lon :23-26.  Vertices in the default order.  isapprox on arrays
+ * compares 2-norms: norm(x - y) <= max(atol, rtol * max(norm(x), norm(y))), rtol = sqrt(eps) unless atol > 0.    */
+int32_t orc_getgridtopology(const double *lonv, const double *latv, int64_t nx, int64_t ny) {
+    int all90 = 1;
+    for (int64_t i = 0; i < nx; ++i)
+        for (int v = 2; v < 4; ++v)
+            if (!(VTX(latv, v, i, ny - 1) == 90)) all90 = 0;
+    if (all90) return 0; /* BipolarGridTopology */
+    /* rot180 of the (2,nx) view: element (v,i) <-> (1-v, nx-1-i), i.e. vertex 3 of cell i <-> vertex 4 of cell nx+1-i */
+    double nlon = 0, ndlat = 0, nlat = 0;
+    for (int64_t i = 0; i < nx; ++i)
+        for (int v = 0; v < 2; ++v) {
+            const double a = VTX(lonv, 2 + v, i, ny - 1), b = VTX(lonv, 2 + (1 - v), nx - 1 - i, ny - 1);
+            const double x = a - b + 180;
+            double md = fmod(x, 360.0); /* Julia mod: result has the sign of the divisor */
+            if (md != 0 && md < 0) md += 360.0;
+            const double d = md - 180;
+            nlon += d * d;
+            const double p = VTX(latv, 2 + v, i, ny - 1), q = VTX(latv, 2 + (1 - v), nx - 1 - i, ny - 1);
+            ndlat += (p - q) * (p - q);
+            nlat += p * p; /* norm(NPlat) == norm(rot180(NPlat)) */
+        }
+    const double eps180 = 2.8421709430404007e-14; /* eps(180.0) */
+    const int lon_ok = sqrt(nlon) <= eps180;
+    const int lat_ok = sqrt(ndlat) <= 1.4901161193847656e-08 * sqrt(nlat); /* rtol = sqrt(eps(Float64)) */
+    return (lon_ok && lat_ok) ? 1 : 2; /* Tripolar : Unknown */
+}
+
+/* replace(x, toreplace...) of makegridmetrics :269-280: missing/nothing (NaN here), 0 and the two _FillValues become NaN.
+ * replace() matches with isequal: -0.0 is NOT isequal to 0, so a negative zero stays what it is.                 */
+static inline double mgm_replace(double x, double fill_a, int has_a, double fill_v, int has_v) {
+    if (x == 0 && !signbit(x)) return NAN;
+    if (has_a && isequal_f64(x, fill_a)) return NAN;
+    if (has_v && isequal_f64(x, fill_v)) return NAN;
+    return x;
+}
+
+/* makegridmetrics, :265-311.  lonv_in/latv_in as given (any vertex order); lonv/latv receive the sorted vertices (:297-298).
+ * The per-direction outputs are in this file's W, E, S, N order.  Returns the topology (0, 1) or -7 for an unknown one
+ * (horizontaldistance would call j₊₁ on UnknownGridTopology -> error, gridtopology.jl:111-116), -1 when
+ * vertexpermutation throws.                                                                                      */
+int32_t orc_makegridmetrics(const double *volcello, const double *areacello, double fill_area, int32_t has_fill_area,
+                            double fill_vol, int32_t has_fill_vol, const double *lon, const double *lat,
+                            const double *lonv_in, const double *latv_in, int64_t nx, int64_t ny, int64_t nz, double *area2D,
+                            double *v3D, double *thk, double *Z3D, double *lonv, double *latv, double *const edge[4],
+                            double *const dist_edge[4], double *const dist_nbr[4]) {
+    const int64_t P = nx * ny;
+    for (int64_t s = 0; s < P; ++s) area2D[s] = mgm_replace(areacello[s], fill_area, has_fill_area, fill_vol, has_fill_vol);
+    for (int64_t s = 0; s < P; ++s) {
+        double zbot = 0; /* cumsum(thkcello, dims = 3): sequential sum from the surface, NaN sticks */
+        for (int64_t k = 0; k < nz; ++k) {
+            const int64_t L = s + P * k;
+            v3D[L] = mgm_replace(volcello[L], fill_area, has_fill_area, fill_vol, has_fill_vol);
+            thk[L] = v3D[L] / area2D[s];                     /* :283 */
+            zbot = (k == 0) ? thk[L] : zbot + thk[L];        /* :284 */
+            Z3D[L] = zbot - 0.5 * thk[L];                    /* :285 */
+        }
+    }
+    int32_t perm[4];
+    if (orc_vertexpermutation(lonv_in, latv_in, nx, ny, perm)) return -1; /* :296 */
+    for (int64_t s = 0; s < P; ++s)
+        for (int v = 0; v < 4; ++v) {
+            lonv[v + 4 * s] = lonv_in[perm[v] + 4 * s];
+            latv[v + 4 * s] = latv_in[perm[v] + 4 * s];
+        }
+    const int32_t topo = orc_getgridtopology(lonv, latv, nx, ny); /* :302 */
+    if (topo == 2) return -7;
+    orc_grid g = {nx, ny, 1, topo};
+    /* vertexindices :209-215 (0-based) for W, E, S, N */
+    static const int va[4] = {0, 1, 0, 2}, vb[4] = {3, 2, 1, 3};
+    for (int64_t j = 0; j < ny; ++j)
+        for (int64_t i = 0; i < nx; ++i) {
+            const int64_t s = i + nx * j;
+            for (int d = 0; d < 4; ++d) {
+                const double aL = VTX(lonv, va[d], i, j), aT = VTX(latv, va[d], i, j);
+                const double bL = VTX(lonv, vb[d], i, j), bT = VTX(latv, vb[d], i, j);
+                edge[d][s] = orc_haversine(aL, aT, bL, bT); /* verticalfacewidth :217-222 */
+                double mL, mT;
+                orc_midpointonsphere(aL, aT, bL, bT, &mL, &mT);
+                dist_edge[d][s] = orc_haversine(lon[s], lat[s], mL, mT); /* centroid2edgedistance :240-247 */
+                /* horizontaldistance(lon, lat, 𝑖, 𝑗(𝑖, gridtopology)) with west<->i₋₁, east<->i₊₁, south<->j₋₁, north<->j₊₁ (:304-308) */
+                const int64_t nb = (d == 0) ? im1(&g, i, j, 0) : (d == 1) ? ip1(&g, i, j, 0) : (d == 2) ? jm1(&g, i, j, 0) : jp1(&g, i, j, 0);
+                dist_nbr[d][s] = (nb < 0) ? NAN : orc_haversine(lon[s], lat[s], lon[nb], lat[nb]); /* :182-189 */
+            }
+        }
+    return topo;
+}
+
+/* getarakawagrid, :50-95 on cell (1,1).  *kind: 0 A, 1 B, 2 C; u_pos/v_pos: index into (C, SW, SE, NE, NW, S, N, W, E), the
+ * field order of the reference's `cell` NamedTuple (findmin returns the FIRST minimum in that order).  -1: "Unknown
+ * Arakawa grid type".  *relerr: (u_distance + v_distance) / perimeter (:89-90).                                   */
+int32_t orc_getarakawagrid(double u_lon, double u_lat, double v_lon, double v_lat, const double *lon, const double *lat,
+                           const double *lonv, const double *latv, int32_t *kind, int32_t *u_pos, int32_t *v_pos, double *relerr) {
+    double PL[9], PT[9];
+    PL[0] = lon[0]; PT[0] = lat[0];
+    for (int v = 0; v < 4; ++v) { PL[1 + v] = lonv[v]; PT[1 + v] = latv[v]; } /* SW, SE, NE, NW */
+    orc_midpointonsphere(PL[1], PT[1], PL[2], PT[2], &PL[5], &PT[5]); /* S = mid(SW, SE) */
+    orc_midpointonsphere(PL[3], PT[3], PL[4], PT[4], &PL[6], &PT[6]); /* N = mid(NE, NW) */
+    orc_midpointonsphere(PL[1], PT[1], PL[4], PT[4], &PL[7], &PT[7]); /* W = mid(SW, NW) */
+    orc_midpointonsphere(PL[2], PT[2], PL[3], PT[3], &PL[8], &PT[8]); /* E = mid(SE, NE) */
+    double ud = 0, vd = 0;
+    int up = -1, vp = -1;
+    for (int q = 0; q < 9; ++q) {
+        const double du = orc_haversine(PL[q], PT[q], u_lon, u_lat), dv = orc_haversine(PL[q], PT[q], v_lon, v_lat);
+        if (up < 0 || du < ud) { ud = du; up = q; }
+        if (vp < 0 || dv < vd) { vd = dv; vp = q; }
+    }
+    *u_pos = up; *v_pos = vp;
+    const int corner_u = up >= 1 && up <= 4;
+    if (up == 0 && vp == 0) *kind = 0;
+    else if (up == vp && corner_u) *kind = 1;
+    else if ((up == 8 || up == 7) && (vp == 6 || vp == 5)) *kind = 2;
+    else return -1;
+    const double per = orc_haversine(PL[1], PT[1], PL[2], PT[2]) + orc_haversine(PL[2], PT[2], PL[3], PT[3]) +
+                       orc_haversine(PL[3], PT[3], PL[4], PT[4]) + orc_haversine(PL[4], PT[4], PL[1], PT[1]);
+    *relerr = (ud + vd) / per;
+    return 0;
+}
+
+/* interpolateontodefaultCgrid(…, ::BGridCell), :106-140 (NE-corner B-grid): _FillValue -> 0 (replace: isequal), then
+ * u2 = 0.5 (u2 + [zeros ;; u2[:, 1:end-1, :]]) (one row south), v2 = 0.5 (v2 + [zeros; v2[1:end-1, :, :]]) (one cell west);
+ * the new velocity points are midpointonsphere(NE, SE) and midpointonsphere(NW, NE) -- the reference zips
+ * (NE_points, SE_points) and (NW_points, NE_points) in that order (:131-132).                                     */
+void orc_bgrid_to_cgrid(const double *u, const double *v, double fill, int64_t nx, int64_t ny, int64_t nz, const double *lonv,
+                        const double *latv, double *u2, double *v2, double *u2_lon, double *u2_lat, double *v2_lon,
+                        double *v2_lat) {
+    const int64_t P = nx * ny;
+    for (int64_t k = 0; k < nz; ++k)
+        for (int64_t j = 0; j < ny; ++j)
+            for (int64_t i = 0; i < nx; ++i) {
+                const int64_t L = i + nx * j + P * k;
+                const double uc = isequal_f64(u[L], fill) ? 0.0 : u[L], vc = isequal_f64(v[L], fill) ? 0.0 : v[L];
+                const double us = (j == 0) ? 0.0 : (isequal_f64(u[L - nx], fill) ? 0.0 : u[L - nx]);
+                const double vw = (i == 0) ? 0.0 : (isequal_f64(v[L - 1], fill) ? 0.0 : v[L - 1]);
+                u2[L] = 0.5 * (uc + us);
+                v2[L] = 0.5 * (vc + vw);
+            }
+    for (int64_t j = 0; j < ny; ++j)
+        for (int64_t i = 0; i < nx; ++i) {
+            const int64_t s = i + nx * j;
+            orc_midpointonsphere(VTX(lonv, 2, i, j), VTX(latv, 2, i, j), VTX(lonv, 1, i, j), VTX(latv, 1, i, j), &u2_lon[s], &u2_lat[s]);
+            orc_midpointonsphere(VTX(lonv, 3, i, j), VTX(latv, 3, i, j), VTX(lonv, 2, i, j), VTX(latv, 2, i, j), &v2_lon[s], &v2_lat[s]);
+        }
+}

@@ -348,6 +348,55 @@ def gridmetrics_2d(lon, lat, lonv, latv, kind):
     return el, de, dn
 
 
+def getarakawagrid(u_lon, u_lat, v_lon, v_lat, lon, lat, lonv, latv):
+    """gridcellgeometry.jl:50-95, literally: the position (key of `cell`, in its field order) nearest to the u and v points
+    of cell (1,1) -> ("A"|"B"|"C", u_pos, v_pos, relerr)."""
+    up = (float(u_lon[0, 0]), float(u_lat[0, 0]))
+    vp = (float(v_lon[0, 0]), float(v_lat[0, 0]))
+    Cc = (float(lon[0, 0]), float(lat[0, 0]))
+    SW, SE, NE, NW = [(float(lonv[q, 0, 0]), float(latv[q, 0, 0])) for q in range(4)]
+    cell = dict(C=Cc, SW=SW, SE=SE, NE=NE, NW=NW, S=midpointonsphere(SW, SE), N=midpointonsphere(NE, NW),
+                W=midpointonsphere(SW, NW), E=midpointonsphere(SE, NE))
+    ud = {k: haversine(P, up) for k, P in cell.items()}
+    vd = {k: haversine(P, vp) for k, P in cell.items()}
+    u_pos = min(ud, key=ud.get)  # findmin: the first minimum
+    v_pos = min(vd, key=vd.get)
+    if u_pos == v_pos == "C":
+        kind = "A"
+    elif u_pos == v_pos and u_pos in ("NE", "NW", "SE", "SW"):
+        kind = "B"
+    elif u_pos in ("E", "W") and v_pos in ("N", "S"):
+        kind = "C"
+    else:
+        raise RuntimeError("Unknown Arakawa grid type")
+    per = haversine(SW, SE) + haversine(SE, NE) + haversine(NE, NW) + haversine(NW, SW)
+    return kind, u_pos, v_pos, (ud[u_pos] + vd[v_pos]) / per
+
+
+def bgrid_to_cgrid(u, v, fill, lonv, latv):
+    """interpolateontodefaultCgrid(…, ::BGridCell), gridcellgeometry.jl:106-140, by scalar loops."""
+    nx, ny, nz = u.shape
+    rep = lambda x: 0.0 if (x == fill or (x != x and fill != fill)) else float(x)  # replace(u, _FillValue => 0.0)
+    u2 = np.empty(u.shape, order="F")
+    v2 = np.empty(u.shape, order="F")
+    for k in range(nz):
+        for j in range(ny):
+            for i in range(nx):
+                us = 0.0 if j == 0 else rep(u[i, j - 1, k])
+                vw = 0.0 if i == 0 else rep(v[i - 1, j, k])
+                u2[i, j, k] = 0.5 * (rep(u[i, j, k]) + us)
+                v2[i, j, k] = 0.5 * (rep(v[i, j, k]) + vw)
+    pts = [np.empty((nx, ny), order="F") for _ in range(4)]
+    for j in range(ny):
+        for i in range(nx):
+            SE = (float(lonv[1, i, j]), float(latv[1, i, j]))
+            NE = (float(lonv[2, i, j]), float(latv[2, i, j]))
+            NW = (float(lonv[3, i, j]), float(latv[3, i, j]))
+            pts[0][i, j], pts[1][i, j] = midpointonsphere(NE, SE)  # zip(NE_points, SE_points), :131
+            pts[2][i, j], pts[3][i, j] = midpointonsphere(NW, NE)  # zip(NW_points, NE_points), :132
+    return u2, pts[0], pts[1], v2, pts[2], pts[3]
+
+
 # ---- velocity2fluxes / fluxes2velocity: src/velocities.jl:10-39, :50-74 -----------------------------
 def nanmean2(a, b):  # :89-93 (false * NaN == 0.0 in Julia)
     wa, wb = not math.isnan(a), not math.isnan(b)

@@ -41,15 +41,51 @@ def test_oracle_velocity_flux_bipolar_raises(oracle):
         oracle.velocity_flux(u, v, 1035.0, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], 0)
 
 
-def test_getarakawagrid_detects_c_grid():
+def _bgrid_fields(gm, dtype, seed=8):
+    rng = np.random.default_rng(seed)
+    wet = ~np.isnan(gm.v3D)
+    fill = float(dtype(1e20))
+    u = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, fill).astype(dtype))
+    v = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, fill).astype(dtype))
+    return u, v, fill
+
+
+@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_bipolar", "odd_nx_fold"])
+def test_getarakawagrid_host_detection_matches_oracle_and_transliteration(oracle, name):
+    """getarakawagrid (gridcellgeometry.jl:50-95): the product's host detection, the oracle's C restatement and the
+    literal Python transliteration agree on A-, B- (all four corners) and C-grid placements, and on what is none of them."""
     from otmb_amd.gridmetrics import getarakawagrid
 
-    g, gm = make_case("tiny_tripolar")
+    g, gm = make_case(name)
     u, u_lon, u_lat, v, v_lon, v_lat = _velocities(g, gm)
-    assert getarakawagrid(u_lon, u_lat, v_lon, v_lat, gm) == ("C", "E", "N")
-    assert getarakawagrid(gm.lon, gm.lat, gm.lon, gm.lat, gm)[0] == "A"
-    ne_lon, ne_lat = gm.lon_vertices[2], gm.lat_vertices[2]
-    assert getarakawagrid(ne_lon, ne_lat, ne_lon, ne_lat, gm) == ("B", "NE", "NE")
+    lv, tv = gm.lon_vertices, gm.lat_vertices
+    placements = {"C": (u_lon, u_lat, v_lon, v_lat), "A": (gm.lon, gm.lat, gm.lon, gm.lat),
+                  "C_WS": ((lv[0] + lv[3]) / 2, (tv[0] + tv[3]) / 2, (lv[0] + lv[1]) / 2, (tv[0] + tv[1]) / 2)}
+    for q, corner in enumerate(("SW", "SE", "NE", "NW")):
+        placements["B_" + corner] = (lv[q], tv[q], lv[q], tv[q])
+    for label, (ul, ut, vl, vt) in placements.items():
+        want = oracle.getarakawagrid(ul, ut, vl, vt, gm)
+        assert want[:3] == pyref.getarakawagrid(ul, ut, vl, vt, gm.lon, gm.lat, lv, tv)[:3], label
+        assert getarakawagrid(ul, ut, vl, vt, gm) == want[:3], label
+        assert want[0] == label[0] and want[3] < 1e-9
+    assert oracle.getarakawagrid(u_lon, u_lat, v_lon, v_lat, gm)[:3] == ("C", "E", "N")
+    # u on a corner, v in the centre: none of the three
+    with pytest.raises(oracle.OracleError):
+        oracle.getarakawagrid(lv[2], tv[2], gm.lon, gm.lat, gm)
+    with pytest.raises(RuntimeError, match="Unknown Arakawa grid type"):
+        getarakawagrid(lv[2], tv[2], gm.lon, gm.lat, gm)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_oracle_bgrid_interpolation_matches_transliteration(oracle, dtype):
+    g, gm = make_case("tiny_tripolar")
+    u, v, fill = _bgrid_fields(gm, dtype)
+    got = oracle.bgrid_to_cgrid(u, v, fill, gm)
+    want = pyref.bgrid_to_cgrid(u.astype(np.float64), v.astype(np.float64), fill, gm.lon_vertices, gm.lat_vertices)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # the interpolated points are the east / north face midpoints: a C-grid as far as getarakawagrid is concerned
+    assert oracle.getarakawagrid(got[1], got[2], got[4], got[5], gm)[:3] == ("C", "E", "N")
 
 
 @pytest.mark.gpu
@@ -96,28 +132,21 @@ def test_hip_velocity2fluxes_bipolar_is_an_error():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_hip_bgrid_interpolation(oracle, dtype):
-    """interpolateontodefaultCgrid(…, ::BGridCell) (gridcellgeometry.jl:106-140) against its array expression."""
+    """interpolateontodefaultCgrid(…, ::BGridCell) (gridcellgeometry.jl:106-140): the HIP path against the oracle's
+    restatement -- fields and the six returned arrays, bit for bit."""
     import otmb_amd.api as api
     from otmb_amd import Cube
 
     g, gm = make_case("small_rho3d")
-    rng = np.random.default_rng(8)
-    wet = ~np.isnan(gm.v3D)
-    fill = float(dtype(1e20))
-    u = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, fill).astype(dtype))
-    v = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, fill).astype(dtype))
+    u, v, fill = _bgrid_fields(gm, dtype)
     ne_lon, ne_lat = gm.lon_vertices[2], gm.lat_vertices[2]  # B-grid: both velocity points on the NE corner
+    assert oracle.getarakawagrid(ne_lon, ne_lat, ne_lon, ne_lat, gm)[:3] == ("B", "NE", "NE")
     u2, u2_lon, u2_lat, v2, v2_lon, v2_lat = api.interpolateontodefaultCgrid(Cube(u, _FillValue=fill), ne_lon, ne_lat,
                                                                               Cube(v, _FillValue=fill), ne_lon, ne_lat, gm)
-    ur = np.where(u.astype(np.float64) == fill, 0.0, u.astype(np.float64))
-    vr = np.where(v.astype(np.float64) == fill, 0.0, v.astype(np.float64))
-    us = np.zeros_like(ur); us[:, 1:, :] = ur[:, :-1, :]
-    vw = np.zeros_like(vr); vw[1:, :, :] = vr[:-1, :, :]
-    assert np.array_equal(u2, 0.5 * (ur + us)) and np.array_equal(v2, 0.5 * (vr + vw))
-    # the interpolated points are the east / north face midpoints: a C-grid as far as getarakawagrid is concerned
-    from otmb_amd.gridmetrics import getarakawagrid
-
-    assert getarakawagrid(u2_lon, u2_lat, v2_lon, v2_lat, gm) == ("C", "E", "N")
+    want = oracle.bgrid_to_cgrid(u, v, fill, gm)
+    for name, a, b in zip(("u2", "u2_lon", "u2_lat", "v2", "v2_lon", "v2_lat"), (u2, u2_lon, u2_lat, v2, v2_lon, v2_lat), want):
+        assert np.array_equal(np.asarray(a), b), name
+    assert oracle.getarakawagrid(u2_lon, u2_lat, v2_lon, v2_lat, gm)[:3] == ("C", "E", "N")
     # and the whole chain runs: B-grid velocities -> fluxes, same as feeding the interpolated fields directly
     fi, fj = api.velocity2fluxes(Cube(u, _FillValue=fill), ne_lon, ne_lat, Cube(v, _FillValue=fill), ne_lon, ne_lat, gm, g.rho)
     ri, rj = oracle.velocity_flux(u2, v2, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], gm.gridtopology.kind)
