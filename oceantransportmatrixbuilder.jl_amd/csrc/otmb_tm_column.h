@@ -49,6 +49,24 @@ struct TmParams {
     int *flags;
 };
 
+// Diagnostic build only (-DOTMB_DBG_STAMPS, tools/stamps.py): s_memtime stamps of the phases of a wave of the fill
+// pass, kept in SGPR pairs and written by lane 0 at the end to a buffer nothing else reads (p.status).  STAMP(n, WAITVM)
+// with WAITVM drains the wave's vector-memory operations first, so the stamp says when the loads were back.
+#ifdef OTMB_DBG_STAMPS
+#define OTMB_NSTAMP 8
+struct Stamps { unsigned long long t[OTMB_NSTAMP]; };
+#define STAMP(st, n, WAITVM)                                                                              \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (WAITVM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"((st).t[n])::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    } while (0)
+#else
+struct Stamps {};
+#define STAMP(st, n, WAITVM) do { } while (0)
+#endif
+
 // slots of a column: the cells that can hold a row of column c
 enum { S_A = 0, S_S = 1, S_SELF = 2, S_EC = 3, S_WC = 4, S_FQ = 5, S_N = 6, S_B = 7, NSLOT = 8 };
 
@@ -332,7 +350,7 @@ __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(c
 // The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
 template <bool CHECKS>
 __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
-                                            i64 c, Column &col) {
+                                            i64 c, Column &col, Stamps &st) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
     const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
@@ -394,6 +412,7 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
     const double ar = ldv((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
     const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
 
+    STAMP(st, 2, 1);  // every stencil load is back
     const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
     const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
 

@@ -231,6 +231,11 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     __shared__ int s_tile;
     __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // rows, then value bits
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    Stamps st;
+#ifdef OTMB_DBG_STAMPS
+    for (int q = 0; q < OTMB_NSTAMP; ++q) st.t[q] = 0;
+#endif
+    STAMP(st, 0, 0);
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
     // contiguous eighth of the tiles, so that a tile's south/north rows and the levels above/below, which
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         const i64 L = p.lwet[w] - 1;
         const i64 Lnext = (w + 1 < p.n_own) ? p.lwet[w + 1] - 1 : p.G;
         const i64 c = p.wet_base + w + 1;  // this column's (global) wet rank
+        STAMP(st, 1, 1);  // Lwet is back
         // Lwet ascending inside [Lmin, Lmax] and Lwet3D[Lwet[w]] == w + 1: together they make the wet
         // rank monotone in the linear index, which is what orders the rows of a column
         if (L < Lmin || L > Lmax || Lnext <= L) {
@@ -314,9 +320,9 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
                 {
 #ifdef OTMB_CHECKS_IN_FILL
-                    if (regular) fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col);
+                    if (regular) fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
 #else
-                    if (regular) fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col);  // the input checks ran with the counts
+                    if (regular) fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
 #endif
 #ifdef OTMB_DBG_NOGENERIC  // timing experiment only (wrong on the seam row)
                     else { col.padv = col.phh = col.pml = col.pdp = 0; }
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         }
     }
 
+    STAMP(st, 3, 0);  // the column's arithmetic is done
     // ---- 2. packed block scan: T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 bits ----
     const u64 mine = (u64)nU | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43);
     u64 incl = mine;
@@ -409,6 +416,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         }
     }
 
+    STAMP(st, 4, 0);  // the tile's offsets are known
     // ---- 4. write: colptr, then LDS-staged entries ----
     // Each wave stages the entries of ITS 64 columns in its own LDS region and streams them out itself:
     // a wave's columns are contiguous, so its entries of matrix m are one contiguous run starting at
@@ -504,6 +512,15 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef OTMB_DBG_STAMPS
+    STAMP(st, 5, 0);  // every store is issued
+    STAMP(st, 6, 1);  // ... and acknowledged
+    if (MODE == MODE_FILL && p.status && lane == 0) {
+        u64 *o = p.status + ((u64)tile * (TM_THREADS / 64) + wid) * OTMB_NSTAMP;
+        for (int q = 0; q < 7; ++q) o[q] = st.t[q];
+        o[7] = (u64)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: CU / SIMD / wave slot
+    }
+#endif
 }
 
 // closing colptr entry of each matrix: nnz_base + nnz + 1 (values known on the host since the plan)
@@ -800,6 +817,16 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     return OTMB_OK;
 }
 
+#ifdef OTMB_DBG_STAMPS
+// diagnostic build only: copy the stamp buffer of the last asynchronous fill pass to the host (tools/stamps.py)
+int32_t otmb_debug_stamps(otmb_ctx *ctx, uint64_t *host, int64_t n_words) {
+    if (!ctx || !host || !ctx->lookback.p || (size_t)n_words * 8 > ctx->lookback.cap) return OTMB_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host, ctx->lookback.p, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    return OTMB_OK;
+}
+#endif
+
 int32_t otmb_transportmatrix_failed_step(otmb_ctx *ctx, int64_t *step) {
     if (!ctx || !step) return OTMB_ERR_INVALID_ARG;
     *step = ctx->tm_failed_step;
@@ -900,6 +927,10 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
             }
         }
         {
+#ifdef OTMB_DBG_STAMPS
+            if ((rc = otmb_reserve(ctx, ctx->lookback, (size_t)ntiles * (TM_THREADS / 64) * OTMB_NSTAMP * sizeof(u64)))) return rc;
+            p.status = (u64 *)ctx->lookback.p;
+#endif
             KernelTimer kt(ctx, K_TM_FILL);
             hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
         }
