@@ -348,8 +348,9 @@ __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(c
 
 // CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
 // The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
+// Returns whether Lwet3D holds c at the cell itself (the canonical-indices check, loaded with the stencil).
 template <bool CHECKS>
-__device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
+__device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
                                             i64 c, Column &col, Stamps &st) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
@@ -363,8 +364,8 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
     const unsigned sS = hS ? s2 - nx8 : s2, sN = hN ? s2 + nx8 : s2;
 
     // ---- all loads ----
-    const i64 lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN), lA = ldi(tb.lw, oA),
-              lB = ldi(tb.lw, oB);
+    const i64 lC = ldi(tb.lw, oC), lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN),
+              lA = ldi(tb.lw, oA), lB = ldi(tb.lw, oB);
     const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
                  gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
     double qW0 = 0, qE0 = 0, qS0 = 0, qN0 = 0, qB0 = 0, qT0 = 0;
@@ -538,6 +539,7 @@ __device__ __forceinline__ void fast_column(const TmParams &p, const TileBase &t
             col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
         }
     }
+    return lC == c;
 }
 
 // Presence only (regular cells): which rows the four operator matrices hold in this column -- a function

@@ -228,6 +228,7 @@ template <int MODE>
 __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
+    __shared__ unsigned s_presum[TM_NF];
     __shared__ int s_tile;
     __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // rows, then value bits
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -269,6 +270,19 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         for (int q = 0; q < TM_THREADS / 64; ++q) early_all += wave_tot[q];
         __syncthreads();  // wave_tot is reused by the block scan below
         if (wid == 0) tm_lookback(p, tile, lane, early_all, s_prefix);
+    }
+    // The tile's reserved offsets (counting pass + scan) do not depend on anything this workgroup computes: their loads
+    // are issued first, so that this memory round trip runs beside the Lwet and stencil round trips instead of after
+    // the arithmetic (measured with tools/stamps.py: the late fetch held every wave for ~15 % of its life).
+    unsigned pre_sum = 0;
+    i64 pre_off = 0;
+    if (MODE == MODE_FILL && tid < TM_NF) {
+        pre_sum = p.tilesums[tile * TM_NF + tid];
+        pre_off = p.tileoffs[tile * TM_NF + tid];
+        if (p.gsum) {  // offsets are relative to the tile's scan group: add the totals of the groups before it
+            const i64 g = tile / OTMB_SCAN_GROUP;
+            for (i64 q = 0; q < g; ++q) pre_off += p.gsum[q * TM_NF + tid];
+        }
     }
     const i64 w0 = tile * TM_THREADS;
     const i64 w = w0 + tid;
@@ -314,22 +328,29 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         } else {
             const Cell cell = cell_of(L, p.nx, p.ny, p.P);
             const unsigned oC = (unsigned)(L - base_elem) * 8u;
-            if (ldi(tb.lw, oC) != c) {
-                raise_flag(p.flags, FLAG_NONCANONICAL);
-            } else {
-                const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
-                {
+            // Lwet3D[Lwet[w]] == w + 1 is verified with a load that travels WITH the stencil loads (every stencil address
+            // follows from L and the tile's base, none from Lwet3D's contents, so nothing is read out of bounds if the
+            // check fails): a separate round trip in front of them cost every wave ~12 % of its life.
+            bool canonical;
+            const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
+            {
 #ifdef OTMB_CHECKS_IN_FILL
-                    if (regular) fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
+                if (regular) canonical = fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
 #else
-                    if (regular) fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
+                if (regular) canonical = fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
 #endif
 #ifdef OTMB_DBG_NOGENERIC  // timing experiment only (wrong on the seam row)
-                    else { col.padv = col.phh = col.pml = col.pdp = 0; }
+                else { canonical = true; col.padv = col.phh = col.pml = col.pdp = 0; }
 #else
-                    else build_column(p, cell, c, col);
-#endif
+                else {
+                    canonical = ldi(tb.lw, oC) == c;
+                    if (canonical) build_column(p, cell, c, col);
                 }
+#endif
+            }
+            if (!canonical) {
+                raise_flag(p.flags, FLAG_NONCANONICAL);
+            } else {
                 live = true;
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
                 nU = __popc(uni);
@@ -358,6 +379,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         if (lane >= d) incl += y;
     }
     if (lane == 63) wave_tot[wid] = incl;
+    if (MODE == MODE_FILL && tid < TM_NF) {  // the offsets fetched at the top travel through the scan's barrier
+        s_prefix[tid] = pre_off;
+        s_presum[tid] = pre_sum;
+    }
     __syncthreads();
     u64 before = 0, all = 0;
 #pragma unroll
@@ -377,30 +402,21 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         if (tid == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
         return;
     }
-    if (MODE == MODE_FILL) {
-        // The space of this tile was reserved by the counting pass from the push mask.  A mask that does not
-        // describe these ϕ / Lwet3D (stale, or not a makeindices result) would make the two passes disagree:
-        // compare the tile's counts and write nothing on a mismatch (-1 = poisoned offset).
-        if (tid < TM_NF) {
-            unsigned mine_agg = 0;
-#pragma unroll
-            for (int m = 0; m < TM_NF; ++m)
-                if (m == tid) mine_agg = agg[m];
-            i64 base = 0;
-            if (p.gsum) {  // offsets are relative to the tile's scan group: add the totals of the groups before it
-                const i64 g = tile / OTMB_SCAN_GROUP;
-                for (i64 q = 0; q < g; ++q) base += p.gsum[q * TM_NF + tid];
-            }
-            s_prefix[tid] = (p.tilesums[tile * TM_NF + tid] == mine_agg) ? p.tileoffs[tile * TM_NF + tid] + base : -1;
-        }
-    }
-    __syncthreads();
+    if (MODE == MODE_ONEPASS) __syncthreads();  // s_prefix comes from the look-back of wave 0
     i64 g0[5];
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) g0[m] = s_prefix[m];  // entries of matrix m before this tile (this launch)
-    if (MODE == MODE_FILL && (g0[0] | g0[1] | g0[2] | g0[3] | g0[4]) < 0) {
-        if (tid == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
-        return;
+    if (MODE == MODE_FILL) {
+        // The space of this tile was reserved by the counting pass from the push mask.  A mask that does not
+        // describe these ϕ / Lwet3D (stale, or not a makeindices result) would make the two passes disagree:
+        // compare the tile's counts and write nothing on a mismatch.
+        bool same = true;
+#pragma unroll
+        for (int m = 0; m < TM_NF; ++m) same &= s_presum[m] == agg[m];
+        if (!same) {
+            if (tid == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
+            return;
+        }
     }
 
     if (w0 + TM_THREADS >= p.n_own) {  // last tile: the closing colptr entry (and the totals, if no scan produced them)
