@@ -5,19 +5,25 @@ One "step" = one pass of the hot path over one (umo, vmo) field, all device resi
     facefluxesfrommasstransport -> transportmatrix (T, Tadv, TκH, TκVML, TκVdeep in CSC)
 Inputs are in HBM before the timed region starts and the five CSC matrices are left in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload access1deg|quarterdeg|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload access1deg|quarterdeg|tenthdeg|small]
+                    [--scaling weak|strong] [--repeats R]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is partitioned in depth,
-see otmb_amd/dist.py; value = wet cells of all ranks / max-over-ranks time.
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU.  Launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the environment) each process
+is one rank; launched plainly (`python bench.py --gpus N`) this process only SPAWNS the N ranks -- before anything here
+touches a GPU -- relays rank 0's JSON line and exits with the worst return code.  The grid is partitioned in depth
+(otmb_amd/dist.py):
+    --scaling weak   (default) the global grid is the workload's horizontal grid with nz*N levels: per-GPU work fixed;
+    --scaling strong the workload's own grid (e.g. --workload quarterdeg: BASELINE.json configs[3], the fixed
+                     1440x1080x75 grid) cut into N depth slabs with balanced wet counts: total work fixed.
+value = wet cells of all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,9 +36,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated R times; ms_per_step is the median")
     ap.add_argument("--workload", default="access1deg")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--rho", default="array", choices=["array", "scalar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--seed", type=int, default=20260501)
     ap.add_argument("--protocol", default="async", choices=["async", "twophase"],
                     help="async: otmb_transportmatrix_dev (count -> scan -> fill enqueued back to back, outputs preallocated "
@@ -40,7 +49,31 @@ def parse():
     args = ap.parse_args()
     args.steps = max(1, args.steps)
     args.warmup = max(0, args.warmup)
+    args.repeats = max(1, args.repeats)
     return args
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never
+    initialises a GPU and never re-executes itself), relay rank 0's JSON line."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    line = next((l for l in out.splitlines() if l.startswith("{")), None)
+    if line:
+        print(line, flush=True)
+    return max(abs(rc) for rc in rcs) or (0 if line else 1)
 
 
 def cpu_baseline(g, gm, workload, reps=5):
@@ -48,6 +81,8 @@ def cpu_baseline(g, gm, workload, reps=5):
     3 sparse adds) timed on this box's host cores over the same workload: 1 warm-up + median of `reps`
     passes.  kind = "port": the Julia reference cannot run here (no julia binary; SURVEY.md
     section 8c)."""
+    import numpy as np
+
     from oracle import oracle as orc
 
     orc.build()
@@ -92,8 +127,47 @@ def cpu_baseline(g, gm, workload, reps=5):
     }
 
 
+def kernel_source_hash():
+    """profiles/traffic.json holds counter traffic measured for ONE version of the dominant kernel: it is keyed to a hash of
+    the kernel's sources and ignored (traffic: null) when they have changed since."""
+    h = hashlib.sha256()
+    for f in ("otmb_transportmatrix.hip", "otmb_tm_column.h", "otmb_facefluxes.hip"):
+        with open(os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def end_to_end(g, gm, asm_N, reps=3):
+    """What a Julia caller of the host-pointer C ABI sees (PCIe included; never `value`): facefluxesfrommasstransport +
+    transportmatrix through otmb_amd.api on host arrays, median of `reps` after one warm-up."""
+    import numpy as np
+
+    import otmb_amd
+    import otmb_amd.api as api
+
+    idx = api.makeindices(gm.v3D)
+    ts = []
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+        t1 = time.perf_counter()
+        api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML,
+                            κVdeep=g.kappaVdeep)
+        t2 = time.perf_counter()
+        if rep:
+            ts.append((t1 - t0, t2 - t1))
+    ff = float(np.median([a for a, _ in ts]))
+    tm = float(np.median([b for _, b in ts]))
+    return {"value": asm_N / (ff + tm), "unit": "wet-cells/s", "facefluxes_ms": 1e3 * ff, "transportmatrix_ms": 1e3 * tm,
+            "note": "host-pointer C ABI (what a Julia ccall passes): host arrays in, five host CSC matrices out, PCIe both ways"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -107,15 +181,19 @@ def main():
     # OTMB_FORCE_SLAB=1: take the depth-slab (distributed) code path even with one rank, e.g. under
     # `torchrun --nproc-per-node 1`, to exercise RCCL initialisation and collectives on a one-GPU box
     force_slab = os.environ.get("OTMB_FORCE_SLAB") == "1" and "RANK" in os.environ
+    # OTMB_BENCH_CHECKER_BACKEND=1 (tests only): rehearse the multi-rank orchestration of this script on a box without
+    # GPUs -- gloo, the CPU checker backend of tests/ -- the line it prints is labelled as not being a measurement
+    rehearsal = os.environ.get("OTMB_BENCH_CHECKER_BACKEND") == "1"
     saved_stdout_fd = None
+    backend = os.environ.get("OTMB_DIST_BACKEND", "gloo" if rehearsal else "nccl")
     if world > 1 or force_slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # OTMB_DIST_BACKEND=gloo + OTMB_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
-        backend = os.environ.get("OTMB_DIST_BACKEND", "nccl")
         if os.environ.get("OTMB_SHARE_GPU") == "1":
             local_rank = 0
-        torch.cuda.set_device(local_rank)
+        if not rehearsal:
+            torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on the process's stdout when its first communicator comes up; stdout must carry
         # exactly one JSON line, so file descriptor 1 points at stderr until the result is printed
         sys.stdout.flush()
@@ -126,33 +204,36 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
 
     nx, ny, nz, lf = synthetic.PRESETS[args.workload]
+    host_grid = None  # (g, gm) when the whole grid also exists on the host (cpu_baseline / end_to_end legs)
     if world > 1 or force_slab:
-        # weak scaling: the global grid is nx x ny x (nz*world) (levels stretched over the same depth), cut
-        # into `world` depth slabs with balanced wet counts; every rank generates only its own levels
         from otmb_amd import dist as odist
+        from otmb_amd import synthetic_device
 
-        nzg = nz * world
+        # weak: nz*world levels stretched over the same depth, per-GPU work fixed; strong: the workload's own grid
+        nzg = nz * world if args.scaling == "weak" else nz
         counts = synthetic.level_wet_counts(nx, ny, nzg, seed=args.seed, land_fraction=lf)
         k0, k1 = odist.balanced_partition(counts, world)[rank]
-        g = synthetic.make_slab(nx, ny, nzg, k0, k1, seed=args.seed, land_fraction=lf, rho=args.rho)
-        gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat,
-                                      lev=g.lev[k0:k1], lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
-        local = odist.make_local_grid(gm, g.mlotst, g.rho, k0, k1, nzg, g.lev,
-                                      kappa=(g.kappaH, g.kappaVML, g.kappaVdeep), upwind=True)
-        be = odist.HipSlabBackend(local_rank)
+        # every rank generates only its own levels, on its own device
+        dg = synthetic_device.make_device_grid((nx, ny, nzg), dev, seed=args.seed, land_fraction=lf, rho=args.rho, k0=k0, k1=k1)
+        local = odist.make_local_grid_from_device(dg)
+        if rehearsal:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from slab_checker_backend import OracleSlabBackend
+
+            be = OracleSlabBackend()
+        else:
+            be = odist.HipSlabBackend(local_rank)
         srun = odist.SlabRunner(be, odist.Comm(), local)
-        umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
-        vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
-        fill = g.umo.properties["_FillValue"]
+        umo, vmo, fill = dg.umo, dg.vmo, dg.fill
 
         class _Slab:
             n_wet_total = srun.n_global
-            ctx = be.ctx
-
+            ctx = getattr(be, "ctx", None)
             pending = False
+            slab = (k0, k1, nzg)
 
             def step(self):
                 if args.protocol == "async":
@@ -180,26 +261,34 @@ def main():
 
         runner = _Slab()
     else:
-        g = synthetic.make_grid(nx, ny, nz, seed=args.seed, land_fraction=lf, rho=args.rho)
-        gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
-                                      lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
-        asm = DeviceAssembler(local_rank)
-        asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep, upwind=True)
-        umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
-        vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
-        fill = g.umo.properties["_FillValue"]
+        if args.workload in ("quarterdeg", "tenthdeg"):  # too large to build on the host and copy: generated on the device
+            from otmb_amd import synthetic_device
+
+            dg = synthetic_device.make_device_grid(args.workload, dev, seed=args.seed, rho=args.rho)
+            asm = synthetic_device.assembler_for(dg, local_rank)
+            umo, vmo, fill = dg.umo, dg.vmo, dg.fill
+        else:
+            g = synthetic.make_grid(nx, ny, nz, seed=args.seed, land_fraction=lf, rho=args.rho)
+            gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
+                                          lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
+            host_grid = (g, gm)
+            asm = DeviceAssembler(local_rank)
+            asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep, upwind=True)
+            umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
+            vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
+            fill = g.umo.properties["_FillValue"]
 
         class _Single:
             n_wet_total = asm.N
             ctx = asm.ctx
-
             pending = False
+            slab = (0, nz, nz)
 
             def step(self):
-                if args.protocol == "async":
+                if args.protocol == "async" and args.workload != "tenthdeg":
                     asm.step_async(umo, vmo, fill)  # no host round trip inside a step; errors surface in sync()
                     self.pending = True
-                else:
+                else:  # (the upper-bound output buffers of the asynchronous protocol do not fit at 0.1 degree)
                     asm.step(umo, vmo, fill, onepass=False)
 
             def sync(self):
@@ -223,71 +312,90 @@ def main():
     def barrier():
         if dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         runner.step()
     runner.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step()
-    runner.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # EXACTLY K steps between two barrier + synchronize brackets, max over ranks; repeated R times: the pool's boxes
+    # differ by ~15 % and a single 10 ms region says little, so the median is reported with the spread beside it
+    per_repeat = []
+    for _ in range(args.repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.step()
+        runner.sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_repeat.append(elapsed)
+    elapsed = float(np.median(per_repeat))
 
-    # per-kernel durations with HIP events on the launch stream, over a second pass of the same K steps
-    runner.ctx.timing_enable(True)
-    for _ in range(args.steps):
-        runner.step()
-    runner.sync()
-    ktimes = runner.ctx.timing_collect()
-    runner.ctx.timing_enable(False)
+    # per-kernel durations with HIP events on the launch stream, over one more pass of the same K steps
+    ktimes = {}
+    if runner.ctx is not None:
+        runner.ctx.timing_enable(True)
+        for _ in range(args.steps):
+            runner.step()
+        runner.sync()
+        ktimes = runner.ctx.timing_collect()
+        runner.ctx.timing_enable(False)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         n_total = runner.n_wet_total
         value = n_total * args.steps / elapsed
         kavg = {k: v[0] / v[1] for k, v in ktimes.items()}
-        dom = max(kavg, key=kavg.get)
-        bytes_alg = runner.algorithmic_bytes() if dom.startswith("tm_kernel") else runner.facefluxes_bytes()
-        achieved = bytes_alg / (kavg[dom] * 1e-3) / 1e9
-        # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same
-        # command (profiles/traffic.json; bytes do not depend on the box, unlike times)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("workload") == args.workload and world == 1 and args.rho == "array":
-                traffic = tj["kernels"].get(dom, {}).get("traffic_bytes")
-        except (OSError, ValueError):
-            pass
+        roof = None
+        if kavg:
+            dom = max(kavg, key=kavg.get)
+            bytes_alg = runner.algorithmic_bytes() if dom.startswith("tm_kernel") else runner.facefluxes_bytes()
+            achieved = bytes_alg / (kavg[dom] * 1e-3) / 1e9
+            # HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+            # command (profiles/traffic.json) -- valid only for the kernel sources they were measured on
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if (tj.get("workload") == args.workload and world == 1 and args.rho == "array"
+                        and tj.get("kernel_source_sha16") == kernel_source_hash()):
+                    traffic = tj["kernels"].get(dom, {}).get("traffic_bytes")
+            except (OSError, ValueError):
+                pass
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg,
+                    "avg_kernel_ms": kavg[dom]}
+        k0, k1, nzg = runner.slab
+        if world > 1:
+            shape = (f"{nx}x{ny}x{nzg} cut into {world} depth slabs (rank 0: levels [{k0},{k1}))"
+                     + (f"; weak scaling: {nz} levels per rank" if args.scaling == "weak" else "; strong scaling: fixed grid"))
+        else:
+            shape = f"{nx}x{ny}x{nz}"
         out = {
-            "metric": "wet-cells/s assembled into T", "value": value, "unit": "wet-cells/s",
+            "metric": "wet-cells/s assembled into T" if not rehearsal else "REHEARSAL of the multi-rank orchestration (CPU checker backend): not a measurement",
+            "value": value, "unit": "wet-cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: synthetic ACCESS-ESM1-5-like tripolar grid {nx}x{ny}x{nz}"
-                            + (f" per rank, stacked in depth x{world}" if world > 1 else "")
-                            + f", facefluxes + full transportmatrix (5 CSC matrices), rho={args.rho}, upwind",
+                "workload": f"{args.workload}: synthetic ACCESS-ESM1-5-like tripolar grid {shape}"
+                            f", facefluxes + full transportmatrix (5 CSC matrices), rho={args.rho}, upwind",
                 "wet_cells": n_total, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), runner.nnz)),
-                "seed": args.seed,
+                "seed": args.seed, "protocol": args.protocol,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_alg, "avg_kernel_ms": kavg[dom],
-            },
+            "repeats": {"n": args.repeats, "ms_per_step_median": ms_step, "ms_per_step_min": 1e3 * min(per_repeat) / args.steps,
+                        "ms_per_step_max": 1e3 * max(per_repeat) / args.steps},
+            "roofline": roof,
             "kernels_ms": {k: round(v, 5) for k, v in kavg.items()},
-            "step_gbs": (runner.algorithmic_bytes() + runner.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
+            "step_gbs": None if rehearsal else (runner.algorithmic_bytes() + runner.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(g, gm, args.workload)
-        elif world == 1:
-            out["cpu_baseline"] = None
+        if world == 1 and host_grid is not None and not rehearsal:
+            out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
+            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
         sys.stdout.flush()
         if saved_stdout_fd is not None:
             os.dup2(saved_stdout_fd, 1)
@@ -295,6 +403,7 @@ def main():
         if saved_stdout_fd is not None:
             os.dup2(2, 1)  # anything the communicator says while shutting down goes to stderr too
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

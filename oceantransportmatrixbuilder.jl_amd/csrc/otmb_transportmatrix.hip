@@ -237,6 +237,14 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     for (int q = 0; q < OTMB_NSTAMP; ++q) st.t[q] = 0;
 #endif
     STAMP(st, 0, 0);
+#ifdef OTMB_STAGGER_UNITS
+    // Experiment: the workgroups of the first dispatch round start together and march through their phases (loads,
+    // arithmetic, stores) in lockstep; delay the k-th workgroup of a CU by k * OTMB_STAGGER_UNITS * 64 * 127 cycles
+    if (MODE == MODE_FILL && blockIdx.x < 1024) {
+        const int slot = blockIdx.x / 256;
+        for (int q = 0; q < slot * OTMB_STAGGER_UNITS; ++q) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
     // contiguous eighth of the tiles, so that a tile's south/north rows and the levels above/below, which

@@ -96,6 +96,24 @@ class Comm:
         if handle is not None:
             handle[0].wait()
 
+    def irecv(self, t, src):
+        """Non-blocking receive into t; returns a handle for wait_recv.  With RCCL the transfer runs on the communicator's
+        own stream, concurrently with whatever the caller enqueues next on the compute stream."""
+        if self.backend == "gloo" and t.is_cuda:
+            b = torch.empty(t.shape, dtype=t.dtype)
+            return (dist.irecv(b, src), b, t)
+        return (dist.irecv(t, src), None, t)
+
+    @staticmethod
+    def wait_recv(handle):
+        """The current stream (RCCL) or the host (gloo) waits for the receive posted by irecv."""
+        if handle is None:
+            return
+        work, staged, t = handle
+        work.wait()
+        if staged is not None:
+            t.copy_(staged)
+
     def recv(self, t, src):
         if self.backend == "gloo" and t.is_cuda:
             b = torch.empty(t.shape, dtype=t.dtype)
@@ -132,80 +150,79 @@ class SlabRunner:
         self.setup()
 
     def setup(self):
+        """Everything here runs on the backend's device with torch (the CPU for the gloo tests): the slab's own levels
+        arrive as host arrays or as device tensors (make_local_grid), the halo planes arrive over the wire, and the
+        extended local grid (halo + owned + halo), the wet mask and the GLOBAL wet ranks are built where they will be
+        used -- nothing of size G passes through host numpy."""
         g, cm = self.g, self.comm
+        dev = self.device
         nx, ny, nzg = g["nx"], g["ny"], g["nz_global"]
         k0, k1 = g["k0"], g["k1"]
-        P = nx * ny
+        P, nl = nx * ny, k1 - k0
         self.P, self.k0, self.k1 = P, k0, k1
         self.has_above, self.has_below = self.rank > 0, self.rank < self.world - 1
-        wet_own = ~np.isnan(g["v3D"])  # makeindices: wet = !isnan(v3D)  (matrixbuilding.jl:15)
+
+        def flat(a, dtype=torch.float64):  # (nx,ny,nl) host array or flat tensor -> flat tensor on the device (Julia order)
+            if torch.is_tensor(a):
+                return a.to(device=dev, dtype=dtype).reshape(-1)
+            return torch.from_numpy(np.asfortranarray(a, dtype=np.float64).ravel(order="F")).to(device=dev, dtype=dtype)
+
+        v_own, thk_own = flat(g["v3D"]), flat(g["thkcello"])
+        rho3d = None if (not torch.is_tensor(g["rho"]) and np.ndim(g["rho"]) == 0) else flat(g["rho"])
+        wet_own = ~torch.isnan(v_own)  # makeindices: wet = !isnan(v3D)  (matrixbuilding.jl:15)
         counts = np.zeros(nzg, dtype=np.int64)
-        counts[k0:k1] = wet_own.reshape(P, k1 - k0, order="F").sum(axis=0)
-        counts = cm.allreduce_sum_i64(counts, self.device)  # every rank learns every level's wet count
+        counts[k0:k1] = wet_own.view(nl, P).sum(dim=1).cpu().numpy()
+        counts = cm.allreduce_sum_i64(counts, dev)  # every rank learns every level's wet count
         self.level_offset = np.concatenate([[0], np.cumsum(counts)])
         self.n_global = int(self.level_offset[-1])
         self.n_own = int(self.level_offset[k1] - self.level_offset[k0])
         self.wet_base = int(self.level_offset[k0])
 
         # ---- static halo exchange: one boundary level of v3D, rho, wet mask each way ----
-        rho3d = g["rho"] if np.ndim(g["rho"]) else None
         nf = 2 + (rho3d is not None)
 
-        def plane(a, q):
-            return np.ascontiguousarray(np.asarray(a, dtype=np.float64)[:, :, q].ravel(order="F"))
-
         def pack(q):
-            fields = [plane(g["v3D"], q), plane(wet_own.astype(np.float64), q)]
+            sl = slice(q * P, (q + 1) * P)
+            fields = [v_own[sl], wet_own[sl].to(torch.float64)]
             if rho3d is not None:
-                fields.append(plane(rho3d, q))
-            return torch.from_numpy(np.stack(fields)).to(self.device)
+                fields.append(rho3d[sl])
+            return torch.stack(fields).contiguous()
 
-        up_recv = torch.empty((nf, P), dtype=torch.float64, device=self.device) if self.has_above else None
-        dn_recv = torch.empty((nf, P), dtype=torch.float64, device=self.device) if self.has_below else None
+        up_recv = torch.empty((nf, P), dtype=torch.float64, device=dev) if self.has_above else None
+        dn_recv = torch.empty((nf, P), dtype=torch.float64, device=dev) if self.has_below else None
         sends, recvs = [], []
         if self.has_above:
             sends.append((pack(0), self.rank - 1))
             recvs.append((up_recv, self.rank - 1))
         if self.has_below:
-            sends.append((pack(k1 - k0 - 1), self.rank + 1))
+            sends.append((pack(nl - 1), self.rank + 1))
             recvs.append((dn_recv, self.rank + 1))
         cm.exchange(sends, recvs)
 
         # ---- extended local grid: [halo above] + owned + [halo below] ----
         ha, hb = int(self.has_above), int(self.has_below)
-        nze = (k1 - k0) + ha + hb
-        shape = (nx, ny, nze)
+        nze = nl + ha + hb
+        nanp = torch.full((P,), float("nan"), dtype=torch.float64, device=dev)
 
-        def ext(own, up, dn, fillv=np.nan):
-            e = np.full(shape, fillv, dtype=np.float64, order="F")
-            e[:, :, ha:ha + (k1 - k0)] = own
-            if ha:
-                e[:, :, 0] = up.reshape(nx, ny, order="F")
-            if hb:
-                e[:, :, -1] = dn.reshape(nx, ny, order="F")
-            return e
+        def ext(own, up, dn):
+            return torch.cat(([up] if ha else []) + [own] + ([dn] if hb else []))
 
-        upn = up_recv.cpu().numpy() if ha else None
-        dnn = dn_recv.cpu().numpy() if hb else None
-        v_ext = ext(g["v3D"], upn[0] if ha else None, dnn[0] if hb else None)
-        wet_ext = ext(wet_own.astype(np.float64), upn[1] if ha else None, dnn[1] if hb else None, 0.0) > 0.5
-        rho_ext = ext(rho3d, upn[2] if ha else None, dnn[2] if hb else None) if rho3d is not None else g["rho"]
-        thk_ext = ext(g["thkcello"], np.full(P, np.nan), np.full(P, np.nan))  # halos' thickness is never read
+        v_ext = ext(v_own, up_recv[0] if ha else None, dn_recv[0] if hb else None)
+        wet_ext = ext(wet_own, (up_recv[1] > 0.5) if ha else None, (dn_recv[1] > 0.5) if hb else None)
+        rho_ext = ext(rho3d, up_recv[2] if ha else None, dn_recv[2] if hb else None) if rho3d is not None else float(g["rho"])
+        thk_ext = ext(thk_own, nanp, nanp)  # halos' thickness is never read
         # GLOBAL wet ranks of the extended grid: level offset + rank inside the level (+1), 0 = missing
-        lw_ext = np.zeros(shape, dtype=np.int64, order="F")
-        for q in range(nze):
-            kg = k0 - ha + q
-            m = wet_ext[:, :, q].ravel(order="F")
-            r = np.cumsum(m) + self.level_offset[kg]
-            lw_ext[:, :, q] = np.where(m, r, 0).reshape(nx, ny, order="F")
+        offs = torch.from_numpy(self.level_offset[k0 - ha:k0 - ha + nze].astype(np.int64)).to(dev)
+        w2 = wet_ext.view(nze, P)
+        lw_ext = ((torch.cumsum(w2.to(torch.int64), dim=1) + offs[:, None]) * w2).reshape(-1)
         zt_ext = np.asarray(g["zt_global"], dtype=np.float64)[k0 - ha:k1 + hb]
         self.nze, self.ha, self.hb = nze, ha, hb
-        self.be.setup(dict(nx=nx, ny=ny, nz=nze, topology=g["topology"], k_own0=ha, k_own1=ha + (k1 - k0),
+        self.be.setup(dict(nx=nx, ny=ny, nz=nze, topology=g["topology"], k_own0=ha, k_own1=ha + nl,
                            wet_base=self.wet_base, n_own=self.n_own, v3D=v_ext, thkcello=thk_ext, rho=rho_ext,
-                           lwet3d=lw_ext, wet_own=wet_own, zt=zt_ext, edge_length_2D=g["edge_length_2D"],
+                           lwet3d=lw_ext, wet_own=wet_own.to(torch.uint8), zt=zt_ext, edge_length_2D=g["edge_length_2D"],
                            distance_to_neighbour_2D=g["distance_to_neighbour_2D"], area2D=g["area2D"],
                            mlotst=g["mlotst"], kappa=g["kappa"], upwind=g["upwind"]))
-        self.top_below = torch.empty(P, dtype=torch.float64, device=self.device) if self.has_below else None
+        self.top_below = torch.empty(P, dtype=torch.float64, device=dev) if self.has_below else None
         self.n_wet_total = self.n_global
 
     def step(self, umo, vmo, fill):
@@ -249,8 +266,17 @@ class SlabRunner:
         cm.wait_send(getattr(self, "_pending_send", None))  # the plane handed up by the previous field has left
         self._pending_send = None
         if self.has_below:
-            cm.recv(self.top_below, self.rank + 1)
-        top_first = self.be.facefluxes(umo, vmo, fill, self.top_below)
+            # The plane from below was posted as a non-blocking receive BEFORE the previous field's count/fill kernels
+            # were enqueued (see below), so the transfer ran beside them; here the compute stream only waits for it.
+            if getattr(self, "_recv", None) is None:  # first field since setup / finish
+                self._recv_bufs = getattr(self, "_recv_bufs", None) or [self.top_below, torch.empty_like(self.top_below)]
+                self._recv_cur = 0
+                self._recv = cm.irecv(self._recv_bufs[0], self.rank + 1)
+            cm.wait_recv(self._recv)
+            plane = self._recv_bufs[self._recv_cur]
+        else:
+            plane = None
+        top_first = self.be.facefluxes(umo, vmo, fill, plane)
         if self.has_above:
             # the plane goes up from its own buffer without holding back this rank's count/fill kernels: nothing waits
             # for the send until the next field is about to reuse the buffer
@@ -258,6 +284,9 @@ class SlabRunner:
                 self._send_buf = torch.empty_like(top_first)
             self._send_buf.copy_(top_first)
             self._pending_send = cm.isend(self._send_buf, self.rank - 1)
+        if self.has_below:  # the NEXT field's plane (or finish()'s closing message) lands in the other buffer meanwhile
+            self._recv_cur ^= 1
+            self._recv = cm.irecv(self._recv_bufs[self._recv_cur], self.rank + 1)
         self.be.assemble_async()
 
     PIPELINE_DEPTH = 60  # the library keeps the verdicts of its 64 most recent asynchronous calls
@@ -273,6 +302,12 @@ class SlabRunner:
         cm = self.comm
         cm.wait_send(getattr(self, "_pending_send", None))
         self._pending_send = None
+        # every rank with a slab below keeps one receive posted ahead: close it with one last (unused) plane
+        if self.has_above and getattr(self, "_send_buf", None) is not None and getattr(self, "_n_async", 0) > 0:
+            cm.wait_send(cm.isend(self._send_buf, self.rank - 1))
+        if self.has_below and getattr(self, "_recv", None) is not None:
+            cm.wait_recv(self._recv)
+            self._recv = None
         r = self.be.result()  # never raises for the reference's own errors: dict(nnz, u, v, status, step, message)
         D = self.PIPELINE_DEPTH + 4
         n_steps = len(r["u"])
@@ -320,6 +355,9 @@ class HipSlabBackend:
         self.out = None
 
     def _t(self, a, dtype=np.float64):
+        if torch.is_tensor(a):  # already on a device (SlabRunner.setup builds the extended grid there)
+            tdt = {np.float64: torch.float64, np.int64: torch.int64, np.uint8: torch.uint8}[dtype]
+            return a.to(device=self.device, dtype=tdt).reshape(-1).contiguous()
         return torch.from_numpy(np.asfortranarray(a, dtype=dtype).ravel(order="F")).to(self.device)
 
     def setup(self, s):
@@ -329,8 +367,9 @@ class HipSlabBackend:
         self.G = self.P * self.nz
         self.n_own = s["n_own"]
         self.v3d, self.thk, self.lw = self._t(s["v3D"]), self._t(s["thkcello"]), self._t(s["lwet3d"], np.int64)
-        self.rho = None if np.ndim(s["rho"]) == 0 else self._t(s["rho"])
-        self.rho_scalar = float(s["rho"]) if np.ndim(s["rho"]) == 0 else 0.0
+        scalar_rho = not torch.is_tensor(s["rho"]) and np.ndim(s["rho"]) == 0
+        self.rho = None if scalar_rho else self._t(s["rho"])
+        self.rho_scalar = float(s["rho"]) if scalar_rho else 0.0
         self.edge = [self._t(s["edge_length_2D"][d]) for d in HDIRS]
         self.dist_ = [self._t(s["distance_to_neighbour_2D"][d]) for d in HDIRS]
         self.area, self.zt, self.ml = self._t(s["area2D"]), self._t(s["zt"]), self._t(s["mlotst"])
@@ -340,10 +379,9 @@ class HipSlabBackend:
         self.own0 = s["k_own0"] * self.P
         self.nown_lev = s["k_own1"] - s["k_own0"]
         # Lwet of the owned cells: local linear indices (1-based) inside the extended grid, ascending
-        lw = np.asfortranarray(s["lwet3d"]).ravel(order="F")
-        own = np.flatnonzero(lw[self.own0:self.own0 + self.nown_lev * self.P]) + self.own0 + 1
-        assert len(own) == self.n_own
-        self.lwet = torch.from_numpy(own.astype(np.int64)).to(self.device)
+        own = torch.nonzero(self.lw[self.own0:self.own0 + self.nown_lev * self.P]).flatten() + (self.own0 + 1)
+        assert own.numel() == self.n_own
+        self.lwet = own.to(torch.int64).contiguous()
 
     def facefluxes(self, umo, vmo, fill, top_below):
         o, n = self.own0, self.nown_lev * self.P
@@ -483,6 +521,16 @@ def make_local_grid(gridmetrics, mlotst, rho, k0, k1, nz_global, zt_global, kapp
                 v3D=gridmetrics["v3D"], thkcello=gridmetrics["thkcello"], rho=rho, zt_global=zt_global,
                 edge_length_2D=gridmetrics["edge_length_2D"], distance_to_neighbour_2D=gridmetrics["distance_to_neighbour_2D"],
                 area2D=gridmetrics["area2D"], mlotst=mlotst, kappa=kappa, upwind=upwind)
+
+
+def make_local_grid_from_device(dg, upwind=True):
+    """The same bundle from a device-generated slab (synthetic_device.make_device_grid(..., k0=, k1=)): the 3-D fields stay
+    on the device as flat tensors, the replicated 2-D metrics are the host arrays of its gridmetrics."""
+    gm = dg.gm
+    return dict(nx=dg.nx, ny=dg.ny, nz_global=dg.nz, k0=dg.k0, k1=dg.k1, topology=dg.topology, v3D=dg.v3d, thkcello=dg.thkcello,
+                rho=dg.rho, zt_global=dg.zt_host, edge_length_2D=gm["edge_length_2D"],
+                distance_to_neighbour_2D=gm["distance_to_neighbour_2D"], area2D=gm["area2D"], mlotst=dg.mlotst_host,
+                kappa=(dg.kappaH, dg.kappaVML, dg.kappaVdeep), upwind=upwind)
 
 
 def gather_global_csc(comm, local, n_own, nnz, device):

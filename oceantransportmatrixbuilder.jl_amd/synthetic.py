@@ -183,7 +183,9 @@ def _grid2d(nx, ny, nz, seed, land_fraction, topology):
     lat_s = np.deg2rad(latv[0])
     lat_n = np.deg2rad(np.maximum(latv[3], latv[2]))
     area = np.asfortranarray(np.maximum(R * R * np.deg2rad(360.0 / nx) * np.abs(np.sin(lat_n) - np.sin(lat_s)), 1.0e6))
-    scale = max(3, min(nx, ny) // 12)
+    import os
+
+    scale = int(os.environ.get("OTMB_SYN_SCALE", "0")) or max(3, min(nx, ny) // 12)  # (experiments: coarser / finer coastlines)
     f = _smooth_field(rng, nx, ny, scale)
     land = f < np.quantile(f, land_fraction)
     mid = nx // 2

@@ -71,7 +71,7 @@ def make_device_grid(name_or_shape, device, *, seed=20260501, land_fraction=None
         rho_t = 1035.0
     ml = dev2(g2.mlotst)
     del thk, wet, noise
-    return NT(nx=nx, ny=ny, nz=nz, k0=k0, k1=k1, gm=gm, topology=int(gm.gridtopology.kind), fill=FILL, zt_host=zt,
+    return NT(nx=nx, ny=ny, nz=nz, k0=k0, k1=k1, gm=gm, topology=int(gm.gridtopology.kind), fill=FILL, zt_host=zt, mlotst_host=g2.mlotst,
               v3d=v3d.reshape(-1), thkcello=thkc.reshape(-1), umo=umo.reshape(-1), vmo=vmo.reshape(-1), rho=rho_t,
               mlotst=ml.reshape(-1), area2d=d_area.reshape(-1), zt=torch.from_numpy(zt[k0:k1].copy()).to(device),
               edge_length=[dev2(gm.edge_length_2D[d]).reshape(-1) for d in HDIRS],

@@ -42,7 +42,8 @@ def run(rank, world, port, backend_kind, case, outdir):
 
         frank, fstep, kind = fault.split(":")
         frank, fstep = int(frank), int(fstep)
-        lw = np.asfortranarray(be.s["lwet3d"]).ravel(order="F")
+        lw3 = be.s["lwet3d"]
+        lw = lw3.cpu().numpy().ravel() if torch.is_tensor(lw3) else np.asfortranarray(lw3).ravel(order="F")
         P = nx * ny
         own = np.flatnonzero(lw[be.s["k_own0"] * P:be.s["k_own1"] * P]) + be.s["k_own0"] * P
         L = int(own[len(own) // 2])

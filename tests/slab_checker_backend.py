@@ -14,6 +14,13 @@ class OracleSlabBackend:
     device = torch.device("cpu")
 
     def setup(self, s):
+        s = dict(s)
+        shape3 = (s["nx"], s["ny"], s["nz"])
+        for key in ("v3D", "thkcello", "rho", "lwet3d"):  # SlabRunner.setup hands over flat tensors (Julia order)
+            if torch.is_tensor(s[key]):
+                s[key] = np.asfortranarray(s[key].cpu().numpy().reshape(shape3, order="F"))
+        if torch.is_tensor(s["wet_own"]):
+            s["wet_own"] = s["wet_own"].cpu().numpy().reshape((s["nx"], s["ny"], s["k_own1"] - s["k_own0"]), order="F") != 0
         self.s = s
         self.nx, self.ny, self.nz = s["nx"], s["ny"], s["nz"]
         self.P = self.nx * self.ny

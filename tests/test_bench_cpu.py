@@ -1,0 +1,40 @@
+"""bench.py's launcher and multi-rank plumbing on a box without GPUs: `python bench.py --gpus N` (no torchrun) must spawn
+its N ranks itself and print exactly ONE JSON line.  The ranks run the depth-slab orchestration over gloo with the CPU
+checker backend of tests/ (OTMB_BENCH_CHECKER_BACKEND=1) -- the line says that it is a rehearsal, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("gpus,scaling", [(2, "weak"), (3, "strong")])
+def test_bench_spawns_its_ranks_and_prints_one_json_line(gpus, scaling):
+    env = dict(os.environ, OTMB_BENCH_CHECKER_BACKEND="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "small", "--scaling", scaling,
+                        "--steps", "2", "--warmup", "1", "--repeats", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["scaling"] == scaling and d["steps"] == 2 and d["unit"] == "wet-cells/s"
+    assert "REHEARSAL" in d["metric"] and d["roofline"] is None
+    assert f"cut into {gpus} depth slabs" in d["config"]["workload"]
+    nz = 10 * gpus if scaling == "weak" else 10
+    assert f"36x30x{nz}" in d["config"]["workload"]
+
+
+def test_traffic_json_is_keyed_to_the_kernel_sources():
+    """roofline.traffic comes from committed PMC passes: it must name the kernel sources it was measured on."""
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert "kernel_source_sha16" in tj and len(tj["kernel_source_sha16"]) == 16
+    assert len(bench.kernel_source_hash()) == 16
