@@ -70,6 +70,12 @@ int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *hip_stream);
  * library's kernels are then ordered with the caller's own kernels and copies on that stream.                  */
 int32_t otmb_ctx_use_default_stream(otmb_ctx *ctx);
 int32_t otmb_ctx_synchronize(otmb_ctx *ctx);
+/* Host-pointer entry points only.  The grid (gridmetrics, indices) does not change between the time slices a TMIP script
+ * loops over (README.md:65-80), but every call hands the same host arrays over again: with reuse_grid on, a
+ * grid-constant array (v3D, thkcello, Lwet3D, Lwet, wet3D, the 2-D metrics, zt) whose host pointer and size equal those
+ * of the previous upload into its staging slot is NOT copied again -- the caller promises not to have modified it in
+ * between.  Off by default (every call uploads everything, like the reference reads everything).                   */
+int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
 const char *otmb_version(void);

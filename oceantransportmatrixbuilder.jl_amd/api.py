@@ -218,8 +218,18 @@ def bolus_GM_velocity(ρ, gridmetrics, indices, *, κGM=600, maxslope=0.01, devi
     return u, v
 
 
-def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep):
-    v3d = _f64(gridmetrics["v3D"])
+def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, grid_passthrough=None):
+    """grid_passthrough (list): receives False for every grid-constant array that had to be converted (copied) on the way
+    to the C ABI -- a temporary's address says nothing about its content, so reuse_grid must not rely on it."""
+    if grid_passthrough is None:
+        grid_passthrough = []
+
+    def grid(x, conv):
+        y = conv(x)
+        grid_passthrough.append(y is x)
+        return y
+
+    v3d = grid(gridmetrics["v3D"], _f64)
     nx, ny, nz = v3d.shape
     a = capi.TmArgs()
     a.nx, a.ny, a.nz = nx, ny, nz
@@ -234,7 +244,7 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
     for k, name in enumerate(PHI_ORDER):
         a.phi[k] = hold(_f64(phi[name]))
     a.v3d = hold(v3d)
-    a.thkcello = hold(_f64(gridmetrics["thkcello"]))
+    a.thkcello = hold(grid(gridmetrics["thkcello"], _f64))
     if np.ndim(rho) == 0:
         a.rho = None
         a.rho_scalar = float(rho)
@@ -242,13 +252,13 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
         r = _f64(rho)
         assert r.shape == v3d.shape
         a.rho = hold(r)
-    a.lwet3d = hold(np.asfortranarray(indices["Lwet3D"], dtype=np.int64))
-    a.lwet = hold(np.ascontiguousarray(indices["Lwet"], dtype=np.int64))
+    a.lwet3d = hold(grid(indices["Lwet3D"], lambda x: np.asfortranarray(x, dtype=np.int64)))
+    a.lwet = hold(grid(indices["Lwet"], lambda x: np.ascontiguousarray(x, dtype=np.int64)))
     for k, d in enumerate(HDIRS):
-        a.edge_length[k] = hold(_f64(gridmetrics["edge_length_2D"][d]))
-        a.dist_nbr[k] = hold(_f64(gridmetrics["distance_to_neighbour_2D"][d]))
-    a.area2d = hold(_f64(gridmetrics["area2D"]))
-    a.zt = hold(np.ascontiguousarray(gridmetrics["zt"], dtype=np.float64))
+        a.edge_length[k] = hold(grid(gridmetrics["edge_length_2D"][d], _f64))
+        a.dist_nbr[k] = hold(grid(gridmetrics["distance_to_neighbour_2D"][d], _f64))
+    a.area2d = hold(grid(gridmetrics["area2D"], _f64))
+    a.zt = hold(grid(gridmetrics["zt"], lambda x: np.ascontiguousarray(x, dtype=np.float64)))
     ml, _ = data_and_props(mlotst)
     a.mlotst = hold(_f64(ml))
     a.kappa_h, a.kappa_vml, a.kappa_vdeep = float(kH), float(kVML), float(kVdeep)
@@ -257,11 +267,13 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
 
 def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None, rho=None, κH=500.0, κVML=0.1,
                     κVdeep=1.0e-5, kappaH=None, kappaVML=None, kappaVdeep=None, Tadv=None, TκH=None, TκVML=None,
-                    TκVdeep=None, upwind=True, operators=True, device=0):
+                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, device=0):
     """matrixbuilding.jl:128-150 -> NT(T, Tadv, TκH, TκVML, TκVdeep), each a SparseMatrixCSC.
     ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords.
     operators=False (extension; the reference always returns all five): only T is materialised, the other four come
-    back as None -- the same T, half the bytes written and a third of the bytes copied back to the host."""
+    back as None -- the same T, half the bytes written and a third of the bytes copied back to the host.
+    reuse_grid=True (extension): the caller promises that the gridmetrics / indices arrays are the very arrays of the
+    previous call, unmodified (a loop over time slices): they are not copied to the device again (otmb_ctx_set_reuse_grid)."""
     phi = ϕ if ϕ is not None else phi
     rho = ρ if ρ is not None else rho
     kH = κH if kappaH is None else kappaH
@@ -277,8 +289,9 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
         T = spadd(spadd(spadd(ops["Tadv"], ops["TκH"], device=device), ops["TκVML"], device=device), ops["TκVdeep"], device=device)
         return NT(T=T, **ops)
     ctx = context(device)
-    keep = []
-    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep)
+    keep, passthrough = [], []
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
+    ctx.set_reuse_grid(bool(reuse_grid) and all(passthrough))  # converted temporaries have no identity to rely on
     a.only_t = 0 if operators else 1
     nnz = (C.c_int64 * 5)()
     ctx.check(capi.lib().otmb_transportmatrix_plan(ctx.handle, C.byref(a), C.byref(nnz)))

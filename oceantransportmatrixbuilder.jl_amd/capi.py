@@ -53,6 +53,7 @@ SYMBOLS = {
     "otmb_ctx_set_stream": (C.c_int32, [_vp, _vp]),
     "otmb_ctx_use_default_stream": (C.c_int32, [_vp]),
     "otmb_ctx_synchronize": (C.c_int32, [_vp]),
+    "otmb_ctx_set_reuse_grid": (C.c_int32, [_vp, C.c_int32]),
     "otmb_last_error": (C.c_char_p, [_vp]),
     "otmb_status_string": (C.c_char_p, [C.c_int32]),
     "otmb_version": (C.c_char_p, []),
@@ -192,6 +193,9 @@ class Context:
             self.check(lib().otmb_ctx_use_default_stream(self._h))
         else:
             self.check(lib().otmb_ctx_set_stream(self._h, _vp(stream_ptr)))
+
+    def set_reuse_grid(self, on=True):
+        self.check(lib().otmb_ctx_set_reuse_grid(self._h, int(bool(on))))
 
     def use_own_stream(self):
         self.check(lib().otmb_ctx_set_stream(self._h, _vp(0)))

@@ -20,6 +20,7 @@ struct DevBuf {
 };
 
 struct TmPlan;  // otmb_transportmatrix.hip
+struct OtmbXfer;  // otmb_xfer.h: pinned staging ring + host copy threads of the host-pointer entry points
 
 // pending plan of the general path (otmb_coo.hip): COO generator and sparse()
 struct CooPlan { int which = -1; otmb_tm_args args; int64_t ntiles = 0, len = 0; };
@@ -64,6 +65,10 @@ struct otmb_ctx {
     SpPlan sp;
     // staging for the host-pointer entry points
     std::vector<DevBuf> stage;
+    OtmbXfer *xfer = nullptr;
+    bool reuse_grid = false;  // otmb_ctx_set_reuse_grid: grid-constant host arrays are uploaded once (see include/otmb.h)
+    struct StageKey { const void *host = nullptr; size_t bytes = 0; };
+    std::vector<StageKey> stage_key;  // what each staging slot currently holds (host pointer it was uploaded from)
     // optional per-kernel timing with HIP events recorded on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 2 * OTMB_TIMING_POOL events, created on first enable
@@ -112,6 +117,8 @@ int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);
 int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
                               uint16_t *push_mask);  // otmb_facefluxes.hip
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
+void otmb_tm_plan_invalidate(otmb_ctx *ctx);                         // otmb_transportmatrix.hip
+void otmb_xfer_free(otmb_ctx *ctx);                                  // otmb_host.hip
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
 bool otmb_tm_plan_only_t(otmb_ctx *ctx);                              // otmb_transportmatrix.hip
 

@@ -2,6 +2,7 @@
 // arrays through device buffers owned by the context, run the _dev path, copy the results back
 // into the caller's buffers.  No CPU compute path exists here: without a GPU these calls fail.
 #include "otmb_common.h"
+#include "otmb_xfer.h"
 
 // staging slots
 enum {
@@ -16,13 +17,38 @@ static int32_t stage(otmb_ctx *ctx, int slot, size_t bytes, void **dptr) {
     *dptr = ctx->stage[slot].p;
     return rc;
 }
-static int32_t upload(otmb_ctx *ctx, int slot, const void *h, size_t bytes, const void **dptr) {
+// Uploads are collected and handed to the transfer engine (otmb_xfer.hip) in one batch, so that its pipeline of pinned
+// chunks runs across arrays.  grid_constant: the array belongs to gridmetrics / indices; with otmb_ctx_set_reuse_grid it is
+// uploaded only when the slot does not already hold this very host array (same pointer, same size).
+struct Uploads {
+    std::vector<OtmbXferItem> items;
+};
+static int32_t upload(otmb_ctx *ctx, Uploads &up, int slot, const void *h, size_t bytes, const void **dptr, bool grid_constant = false) {
     void *d = nullptr;
     int32_t rc = stage(ctx, slot, bytes, &d);
     if (rc) return rc;
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->stage_key.size() < (size_t)ST_COUNT) ctx->stage_key.resize(ST_COUNT);
+    otmb_ctx::StageKey &key = ctx->stage_key[slot];
+    const bool resident = ctx->reuse_grid && grid_constant && key.host == h && key.bytes == bytes && bytes > 0;
+    if (bytes && !resident) up.items.push_back({d, const_cast<void *>(h), bytes});
+    key.host = (ctx->reuse_grid && grid_constant) ? h : nullptr;
+    key.bytes = bytes;
     *dptr = d;
     return OTMB_OK;
+}
+static int32_t flush(otmb_ctx *ctx, Uploads &up) {
+    if (up.items.empty()) return OTMB_OK;
+    int32_t rc = otmb_xfer(ctx, true, up.items.data(), (int)up.items.size());
+    up.items.clear();
+    return rc;
+}
+static int32_t download(otmb_ctx *ctx, std::vector<OtmbXferItem> &items) {
+    if (items.empty()) return OTMB_OK;
+    return otmb_xfer(ctx, false, items.data(), (int)items.size());
+}
+void otmb_xfer_free(otmb_ctx *ctx) {
+    delete ctx->xfer;
+    ctx->xfer = nullptr;
 }
 #define TRY(x)                  \
     do {                        \
@@ -40,14 +66,20 @@ int32_t otmb_makeindices(otmb_ctx *ctx, const double *v3d, int64_t nx, int64_t n
     const size_t G = (size_t)(nx * ny * nz);
     const void *dv;
     void *dlw3 = nullptr, *dlw = nullptr, *dwet = nullptr;
-    TRY(upload(ctx, ST_V, v3d, G * 8, &dv));
+    otmb_tm_plan_invalidate(ctx);  // a pending host plan points into the staging slots written below
+    Uploads up;
+    TRY(upload(ctx, up, ST_V, v3d, G * 8, &dv));
+    ctx->stage_key[ST_LW] = ctx->stage_key[ST_LWET] = ctx->stage_key[ST_WET] = otmb_ctx::StageKey();
     if (lwet3d) TRY(stage(ctx, ST_LW, G * 8, &dlw3));
     if (lwet) TRY(stage(ctx, ST_LWET, G * 8, &dlw));
     if (wet3d) TRY(stage(ctx, ST_WET, G, &dwet));
+    TRY(flush(ctx, up));
     TRY(otmb_makeindices_dev(ctx, (const double *)dv, nx, ny, nz, (int64_t *)dlw3, (int64_t *)dlw, (uint8_t *)dwet, n_wet));
-    if (lwet3d) HIP_TRY(ctx, hipMemcpyAsync(lwet3d, dlw3, G * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (lwet && *n_wet > 0) HIP_TRY(ctx, hipMemcpyAsync(lwet, dlw, (size_t)*n_wet * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (wet3d) HIP_TRY(ctx, hipMemcpyAsync(wet3d, dwet, G, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<OtmbXferItem> down;
+    if (lwet3d) down.push_back({dlw3, lwet3d, G * 8});
+    if (lwet && *n_wet > 0) down.push_back({dlw, lwet, (size_t)*n_wet * 8});
+    if (wet3d) down.push_back({dwet, wet3d, G});
+    TRY(download(ctx, down));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return OTMB_OK;
 }
@@ -59,18 +91,24 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t G = (size_t)(nx * ny * nz), es = src_is_f32 ? 4 : 8;
     const void *du, *dv, *dw;
-    TRY(upload(ctx, ST_UMO, umo, G * es, &du));
-    TRY(upload(ctx, ST_VMO, vmo, G * es, &dv));
-    TRY(upload(ctx, ST_WET, wet3d, G, &dw));
+    otmb_tm_plan_invalidate(ctx);  // (the ϕ staging slots are shared with a pending host plan)
+    Uploads up;
+    TRY(upload(ctx, up, ST_UMO, umo, G * es, &du));
+    TRY(upload(ctx, up, ST_VMO, vmo, G * es, &dv));
+    TRY(upload(ctx, up, ST_WET, wet3d, G, &dw, true));
     double *dphi[6];
     for (int f = 0; f < 6; ++f) {
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         void *d;
         TRY(stage(ctx, ST_PHI0 + f, G * 8, &d));
+        ctx->stage_key[ST_PHI0 + f] = otmb_ctx::StageKey();
         dphi[f] = (double *)d;
     }
+    TRY(flush(ctx, up));
     TRY(otmb_facefluxes_dev(ctx, du, dv, src_is_f32, (const uint8_t *)dw, fill, nx, ny, nz, topology, dphi));
-    for (int f = 0; f < 6; ++f) HIP_TRY(ctx, hipMemcpyAsync(phi[f], dphi[f], G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<OtmbXferItem> down;
+    for (int f = 0; f < 6; ++f) down.push_back({dphi[f], phi[f], G * 8});
+    TRY(download(ctx, down));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return OTMB_OK;
 }
@@ -83,23 +121,27 @@ static int32_t vf_host(otmb_ctx *ctx, bool to_velocity, const void *a_i, const v
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)(nx * ny), G = P * (size_t)nz, es = src_is_f32 ? 4 : 8;
     const void *di, *dj, *dr = nullptr, *dt, *de, *dn;
-    TRY(upload(ctx, ST_UMO, a_i, G * es, &di));
-    TRY(upload(ctx, ST_VMO, a_j, G * es, &dj));
-    if (rho) TRY(upload(ctx, ST_RHO, rho, G * 8, &dr));
-    TRY(upload(ctx, ST_THK, thk, G * 8, &dt));
-    TRY(upload(ctx, ST_EDGE0, ee, P * 8, &de));
-    TRY(upload(ctx, ST_EDGE0 + 1, en, P * 8, &dn));
+    otmb_tm_plan_invalidate(ctx);
+    Uploads up;
+    TRY(upload(ctx, up, ST_UMO, a_i, G * es, &di));
+    TRY(upload(ctx, up, ST_VMO, a_j, G * es, &dj));
+    if (rho) TRY(upload(ctx, up, ST_RHO, rho, G * 8, &dr));
+    TRY(upload(ctx, up, ST_THK, thk, G * 8, &dt));
+    TRY(upload(ctx, up, ST_EDGE0, ee, P * 8, &de));
+    TRY(upload(ctx, up, ST_EDGE0 + 1, en, P * 8, &dn));
     void *oi, *oj;
     TRY(stage(ctx, ST_PHI0, G * 8, &oi));
     TRY(stage(ctx, ST_PHI0 + 1, G * 8, &oj));
+    ctx->stage_key[ST_PHI0] = ctx->stage_key[ST_PHI0 + 1] = otmb_ctx::StageKey();
+    TRY(flush(ctx, up));
     if (to_velocity)
         TRY(otmb_fluxes2velocity_dev(ctx, di, dj, src_is_f32, (const double *)dr, rho_scalar, (const double *)dt, (const double *)de,
                                      (const double *)dn, nx, ny, nz, topology, (double *)oi, (double *)oj));
     else
         TRY(otmb_velocity2fluxes_dev(ctx, di, dj, src_is_f32, (const double *)dr, rho_scalar, (const double *)dt, (const double *)de,
                                      (const double *)dn, nx, ny, nz, topology, (double *)oi, (double *)oj));
-    HIP_TRY(ctx, hipMemcpyAsync(o_i, oi, G * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(o_j, oj, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<OtmbXferItem> down = {{oi, o_i, G * 8}, {oj, o_j, G * 8}};
+    TRY(download(ctx, down));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return OTMB_OK;
 }
@@ -112,18 +154,22 @@ int32_t otmb_bolus_gm_velocity(otmb_ctx *ctx, const double *rho, const double *z
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)(nx * ny), G = P * (size_t)nz;
     const void *dr, *dz, *dw, *de, *dn;
-    TRY(upload(ctx, ST_RHO, rho, G * 8, &dr));
-    TRY(upload(ctx, ST_V, z3d, G * 8, &dz));
-    TRY(upload(ctx, ST_WET, wet3d, G, &dw));
-    TRY(upload(ctx, ST_DIST0, dist_east, P * 8, &de));
-    TRY(upload(ctx, ST_DIST0 + 1, dist_north, P * 8, &dn));
+    otmb_tm_plan_invalidate(ctx);
+    Uploads up;
+    TRY(upload(ctx, up, ST_RHO, rho, G * 8, &dr));
+    TRY(upload(ctx, up, ST_V, z3d, G * 8, &dz));
+    TRY(upload(ctx, up, ST_WET, wet3d, G, &dw));
+    TRY(upload(ctx, up, ST_DIST0, dist_east, P * 8, &de));
+    TRY(upload(ctx, up, ST_DIST0 + 1, dist_north, P * 8, &dn));
     void *du, *dv;
     TRY(stage(ctx, ST_PHI0, G * 8, &du));
     TRY(stage(ctx, ST_PHI0 + 1, G * 8, &dv));
+    ctx->stage_key[ST_PHI0] = ctx->stage_key[ST_PHI0 + 1] = otmb_ctx::StageKey();
+    TRY(flush(ctx, up));
     TRY(otmb_bolus_gm_velocity_dev(ctx, (const double *)dr, (const double *)dz, (const uint8_t *)dw, (const double *)de,
                                    (const double *)dn, nx, ny, nz, topology, kappa_gm, maxslope, (double *)du, (double *)dv));
-    HIP_TRY(ctx, hipMemcpyAsync(u, du, G * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(v, dv, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<OtmbXferItem> down = {{du, u, G * 8}, {dv, v, G * 8}};
+    TRY(download(ctx, down));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return OTMB_OK;
 }
@@ -135,14 +181,18 @@ int32_t otmb_bgrid_to_cgrid(otmb_ctx *ctx, const void *u, const void *v, int32_t
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t G = (size_t)(nx * ny * nz), es = src_is_f32 ? 4 : 8;
     const void *du, *dv;
-    TRY(upload(ctx, ST_UMO, u, G * es, &du));
-    TRY(upload(ctx, ST_VMO, v, G * es, &dv));
+    otmb_tm_plan_invalidate(ctx);
+    Uploads up;
+    TRY(upload(ctx, up, ST_UMO, u, G * es, &du));
+    TRY(upload(ctx, up, ST_VMO, v, G * es, &dv));
     void *o1, *o2;
     TRY(stage(ctx, ST_PHI0, G * 8, &o1));
     TRY(stage(ctx, ST_PHI0 + 1, G * 8, &o2));
+    ctx->stage_key[ST_PHI0] = ctx->stage_key[ST_PHI0 + 1] = otmb_ctx::StageKey();
+    TRY(flush(ctx, up));
     TRY(otmb_bgrid_to_cgrid_dev(ctx, du, dv, src_is_f32, fill, nx, ny, nz, (double *)o1, (double *)o2));
-    HIP_TRY(ctx, hipMemcpyAsync(u2, o1, G * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(v2, o2, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<OtmbXferItem> down = {{o1, u2, G * 8}, {o2, v2, G * 8}};
+    TRY(download(ctx, down));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return OTMB_OK;
 }
@@ -173,20 +223,24 @@ int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t 
     otmb_tm_args d = *a;
     d.push_mask = nullptr;  // host entry point: a caller's mask pointer would be host memory; derive it on the device
     const void *p;
-    for (int f = 0; f < 6; ++f) { TRY(upload(ctx, ST_PHI0 + f, a->phi[f], G * 8, &p)); d.phi[f] = (const double *)p; }
-    TRY(upload(ctx, ST_V, a->v3d, G * 8, &p)); d.v3d = (const double *)p;
-    TRY(upload(ctx, ST_THK, a->thkcello, G * 8, &p)); d.thkcello = (const double *)p;
-    if (a->rho) { TRY(upload(ctx, ST_RHO, a->rho, G * 8, &p)); d.rho = (const double *)p; }
-    TRY(upload(ctx, ST_LW, a->lwet3d, G * 8, &p)); d.lwet3d = (const int64_t *)p;
+    otmb_tm_plan_invalidate(ctx);
+    Uploads up;
+    // ϕ, ρ and mlotst change from one time slice to the next; gridmetrics and indices do not (otmb_ctx_set_reuse_grid)
+    for (int f = 0; f < 6; ++f) { TRY(upload(ctx, up, ST_PHI0 + f, a->phi[f], G * 8, &p)); d.phi[f] = (const double *)p; }
+    TRY(upload(ctx, up, ST_V, a->v3d, G * 8, &p, true)); d.v3d = (const double *)p;
+    TRY(upload(ctx, up, ST_THK, a->thkcello, G * 8, &p, true)); d.thkcello = (const double *)p;
+    if (a->rho) { TRY(upload(ctx, up, ST_RHO, a->rho, G * 8, &p)); d.rho = (const double *)p; }
+    TRY(upload(ctx, up, ST_LW, a->lwet3d, G * 8, &p, true)); d.lwet3d = (const int64_t *)p;
     if (a->n_wet > 0 && !a->lwet) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "lwet");
-    TRY(upload(ctx, ST_LWET, a->lwet, (size_t)(a->n_wet > 0 ? a->n_wet : 0) * 8, &p)); d.lwet = (const int64_t *)p;
+    TRY(upload(ctx, up, ST_LWET, a->lwet, (size_t)(a->n_wet > 0 ? a->n_wet : 0) * 8, &p, true)); d.lwet = (const int64_t *)p;
     for (int k = 0; k < 4; ++k) {
-        TRY(upload(ctx, ST_EDGE0 + k, a->edge_length[k], P * 8, &p)); d.edge_length[k] = (const double *)p;
-        TRY(upload(ctx, ST_DIST0 + k, a->dist_nbr[k], P * 8, &p)); d.dist_nbr[k] = (const double *)p;
+        TRY(upload(ctx, up, ST_EDGE0 + k, a->edge_length[k], P * 8, &p, true)); d.edge_length[k] = (const double *)p;
+        TRY(upload(ctx, up, ST_DIST0 + k, a->dist_nbr[k], P * 8, &p, true)); d.dist_nbr[k] = (const double *)p;
     }
-    TRY(upload(ctx, ST_AREA, a->area2d, P * 8, &p)); d.area2d = (const double *)p;
-    TRY(upload(ctx, ST_ZT, a->zt, (size_t)a->nz * 8, &p)); d.zt = (const double *)p;
-    TRY(upload(ctx, ST_ML, a->mlotst, P * 8, &p)); d.mlotst = (const double *)p;
+    TRY(upload(ctx, up, ST_AREA, a->area2d, P * 8, &p, true)); d.area2d = (const double *)p;
+    TRY(upload(ctx, up, ST_ZT, a->zt, (size_t)a->nz * 8, &p, true)); d.zt = (const double *)p;
+    TRY(upload(ctx, up, ST_ML, a->mlotst, P * 8, &p)); d.mlotst = (const double *)p;
+    TRY(flush(ctx, up));
     return otmb_transportmatrix_plan_dev(ctx, &d, nnz);
 }
 
@@ -211,14 +265,23 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     TRY(otmb_transportmatrix_fill_dev(ctx, dcp, drv, dnz));
     TRY(otmb_transportmatrix_nnz(ctx, nnz));  // T's count can only shrink (entries that summed to exactly zero)
     for (int m = 0; m < 5; ++m) nnz_out[m] = nnz[m];
+    std::vector<OtmbXferItem> down;
     for (int m = 0; m < nm; ++m) {
-        HIP_TRY(ctx, hipMemcpyAsync(colptr[m], dcp[m], (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        down.push_back({dcp[m], colptr[m], (size_t)(N + 1) * 8});
         if (nnz[m] > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(rowval[m], drv[m], (size_t)nnz[m] * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(nzval[m], dnz[m], (size_t)nnz[m] * 8, hipMemcpyDeviceToHost, ctx->stream));
+            down.push_back({drv[m], rowval[m], (size_t)nnz[m] * 8});
+            down.push_back({dnz[m], nzval[m], (size_t)nnz[m] * 8});
         }
     }
+    TRY(download(ctx, down));
     return otmb_ctx_synchronize(ctx);
+}
+
+int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    ctx->reuse_grid = on != 0;
+    if (!ctx->reuse_grid) ctx->stage_key.assign(ctx->stage_key.size(), otmb_ctx::StageKey());
+    return OTMB_OK;
 }
 
 }  // extern "C"

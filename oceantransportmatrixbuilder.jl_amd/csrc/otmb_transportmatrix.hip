@@ -735,6 +735,10 @@ void otmb_tm_plan_free(otmb_ctx *ctx) {
     ctx->plan = nullptr;
 }
 
+void otmb_tm_plan_invalidate(otmb_ctx *ctx) {
+    if (ctx->plan) { ctx->plan->valid = false; ctx->plan->onepass_pending = false; }
+}
+
 bool otmb_tm_plan_only_t(otmb_ctx *ctx) { return ctx->plan && ctx->plan->args.only_t != 0; }
 
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N) {

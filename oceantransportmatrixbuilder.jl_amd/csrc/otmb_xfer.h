@@ -1,0 +1,50 @@
+// otmb_xfer.h -- host <-> device transfers of the HOST-pointer entry points (what a Julia ccall hands over is ordinary
+// pageable memory).  hipMemcpy from pageable memory stages through a small internal buffer with one host thread and
+// reaches ~13 GB/s on this platform; here the staging is explicit: a ring of pinned chunks, a few host threads that
+// copy pageable <-> pinned in parallel, and the DMA of one chunk overlapped with the host copy of the next, which
+// brings the transfers close to the PCIe rate.  Only data movement: no compute ever happens on the host.
+#pragma once
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "otmb_common.h"
+
+struct OtmbXferItem {
+    void *dev;
+    void *host;
+    size_t bytes;
+};
+
+class OtmbThreadPool {
+   public:
+    explicit OtmbThreadPool(int n);
+    ~OtmbThreadPool();
+    int size() const { return (int)workers_.size() + 1; }
+    // run fn(part) for part = 0..parts-1 on the pool (the caller takes part in the work); returns when all are done
+    void parallel_for(int parts, const std::function<void(int)> &fn);
+
+   private:
+    void loop();
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, parts_ = 0, pending_ = 0;
+    unsigned long generation_ = 0;
+    bool stop_ = false;
+};
+
+struct OtmbXfer {
+    static const int NSLOT = 6;
+    size_t chunk = (size_t)8 << 20;
+    char *pin = nullptr;  // NSLOT * chunk bytes of pinned host memory
+    hipEvent_t ev[NSLOT] = {};
+    OtmbThreadPool *pool = nullptr;
+    ~OtmbXfer();
+};
+
+// to_device: enqueue on ctx->stream; returns once every byte has been handed to the DMA engine (the caller's buffers may
+// be reused).  !to_device: returns when the host buffers are filled (the stream's earlier work is waited for).
+int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int n);

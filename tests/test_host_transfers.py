@@ -1,0 +1,79 @@
+"""The host-pointer entry points move their arrays through the library's own staging (csrc/otmb_xfer.hip: pinned ring,
+parallel host copies): results must be what they were, for arrays smaller than a chunk, spanning many chunks and with
+odd sizes, and the reuse_grid option must not change results (run with -m gpu)."""
+import numpy as np
+import pytest
+
+from helpers import MATS, assert_csc_equal, gridmetrics_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,chunk_mb", [((37, 29, 11), 8), ((90, 80, 20), 1), ((120, 100, 23), 1)])
+def test_host_api_through_the_transfer_engine_matches_oracle(oracle, monkeypatch, shape, chunk_mb):
+    import otmb_amd.api as api
+    from otmb_amd import capi, synthetic
+
+    monkeypatch.setenv("OTMB_XFER_CHUNK_MB", str(chunk_mb))  # read when a context creates its ring
+    g = synthetic.make_grid(*shape, seed=51, rho="array")
+    gm = gridmetrics_of(g)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    api._ctx.pop(7, None)
+    api._ctx[7] = capi.Context(0)  # a fresh context (device key 7 is only a dictionary key here) with this chunk size
+    try:
+        ctx_kw = dict(device=7)
+        idx = api.makeindices(gm.v3D, **ctx_kw)
+        assert np.array_equal(idx.Lwet3D, ref["Lwet3D"]) and np.array_equal(idx.Lwet, ref["Lwet"])
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, **ctx_kw)
+        for k in rphi:
+            assert np.array_equal(phi[k], rphi[k]), k
+        for reuse in (False, True, True, False):
+            tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, reuse_grid=reuse, **ctx_kw)
+            for m in MATS:
+                assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/reuse={reuse}")
+        # reuse_grid with ANOTHER grid behind other arrays: nothing stale may be used
+        g2 = synthetic.make_grid(*shape, seed=52, rho="array")
+        gm2 = gridmetrics_of(g2)
+        ref2 = oracle.makeindices(gm2.v3D)
+        rphi2 = oracle.facefluxes(g2.umo.data, g2.vmo.data, ref2["wet3D"], 1e20, gm2.gridtopology.kind)
+        rtm2 = oracle.transportmatrix(rphi2, gm2, ref2, g2.rho, g2.mlotst, g2.kappaH, g2.kappaVML, g2.kappaVdeep, True)
+        idx2 = api.makeindices(gm2.v3D, **ctx_kw)
+        tm2 = api.transportmatrix(ϕ=rphi2, mlotst=g2.mlotst, gridmetrics=gm2, indices=idx2, ρ=g2.rho, reuse_grid=True, **ctx_kw)
+        for m in MATS:
+            assert_csc_equal(tuple(tm2[m]), rtm2[m], f"{m}/second grid")
+    finally:
+        api._ctx.pop(7).close()
+
+
+def test_plan_is_invalidated_by_other_host_calls(oracle):
+    """plan (host) -> makeindices of ANOTHER grid (host; reuses the staging slots) -> fetch must refuse, not fill garbage."""
+    import ctypes as C
+
+    import otmb_amd.api as api
+    from otmb_amd import capi, synthetic
+    from otmb_amd.capi import OtmbError
+
+    g = synthetic.make_grid(20, 16, 6, seed=53, rho="array")
+    gm = gridmetrics_of(g)
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    ctx = api.context(0)
+    keep = []
+    a = api._tm_args(phi, g.mlotst, gm, idx, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep, True, keep)
+    nnz = (C.c_int64 * 5)()
+    ctx.check(capi.lib().otmb_transportmatrix_plan(ctx.handle, C.byref(a), C.byref(nnz)))
+    other = synthetic.make_grid(20, 16, 6, seed=54)
+    api.makeindices(gridmetrics_of(other).v3D)  # overwrites the staged v3D / Lwet3D the plan pointed at
+    N = int(idx["N"])
+    colptr = [np.empty(N + 1, np.int64) for _ in range(5)]
+    rowval = [np.empty(int(nnz[m]), np.int64) for m in range(5)]
+    nzval = [np.empty(int(nnz[m]), np.float64) for m in range(5)]
+    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
+    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
+    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    final = (C.c_int64 * 5)()
+    with pytest.raises(OtmbError) as e:
+        ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
+    assert e.value.name == "NO_PLAN"
