@@ -157,13 +157,15 @@ def end_to_end(g, gm, asm_N, reps=3):
                                 κVdeep=g.kappaVdeep, reuse_grid=reuse)
             t2 = time.perf_counter()
             if rep:
-                ts.append((t1 - t0, t2 - t1))
-        res[reuse] = (float(np.median([a for a, _ in ts])), float(np.median([b for _, b in ts])))
-    ff, tm = res[False]
+                ts.append((t1 - t0, t2 - t1, api.last_call_seconds["plan"] + api.last_call_seconds["fetch"]))
+        res[reuse] = tuple(float(np.median([x[q] for x in ts])) for q in range(3))
+    ff, tm, cabi = res[False]
     return {"value": asm_N / (ff + tm), "unit": "wet-cells/s", "facefluxes_ms": 1e3 * ff, "transportmatrix_ms": 1e3 * tm,
-            "transportmatrix_ms_reuse_grid": 1e3 * res[True][1],
+            "transportmatrix_c_abi_ms": 1e3 * cabi, "transportmatrix_ms_reuse_grid": 1e3 * res[True][1],
+            "transportmatrix_c_abi_ms_reuse_grid": 1e3 * res[True][2],
             "note": "host-pointer C ABI (what a Julia ccall passes): pageable host arrays in, five host CSC matrices out, PCIe both "
-                    "ways through the library's pinned staging ring; reuse_grid: gridmetrics / indices uploaded once"}
+                    "ways through the library's pinned staging ring; c_abi_ms: inside otmb_transportmatrix_plan + _fetch (the rest is the "
+                    "caller allocating ~1 GB of fresh output arrays); reuse_grid: gridmetrics / indices uploaded once"}
 
 
 def main():

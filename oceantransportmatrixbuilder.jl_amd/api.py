@@ -18,6 +18,7 @@ from ._nt import NT, data_and_props
 from .capi import HDIRS, MATS, PHI_ORDER
 
 _ctx = {}
+last_call_seconds = {}  # time spent inside the C ABI by the last transportmatrix call: {"plan": s, "fetch": s} (bench.py)
 
 
 def context(device=0):
@@ -294,7 +295,11 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     ctx.set_reuse_grid(bool(reuse_grid) and all(passthrough))  # converted temporaries have no identity to rely on
     a.only_t = 0 if operators else 1
     nnz = (C.c_int64 * 5)()
+    import time as _time
+
+    t0 = _time.perf_counter()
     ctx.check(capi.lib().otmb_transportmatrix_plan(ctx.handle, C.byref(a), C.byref(nnz)))
+    last_call_seconds["plan"] = _time.perf_counter() - t0
     N = int(indices["N"])
     colptr = [np.empty(N + 1, dtype=np.int64) for _ in range(5)]
     rowval = [np.empty(int(nnz[m]), dtype=np.int64) for m in range(5)]
@@ -303,7 +308,9 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
     nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
     final = (C.c_int64 * 5)()
+    t0 = _time.perf_counter()
     ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
+    last_call_seconds["fetch"] = _time.perf_counter() - t0
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
     return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
                  for m, name in enumerate(MATS)})

@@ -65,7 +65,7 @@ OtmbXfer::~OtmbXfer() {
 static int32_t xfer_init(otmb_ctx *ctx) {
     if (ctx->xfer) return OTMB_OK;
     OtmbXfer *x = new OtmbXfer();
-    if (const char *e = getenv("OTMB_XFER_CHUNK_MB")) x->chunk = (size_t)(atoi(e) > 0 ? atoi(e) : 8) << 20;
+    if (const char *e = getenv("OTMB_XFER_CHUNK_MB")) x->chunk = (size_t)(atoi(e) > 0 ? atoi(e) : 32) << 20;
     if (hipHostMalloc((void **)&x->pin, OtmbXfer::NSLOT * x->chunk) != hipSuccess) {
         x->pin = nullptr;
         delete x;
