@@ -282,13 +282,12 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     kVdeep = κVdeep if kappaVdeep is None else kappaVdeep
     given = dict(Tadv=Tadv, TκH=TκH, TκVML=TκVML, TκVdeep=TκVdeep)
     if any(x is not None for x in given.values()):
-        # matrixbuilding.jl:140-143: operators passed in are used as they are; the others are built, and
-        # T = ((Tadv + TκH) + TκVML) + TκVdeep is formed with the sparse add (:147)
-        built = transportmatrix(phi=phi, mlotst=mlotst, gridmetrics=gridmetrics, indices=indices, rho=rho, kappaH=kH,
-                                kappaVML=kVML, kappaVdeep=kVdeep, upwind=upwind, device=device)
-        ops = {k: (v if v is not None else built[k]) for k, v in given.items()}
-        T = spadd(spadd(spadd(ops["Tadv"], ops["TκH"], device=device), ops["TκVML"], device=device), ops["TκVdeep"], device=device)
-        return NT(T=T, **ops)
+        # matrixbuilding.jl:140-143: operators passed in are used as they are and ONLY the missing ones are built (so ϕ,
+        # ρ, mlotst are not even looked at when their operator is given: no error the reference would not raise);
+        # T = ((Tadv + TκH) + TκVML) + TκVdeep is formed with the sparse add (:147).  Everything stays on the device:
+        # the missing operators come from the general path (COO generator -> sparse(), csrc/otmb_coo.hip), the given ones
+        # are uploaded once, the three adds run on the device and only T and the built operators come back.
+        return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device)
     ctx = context(device)
     keep, passthrough = [], []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
@@ -314,6 +313,41 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
     return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
                  for m, name in enumerate(MATS)})
+
+
+def _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, kappa, upwind, device):
+    import torch
+
+    from .device import DeviceAssembler
+
+    asm = DeviceAssembler(device)
+    shape = np.asarray(gridmetrics["v3D"]).shape
+    need_ml = given["TκVML"] is None
+    ml = data_and_props(mlotst)[0] if (need_ml and mlotst is not None) else np.full(shape[:2], np.nan)
+    asm.set_grid(gridmetrics, ml, rho if (given["Tadv"] is None and rho is not None) else 1035.0, *kappa, upwind=upwind)
+    N = asm.N
+    if N != int(indices["N"]):
+        raise ValueError("indices do not belong to gridmetrics.v3D")
+    dphi = None
+    if given["Tadv"] is None:
+        dphi = [asm._t(np.asarray(phi[k])) for k in PHI_ORDER]
+    else:
+        dphi = [torch.zeros(asm.G, dtype=torch.float64, device=asm.device) for _ in range(6)]
+    dev_ops, out = {}, {}
+    for name in MATS[1:]:
+        if given[name] is not None:
+            A = given[name]
+            if A.shape != (N, N):
+                raise ValueError(f"{name} is {A.shape[0]}x{A.shape[1]}, expected {N}x{N}")
+            dev_ops[name] = tuple(torch.from_numpy(np.ascontiguousarray(x, dtype=t)).to(asm.device)
+                                  for x, t in ((A.colptr, np.int64), (A.rowval, np.int64), (A.nzval, np.float64)))
+            out[name] = A
+        else:
+            I, J, V = asm.sparse_entries(name, dphi)
+            dev_ops[name] = asm.sparse(I, J, V, N, N)
+            out[name] = SparseMatrixCSC(N, N, *(t.cpu().numpy() for t in dev_ops[name]))
+    T = asm.spadd(asm.spadd(asm.spadd(dev_ops["Tadv"], dev_ops["TκH"], N), dev_ops["TκVML"], N), dev_ops["TκVdeep"], N)
+    return NT(T=SparseMatrixCSC(N, N, *(t.cpu().numpy() for t in T)), **out)
 
 
 # ---- buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120) -----------------------------

@@ -387,6 +387,23 @@ class DeviceAssembler:
         self.ctx.synchronize()
         return cp, rv[:k], nz[:k]
 
+    def spadd(self, A, B, n):
+        """A + B on the device (SparseArrays' map(+): union pattern, exact-zero sums dropped; src/matrixbuilding.jl:147).
+        A, B: (colptr, rowval, nzval) device tensors of n columns; returns the same triple."""
+        Ap, Ai, Ax = (t.contiguous() for t in A)
+        Bp, Bi, Bx = (t.contiguous() for t in B)
+        nnz = C.c_int64(0)
+        self.ctx.check(self.lib.otmb_spadd_plan_dev(self.ctx.handle, n, Ap.data_ptr(), Ai.data_ptr(), Ax.data_ptr(), Bp.data_ptr(),
+                                                    Bi.data_ptr(), Bx.data_ptr(), C.byref(nnz)))
+        k = int(nnz.value)
+        Cp = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        Ci = torch.empty(max(k, 1), dtype=torch.int64, device=self.device)
+        Cx = torch.empty(max(k, 1), dtype=torch.float64, device=self.device)
+        self.ctx.check(self.lib.otmb_spadd_fill_dev(self.ctx.handle, n, Ap.data_ptr(), Ai.data_ptr(), Ax.data_ptr(), Bp.data_ptr(),
+                                                    Bi.data_ptr(), Bx.data_ptr(), Cp.data_ptr(), Ci.data_ptr(), Cx.data_ptr()))
+        self.ctx.synchronize()
+        return Cp, Ci[:k], Cx[:k]
+
     # ---- accounting ---------------------------------------------------------------------------
     def algorithmic_bytes(self):
         """bytes the assembly must move with all five matrices returned

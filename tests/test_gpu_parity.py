@@ -229,6 +229,27 @@ def test_transportmatrix_with_precomputed_operators(api, oracle):
                         tuple(base.TκVdeep), ref["N"])
     assert_csc_equal(tuple(mixed.T), want, "T from precomputed TκH")
     assert_csc_equal(tuple(mixed.T), tuple(other.T), "same as building with κH=123")
+    for m in ("TκVML", "TκVdeep"):
+        assert_csc_equal(tuple(mixed[m]), tuple(base[m]), m)
+    # only the MISSING operators are built (matrixbuilding.jl:140-143): with Tadv handed in, ϕ and ρ are never looked at,
+    # so a NaN in ρ or a flux into land is not an error, exactly as in the reference
+    bad_phi = {k: v.copy(order="F") for k, v in rphi.items()}
+    wet = ref["wet3D"].astype(bool)
+    i, j, k = np.argwhere(wet & ~np.roll(wet, 1, axis=0))[0]
+    bad_phi["west"][i, j, k] = 5.0
+    rho_nan = g.rho.copy(order="F")
+    rho_nan.ravel(order="F")[ref["Lwet"][5] - 1] = np.nan
+    kw2 = dict(mlotst=g.mlotst, gridmetrics=gm, indices=idx)
+    with_adv = api.transportmatrix(ϕ=bad_phi, ρ=rho_nan, Tadv=base.Tadv, **kw2)
+    assert with_adv.Tadv is base.Tadv
+    assert_csc_equal(tuple(with_adv.T), tuple(base.T), "T with Tadv given")
+    all_given = api.transportmatrix(ϕ=None, ρ=None, mlotst=None, gridmetrics=gm, indices=idx, Tadv=base.Tadv, TκH=base.TκH,
+                                    TκVML=base.TκVML, TκVdeep=base.TκVdeep)
+    assert_csc_equal(tuple(all_given.T), tuple(base.T), "T from four given operators")
+    from otmb_amd.capi import OtmbError
+
+    with pytest.raises(OtmbError, match="ρ contains NaNs"):  # TκH given, Tadv not: ρ is checked (matrixbuilding.jl:233)
+        api.transportmatrix(ϕ=rphi, ρ=rho_nan, TκH=base.TκH, **kw2)
 
 
 # ---- edge cases: empty, single level, single wet cell ------------------------------------------------
