@@ -206,7 +206,7 @@ typedef struct {
  * fill (synchronous): writes colptr[m] (n_wet+1), rowval[m], nzval[m] for the five matrices in
  *   OTMB_T..OTMB_TKVDEEP order, raises the reference's errors, compacts T if entries cancelled;
  *   otmb_transportmatrix_nnz then gives the final counts (nnz[0] <= the planned bound).
- * The args of the last plan are remembered by the context.                                           */
+ * The args of the last plan are remembered by the context; a plan is consumed by its fill (fill again = plan again). */
 int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                       double *const nzval[5]);

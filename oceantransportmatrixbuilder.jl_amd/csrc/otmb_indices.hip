@@ -55,7 +55,7 @@ extern "C" int32_t otmb_makeindices_dev(otmb_ctx *ctx, const double *v3d, int64_
     if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(ntiles + 1) * sizeof(i64) + otmb_scan_scratch(ntiles, 1)))) return rc;
     uint32_t *sums = (uint32_t *)ctx->blocksums.p;
     i64 *offs = (i64 *)ctx->blockoffs.p;
-    i64 *dtot = (i64 *)((int *)ctx->flags.p + OTMB_NFLAGS);
+    i64 *dtot = (i64 *)((int *)ctx->flags.p + OTMB_NFLAGS) + 13;  // a totals word of its own (0-7 belong to transportmatrix)
     {
     KernelTimer kt(ctx, K_IDX_COUNT);
     hipLaunchKernelGGL(indices_kernel<false>, dim3((unsigned)ntiles), dim3(IX_THREADS), 0, ctx->stream, v3d, G, sums,
@@ -71,8 +71,8 @@ extern "C" int32_t otmb_makeindices_dev(otmb_ctx *ctx, const double *v3d, int64_
                            (uint32_t *)nullptr, (const i64 *)offs, (i64 *)lwet3d, (i64 *)lwet, wet3d);
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot, dtot, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot + 13, dtot, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *n_wet = ctx->h_tot[0];
+    *n_wet = ctx->h_tot[13];
     return OTMB_OK;
 }

@@ -838,7 +838,10 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     // the values exist only now: raise the reference's errors, and repair T if entries cancelled
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = check_flags(ctx))) { pl.valid = false; return rc; }
+    // a plan is consumed by its fill: T's final count may be smaller than the reserved (union) one, so a second fill into
+    // buffers sized from otmb_transportmatrix_nnz would overflow them -- plan again instead
+    pl.valid = false;
+    if ((rc = check_flags(ctx))) return rc;
     if (ctx->h_flags[FLAG_T_CANCEL]) {
         if ((rc = t_fixup(ctx, pl, p.colptr[0], p.rowval[0], p.nzval[0]))) return rc;
     }
