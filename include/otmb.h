@@ -197,18 +197,7 @@ typedef struct {
     int32_t only_t;              /* extension (0 = the reference's behaviour): non-zero builds T alone -- the four operator
                                   * matrices are still evaluated (T is their sum) but neither counted nor written: their
                                   * nnz come out 0 and their output pointers may be NULL.  Halves the bytes written.      */
-    const void *cell_records;    /* optional (device pointers, NULL = packed by the library on every call): the grid's inputs */
-    const void *metric_records;  /* laid out for the GPU by otmb_pack_cells_dev / otmb_pack_metrics_dev FROM the arrays
-                                  * above (v3d, lwet3d, rho / rho_scalar, thkcello; the ten (nx,ny) arrays): the assembly
-                                  * kernel is bound by the number of its memory instructions, and one 16-byte load of a
-                                  * record pair replaces two 8-byte loads from two arrays.  A caller whose grid does not
-                                  * change between time slices packs once.  Host-pointer entry points ignore them.       */
 } otmb_tm_args;
-#define OTMB_CELL_RECORD_BYTES 32   /* per cell (nx,ny,nz):   { v3d, lwet3d | rho, thkcello }                              */
-#define OTMB_METRIC_RECORD_BYTES 80 /* per column (nx,ny):    { edge W, dist W | E | S | N | area2d, mlotst }              */
-/* Write the records of args' grid (asynchronous; cells: nx*ny*nz records, metrics: nx*ny records).             */
-int32_t otmb_pack_cells_dev(otmb_ctx *ctx, const otmb_tm_args *args, void *cell_records);
-int32_t otmb_pack_metrics_dev(otmb_ctx *ctx, const otmb_tm_args *args, void *metric_records);
 
 /* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).
  * plan: the nnz of the four operator matrices (exact: their patterns depend on the wet mask, the flux

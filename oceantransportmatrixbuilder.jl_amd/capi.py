@@ -42,7 +42,6 @@ class TmArgs(C.Structure):
         ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
         ("push_mask", C.c_void_p),
         ("only_t", C.c_int32),
-        ("cell_records", C.c_void_p), ("metric_records", C.c_void_p),
     ]
 
 
@@ -97,8 +96,6 @@ SYMBOLS = {
     "otmb_spadd_plan_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),
     "otmb_spadd_fill_dev": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "otmb_spadd": (C.c_int32, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ip]),
-    "otmb_pack_cells_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), _vp]),
-    "otmb_pack_metrics_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), _vp]),
     "otmb_transportmatrix_plan_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_fill_dev": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5)]),
     "otmb_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
@@ -209,7 +206,7 @@ class Context:
     def timing_enable(self, on=True):
         self.check(lib().otmb_ctx_timing_enable(self._h, int(on)))
 
-    def timing_collect(self, n=13):
+    def timing_collect(self, n=12):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()

@@ -28,7 +28,7 @@ struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = null
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_PACK, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 
@@ -42,7 +42,6 @@ struct otmb_ctx {
     DevBuf sort[5];            // radix-sort keys/values/temporary of the general sparse() path
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     DevBuf mask;              // push mask derived by the library when the caller passes none
-    DevBuf cellrec, metricrec;  // cell / metric records packed by the library when the caller passes none (otmb_pack.hip)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)
     DevBuf lump_host;         // staging of the host-pointer entry point
     bool lump_valid = false;
@@ -117,8 +116,6 @@ int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
 int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);
 int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
                               uint16_t *push_mask);  // otmb_facefluxes.hip
-int32_t otmb_launch_pack_cells(otmb_ctx *ctx, const otmb_tm_args *a, void *rec);    // otmb_pack.hip
-int32_t otmb_launch_pack_metrics(otmb_ctx *ctx, const otmb_tm_args *a, void *rec);  // otmb_pack.hip
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
 void otmb_tm_plan_invalidate(otmb_ctx *ctx);                         // otmb_transportmatrix.hip
 void otmb_xfer_free(otmb_ctx *ctx);                                  // otmb_host.hip

@@ -106,8 +106,6 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     for (DevBuf &b : ctx->lump)
         if (b.p) (void)hipFree(b.p);
     if (ctx->mask.p) (void)hipFree(ctx->mask.p);
-    if (ctx->cellrec.p) (void)hipFree(ctx->cellrec.p);
-    if (ctx->metricrec.p) (void)hipFree(ctx->metricrec.p);
     if (ctx->lump_host.p) (void)hipFree(ctx->lump_host.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
@@ -173,7 +171,7 @@ const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
                                             "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
-                                            "push_mask_kernel", "pack_cells+pack_metrics"};
+                                            "push_mask_kernel"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

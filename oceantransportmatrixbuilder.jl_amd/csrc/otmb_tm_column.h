@@ -24,7 +24,6 @@ struct TmParams {
     const uint16_t *mask;  // push mask of every cell of the grid (counting pass; otmb_push_bits)
     const double *edge[4], *dist[4];
     const double *area, *zt, *ml;
-    const char *rec3, *rec2;  // cell records (32 B per cell) and metric records (80 B per column), see otmb_pack.hip; fill pass
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
     int only_t;        // build T alone: the operators are evaluated but neither counted nor written (otmb_tm_args.only_t)
@@ -332,25 +331,14 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
 //    sparse()'s "first touch copies, later ones add" without tracking the first touch.
 struct TileBase {  // array pointers advanced to the tile's lowest neighbour (uniform per workgroup)
     const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb, *mk;
-    const char *rec;  // cell records, advanced likewise (byte offset of a cell = 4 x its offset in an 8-byte array)
 };
-typedef double d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ d2 ldp(const char *b, unsigned byteoff) { return *(const d2 *)(b + byteoff); }
-#if defined(OTMB_NT_LOADS)  // experiment: stencil loads bypass the CU's L1 (served by L2): no hit-on-miss stalls in the L1 pipeline
-__device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return __builtin_nontemporal_load((const double *)(b + byteoff)); }
-#else
 __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
-#endif
 #ifdef OTMB_DBG_NOVALLOAD  // timing experiment only (wrong values): value-only inputs are not loaded, the pattern inputs are
 __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return 1.0 + (double)byteoff * 1e-9 + (double)((size_t)b & 0xfff) * 1e-7; }
 #else
 __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return ldd(b, byteoff); }
 #endif
-#if defined(OTMB_NT_LOADS)
-__device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return __builtin_nontemporal_load((const i64 *)(b + byteoff)); }
-#else
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
-#endif
 #define NEG0 (-0.0)
 #ifdef OTMB_DBG_MULDIV  // timing experiment only: what the 28 divisions of a column cost (wrong values)
 #define FDIV(a, b) ((a) * (b))
@@ -376,54 +364,54 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
     const unsigned sS = hS ? s2 - nx8 : s2, sN = hN ? s2 + nx8 : s2;
 
     // ---- all loads ----
-    // Cell records { v, Lwet3D | ρ, thk } and metric records { edge, dist } x W E S N | { area, mlotst }: one 16-byte load per
-    // pair (otmb_pack.hip) -- 14 + 9 load instructions where separate arrays took 26 + 18.
-    const unsigned rC_o = oC * 4u, rE_o = oE * 4u, rW_o = oW * 4u, rS_o = oS * 4u, rN_o = oN * 4u, rA_o = oA * 4u, rB_o = oB * 4u;
-    const d2 c0 = ldp(tb.rec, rC_o), c1 = ldp(tb.rec, rC_o + 16u);
-    const d2 s0 = ldp(tb.rec, rS_o), s1 = ldp(tb.rec, rS_o + 16u);
-    const d2 n0 = ldp(tb.rec, rN_o), n1 = ldp(tb.rec, rN_o + 16u);
-    const d2 a0 = ldp(tb.rec, rA_o), a1 = ldp(tb.rec, rA_o + 16u);
-    const d2 b0 = ldp(tb.rec, rB_o), b1 = ldp(tb.rec, rB_o + 16u);
-    const double gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN), gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
+    const i64 lC = ldi(tb.lw, oC), lE = ldi(tb.lw, oE), lW = ldi(tb.lw, oW), lS = ldi(tb.lw, oS), lN = ldi(tb.lw, oN),
+              lA = ldi(tb.lw, oA), lB = ldi(tb.lw, oB);
+    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW), gS0 = ldd(tb.pn, oS), gN0 = ldd(tb.ps, oN),
+                 gA0 = ldd(tb.pb, oA), gB0 = ldd(tb.pt, oB);
     double qW0 = 0, qE0 = 0, qS0 = 0, qN0 = 0, qB0 = 0, qT0 = 0;
     if (CHECKS) {  // own fluxes, for the outgoing check
         qW0 = ldd(tb.pw, oC); qE0 = ldd(tb.pe, oC); qS0 = ldd(tb.ps, oC); qN0 = ldd(tb.pn, oC); qB0 = ldd(tb.pb, oC);
         qT0 = ldd(tb.pt, oC);
     }
-    const unsigned m2 = s2 * 10u, m2E = sE * 10u, m2W = sW * 10u, m2S = sS * 10u, m2N = sN * 10u;  // 80-byte metric records
-    const d2 mW = ldp(p.rec2, m2), mE = ldp(p.rec2, m2 + 16u), mS = ldp(p.rec2, m2 + 32u), mN = ldp(p.rec2, m2 + 48u),
-             mAM = ldp(p.rec2, m2 + 64u);
-    const d2 mE_w = ldp(p.rec2, m2W + 16u);  // west cell's east edge / distance to its east neighbour
-    const d2 mW_e = ldp(p.rec2, m2E);        // east cell's west edge / distance
-    const d2 mN_s = ldp(p.rec2, m2S + 48u);  // south cell's north edge / distance
-    const d2 mS_n = ldp(p.rec2, m2N + 32u);  // north cell's south edge / distance: oppdir = south away from the seam row (:407)
-    // zt[k-1], zt[k], zt[k+1]: k is (nearly) uniform in a wave, so the four levels around the wave's first k come through the
-    // scalar cache; a wave that spans more than two levels (tiny grids) takes vector loads
-    const int k0w = __builtin_amdgcn_readfirstlane(k);
-    double ztk, zta, ztb;
-    if (__builtin_amdgcn_ballot_w64(k - k0w > 1 || k < k0w) == 0) {
-        const double z0 = p.zt[k0w > 0 ? k0w - 1 : 0], z1 = p.zt[k0w], z2 = p.zt[k0w + 1 < nz ? k0w + 1 : nz - 1],
-                     z3 = p.zt[k0w + 2 < nz ? k0w + 2 : nz - 1];
-        const bool up = k != k0w;  // k == k0w + 1
-        ztk = up ? z2 : z1;
-        zta = hA ? (up ? z1 : z0) : ztk;
-        ztb = hB ? (up ? z3 : z2) : ztk;
+#ifdef OTMB_DBG_NOEW  // timing experiment only (wrong values): no second load instruction into lines that are in flight
+    const double vC = ldv(tb.v, oC), vE = vC, vW = vC, vS = ldv(tb.v, oS), vN = ldv(tb.v, oN), vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
+#else
+    const double vC = ldv(tb.v, oC), vE = ldv(tb.v, oE), vW = ldv(tb.v, oW), vS = ldv(tb.v, oS), vN = ldv(tb.v, oN),
+                 vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
+#endif
+    double rC, rE, rW, rS, rN, rA, rB;
+    if (tb.rho) {
+        rC = ldv(tb.rho, oC); rS = ldv(tb.rho, oS); rN = ldv(tb.rho, oN); rA = ldv(tb.rho, oA); rB = ldv(tb.rho, oB);
+#ifdef OTMB_DBG_NOEW
+        rE = rC; rW = rC;
+#else
+        rE = ldv(tb.rho, oE); rW = ldv(tb.rho, oW);
+#endif
     } else {
-        ztk = p.zt[k]; zta = p.zt[hA ? k - 1 : k]; ztb = p.zt[hB ? k + 1 : k];
+        rC = rE = rW = rS = rN = rA = rB = p.rho_s;
     }
-    // ---- east / west neighbours ----
-    const d2 e0 = ldp(tb.rec, rE_o), e1 = ldp(tb.rec, rE_o + 16u);
-    const d2 w0 = ldp(tb.rec, rW_o), w1 = ldp(tb.rec, rW_o + 16u);
-    const double gE0 = ldd(tb.pw, oE), gW0 = ldd(tb.pe, oW);
-    const i64 lC = __double_as_longlong(c0.y), lE = __double_as_longlong(e0.y), lW = __double_as_longlong(w0.y),
-              lS = __double_as_longlong(s0.y), lN = __double_as_longlong(n0.y), lA = __double_as_longlong(a0.y),
-              lB = __double_as_longlong(b0.y);
-    const double vC = c0.x, vE = e0.x, vW = w0.x, vS = s0.x, vN = n0.x, vA = a0.x, vB = b0.x;
-    const double rC = c1.x, rE = e1.x, rW = w1.x, rS = s1.x, rN = n1.x, rA = a1.x, rB = b1.x;
-    const double tC = c1.y, tE = e1.y, tW = w1.y, tS = s1.y, tN = n1.y;
-    const double eW_c = mW.x, dW_c = mW.y, eE_c = mE.x, dE_c = mE.y, eS_c = mS.x, dS_c = mS.y, eN_c = mN.x, dN_c = mN.y;
-    const double ar = mAM.x, mld = mAM.y;
-    const double eE_w = mE_w.x, dE_w = mE_w.y, eW_e = mW_e.x, dW_e = mW_e.y, eN_s = mN_s.x, dN_s = mN_s.y, eS_n = mS_n.x, dS_n = mS_n.y;
+#ifdef OTMB_DBG_NOEW
+    const double tC = ldv(tb.thk, oC), tE = tC, tW = tC, tS = ldv(tb.thk, oS), tN = ldv(tb.thk, oN);
+#else
+    const double tC = ldv(tb.thk, oC), tE = ldv(tb.thk, oE), tW = ldv(tb.thk, oW), tS = ldv(tb.thk, oS),
+                 tN = ldv(tb.thk, oN);
+#endif
+    const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
+               *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
+    const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
+               *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
+    const double eW_c = ldv(eWp, s2), eE_c = ldv(eEp, s2), eS_c = ldv(eSp, s2), eN_c = ldv(eNp, s2);
+    const double dW_c = ldv(dWp, s2), dE_c = ldv(dEp, s2), dS_c = ldv(dSp, s2), dN_c = ldv(dNp, s2);
+#ifdef OTMB_DBG_NOEW
+    const double eE_w = eE_c, dE_w = dE_c, eW_e = eW_c, dW_e = dW_c;
+#else
+    const double eE_w = ldv(eEp, sW), dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
+    const double eW_e = ldv(eWp, sE), dW_e = ldv(dWp, sE);
+#endif
+    const double eN_s = ldv(eNp, sS), dN_s = ldv(dNp, sS);
+    const double eS_n = ldv(eSp, sN), dS_n = ldv(dSp, sN);  // oppdir = south away from the seam row (:407)
+    const double ar = ldv((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
+    const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
 
     STAMP(st, 2, 1);  // every stencil load is back
     const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;

@@ -91,7 +91,7 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
     tb.lw = (const char *)(p.lw + base_elem);
     tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
     tb.mk = (const char *)(p.mask + base_elem);
-    tb.v = tb.thk = tb.pe = tb.pw = tb.pn = tb.ps = tb.pt = tb.pb = tb.rec = nullptr;  // not read by the presence pass
+    tb.v = tb.thk = tb.pe = tb.pw = tb.pn = tb.ps = tb.pt = tb.pb = nullptr;  // not read by the presence pass
     const Cell cell = cell_of(L, p.nx, p.ny, p.P);
     const unsigned oC = (unsigned)(L - base_elem) * 8u;
     // (Lwet3D[Lwet[w]] == w + 1 is verified by the fill pass, which loads Lwet3D anyway)
@@ -232,11 +232,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     __shared__ int s_tile;
     __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // rows, then value bits
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#ifdef OTMB_DBG_LDS_PAD  // occupancy experiment only: extra LDS per workgroup lowers the number of resident workgroups
-    __shared__ int s_pad[OTMB_DBG_LDS_PAD / 4];
-    if (threadIdx.x == 0 && p.n_own < 0) s_pad[p.nx] = 1;
-    asm volatile("" ::"v"(s_pad[threadIdx.x]));
-#endif
     Stamps st;
 #ifdef OTMB_DBG_STAMPS
     for (int q = 0; q < OTMB_NSTAMP; ++q) st.t[q] = 0;
@@ -259,12 +254,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     if (MODE != MODE_ONEPASS) {
         const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-#ifdef OTMB_DBG_XCD_GROUPS  // experiment: C groups of 8/C XCDs share a contiguous chunk (1 = natural order, 8 = the default)
-        if (r == 0) {
-            const i64 Cg = OTMB_DBG_XCD_GROUPS, M = 8 / Cg, g = x % Cg, m = x / Cg;
-            tile = g * (nt / Cg) + y * M + m;
-        }
-#endif
     }
     if (MODE == MODE_ONEPASS) {
         // dynamic tile id: tiles start in ticket order, so every predecessor a tile waits for is already
@@ -313,8 +302,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
     const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
-    // (32-bit byte offsets into the 32-byte cell records: the tile's neighbourhood must span fewer than 2^27 cells)
-    const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 27) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
+    const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
     if (!span_ok && tid == 0) raise_flag(p.flags, FLAG_NONCANONICAL);
     TileBase tb;
     tb.lw = (const char *)(p.lw + base_elem);
@@ -328,7 +316,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
     tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
     tb.mk = nullptr;  // the push mask is read by the counting pass only
-    tb.rec = p.rec3 + base_elem * OTMB_CELL_RECORD_BYTES;
 
     // ---- 1. the column ----
     // T's rows are RESERVED as the union of the four operators' rows (known without arithmetic); the rows
@@ -662,27 +649,6 @@ static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &
     return otmb_launch_push_mask(ctx, a.phi, a.lwet3d, 0, p.G, (uint16_t *)ctx->mask.p);
 }
 
-// The fill pass reads the grid through cell / metric records (otmb_pack.hip): the caller's (packed once for a grid that does
-// not change between time slices), or packed here on every call.
-static int32_t ensure_records(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &p) {
-    int32_t rc;
-    if (a.cell_records) {
-        p.rec3 = (const char *)a.cell_records;
-    } else {
-        if ((rc = otmb_reserve(ctx, ctx->cellrec, (size_t)p.G * OTMB_CELL_RECORD_BYTES + 64))) return rc;
-        if ((rc = otmb_launch_pack_cells(ctx, &a, ctx->cellrec.p))) return rc;
-        p.rec3 = (const char *)ctx->cellrec.p;
-    }
-    if (a.metric_records) {
-        p.rec2 = (const char *)a.metric_records;
-    } else {
-        if ((rc = otmb_reserve(ctx, ctx->metricrec, (size_t)p.P * OTMB_METRIC_RECORD_BYTES + 64))) return rc;
-        if ((rc = otmb_launch_pack_metrics(ctx, &a, ctx->metricrec.p))) return rc;
-        p.rec2 = (const char *)ctx->metricrec.p;
-    }
-    return OTMB_OK;
-}
-
 static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr) {
     if (!f) f = ctx->h_flags;
     if (f[FLAG_NONCANONICAL]) return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
@@ -701,7 +667,7 @@ static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr) {
 static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a) {
     if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
     const i64 G = a->nx * a->ny * a->nz;
-    if (a->nx * a->ny >= (1ll << 25) || G >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
+    if (a->nx * a->ny >= (1ll << 27) || G >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
     if (a->topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);
     if (a->topology != OTMB_BIPOLAR && a->topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     for (int f = 0; f < 6; ++f)
@@ -858,7 +824,6 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)pl.args.n_wet + 16))) return rc;
     p.tcount = (uint8_t *)ctx->tcount.p;
     int *dflags = (int *)ctx->flags.p;
-    if (pl.ntiles > 0 && (rc = ensure_records(ctx, pl.args, p))) return rc;
     if (pl.ntiles > 0) {
         KernelTimer kt(ctx, K_TM_FILL);
         hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
@@ -972,7 +937,6 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         p.n_tiles = ntiles + 1;
         p.ticket = (int *)((char *)ctx->lookback.p + stbytes);
         HIP_TRY(ctx, hipMemsetAsync(ctx->lookback.p, 0, stbytes + 64, ctx->stream));
-        if ((rc = ensure_records(ctx, *a, p))) return rc;
         KernelTimer kt(ctx, K_TM_ONEPASS);
         hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     } else {
@@ -993,7 +957,6 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
                 otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, ntiles, TM_NF, gsum);
             }
         }
-        if ((rc = ensure_records(ctx, *a, p))) return rc;
         {
 #ifdef OTMB_DBG_STAMPS
             if ((rc = otmb_reserve(ctx, ctx->lookback, (size_t)ntiles * (TM_THREADS / 64) * OTMB_NSTAMP * sizeof(u64)))) return rc;

@@ -252,30 +252,7 @@ class DeviceAssembler:
         fresh = getattr(self, "_mask_key", None) is not None and self._mask_key == self._phi_key(phi)
         a.push_mask = self.push_mask.data_ptr() if fresh else None
         a.only_t = 1 if getattr(self, "only_T", False) else 0  # extension: materialise T alone (outputs of the operators unused)
-        self._records(a)
         return a
-
-    def _records(self, a):
-        """Cell / metric records (include/otmb.h: otmb_pack_*_dev) of the resident grid: packed once and again only when one
-        of the tensors they were packed from has been written to since (torch's version counters), so that a stream of time
-        slices over one grid pays for the packing once."""
-        cells = (self.v3d, self.lwet3d, self.thk) + ((self.rho,) if self.rho is not None else ())
-        ckey = tuple((t.data_ptr(), t._version) for t in cells) + (self.rho_scalar,)
-        if getattr(self, "_cell_key", None) != ckey:
-            if getattr(self, "_cell_rec", None) is None or self._cell_rec.numel() != self.G * 4:
-                self._cell_rec = torch.empty(self.G * 4, dtype=torch.float64, device=self.device)
-            self.ctx.check(self.lib.otmb_pack_cells_dev(self.ctx.handle, C.byref(a), self._cell_rec.data_ptr()))
-            self._cell_key = ckey
-        metrics = (*self.edge, *self.dist, self.area, self.mlotst)
-        mkey = tuple((t.data_ptr(), t._version) for t in metrics)
-        if getattr(self, "_metric_key", None) != mkey:
-            P = self.nx * self.ny
-            if getattr(self, "_metric_rec", None) is None or self._metric_rec.numel() != P * 10:
-                self._metric_rec = torch.empty(P * 10, dtype=torch.float64, device=self.device)
-            self.ctx.check(self.lib.otmb_pack_metrics_dev(self.ctx.handle, C.byref(a), self._metric_rec.data_ptr()))
-            self._metric_key = mkey
-        a.cell_records = self._cell_rec.data_ptr()
-        a.metric_records = self._metric_rec.data_ptr()
 
     def plan(self, phi):
         a = self._args(phi)

@@ -422,18 +422,6 @@ class HipSlabBackend:
         a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.ml.data_ptr()
         a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.s["kappa"]
         a.push_mask = self.push_mask.data_ptr()  # written by facefluxes() for exactly self.phi
-        # cell / metric records of the slab's (constant) grid: packed once, again only if a tensor was written to since
-        cells = (self.v3d, self.lw, self.thk) + ((self.rho,) if self.rho is not None else ())
-        metrics = (*self.edge, *self.dist_, self.area, self.ml)
-        key = tuple((t.data_ptr(), t._version) for t in cells + metrics)
-        if getattr(self, "_rec_key", None) != key:
-            self._cell_rec = torch.empty(self.G * 4, dtype=torch.float64, device=self.device)
-            self._metric_rec = torch.empty(self.P * 10, dtype=torch.float64, device=self.device)
-            self.ctx.check(self.lib.otmb_pack_cells_dev(self.ctx.handle, C.byref(a), self._cell_rec.data_ptr()))
-            self.ctx.check(self.lib.otmb_pack_metrics_dev(self.ctx.handle, C.byref(a), self._metric_rec.data_ptr()))
-            self._rec_key = key
-        a.cell_records = self._cell_rec.data_ptr()
-        a.metric_records = self._metric_rec.data_ptr()
         return a
 
     def plan(self):
