@@ -162,14 +162,15 @@ class Context:
 
     def __init__(self, device=0):
         self._h = _vp()
-        rc = lib().otmb_ctx_create(int(device), C.byref(self._h))
+        self._lib = lib()  # a context belongs to the build of the library that created it (tools/ab_variants.py mixes builds)
+        rc = self._lib.otmb_ctx_create(int(device), C.byref(self._h))
         if rc != OK:
-            raise OtmbError(rc, f"otmb_ctx_create(device={device}) failed: " + lib().otmb_status_string(rc).decode())
+            raise OtmbError(rc, f"otmb_ctx_create(device={device}) failed: " + self._lib.otmb_status_string(rc).decode())
         self.device = device
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            lib().otmb_ctx_destroy(self._h)
+            self._lib.otmb_ctx_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):
@@ -184,34 +185,34 @@ class Context:
 
     def check(self, rc):
         if rc != OK:
-            raise OtmbError(rc, lib().otmb_last_error(self._h).decode("utf-8"))
+            raise OtmbError(rc, self._lib.otmb_last_error(self._h).decode("utf-8"))
 
     def set_stream(self, stream_ptr):
         """Borrow a HIP stream for every _dev call.  Handle 0 is the device's default (null) stream -- torch's default
         stream -- so that the library's kernels are ordered with the caller's torch operations."""
         if not stream_ptr:
-            self.check(lib().otmb_ctx_use_default_stream(self._h))
+            self.check(self._lib.otmb_ctx_use_default_stream(self._h))
         else:
-            self.check(lib().otmb_ctx_set_stream(self._h, _vp(stream_ptr)))
+            self.check(self._lib.otmb_ctx_set_stream(self._h, _vp(stream_ptr)))
 
     def set_reuse_grid(self, on=True):
-        self.check(lib().otmb_ctx_set_reuse_grid(self._h, int(bool(on))))
+        self.check(self._lib.otmb_ctx_set_reuse_grid(self._h, int(bool(on))))
 
     def use_own_stream(self):
-        self.check(lib().otmb_ctx_set_stream(self._h, _vp(0)))
+        self.check(self._lib.otmb_ctx_set_stream(self._h, _vp(0)))
 
     def synchronize(self):
-        self.check(lib().otmb_ctx_synchronize(self._h))
+        self.check(self._lib.otmb_ctx_synchronize(self._h))
 
     def timing_enable(self, on=True):
-        self.check(lib().otmb_ctx_timing_enable(self._h, int(on)))
+        self.check(self._lib.otmb_ctx_timing_enable(self._h, int(on)))
 
     def timing_collect(self, n=12):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()
-        self.check(lib().otmb_ctx_timing_collect(self._h, ms, cnt, n))
-        return {lib().otmb_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(n) if cnt[k]}
+        self.check(self._lib.otmb_ctx_timing_collect(self._h, ms, cnt, n))
+        return {self._lib.otmb_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(n) if cnt[k]}
 
 
 def ptr_array(n, ptrs):

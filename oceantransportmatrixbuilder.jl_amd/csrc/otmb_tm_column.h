@@ -411,7 +411,20 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
     const double eN_s = ldv(eNp, sS), dN_s = ldv(dNp, sS);
     const double eS_n = ldv(eSp, sN), dS_n = ldv(dSp, sN);  // oppdir = south away from the seam row (:407)
     const double ar = ldv((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
-    const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
+    // zt[k-1], zt[k], zt[k+1]: k is (nearly) uniform in a wave, so the four levels around the wave's first k come through the
+    // scalar cache instead of three more vector loads; a wave that spans more than two levels (tiny grids) takes vector loads
+    const int k0w = __builtin_amdgcn_readfirstlane(k);
+    double ztk, zta, ztb;
+    if (__builtin_amdgcn_ballot_w64(k - k0w > 1 || k < k0w) == 0) {
+        const double z0 = p.zt[k0w > 0 ? k0w - 1 : 0], z1 = p.zt[k0w], z2 = p.zt[k0w + 1 < nz ? k0w + 1 : nz - 1],
+                     z3 = p.zt[k0w + 2 < nz ? k0w + 2 : nz - 1];
+        const bool lower = k != k0w;  // k == k0w + 1
+        ztk = lower ? z2 : z1;
+        zta = hA ? (lower ? z1 : z0) : ztk;
+        ztb = hB ? (lower ? z3 : z2) : ztk;
+    } else {
+        ztk = p.zt[k]; zta = p.zt[hA ? k - 1 : k]; ztb = p.zt[hB ? k + 1 : k];
+    }
 
     STAMP(st, 2, 1);  // every stencil load is back
     const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
