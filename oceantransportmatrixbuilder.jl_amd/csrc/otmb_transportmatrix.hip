@@ -464,21 +464,32 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const unsigned wc[5] = {(unsigned)(wtot & 0x7ff), (unsigned)((wtot >> 11) & 0x7ff), (unsigned)((wtot >> 22) & 0x7ff),
                             (unsigned)((wtot >> 33) & 0x3ff), (unsigned)((wtot >> 43) & 0x3ff)};
     typedef i64 i64x2 __attribute__((ext_vector_type(2)));
+#ifdef OTMB_ALIGNED16
+    typedef i64x2 i64x2g;
+#else
+    typedef i64x2 i64x2g __attribute__((aligned(8)));
+#endif
     // rows and value bits are staged in two arrays: an entry is two 8-byte LDS writes straight from the registers
     // that hold it, a pair of entries one 16-byte LDS read per array
     i64 *my_row = s_stage + wid * TM_WSTAGE;
     i64 *my_val = my_row + TM_STAGE;  // a constant distance: one address register, the LDS offset field does the rest
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) {
-        // The run is streamed out with 16-byte stores (two entries per lane): 8-byte-per-lane stores are
-        // store-issue bound per CU (measured: the write phase cost as much as loads + arithmetic).  The
-        // run starts at an arbitrary 8-byte position, so entries are staged at LDS index q + par where par
-        // is the run's parity: entry pairs (u, u+1), u even, are then 16-byte aligned in global memory.
+        // The run is streamed out with 16-byte stores (two entries per lane): 8-byte-per-lane stores are store-issue
+        // bound per CU (measured: the write phase cost as much as loads + arithmetic).  The run starts at an arbitrary
+        // 8-byte position; global_store_dwordx4 does not need more alignment than that, so pairs are simply counted from
+        // the run's first entry (an earlier version shifted the staging by the run's parity to keep the stores 16-byte
+        // aligned and paid two more 8-byte store instructions per matrix and array for the unpaired ends: +6 % time).
         const i64 run0 = wave_uniform(g0[m]) + wb[m];
         i64 *rv = p.rowval[m] + run0;
         double *nz = p.nzval[m] + run0;
+#ifdef OTMB_ALIGNED16  // the earlier variant, kept for A/B runs
         const unsigned par = (unsigned)(((unsigned long long)rv >> 3) & 1ull);
         const bool wide = ((((unsigned long long)rv) ^ ((unsigned long long)nz)) & 15ull) == 0;  // same parity for both arrays
+#else
+        const unsigned par = 0;
+        const bool wide = true;
+#endif
 #ifdef OTMB_DBG_NOLDS
         if (false) {
 #else
@@ -514,18 +525,27 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 for (unsigned base = 0; base < end; base += 128) {  // full pairs
                     const unsigned u = base + 2 * lane;
                     if ((u >= par) & (u + 1 < end)) {
-                        *(i64x2 *)(rvb + u * 8u) = *(const i64x2 *)(my_row + u);
-                        *(i64x2 *)(nzb + u * 8u) = *(const i64x2 *)(my_val + u);
+                        *(i64x2g *)(rvb + u * 8u) = *(const i64x2 *)(my_row + u);
+                        *(i64x2g *)(nzb + u * 8u) = *(const i64x2 *)(my_val + u);
                     }
                 }
                 // the (at most two) entries without a partner: index 1 of an odd-parity run, and the last one if
                 // it sits at an even index
+#ifdef OTMB_ALIGNED16
                 const unsigned e = (lane == 0) ? 1u : end - 1;
                 const bool single = (lane == 0) ? ((par == 1) & (end > 1)) : ((lane == 1) & ((end & 1u) == 1u) & (end > par));
                 if (single) {
                     *(i64 *)(rvb + e * 8u) = my_row[e];
                     *(i64 *)(nzb + e * 8u) = my_val[e];
                 }
+#else
+                // an odd run's last entry: ONE 8-byte store instruction, lane 0 writes the row, lane 1 the value
+                if ((lane < 2) & ((end & 1u) == 1u)) {
+                    const unsigned e = end - 1;
+                    i64 *dst = (lane == 0) ? (i64 *)(rvb + e * 8u) : (i64 *)(nzb + e * 8u);
+                    *dst = (lane == 0) ? my_row[e] : my_val[e];
+                }
+#endif
             } else {
                 for (unsigned e = lane; e < cnt; e += 64) {
                     rv[e] = my_row[par + e];
