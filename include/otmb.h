@@ -136,18 +136,6 @@ int32_t otmb_facefluxes_pending_flags(otmb_ctx *ctx, int32_t capacity, int32_t *
 int32_t otmb_push_mask_dev(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first,
                            int64_t count, uint16_t *push_mask);
 
-/* facefluxes for a caller that goes on to transportmatrix with the SAME mlotst, zt and weighting (the fused pipeline of one
- * time slice): instead of the push mask it writes COUNT WORDS, 16 bits per cell -- the number of rows the cell's column will
- * hold in T (union pattern), Tadv, TκH, TκVML, TκVdeep (3|3|3|2|2 bits).  The pattern of a column follows from the pushes of
- * its six neighbours, and for fluxes made by facefluxes those are the cell's own six fluxes seen from the other side
- * (src/velocities.jl:206-211, :219-224, :238-240), which the kernel has in registers: the counting pass of transportmatrix
- * (otmb_tm_args.count_words) then needs one 2-byte load per wet cell.  0xFFFF = "derive this column yourself" (tripolar seam
- * row, nx < 3), 0xFFFE = the cell pushes a non-zero flux into land (reported by transportmatrix as OTMB_ERR_FLUX_INTO_LAND).
- * Whole grids only (no depth slab).  Asynchronous; validity flags as for otmb_facefluxes_slab_dev.                    */
-int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d,
-                                   double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6],
-                                   const double *mlotst, const double *zt, int32_t upwind, uint16_t *count_words);
-
 /* ---- velocity2fluxes / fluxes2velocity -- src/velocities.jl:10-39, :50-74 (nanmean2 :89-93, nanmin2 :108);
  *      with facefluxes they make facefluxesfromvelocities (:140-151).  Default C-grid (u on east faces, v on
  *      north faces; the reference passes C-grid fields through, src/gridcellgeometry.jl:104).
@@ -209,10 +197,6 @@ typedef struct {
     int32_t only_t;              /* extension (0 = the reference's behaviour): non-zero builds T alone -- the four operator
                                   * matrices are still evaluated (T is their sum) but neither counted nor written: their
                                   * nnz come out 0 and their output pointers may be NULL.  Halves the bytes written.      */
-    const uint16_t *count_words; /* optional (device pointer, takes precedence over push_mask): written by
-                                  * otmb_facefluxes_counts_dev for exactly these phi, this wet mask, mlotst, zt and upwind.
-                                  * Like push_mask it can neither corrupt memory nor produce a wrong matrix: the fill pass
-                                  * re-derives every pattern from phi and refuses tiles whose counts differ.             */
 } otmb_tm_args;
 
 /* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).

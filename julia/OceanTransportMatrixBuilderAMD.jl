@@ -115,7 +115,6 @@ struct TmArgs
     kappa_h::Float64; kappa_vml::Float64; kappa_vdeep::Float64
     push_mask::Ptr{UInt16}        # device-resident callers only; C_NULL here (host arrays)
     only_t::Int32                 # extension: 1 = materialise T alone
-    count_words::Ptr{UInt16}      # device-resident callers only (otmb_facefluxes_counts_dev); C_NULL here
 end
 
 const HDIRS = (:west, :east, :south, :north)      # OTMB_DIR_*
@@ -179,7 +178,7 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
             ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0,
             pointer(lw3), pointer(lw), ntuple(i -> pointer(el[i]), 4), ntuple(i -> pointer(dn[i]), 4),
             pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep), Ptr{UInt16}(C_NULL),
-            Int32(operators ? 0 : 1), Ptr{UInt16}(C_NULL)))
+            Int32(operators ? 0 : 1)))
         check(ccall(sym(:otmb_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), ctx[], a, nnz))
     end
     colptr = [Vector{Int64}(undef, N + 1) for _ in 1:5]

@@ -42,7 +42,6 @@ class TmArgs(C.Structure):
         ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
         ("push_mask", C.c_void_p),
         ("only_t", C.c_int32),
-        ("count_words", C.c_void_p),
     ]
 
 
@@ -73,8 +72,6 @@ SYMBOLS = {
     "otmb_fluxes2velocity": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
     "otmb_push_mask_dev": (C.c_int32, [_vp, C.POINTER(_vp * 6), _vp, C.c_int64, C.c_int64, _vp]),
-    "otmb_facefluxes_counts_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
-                                                C.POINTER(_vp * 6), _vp, _vp, C.c_int32, _vp]),
     "otmb_lump_and_spray_plan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp,
                                                   C.c_int64, C.c_int64, C.c_int64, _ip]),
     "otmb_lump_and_spray_fill_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

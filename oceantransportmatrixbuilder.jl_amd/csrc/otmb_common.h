@@ -140,10 +140,6 @@ void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *t
 void otmb_launch_tilescan_groups(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *gsum, i64 ntiles, int nf);
 static inline size_t otmb_scan_scratch(i64 ntiles, int nf) { return (size_t)(ntiles / 1024 + 2) * nf * sizeof(i64); }
 
-// ---- count words (include/otmb.h, otmb_facefluxes_counts_dev): rows per column of T | Tadv | TκH | TκVML | TκVdeep in 3|3|3|2|2 bits
-#define OTMB_COUNT_UNKNOWN 0xFFFFu    // the counting pass derives this column itself (seam row, nx < 3)
-#define OTMB_COUNT_INTO_LAND 0xFFFEu  // the cell pushes a non-zero flux into land / outside the grid
-
 // ---- push mask (include/otmb.h, otmb_push_mask_dev): bits 0-5 west, east, south, north, bottom, top;
 // bit 6 wet; the centred-weighting variant in the high byte.  x / 2 is the reference's ϕ / 2 (:244-289).
 enum { PM_W = 1u << 0, PM_E = 1u << 1, PM_S = 1u << 2, PM_N = 1u << 3, PM_B = 1u << 4, PM_T = 1u << 5, PM_WET = 1u << 6 };

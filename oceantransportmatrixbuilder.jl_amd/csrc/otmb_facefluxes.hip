@@ -51,28 +51,11 @@ __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo
     }
 }
 
-// Count words (include/otmb.h, otmb_facefluxes_counts_dev): how many rows column (i,j,k) holds in T (union pattern), Tadv, TκH,
-// TκVML, TκVdeep -- 3|3|3|2|2 bits.  The counting pass of transportmatrix derives them from the push masks of the cell's six
-// neighbours, the mixed-layer mask and the wet mask; for fluxes made HERE the six incoming pushes are the cell's own six
-// fluxes seen from the other side (ϕwest[E] is ϕeast[C], ϕnorth[S] is ϕsouth[C], ϕbottom[A] is ϕtop[C], ...: velocities.jl:
-// 206-211, :219-224, :238-240), so the thread that has them in registers writes the counts and the counting pass shrinks
-// to one 2-byte load per wet cell.  Cells on the tripolar seam row (the fold pairs ϕnorth of two different cells) and grids
-// with nx < 3 get OTMB_COUNT_UNKNOWN: the counting pass then derives those columns itself.
-struct FfCount {
-    const double *zt;
-    double ml;          // mlotst of this column (NaN = missing)
-    int nz, upwind;
-    bool regular;       // not on the seam row, nx >= 3
-    bool wet_below;     // wet mask of the level processed before (k + 1)
-};
-__device__ __forceinline__ bool ff_nz(double x) { return (x > 0.0) || (x < 0.0); }
-
-template <typename T, bool COUNTS>
+template <typename T>
 __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
                                           bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
                                           double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
-                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask, FfCount &fc,
-                                          unsigned char wc_next_chunk) {
+                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask) {
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = k0 - q;
@@ -99,39 +82,7 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
             const double t = (((b + w) + so) - e) - n;  // :242
             ff_st(east + o, col.s, e); ff_st(west + o, col.s, w); ff_st(north + o, col.s, n); ff_st(south + o, col.s, so);
             ff_st(top + o, col.s, t); ff_st(bottom + o, col.s, b);
-            if (COUNTS) {
-                unsigned word = 0;
-                if (wc) {
-                    word = OTMB_COUNT_UNKNOWN;
-                    if (fc.regular) {
-                        const bool hA = k > 0, hB = k + 1 < fc.nz;
-                        const bool wA = hA && ((q + 1 < FF_KB) ? c.wc[(q + 1 < FF_KB) ? q + 1 : q] != 0 : wc_next_chunk != 0);
-                        const bool wB = hB && fc.wet_below;
-                        // the six pushes INTO this column (matrixbuilding.jl:244-296, seen from the receiving side) ...
-                        const bool up = fc.upwind != 0;
-                        const double he = e / 2, hw = w / 2, hs = so / 2, hn = n / 2, ht = t / 2, hb = b / 2;
-                        const bool aE = wE && (up ? e > 0.0 : ff_nz(he)), aW = wW && (up ? w < 0.0 : ff_nz(hw));
-                        const bool aS = wS && (up ? so < 0.0 : ff_nz(hs)), aN = wN && (up ? n > 0.0 : ff_nz(hn));
-                        const bool aA = wA && (up ? t > 0.0 : ff_nz(ht)), aB = wB && (up ? b < 0.0 : ff_nz(hb));
-                        // ... and this cell's own pushes, which must land in wet cells (the top face only below the surface, :290)
-                        const bool bad = ((up ? w > 0.0 : ff_nz(hw)) && !wW) | ((up ? e < 0.0 : ff_nz(he)) && !wE) |
-                                         ((up ? so > 0.0 : ff_nz(hs)) && !wS) | ((up ? n < 0.0 : ff_nz(hn)) && !wN) |
-                                         ((up ? b > 0.0 : ff_nz(hb)) && !wB) | (hA && (up ? t < 0.0 : ff_nz(ht)) && !wA);
-                        const double ztk = fc.zt[k], zta = fc.zt[hA ? k - 1 : k], ztb = fc.zt[hB ? k + 1 : k];
-                        const bool omC = ztk < fc.ml;  // Ω (:85); NaN compares false
-                        const bool mlB = wB & omC & (ztb < fc.ml), mlA = wA & omC & (zta < fc.ml);
-                        const unsigned nA = aA + aS + aW + aE + aN + aB, nH = wW + wE + wS + wN, nD = wA + wB, nM = mlA + mlB;
-                        const unsigned nU = nH + nD;  // every operator's rows are wet neighbours: the union is the wet neighbours
-                        word = bad ? OTMB_COUNT_INTO_LAND
-                                   : (nU + (nU > 0)) | ((nA + (nA > 0)) << 3) | ((nH + (nH > 0)) << 6) | ((nM + (nM > 0)) << 9) |
-                                         ((nD + (nD > 0)) << 11);
-                    }
-                }
-                ff_st(push_mask + o, col.s, (uint16_t)word);
-                fc.wet_below = wc;
-            } else if (push_mask) {
-                ff_st(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
-            }
+            if (push_mask) ff_st(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
             topbelow = t;
         }
     }
@@ -140,13 +91,12 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
 // Software pipeline over chunks of FF_KB levels: while chunk A is turned into fluxes and stored, the loads of the
 // next chunk B are already in flight.  A column is one thread and the grid has few columns (1.7 waves per SIMD at
 // 1 degree), so nothing else hides the memory latency of a chunk.
-template <typename T, bool COUNTS>
+template <typename T>
 __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen,
-    const double *__restrict__ mlotst, const double *__restrict__ zt, int upwind) {
+    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen) {
     const unsigned s = blockIdx.x * FF_THREADS + threadIdx.x;
     bool uvalid = false, vvalid = false;
     if (s < (unsigned)P) {
@@ -163,20 +113,16 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
         // seafloor ϕbottom is zero (:238); for a depth slab that is not the deepest, the plane handed up
         // by the slab below (its ϕtop at its first level) continues the chain without re-association
         double topbelow = top_below ? top_below[s] : 0.0;
-        FfCount fc;
-        fc.zt = zt; fc.nz = nz; fc.upwind = upwind; fc.wet_below = false;
-        fc.ml = COUNTS ? mlotst[s] : 0.0;
-        fc.regular = (nx >= 3) && !(topo == OTMB_TRIPOLAR && j + 1 >= (unsigned)ny);
         FfChunk<T> A, B;
         int k0 = nz - 1;
         ff_load(A, umo, vmo, wet, col, P, k0);
         while (k0 >= 0) {
             ff_load(B, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels<T, COUNTS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, fc, B.wc[0]);
+            ff_levels(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
             k0 -= FF_KB;
             if (k0 < 0) break;
             ff_load(A, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels<T, COUNTS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, fc, A.wc[0]);
+            ff_levels(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
             k0 -= FF_KB;
         }
     }
@@ -189,8 +135,7 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
-                               bool check_missing, const double *mlotst = nullptr, const double *zt = nullptr, int32_t upwind = 1,
-                               bool counts = false) {
+                               bool check_missing) {
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -205,17 +150,16 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
-#define FF_LAUNCH(T, C)                                                                                                       \
-    hipLaunchKernelGGL((facefluxes_kernel<T, C>), dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const T *)umo, (const T *)vmo,  \
-                       wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST],               \
-                       phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags,         \
-                       ctx->ff_gen, mlotst, zt, (int)upwind)
-    if (src_is_f32) {
-        if (counts) FF_LAUNCH(float, true); else FF_LAUNCH(float, false);
-    } else {
-        if (counts) FF_LAUNCH(double, true); else FF_LAUNCH(double, false);
-    }
-#undef FF_LAUNCH
+    if (src_is_f32)
+        hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
+                           (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
+                           phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
+                           phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen);
+    else
+        hipLaunchKernelGGL(facefluxes_kernel<double>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const double *)umo,
+                           (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
+                           phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
+                           phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen);
     }
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
@@ -241,16 +185,6 @@ extern "C" int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, cons
                                             int32_t topology, double *const phi[6], const double *top_below,
                                             uint16_t *push_mask) {
     return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, push_mask, false);
-}
-
-// Whole-grid variant that writes COUNT WORDS instead of the push mask (see FfCount above).
-extern "C" int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
-                                              const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
-                                              int32_t topology, double *const phi[6], const double *mlotst, const double *zt,
-                                              int32_t upwind, uint16_t *count_words) {
-    if (!mlotst || !zt || !count_words) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
-    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, nullptr, count_words, false, mlotst, zt,
-                           upwind, true);
 }
 
 // Push mask of existing ϕ arrays (include/otmb.h): one thread per cell of [first, first + count).

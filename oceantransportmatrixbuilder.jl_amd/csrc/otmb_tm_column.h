@@ -22,7 +22,6 @@ struct TmParams {
     const i64 *lw;    // Lwet3D (global wet ranks in a slab run), 0 = missing
     const i64 *lwet;  // Lwet: 1-based linear indices (in this grid) of the wet cells this launch owns
     const uint16_t *mask;  // push mask of every cell of the grid (counting pass; otmb_push_bits)
-    const uint16_t *words; // or count words (otmb_facefluxes_counts_dev): the counting pass reads 2 bytes per wet cell
     const double *edge[4], *dist[4];
     const double *area, *zt, *ml;
     double kH, kML, kDeep;

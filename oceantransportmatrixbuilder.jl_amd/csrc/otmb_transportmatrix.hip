@@ -87,32 +87,16 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
         raise_flag(p.flags, FLAG_NONCANONICAL);
         return 0;
     }
-    // Count words (written by otmb_facefluxes_counts_dev for exactly these fluxes): the five counts of the column in 13 bits.
-    // OTMB_COUNT_UNKNOWN sends the column down the paths below (seam row, nx < 3), which read ϕ and Lwet3D themselves.
-    unsigned word = OTMB_COUNT_UNKNOWN;
-    if (p.words) {
-        word = p.words[L];
-        if (word == OTMB_COUNT_INTO_LAND) {
-            raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-            return 0;
-        }
-        if (!p.rho_in_fill && p.rho && isnan(p.rho[L])) raise_flag(p.flags, FLAG_RHO_NAN);  // :233 (two-phase protocol)
-    }
-    if (word != OTMB_COUNT_UNKNOWN) {
-        const u64 nU = word & 7u, nA = (word >> 3) & 7u, nH = (word >> 6) & 7u, nM = (word >> 9) & 3u, nD = (word >> 11) & 3u;
-        if (p.only_t) return nU;
-        return nU | (nA << 11) | (nH << 22) | (nM << 33) | (nD << 43);
-    }
     TileBase tb;
     tb.lw = (const char *)(p.lw + base_elem);
     tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
-    tb.mk = p.mask ? (const char *)(p.mask + base_elem) : nullptr;
+    tb.mk = (const char *)(p.mask + base_elem);
     tb.v = tb.thk = tb.pe = tb.pw = tb.pn = tb.ps = tb.pt = tb.pb = nullptr;  // not read by the presence pass
     const Cell cell = cell_of(L, p.nx, p.ny, p.P);
     const unsigned oC = (unsigned)(L - base_elem) * 8u;
     // (Lwet3D[Lwet[w]] == w + 1 is verified by the fill pass, which loads Lwet3D anyway)
     unsigned padv, phh, pml, pdp;
-    const bool regular = !p.words && (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
+    const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
     if (regular) {
         fast_presence(p, tb, oC, cell.i, cell.j, cell.k, padv, phh, pml, pdp);
     } else {
@@ -675,11 +659,6 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
 // The counting pass reads the push mask: the caller's (written by facefluxes for exactly these ϕ), or one derived
 // here from ϕ and Lwet3D.
 static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &p) {
-    if (a.count_words) {  // the counting pass reads the count words; columns they leave open are derived from ϕ and Lwet3D
-        p.words = a.count_words;
-        p.mask = nullptr;
-        return OTMB_OK;
-    }
     if (a.push_mask) {
         p.mask = a.push_mask;
         return OTMB_OK;

@@ -160,33 +160,20 @@ class DeviceAssembler:
         return phi
 
     def facefluxes_async(self, umo, vmo, fill):
-        """Same kernel, no host round trip: the "all values missing" assertion is evaluated by finish().  The kernel also
-        writes, 16 bits per cell, what the counting pass of the following transportmatrix needs (include/otmb.h): COUNT
-        WORDS (the rows each column will hold, derived from the fluxes it has in registers together with this grid's
-        mlotst, zt and weighting) -- or, with OTMB_PUSH_MASK=1, the push mask of round 1."""
+        """Same kernel, no host round trip: the "all values missing" assertion is evaluated by finish().  The
+        kernel also writes the push mask of these fluxes (include/otmb.h), which lets the counting pass of the
+        following transportmatrix skip the six ϕ arrays."""
         if getattr(self, "phi", None) is None:
             self.phi = [self._empty(self.G, torch.float64) for _ in range(6)]
             self.push_mask = self._empty(self.G, torch.int16)
         ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
         self._mask_key = None
-        self._mask_is_words = os.environ.get("OTMB_PUSH_MASK") != "1" and hasattr(self.lib, "otmb_facefluxes_counts_dev")
-        if self._mask_is_words:
-            self.ctx.check(self.lib.otmb_facefluxes_counts_dev(
-                self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), self.wet3d.data_ptr(), float(fill),
-                self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), self.mlotst.data_ptr(), self.zt.data_ptr(), int(self.upwind),
-                self.push_mask.data_ptr()))
-        else:
-            self.ctx.check(self.lib.otmb_facefluxes_slab_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
-                                                             int(umo.dtype == torch.float32), self.wet3d.data_ptr(), float(fill),
-                                                             self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
-                                                             self.push_mask.data_ptr()))
-        self._mask_key = self._phi_key(self.phi) + self._words_key()
+        self.ctx.check(self.lib.otmb_facefluxes_slab_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
+                                                         int(umo.dtype == torch.float32), self.wet3d.data_ptr(), float(fill),
+                                                         self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
+                                                         self.push_mask.data_ptr()))
+        self._mask_key = self._phi_key(self.phi)
         return self.phi
-
-    def _words_key(self):
-        # count words also depend on the wet mask, mlotst, zt and the weighting they were derived with
-        return ((self.wet3d.data_ptr(), self.wet3d._version), (self.mlotst.data_ptr(), self.mlotst._version),
-                (self.zt.data_ptr(), self.zt._version), bool(self.upwind))
 
     @staticmethod
     def _phi_key(phi):
@@ -262,10 +249,8 @@ class DeviceAssembler:
         a.area2d, a.zt, a.mlotst = self.area.data_ptr(), self.zt.data_ptr(), self.mlotst.data_ptr()
         a.kappa_h, a.kappa_vml, a.kappa_vdeep = self.kappa
         # ϕ straight from this object's facefluxes and untouched since: hand over its push mask
-        fresh = getattr(self, "_mask_key", None) is not None and self._mask_key == self._phi_key(phi) + self._words_key()
-        words = fresh and getattr(self, "_mask_is_words", False)
-        a.push_mask = self.push_mask.data_ptr() if (fresh and not words) else None
-        a.count_words = self.push_mask.data_ptr() if words else None
+        fresh = getattr(self, "_mask_key", None) is not None and self._mask_key == self._phi_key(phi)
+        a.push_mask = self.push_mask.data_ptr() if fresh else None
         a.only_t = 1 if getattr(self, "only_T", False) else 0  # extension: materialise T alone (outputs of the operators unused)
         return a
 

@@ -40,88 +40,12 @@ def _assembler(g, gm, upwind=True):
     return asm, umo, vmo
 
 
-@pytest.fixture(params=["words", "mask"])
-def mode(request, monkeypatch):
-    """What facefluxes leaves for the counting pass: count words (default) or the push mask of round 1 (OTMB_PUSH_MASK=1)."""
-    if request.param == "mask":
-        monkeypatch.setenv("OTMB_PUSH_MASK", "1")
-    else:
-        monkeypatch.delenv("OTMB_PUSH_MASK", raising=False)
-    return request.param
-
-
-def _summary_ptr(args, mode):
-    return args.count_words if mode == "words" else args.push_mask
-
-
 @pytest.mark.parametrize("name", list(CASES))
-def test_count_words_written_by_facefluxes_are_the_column_counts(oracle, name, monkeypatch):
-    """Count words (otmb_facefluxes_counts_dev): 3|3|3|2|2 bits = rows per column of the union pattern, Tadv, TκH, TκVML,
-    TκVdeep, checked against the oracle's matrices column by column; 0xFFFF on the tripolar seam row and for nx < 3."""
-    monkeypatch.delenv("OTMB_PUSH_MASK", raising=False)
-    g, gm = make_case(name)
-    ref = oracle.makeindices(gm.v3D)
-    fill = g.umo.properties["_FillValue"]
-    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], fill, gm.gridtopology.kind)
-    for upwind in (True, False):
-        rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind)
-        asm, umo, vmo = _assembler(g, gm, upwind=upwind)
-        asm.facefluxes(umo, vmo, fill)
-        assert asm._mask_is_words
-        words = asm.push_mask.cpu().numpy().view(np.uint16)
-        nx, ny, nz = gm.v3D.shape
-        L = ref["Lwet"] - 1
-        j = (L % (nx * ny)) // nx
-        irregular = (nx < 3) | ((gm.gridtopology.kind == 1) & (j == ny - 1))
-        w = words[L].astype(np.int64)
-        assert (w[irregular] == 0xFFFF).all()
-        reg = ~irregular
-        per_col = {m: np.diff(rtm[m][0]) for m in MATS}
-        assert np.array_equal((w[reg] >> 3) & 7, per_col["Tadv"][reg])
-        assert np.array_equal((w[reg] >> 6) & 7, per_col["TκH"][reg])
-        assert np.array_equal((w[reg] >> 9) & 3, per_col["TκVML"][reg])
-        assert np.array_equal((w[reg] >> 11) & 3, per_col["TκVdeep"][reg])
-        assert ((w[reg] & 7) >= per_col["T"][reg]).all()  # the union pattern bounds T (exact-zero sums are dropped, :147)
-        assert (words[np.setdiff1d(np.arange(words.size), L)] == 0).all()  # land
-        # and transportmatrix with these words gives the oracle's matrices, both protocols
-        for onepass in (True, False):
-            asm.step(umo, vmo, fill, onepass=onepass)
-            got = asm.result_to_host()
-            for m in MATS:
-                assert_csc_equal(got[m], rtm[m], f"{name}/{m}/upwind={upwind}/onepass={onepass}")
-
-
-def test_flux_into_land_under_an_overhang_is_reported_in_both_modes(oracle, mode):
-    """A wet cell under a land cell: the continuity chain hands it a top flux that would have to go into land -- the reference
-    throws (Lwet3D[nothing]); count words carry that as 0xFFFE, the push-mask path finds it in the counting pass."""
-    from otmb_amd.capi import OtmbError
-
-    g, gm = make_case("small_rho3d")
-    wet = ~np.isnan(gm.v3D)
-    i, jj = np.argwhere(wet[:, :, 3] & wet[:, :, 2] & wet[:, :, 1])[10]
-    gm.v3D[i, jj, 1] = np.nan      # land at level 2 of a column that is wet at levels 1, 3, 4, ...
-    gm.thkcello[i, jj, 1] = np.nan
-    ref = oracle.makeindices(gm.v3D)
-    fill = g.umo.properties["_FillValue"]
-    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], fill, gm.gridtopology.kind)
-    assert rphi["top"][i, jj, 2] != 0
-    with pytest.raises(oracle.OracleError) as e:
-        oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
-    assert e.value.code == -6
-    asm, umo, vmo = _assembler(g, gm)
-    for onepass in (True, False):
-        with pytest.raises(OtmbError) as e:
-            asm.step(umo, vmo, fill, onepass=onepass)
-        assert e.value.name == "FLUX_INTO_LAND"
-
-
-@pytest.mark.parametrize("name", list(CASES))
-def test_mask_written_by_facefluxes_equals_derived_mask_and_definition(oracle, name, monkeypatch):
+def test_mask_written_by_facefluxes_equals_derived_mask_and_definition(oracle, name):
     import torch
 
     from otmb_amd import capi
 
-    monkeypatch.setenv("OTMB_PUSH_MASK", "1")
     g, gm = make_case(name)
     ref = oracle.makeindices(gm.v3D)
     fill = g.umo.properties["_FillValue"]
@@ -169,7 +93,7 @@ def test_push_mask_subrange_and_smallest_denormal():
 
 
 @pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold", "tiny_bipolar"])
-def test_device_step_with_centred_weighting(oracle, name, mode):
+def test_device_step_with_centred_weighting(oracle, name):
     g, gm = make_case(name)
     ref = oracle.makeindices(gm.v3D)
     fill = g.umo.properties["_FillValue"]
@@ -183,7 +107,7 @@ def test_device_step_with_centred_weighting(oracle, name, mode):
             assert_csc_equal(got[m], rtm[m], f"{name}/{m}/onepass={onepass}")
 
 
-def test_mask_is_dropped_when_fluxes_change_after_facefluxes(oracle, mode):
+def test_mask_is_dropped_when_fluxes_change_after_facefluxes(oracle):
     """ϕ modified in place after facefluxes (here: reversed flow, a different Tadv pattern): the assembler must not
     hand the now stale mask to the library."""
     g, gm = make_case("small_rho3d")
@@ -196,10 +120,10 @@ def test_mask_is_dropped_when_fluxes_change_after_facefluxes(oracle, mode):
     assert not np.array_equal(rtm_fwd["Tadv"][1], rtm_rev["Tadv"][1])  # the patterns do differ
     asm, umo, vmo = _assembler(g, gm)
     phi = asm.facefluxes(umo, vmo, fill)
-    assert _summary_ptr(asm._args(phi), mode) is not None
+    assert asm._args(phi).push_mask is not None
     for p in phi:
         p.neg_()
-    assert asm._args(phi).push_mask is None and asm._args(phi).count_words is None
+    assert asm._args(phi).push_mask is None
     for twophase in (False, True):
         if twophase:
             asm.transportmatrix(phi)
@@ -210,7 +134,7 @@ def test_mask_is_dropped_when_fluxes_change_after_facefluxes(oracle, mode):
             assert_csc_equal(got[m], rtm_rev[m], f"{m}/twophase={twophase}")
 
 
-def test_library_refuses_a_mask_that_does_not_describe_the_fluxes(oracle, mode):
+def test_library_refuses_a_mask_that_does_not_describe_the_fluxes(oracle):
     """C-ABI misuse: the caller hands over the mask of other fluxes.  The fill pass compares its counts with the
     counting pass tile by tile, writes nothing for a tile that disagrees and reports OTMB_ERR_PUSH_MASK."""
     from otmb_amd.capi import OtmbError
@@ -221,8 +145,8 @@ def test_library_refuses_a_mask_that_does_not_describe_the_fluxes(oracle, mode):
     phi = asm.facefluxes(umo, vmo, fill)
     for p in phi:
         p.neg_()
-    asm._mask_key = asm._phi_key(phi) + asm._words_key()  # pretend the mask / the count words are still current
-    assert _summary_ptr(asm._args(phi), mode) is not None
+    asm._mask_key = asm._phi_key(phi)  # pretend the mask is still current
+    assert asm._args(phi).push_mask is not None
     with pytest.raises(OtmbError) as e:
         asm.transportmatrix_onepass(phi)
     assert e.value.name == "PUSH_MASK"
