@@ -598,6 +598,51 @@ __device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase 
     pml = ((unsigned)mlB << S_B) | ((unsigned)mlA << S_A) | ((unsigned)(mlA | mlB) << S_SELF);
 }
 
+// Presence only, ANY cell (tripolar seam row, nx <= 2): build_column's pattern logic -- the canonical slots of row-mates
+// that coincide, the fold's north neighbour living in the cell's own row -- on the push mask alone.  Seven 2-byte loads
+// in one round trip instead of build_column's chain of dependent loads and divisions; the values are the fill pass's
+// business.
+__device__ __forceinline__ void general_presence(const TmParams &p, const Cell &cell, unsigned &padv, unsigned &phh, unsigned &pml,
+                                                 unsigned &pdp) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const int i = cell.i, j = cell.j, k = cell.k;
+    const int ie = (i + 1 < nx) ? i + 1 : 0, iw = (i > 0) ? i - 1 : nx - 1;
+    const i64 L = cell.L, LEc = cell.row0 + ie, LWc = cell.row0 + iw;
+    const i64 LS = nb_jm1(cell, nx), LNq = nb_jp1(cell, nx, ny, p.topo);
+    const i64 LA = nb_km1(cell, p.P), LB = nb_kp1(cell, nz, p.P);
+    const bool fold = (j == ny - 1) && (LNq >= 0);
+    const int ifd = nx - 1 - i;
+    const unsigned sh = p.upwind ? 0u : 8u;
+    const unsigned mC = (unsigned)p.mask[L] >> sh, mE = (unsigned)p.mask[LEc] >> sh, mW = (unsigned)p.mask[LWc] >> sh,
+                   mS = (unsigned)p.mask[LS >= 0 ? LS : L] >> sh, mN = (unsigned)p.mask[LNq >= 0 ? LNq : L] >> sh,
+                   mA = (unsigned)p.mask[LA >= 0 ? LA : L] >> sh, mB = (unsigned)p.mask[LB >= 0 ? LB : L] >> sh;
+    const double mld = p.ml[(i64)j * nx + i];
+    const double ztk = p.zt[k], zta = p.zt[k > 0 ? k - 1 : k], ztb = p.zt[k + 1 < nz ? k + 1 : k];
+    const bool wE = mE & PM_WET, wW = mW & PM_WET, wS = (LS >= 0) && (mS & PM_WET), wN = (LNq >= 0) && (mN & PM_WET),
+               wA = (LA >= 0) && (mA & PM_WET), wB = (LB >= 0) && (mB & PM_WET);
+    {
+        const bool bad = ((mC & PM_W) && !wW) | ((mC & PM_E) && !wE) | ((mC & PM_S) && !wS) | ((mC & PM_N) && !wN) |
+                         ((mC & PM_B) && !wB) | ((k > 0) && (mC & PM_T) && !wA);
+        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+        if (!p.rho_in_fill && p.rho && isnan(p.rho[L])) raise_flag(p.flags, FLAG_RHO_NAN);
+    }
+    // through the seam the north neighbour pushes with its own NORTH flux (:271-278 seen from the other side)
+    const bool aE = wE && (mE & PM_W), aW = wW && (mW & PM_E), aS = wS && (mS & PM_N), aN = wN && (mN & (fold ? PM_N : PM_S));
+    const bool aA = wA && (mA & PM_B), aB = wB && (mB & PM_T);
+    const int cEC = (ie == i) ? S_SELF : S_EC;
+    const int cWC = (iw == i) ? S_SELF : ((iw == ie) ? S_EC : S_WC);
+    const int cFQ = (ifd == i) ? S_SELF : ((ifd == ie) ? S_EC : ((ifd == iw) ? cWC : S_FQ));
+    const int cN = fold ? cFQ : S_N;
+    padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aE << cEC) | ((unsigned)aW << cWC) | ((unsigned)aN << cN) |
+           ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+    phh = ((unsigned)wS << S_S) | ((unsigned)wE << cEC) | ((unsigned)wW << cWC) | ((unsigned)wN << cN) |
+          ((unsigned)(wW | wE | wS | wN) << S_SELF);
+    pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+    const bool omC = ztk < mld;
+    const bool mlB = wB & omC & (ztb < mld), mlA = wA & omC & (zta < mld);
+    pml = ((unsigned)mlB << S_B) | ((unsigned)mlA << S_A) | ((unsigned)(mlA | mlB) << S_SELF);
+}
+
 // T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)
 __device__ __forceinline__ double t_value(const Column &col, int s) {
     const double a = ((col.padv >> s) & 1u) ? col.adv[s] : 0.0;

@@ -70,9 +70,12 @@ __device__ __forceinline__ i64 wave_uniform(i64 x) {
 __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) {
     const i64 w0 = tile * TM_THREADS, w = w0 + tid;
     if (w0 >= p.n_own) return 0;
-    const i64 Lmin = p.lwet[w0] - 1;
+    // every index load is issued before anything is tested: one memory round trip in front of the mask loads
     const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
-    const i64 Lmax = p.lwet[wlast] - 1;
+    const i64 wc = (w < p.n_own) ? w : wlast;
+    const i64 Lmin = p.lwet[w0] - 1, Lmax = p.lwet[wlast] - 1;
+    const i64 L = p.lwet[wc] - 1;
+    const i64 Lnext = (wc + 1 < p.n_own) ? p.lwet[wc + 1] - 1 : p.G;
     const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
     const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
     if (!span_ok) {
@@ -80,9 +83,6 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
         return 0;
     }
     if (w >= p.n_own) return 0;
-    const i64 L = p.lwet[w] - 1;
-    const i64 Lnext = (w + 1 < p.n_own) ? p.lwet[w + 1] - 1 : p.G;
-    const i64 c = p.wet_base + w + 1;
     if (L < Lmin || L > Lmax || Lnext <= L) {
         raise_flag(p.flags, FLAG_NONCANONICAL);
         return 0;
@@ -100,9 +100,7 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
     if (regular) {
         fast_presence(p, tb, oC, cell.i, cell.j, cell.k, padv, phh, pml, pdp);
     } else {
-        Column col;
-        build_column(p, cell, c, col);
-        padv = col.padv; phh = col.phh; pml = col.pml; pdp = col.pdp;
+        general_presence(p, cell, padv, phh, pml, pdp);
     }
     if (p.only_t) return (u64)__popc(padv | phh | pml | pdp);
     return (u64)__popc(padv | phh | pml | pdp) | ((u64)__popc(padv) << 11) | ((u64)__popc(phh) << 22) | ((u64)__popc(pml) << 33) |
