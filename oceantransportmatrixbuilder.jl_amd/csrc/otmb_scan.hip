@@ -46,6 +46,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups(const uint32_t *
     }
 }
 
+// level 1 for the five interleaved fields of the transport-matrix tiles: the tile sums are below 2^11 (a tile has 256
+// columns of at most 7 rows), so a group's prefixes fit 32 bits -- 32-bit shuffles, all five fields behind ONE barrier.
+__global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups5(const uint32_t *__restrict__ sums, i64 *__restrict__ offs,
+                                                                  i64 *__restrict__ gsum, i64 ntiles) {
+    __shared__ uint32_t wave_tot[5][SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const i64 t = (i64)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    uint32_t mine[5], x[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) mine[f] = (t < ntiles) ? sums[t * 5 + f] : 0u;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        x[f] = mine[f];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x[f], d);
+            if (lane >= d) x[f] += y;
+        }
+        if (lane == 63) wave_tot[f][wid] = x[f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+            const uint32_t v = wave_tot[f][w];
+            if (w < wid) before += v;
+            all += v;
+        }
+        if (t < ntiles) offs[t * 5 + f] = (i64)(before + x[f] - mine[f]);
+        if (threadIdx.x == 0) gsum[(i64)blockIdx.x * 5 + f] = (i64)all;
+    }
+}
+
 // level 2: exclusive scan of the group totals (ngroups <= 1024 per pass, looped), totals to tot[f]
 __global__ __launch_bounds__(SCAN_THREADS) void tilescan_top(i64 *__restrict__ gsum, i64 *__restrict__ tot, i64 ngroups, int nf) {
     __shared__ i64 wave_tot[SCAN_MAXF][SCAN_THREADS / 64];
@@ -160,5 +195,8 @@ void otmb_launch_tilescan(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *t
 // two launches fewer on the critical path).
 void otmb_launch_tilescan_groups(hipStream_t s, const uint32_t *sums, i64 *offs, i64 *gsum, i64 ntiles, int nf) {
     const i64 ngroups = (ntiles + SCAN_THREADS - 1) / SCAN_THREADS;
-    hipLaunchKernelGGL(tilescan_groups, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, sums, offs, gsum, ntiles, nf);
+    if (nf == 5)  // (callers pass sums below 2^11 per tile: see tilescan_groups5)
+        hipLaunchKernelGGL(tilescan_groups5, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, sums, offs, gsum, ntiles);
+    else
+        hipLaunchKernelGGL(tilescan_groups, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, sums, offs, gsum, ntiles, nf);
 }

@@ -20,8 +20,7 @@ for topology in ("tripolar", "bipolar"):
                                   lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
     umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
     vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
-    for words in ("0", "1"):
-        os.environ["OTMB_COUNT_WORDS"] = words
+    if True:
         a = DeviceAssembler(0)
         a.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
         for _ in range(3):
@@ -30,5 +29,5 @@ for topology in ("tripolar", "bipolar"):
         for _ in range(20):
             a.step(umo, vmo, 1e20)
         kt = {k: round(v[0] / v[1], 4) for k, v in a.ctx.timing_collect().items()}
-        print(topology, "words" if words == "1" else "mask ", "N =", a.N, kt, flush=True)
+        print(topology, "N =", a.N, kt, flush=True)
         del a
