@@ -55,6 +55,7 @@ struct otmb_ctx {
     // memory, so that a failure in step 3 of 12 is still there when the host finally looks (otmb_transportmatrix_result)
     DevBuf ring;
     int *h_ring = nullptr;
+    unsigned long long ring_clean = 0;  // ring slots (bit per slot) known to be zero on the device and unused
     i64 tm_first = 0, tm_next = 0;   // pending asynchronous transportmatrix steps [tm_first, tm_next)
     int32_t tm_sticky = 0;           // first failure folded out of the ring when it wrapped (status, step index)
     i64 tm_sticky_step = -1;

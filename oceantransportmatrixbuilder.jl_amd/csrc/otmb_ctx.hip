@@ -89,6 +89,8 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
         otmb_ctx_destroy(c);
         return OTMB_ERR_ALLOC;
     }
+    static_assert(OTMB_RING == 64, "ring_clean holds one bit per ring slot");
+    c->ring_clean = ~0ull;
     *out = c;
     return OTMB_OK;
 }

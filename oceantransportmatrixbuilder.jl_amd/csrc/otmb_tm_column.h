@@ -47,6 +47,7 @@ struct TmParams {
     i64 n_tiles;
     int *ticket;           // dynamic tile id (ONEPASS)
     int *flags;
+    int *next_state;       // the NEXT asynchronous step's state block, zeroed by this fill (or NULL): no memset between steps
 };
 
 // Diagnostic build only (-DOTMB_DBG_STAMPS, tools/stamps.py): s_memtime stamps of the phases of a wave of the fill

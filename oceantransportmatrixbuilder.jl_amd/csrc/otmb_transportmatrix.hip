@@ -235,6 +235,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     for (int q = 0; q < OTMB_NSTAMP; ++q) st.t[q] = 0;
 #endif
     STAMP(st, 0, 0);
+    if (p.next_state && blockIdx.x == 0 && tid < (int)(OTMB_TM_STATE_BYTES / sizeof(int))) p.next_state[tid] = 0;
 #ifdef OTMB_STAGGER_UNITS
     // Experiment: the workgroups of the first dispatch round start together and march through their phases (loads,
     // arithmetic, stores) in lockstep; delay the k-th workgroup of a CU by k * OTMB_STAGGER_UNITS * 64 * 127 cycles
@@ -736,6 +737,13 @@ static int32_t t_fixup(otmb_ctx *ctx, TmPlan &pl, i64 *colptrT, i64 *rowvalT, do
     return OTMB_OK;
 }
 
+// The state blocks of the asynchronous steps, device ring -> pinned host mirror, once the stream has drained.
+static int32_t fetch_ring(otmb_ctx *ctx) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ring, ctx->ring.p, (size_t)OTMB_RING * OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
 // Fold the completed pending steps [tm_first, tm_next) of the asynchronous protocol into the sticky (status, step) pair:
 // the first failing step wins.  The stream is idle on entry (the steps' state blocks have landed in h_ring).
 static void fold_pending(otmb_ctx *ctx) {
@@ -933,16 +941,27 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     // this step's own state block (flag words + totals): a ring slot, so that the verdict on every step of a pipeline
     // of asynchronous calls is still there when otmb_transportmatrix_result finally looks.  A full ring is folded
     // into the sticky (status, step) pair first -- one host synchronisation per OTMB_RING steps.
-    if (ctx->tm_next - ctx->tm_first >= OTMB_RING) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (one slot short of the ring: every fill zeroes the slot of the step after it, which must not be a pending one)
+    if (ctx->tm_next - ctx->tm_first >= OTMB_RING - 1) {
+        int32_t frc;
+        if ((frc = fetch_ring(ctx))) return frc;
         fold_pending(ctx);
     }
     int *dflags = otmb_ring_tm((int *)ctx->ring.p, ctx->tm_next);
-    int *hflags = otmb_ring_tm(ctx->h_ring, ctx->tm_next);
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     p.flags = dflags;
     p.totals = dtot;
-    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
+    // The state blocks stay on the device until somebody asks (otmb_transportmatrix_result, or a full ring): no copy per
+    // step, and no memset either when the previous step's fill has already zeroed this block (two 4-5 us blit kernels
+    // per step on the stream otherwise, 1.6 % of a 1-degree step).
+    const int slot = (int)(ctx->tm_next % OTMB_RING), slot_after = (int)((ctx->tm_next + 1) % OTMB_RING);
+    if ((ctx->ring_clean >> slot) & 1ull) {
+        ctx->ring_clean &= ~(1ull << slot);
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
+    }
+    ctx->ring_clean &= ~(1ull << slot_after);
+    p.next_state = (ntiles > 0) ? otmb_ring_tm((int *)ctx->ring.p, ctx->tm_next + 1) : nullptr;
     if (ntiles == 0) {
         KernelTimer kt(ctx, K_TM_FINISH);
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
@@ -985,7 +1004,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(hflags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    if (p.next_state) ctx->ring_clean |= 1ull << slot_after;
     ctx->tm_next += 1;
     pl.onepass_pending = true;
     return OTMB_OK;
@@ -994,7 +1013,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
 int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]) {
     if (!ctx || !nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     if (!ctx->plan || !ctx->plan->onepass_pending) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t frc;
+    if ((frc = fetch_ring(ctx))) return frc;
     ctx->plan->onepass_pending = false;
     // every step enqueued since the previous result: the FIRST one that failed is reported (the reference would have
     // thrown there, src/matrixbuilding.jl:39,61,90,114,233), with its position in the error text
