@@ -7,8 +7,12 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# the trace runs bench.py's default steps / warm-up / repeats (the fill pass needs ~20 steps to reach its steady rate: with
+# --steps 10 --warmup 2 it measures 0.40-0.43 ms where the default run measures 0.38-0.39); the counter passes are short
+TARGS="--no-cpu-baseline --no-end-to-end $@"
 ARGS="--steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rm -rf $OUT/trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $TARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" \
