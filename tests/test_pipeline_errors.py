@@ -128,6 +128,35 @@ def test_pipeline_longer_than_the_ring_keeps_an_early_failure(oracle):
     assert e.value.step == 5 and "step 6 of 100" in str(e.value)
 
 
+def test_clean_pipeline_across_the_ring_returns_the_last_step(oracle):
+    """130 raw asynchronous calls, no failure: the state blocks are zeroed by the preceding fill pass and fetched when the ring is
+    full and at result() -- the totals and the matrices are the last step's, bit for bit."""
+    g, gm, ref, rtm, asm, umo, vmo = _setup(oracle, "tiny_rho3d")
+    phi = asm.facefluxes(umo, vmo, 1e20)
+    for _ in range(130):
+        asm.transportmatrix_onepass(phi, sync=False)
+    out = asm.result()
+    for k, m in enumerate(MATS):
+        n = asm.nnz[k]
+        assert n == len(rtm[m][1])
+        cp, rv, nz = (t.cpu().numpy() for t in out[m])
+        assert_csc_equal((cp, rv[:n], nz[:n]), rtm[m], m)
+    # and a failure after a clean drain is reported relative to the new pipeline
+    from otmb_amd.capi import OtmbError
+
+    L = int(ref["Lwet"][3] - 1)
+    for sidx in range(3):
+        if sidx == 1:
+            old = asm.rho[L].clone()
+            asm.rho[L] = float("nan")
+        asm.transportmatrix_onepass(phi, sync=False)
+        if sidx == 1:
+            asm.rho[L] = old
+    with pytest.raises(OtmbError, match="ρ contains NaNs") as e:
+        asm.result()
+    assert e.value.step == 1 and "step 2 of 3" in str(e.value)
+
+
 @pytest.mark.parametrize("fault", ["1:1:rho", "2:3:rho"])
 def test_hip_slab_pipeline_reports_first_failing_step_on_every_rank(oracle, tmp_path, fault):
     from test_dist_cpu import check_against_whole_grid, check_fault_reports, run_ranks
