@@ -1,0 +1,266 @@
+// Micro-benchmark (tools only): a MODEL of the fill pass's traffic and arithmetic, to ask one question -- can the part of the
+// kernel's time that does not overlap with its memory traffic (profiles/r02/README.md: time = 0.167 ms + bytes / 6.3 TB/s)
+// be made to overlap by restructuring a wave's life?
+//   per wet cell (one lane): an index load, then NLOAD gathers of 8 bytes around it (same cell, +-1, +-nx, +-P in NARR 3-D
+//   arrays, plus 2-D arrays), ~NFMA dependent f64 FMAs, then 320 bytes of output written as contiguous 16-byte-per-lane stores
+//   into ten streams (20 entries of 16 bytes per cell: 7 + 4 + 5 + 1 + 3 like T, Tadv, TkH, TkVML, TkVdeep).
+// Variants: plain (one tile per workgroup) with / without loads, arithmetic, stores; PIPE: persistent workgroups that issue
+// tile t+1's loads before tile t's arithmetic and stores.
+//   hipcc --offload-arch=gfx950 -O3 -o fill_model fill_model.hip && ./fill_model
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef long long i64;
+typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+
+#define NARR 10  // 3-D arrays: v, rho, Lwet3D read at 7 stencil points, thk at 5, the six fluxes at one neighbour each
+#define N2D 10   // 2-D arrays read at the cell, two of them also at 4 neighbours
+#define NVAL (7 + 7 + 7 + 5 + 6 + N2D + 8)
+static const int CNT[5] = {7, 4, 5, 1, 3};
+
+struct Params {
+    const i64 *lwet;
+    const double *a[NARR];
+    const double *b[N2D];
+    double *out[10];
+    i64 n, G, P;
+    int nx, nfma;
+};
+
+template <bool LOADS, bool NOEW = false>
+__device__ __forceinline__ void load_cell(const Params &p, i64 w, double (&v)[NVAL]) {
+    if (!LOADS) {
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q) v[q] = 1.0 + 1e-9 * (double)(w + q);
+        return;
+    }
+    const i64 wc = w < p.n ? w : p.n - 1;
+    const i64 L = p.lwet[wc];
+    const i64 s = L % p.P;
+    const i64 off[7] = {0, 1, -1, p.nx, -(i64)p.nx, p.P, -p.P};
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+            if (k == 3 && o >= 5) continue;
+            if (NOEW && (o == 1 || o == 2)) { v[q++] = 1.0; continue; }
+            i64 x = L + off[o];
+            x = x < 0 ? L : (x >= p.G ? L : x);
+            v[q++] = p.a[k][x];
+        }
+    }
+#pragma unroll
+    for (int k = 4; k < NARR; ++k) {
+        i64 x = L + off[k - 3];
+        x = x < 0 ? L : (x >= p.G ? L : x);
+        v[q++] = p.a[k][x];
+    }
+#pragma unroll
+    for (int k = 0; k < N2D; ++k) v[q++] = p.b[k][s];
+    const i64 o2[4] = {1, -1, p.nx, -(i64)p.nx};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            i64 x = s + o2[o];
+            x = x < 0 ? s : (x >= p.P ? s : x);
+            v[q++] = p.b[k][x];
+        }
+    }
+}
+
+template <bool MATH>
+__device__ __forceinline__ void math(const Params &p, const double (&v)[NVAL], double (&r)[20]) {
+#pragma unroll
+    for (int e = 0; e < 20; ++e) r[e] = v[e % NVAL] + v[(e + 20) % NVAL] * v[(e + 40) % NVAL];
+    if (MATH) {
+        for (int it = 0; it < p.nfma; ++it) {
+#pragma unroll
+            for (int e = 0; e < 20; ++e) r[e] = __builtin_fma(r[e], 1.0000001, v[e % 8]);
+        }
+    }
+}
+
+// a wave's 64 cells own 64 * CNT[m] consecutive entries of matrix m: written as 16-byte-per-lane stores (two 8-byte entries)
+template <bool STORES, bool NT = false>
+__device__ __forceinline__ void store_tile(const Params &p, i64 w0wave, int lane, const double (&r)[20]) {
+    if (!STORES) {
+        double s = 0;
+#pragma unroll
+        for (int e = 0; e < 20; ++e) s += r[e];
+        if (s == 12345.678) p.out[0][0] = s;
+        return;
+    }
+    int e0 = 0;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const i64 base = w0wave * CNT[m];  // entries
+#pragma unroll
+        for (int c = 0; c < CNT[m]; c += 2) {
+            // entries [c*64, c*64 + 128) of the wave's run, 2 per lane; an odd last column is a half store
+            const i64 ent = base + (i64)c * 64 + lane * 2;
+            if (c + 1 < CNT[m] || lane < 32) {
+                d2 x = {r[e0 + c], r[e0 + (c + 1 < CNT[m] ? c + 1 : c)]};
+                if (NT) {
+                    __builtin_nontemporal_store(x, (d2 *)(p.out[2 * m] + ent));
+                    __builtin_nontemporal_store(x, (d2 *)(p.out[2 * m + 1] + ent));
+                } else {
+                    *(d2 *)(p.out[2 * m] + ent) = x;
+                    *(d2 *)(p.out[2 * m + 1] + ent) = x;
+                }
+            }
+        }
+        e0 += CNT[m];
+    }
+}
+
+template <bool LOADS, bool MATH, bool STORES, bool NOEW = false, bool NT = false>
+__global__ __launch_bounds__(256) void plain(Params p) {
+    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    double v[NVAL], r[20];
+    load_cell<LOADS, NOEW>(p, w, v);
+    math<MATH>(p, v, r);
+    store_tile<STORES, NT>(p, w - lane, lane, r);
+}
+
+// persistent: the loads of the next tile are in flight while this tile is computed and stored
+__global__ __launch_bounds__(256) void piped(Params p, i64 ntiles) {
+    const int lane = threadIdx.x & 63;
+    i64 tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    double v[NVAL], vn[NVAL], r[20];
+    load_cell<true>(p, tile * 256 + threadIdx.x, v);
+    while (true) {
+        const i64 next = tile + gridDim.x;
+        if (next < ntiles) load_cell<true>(p, next * 256 + threadIdx.x, vn);
+        math<true>(p, v, r);
+        store_tile<true>(p, tile * 256 + threadIdx.x - lane, lane, r);
+        if (next >= ntiles) break;
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q) v[q] = vn[q];
+        tile = next;
+    }
+}
+
+// k-march model: a wave is 64 consecutive i of one row and walks the levels; the levels above / below stay in registers, east /
+// west would come by DPP: per level only the own level of the ten 3-D arrays and the south / north rows of five of them are
+// loaded (4 cache lines per load instead of ~8), the 2-D arrays once per column.  57 % of the lanes hold a wet cell.
+__global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const i64 wave = (i64)blockIdx.x * 4 + wid;
+    const int j = (int)(wave / nseg), seg = (int)(wave % nseg);
+    if (j >= ny) return;
+    const int i = seg * 64 + lane;
+    const bool in = i < p.nx;
+    const i64 s = (i64)j * p.nx + (in ? i : p.nx - 1);
+    const i64 sS = j > 0 ? s - p.nx : s, sN = j + 1 < ny ? s + p.nx : s;
+    double c2[N2D + 8];
+#pragma unroll
+    for (int k = 0; k < N2D; ++k) c2[k] = p.b[k][s];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c2[N2D + 2 * k] = p.b[k][sS]; c2[N2D + 2 * k + 1] = p.b[k][sN]; }
+    unsigned h = (unsigned)(s * 2654435761u);
+    double prev[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nz; ++k) {
+        const i64 o = (i64)k * p.P;
+        double v[NARR + 10];
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) v[a] = p.a[a][o + s];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) { v[NARR + 2 * a] = p.a[a][o + sS]; v[NARR + 2 * a + 1] = p.a[a][o + sN]; }
+        h = h * 1664525u + 1013904223u;
+        const bool wet = in && ((h >> 16) % 100u) < 57u;
+        const unsigned long long m = __ballot(wet);
+        const int cnt = __popcll(m);
+        double r[20];
+#pragma unroll
+        for (int e = 0; e < 20; ++e) r[e] = v[e % (NARR + 10)] + c2[e % (N2D + 8)] * prev[e % 4];
+        for (int it = 0; it < p.nfma; ++it) {
+#pragma unroll
+            for (int e = 0; e < 20; ++e) r[e] = __builtin_fma(r[e], 1.0000001, v[e % 8]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) prev[q] = v[q];
+        // the wave's run: cnt * CNT[m] entries, contiguous, 16 bytes per lane and store
+        const i64 runbase = (wave * nz + k) * 64;
+        int e0 = 0;
+#pragma unroll
+        for (int mm = 0; mm < 5; ++mm) {
+            const int nent = cnt * CNT[mm];
+#pragma unroll
+            for (int c = 0; c < CNT[mm]; c += 2) {
+                const int first = c * 64 + lane * 2;
+                if (first < nent) {
+                    d2 x = {r[e0 + c], r[e0 + (c + 1 < CNT[mm] ? c + 1 : c)]};
+                    const i64 ent = runbase * CNT[mm] + first;
+                    *(d2 *)(p.out[2 * mm] + ent) = x;
+                    *(d2 *)(p.out[2 * mm + 1] + ent) = x;
+                }
+            }
+            e0 += CNT[mm];
+        }
+    }
+}
+
+int main() {
+    const int nx = 360, ny = 300, nz = 50;
+    const i64 P = (i64)nx * ny, G = P * nz, n = 3051515 / 256 * 256, ntiles = n / 256;
+    std::vector<i64> lwet(n);
+    unsigned long long s = 88172645463325252ull;
+    i64 L = 0;
+    for (i64 w = 0; w < n; ++w) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        L += 1 + ((s & 3) == 0) + ((s & 12) == 0) * 2;
+        if (L >= G) L = G - 1;
+        lwet[w] = L;
+    }
+    Params p{};
+    i64 *d_lwet;
+    CK(hipMalloc(&d_lwet, n * 8));
+    CK(hipMemcpy(d_lwet, lwet.data(), n * 8, hipMemcpyHostToDevice));
+    p.lwet = d_lwet;
+    for (int k = 0; k < NARR; ++k) { double *x; CK(hipMalloc(&x, G * 8)); CK(hipMemset(x, 0, G * 8)); p.a[k] = x; }
+    for (int k = 0; k < N2D; ++k) { double *x; CK(hipMalloc(&x, P * 8)); CK(hipMemset(x, 0, P * 8)); p.b[k] = x; }
+    double out_bytes = 0;
+    for (int m = 0; m < 5; ++m)
+        for (int h = 0; h < 2; ++h) { CK(hipMalloc(&p.out[2 * m + h], ((i64)6 * ny * nz * 64 * CNT[m] + 256) * 8)); out_bytes += (double)n * CNT[m] * 8; }
+    p.n = n; p.G = G; p.P = P; p.nx = nx;
+    const double in_bytes = (double)G * 8 * NARR + (double)n * 8;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int REP = 30;
+    auto timeit = [&](const char *name, auto launch) {
+        for (int r = 0; r < 20; ++r) launch();
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < REP; ++r) launch();
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s %.4f ms\n", name, ms / REP);
+        return ms / REP;
+    };
+    printf("model: %lld cells, reads >= %.0f MB, writes %.0f MB\n", (long long)n, in_bytes / 1e6, out_bytes / 1e6);
+    for (int nf : {0, 60}) {
+        p.nfma = nf;
+        printf("-- %d rounds of 20 dependent FMAs per cell --\n", nf);
+        timeit("plain: loads + math + stores", [&] { hipLaunchKernelGGL((plain<true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain: 8 east/west loads fewer", [&] { hipLaunchKernelGGL((plain<true, true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain: nontemporal stores", [&] { hipLaunchKernelGGL((plain<true, true, true, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain: no stores", [&] { hipLaunchKernelGGL((plain<true, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain: no loads", [&] { hipLaunchKernelGGL((plain<false, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain: math only", [&] { hipLaunchKernelGGL((plain<false, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("k-march model (dense rows, 20 loads per level)", [&] { hipLaunchKernelGGL(march, dim3((6 * ny + 3) / 4), dim3(256), 0, 0, p, ny, nz, 6); });
+        for (int wgs : {768})  {
+            char name[64];
+            snprintf(name, sizeof name, "piped, %d persistent workgroups", wgs);
+            timeit(name, [&] { hipLaunchKernelGGL(piped, dim3(wgs), dim3(256), 0, 0, p, ntiles); });
+        }
+    }
+    return 0;
+}
