@@ -279,27 +279,36 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         if (wid == 0) tm_lookback(p, tile, lane, early_all, s_prefix);
     }
     // The tile's reserved offsets (counting pass + scan) do not depend on anything this workgroup computes: their loads
-    // are issued first, so that this memory round trip runs beside the Lwet and stencil round trips instead of after
-    // the arithmetic (measured with tools/stamps.py: the late fetch held every wave for ~15 % of its life).
-    unsigned pre_sum = 0;
-    i64 pre_off = 0;
-    if (MODE == MODE_FILL && tid < TM_NF) {
-        pre_sum = p.tilesums[tile * TM_NF + tid];
-        pre_off = p.tileoffs[tile * TM_NF + tid];
-        if (p.gsum) {  // offsets are relative to the tile's scan group: add the totals of the groups before it
-            const i64 g = tile / OTMB_SCAN_GROUP;
-            for (i64 q = 0; q < g; ++q) pre_off += p.gsum[q * TM_NF + tid];
-        }
-    }
+    // are issued at the top (right after the index loads below), so that this memory round trip runs beside the Lwet and
+    // stencil round trips instead of after the arithmetic (tools/stamps.py: the late fetch held every wave for ~15 % of its life).
     const i64 w0 = tile * TM_THREADS;
     const i64 w = w0 + tid;
     const bool valid = w < p.n_own;
 
     // tile-uniform base pointers: all neighbours of all cells of the tile sit at non-negative 32-bit
-    // byte offsets from them
-    const i64 Lmin = p.lwet[w0] - 1;
+    // byte offsets from them.  (The lanes' own index loads are issued together with the tile's two: one round trip.)
     const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
+    const i64 wcl = valid ? w : wlast;
+    const i64 L_own = p.lwet[wcl] - 1;
+    const i64 Lnext_own = (wcl + 1 < p.n_own) ? p.lwet[wcl + 1] - 1 : p.G;
+    const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
+    unsigned pre_sum = 0;
+    i64 pre_off = 0;
+    if (MODE == MODE_FILL && tid < TM_NF) {
+        pre_sum = p.tilesums[tile * TM_NF + tid];
+        pre_off = p.tileoffs[tile * TM_NF + tid];
+        if (p.gsum) {  // offsets are relative to the tile's scan group: add the totals of the groups before it, eight loads in flight
+            const i64 g = tile / OTMB_SCAN_GROUP;
+            for (i64 q0 = 0; q0 < g; q0 += 8) {
+                i64 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = p.gsum[((q0 + u < g) ? q0 + u : 0) * TM_NF + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pre_off += (q0 + u < g) ? t[u] : 0;
+            }
+        }
+    }
     const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
     const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
     if (!span_ok && tid == 0) raise_flag(p.flags, FLAG_NONCANONICAL);
@@ -324,8 +333,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     unsigned pT = 0, nU = 0, nA = 0, nH = 0, nM = 0, nD = 0;
     bool live = false;
     if (valid && span_ok) {
-        const i64 L = p.lwet[w] - 1;
-        const i64 Lnext = (w + 1 < p.n_own) ? p.lwet[w + 1] - 1 : p.G;
+        const i64 L = L_own, Lnext = Lnext_own;
         const i64 c = p.wet_base + w + 1;  // this column's (global) wet rank
         STAMP(st, 1, 1);  // Lwet is back
         // Lwet ascending inside [Lmin, Lmax] and Lwet3D[Lwet[w]] == w + 1: together they make the wet

@@ -127,6 +127,42 @@ __global__ __launch_bounds__(256) void plain(Params p) {
     store_tile<STORES, NT>(p, w - lane, lane, r);
 }
 
+// the real kernel's extras: a workgroup barrier between arithmetic and stores (block scan of the counts), and the entries staged
+// through LDS (28 KB per workgroup in the real kernel) before the 16-byte stores
+template <bool BARRIER, bool STAGE>
+__global__ __launch_bounds__(256) void plain_extras(Params p) {
+    __shared__ double stage[4][7 * 64 + 8];
+    __shared__ unsigned long long tot[4];
+    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double v[NVAL], r[20];
+    load_cell<true>(p, w, v);
+    math<true>(p, v, r);
+    if (BARRIER) {
+        unsigned long long x = (unsigned long long)(r[0] != 0.0) + 5;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { unsigned long long y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) tot[wid] = x;
+        __syncthreads();
+        r[1] += (double)(tot[0] + tot[1] + tot[2] + tot[3] == 12345);
+    }
+    if (STAGE) {  // per matrix: column-major scatter into the wave's LDS area, read back as consecutive pairs
+        int e0 = 0;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+#pragma unroll
+            for (int c = 0; c < CNT[m]; ++c) stage[wid][lane * CNT[m] + c] = r[e0 + c];
+#pragma unroll
+            for (int c = 0; c < CNT[m]; c += 2) {
+                r[e0 + c] = stage[wid][c * 64 + lane * 2];
+                if (c + 1 < CNT[m]) r[e0 + c + 1] = stage[wid][c * 64 + lane * 2 + 1];
+            }
+            e0 += CNT[m];
+        }
+    }
+    store_tile<true>(p, w - lane, lane, r);
+}
+
 // persistent: the loads of the next tile are in flight while this tile is computed and stored
 __global__ __launch_bounds__(256) void piped(Params p, i64 ntiles) {
     const int lane = threadIdx.x & 63;
@@ -252,6 +288,9 @@ int main() {
         timeit("plain: loads + math + stores", [&] { hipLaunchKernelGGL((plain<true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: 8 east/west loads fewer", [&] { hipLaunchKernelGGL((plain<true, true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: nontemporal stores", [&] { hipLaunchKernelGGL((plain<true, true, true, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain + barrier", [&] { hipLaunchKernelGGL((plain_extras<true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain + barrier + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: no stores", [&] { hipLaunchKernelGGL((plain<true, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: no loads", [&] { hipLaunchKernelGGL((plain<false, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: math only", [&] { hipLaunchKernelGGL((plain<false, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
