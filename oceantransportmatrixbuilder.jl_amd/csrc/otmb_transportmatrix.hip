@@ -75,7 +75,8 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
     const i64 wc = (w < p.n_own) ? w : wlast;
     const i64 Lmin = p.lwet[w0] - 1, Lmax = p.lwet[wlast] - 1;
     const i64 L = p.lwet[wc] - 1;
-    const i64 Lnext = (wc + 1 < p.n_own) ? p.lwet[wc + 1] - 1 : p.G;
+    const i64 Lnext_ld = p.lwet[(wc + 1 < p.n_own) ? wc + 1 : wc] - 1;
+    const i64 Lnext = (wc + 1 < p.n_own) ? Lnext_ld : p.G;
     const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
     const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
     if (!span_ok) {
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
     const i64 wcl = valid ? w : wlast;
     const i64 L_own = p.lwet[wcl] - 1;
-    const i64 Lnext_own = (wcl + 1 < p.n_own) ? p.lwet[wcl + 1] - 1 : p.G;
+    const i64 Lnext_ld = p.lwet[(wcl + 1 < p.n_own) ? wcl + 1 : wcl] - 1;  // (unconditional: a branch here would wait for the load above)
+    const i64 Lnext_own = (wcl + 1 < p.n_own) ? Lnext_ld : p.G;
     const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
     unsigned pre_sum = 0;
