@@ -380,7 +380,8 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
     const double vC = ldv(tb.v, oC), vE = ldv(tb.v, oE), vW = ldv(tb.v, oW), vS = ldv(tb.v, oS), vN = ldv(tb.v, oN),
                  vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
 #endif
-    double rC, rE, rW, rS, rN, rA, rB;
+    // (a scalar ρ is filled in AFTER the last load is issued: assigning it here makes the compiler drain the loads above first)
+    double rC = 0, rE = 0, rW = 0, rS = 0, rN = 0, rA = 0, rB = 0;
     if (tb.rho) {
         rC = ldv(tb.rho, oC); rS = ldv(tb.rho, oS); rN = ldv(tb.rho, oN); rA = ldv(tb.rho, oA); rB = ldv(tb.rho, oB);
 #ifdef OTMB_DBG_NOEW
@@ -388,8 +389,6 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
 #else
         rE = ldv(tb.rho, oE); rW = ldv(tb.rho, oW);
 #endif
-    } else {
-        rC = rE = rW = rS = rN = rA = rB = p.rho_s;
     }
 #ifdef OTMB_DBG_NOEW
     const double tC = ldv(tb.thk, oC), tE = tC, tW = tC, tS = ldv(tb.thk, oS), tN = ldv(tb.thk, oN);
@@ -428,6 +427,7 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
     }
 
     STAMP(st, 2, 1);  // every stencil load is back
+    if (!tb.rho) rC = rE = rW = rS = rN = rA = rB = p.rho_s;
     const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
     const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
 
