@@ -26,7 +26,7 @@ struct Params {
     const double *b[N2D];
     double *out[10];
     i64 n, G, P;
-    int nx, nfma;
+    int nx, nfma, shift8;
 };
 
 template <bool LOADS, bool NOEW = false>
@@ -85,7 +85,7 @@ __device__ __forceinline__ void math(const Params &p, const double (&v)[NVAL], d
 }
 
 // a wave's 64 cells own 64 * CNT[m] consecutive entries of matrix m: written as 16-byte-per-lane stores (two 8-byte entries)
-template <bool STORES, bool NT = false>
+template <bool STORES, bool NT = false, bool ALIGNCHUNK = false>
 __device__ __forceinline__ void store_tile(const Params &p, i64 w0wave, int lane, const double (&r)[20]) {
     if (!STORES) {
         double s = 0;
@@ -97,7 +97,24 @@ __device__ __forceinline__ void store_tile(const Params &p, i64 w0wave, int lane
     int e0 = 0;
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-        const i64 base = w0wave * CNT[m];  // entries
+        const i64 base = w0wave * CNT[m] + p.shift8;  // entries (shift8: runs start off the cache-line grid)
+        if (ALIGNCHUNK) {
+            // chunks of 128 entries on the absolute 1 KB grid of the array: every store instruction covers whole cache lines,
+            // the first and last chunk of the run are partially masked (one chunk more per run than the unaligned walk)
+            const i64 first = base & ~(i64)127, end = base + 64 * CNT[m];
+#pragma unroll
+            for (int c = 0; c <= CNT[m]; c += 2) {
+                const i64 ent = first + (i64)c * 64 + lane * 2;
+                if (ent >= base && ent + 1 < end + 1) {
+                    const int cc = c < CNT[m] ? c : CNT[m] - 1;
+                    d2 x = {r[e0 + cc], r[e0 + (cc + 1 < CNT[m] ? cc + 1 : cc)]};
+                    *(d2 *)(p.out[2 * m] + ent) = x;
+                    *(d2 *)(p.out[2 * m + 1] + ent) = x;
+                }
+            }
+            e0 += CNT[m];
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < CNT[m]; c += 2) {
             // entries [c*64, c*64 + 128) of the wave's run, 2 per lane; an odd last column is a half store
@@ -117,14 +134,28 @@ __device__ __forceinline__ void store_tile(const Params &p, i64 w0wave, int lane
     }
 }
 
-template <bool LOADS, bool MATH, bool STORES, bool NOEW = false, bool NT = false>
+template <bool LOADS, bool MATH, bool STORES, bool NOEW = false, bool NT = false, bool ALIGNCHUNK = false>
 __global__ __launch_bounds__(256) void plain(Params p) {
     const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     double v[NVAL], r[20];
     load_cell<LOADS, NOEW>(p, w, v);
     math<MATH>(p, v, r);
-    store_tile<STORES, NT>(p, w - lane, lane, r);
+    store_tile<STORES, NT, ALIGNCHUNK>(p, w - lane, lane, r);
+}
+
+// occupancy: the same kernel with LDSB bytes of (unused) LDS per workgroup, i.e. 160 KB / LDSB workgroups of 4 waves per CU
+template <int LDSB>
+__global__ __launch_bounds__(256) void plain_occ(Params p) {
+    __shared__ char pad[LDSB];
+    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    double v[NVAL], r[20];
+    load_cell<true>(p, w, v);
+    if (p.nfma < 0) pad[threadIdx.x] = (char)w;  // keep the array alive
+    math<true>(p, v, r);
+    if (p.nfma < 0) r[0] += pad[(threadIdx.x + 1) & 255];
+    store_tile<true>(p, w - lane, lane, r);
 }
 
 // the real kernel's extras: a workgroup barrier between arithmetic and stores (block scan of the counts), and the entries staged
@@ -282,12 +313,27 @@ int main() {
         return ms / REP;
     };
     printf("model: %lld cells, reads >= %.0f MB, writes %.0f MB\n", (long long)n, in_bytes / 1e6, out_bytes / 1e6);
-    for (int nf : {0, 60}) {
+    for (int nf : {0}) {
         p.nfma = nf;
         printf("-- %d rounds of 20 dependent FMAs per cell --\n", nf);
         timeit("plain: loads + math + stores", [&] { hipLaunchKernelGGL((plain<true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: 8 east/west loads fewer", [&] { hipLaunchKernelGGL((plain<true, true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: nontemporal stores", [&] { hipLaunchKernelGGL((plain<true, true, true, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain, 5 workgroups per CU (32 KB LDS)", [&] { hipLaunchKernelGGL((plain_occ<32 * 1024>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain, 4 workgroups per CU (40 KB LDS)", [&] { hipLaunchKernelGGL((plain_occ<40 * 1024>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain, 3 workgroups per CU (52 KB LDS)", [&] { hipLaunchKernelGGL((plain_occ<52 * 1024>), dim3(ntiles), dim3(256), 0, 0, p); });
+        timeit("plain, 2 workgroups per CU (64 KB LDS)", [&] { hipLaunchKernelGGL((plain_occ<64 * 1024>), dim3(ntiles), dim3(256), 0, 0, p); });
+        for (int sh : {1, 2, 3, 4, 8, 9}) {
+            char name[80];
+            snprintf(name, sizeof name, "plain, every run shifted by %d bytes", sh * 8);
+            p.shift8 = sh;
+            timeit(name, [&] { hipLaunchKernelGGL((plain<true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+            if (sh % 2 == 0) {
+                snprintf(name, sizeof name, "   ... written in line-aligned chunks");
+                timeit(name, [&] { hipLaunchKernelGGL((plain<true, true, true, false, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+            }
+        }
+        p.shift8 = 0;
         timeit("plain + barrier", [&] { hipLaunchKernelGGL((plain_extras<true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain + barrier + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
