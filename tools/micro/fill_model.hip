@@ -216,11 +216,14 @@ __global__ __launch_bounds__(256) void piped(Params p, i64 ntiles) {
 // k-march model: a wave is 64 consecutive i of one row and walks the levels; the levels above / below stay in registers, east /
 // west would come by DPP: per level only the own level of the ten 3-D arrays and the south / north rows of five of them are
 // loaded (4 cache lines per load instead of ~8), the 2-D arrays once per column.  57 % of the lanes hold a wet cell.
-__global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg) {
+__global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg, int kparts) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const i64 wave = (i64)blockIdx.x * 4 + wid;
-    const int j = (int)(wave / nseg), seg = (int)(wave % nseg);
+    const int kp = (int)(wave % kparts);  // the levels are cut into kparts segments: more waves, shorter marches
+    const i64 col = wave / kparts;
+    const int j = (int)(col / nseg), seg = (int)(col % nseg);
     if (j >= ny) return;
+    const int k_lo = (int)((i64)nz * kp / kparts), k_hi = (int)((i64)nz * (kp + 1) / kparts);
     const int i = seg * 64 + lane;
     const bool in = i < p.nx;
     const i64 s = (i64)j * p.nx + (in ? i : p.nx - 1);
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg)
     for (int k = 0; k < 4; ++k) { c2[N2D + 2 * k] = p.b[k][sS]; c2[N2D + 2 * k + 1] = p.b[k][sN]; }
     unsigned h = (unsigned)(s * 2654435761u);
     double prev[4] = {0, 0, 0, 0};
-    for (int k = 0; k < nz; ++k) {
+    for (int k = k_lo; k < k_hi; ++k) {
         const i64 o = (i64)k * p.P;
         double v[NARR + 10];
 #pragma unroll
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg)
 #pragma unroll
         for (int q = 0; q < 4; ++q) prev[q] = v[q];
         // the wave's run: cnt * CNT[m] entries, contiguous, 16 bytes per lane and store
-        const i64 runbase = (wave * nz + k) * 64;
+        const i64 runbase = (col * nz + k) * 64;
         int e0 = 0;
 #pragma unroll
         for (int mm = 0; mm < 5; ++mm) {
@@ -340,7 +343,11 @@ int main() {
         timeit("plain: no stores", [&] { hipLaunchKernelGGL((plain<true, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: no loads", [&] { hipLaunchKernelGGL((plain<false, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: math only", [&] { hipLaunchKernelGGL((plain<false, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
-        timeit("k-march model (dense rows, 20 loads per level)", [&] { hipLaunchKernelGGL(march, dim3((6 * ny + 3) / 4), dim3(256), 0, 0, p, ny, nz, 6); });
+        for (int kparts : {1, 2, 5, 10, 25}) {
+            char name[96];
+            snprintf(name, sizeof name, "march model: dense rows, %d level segments (%d waves)", kparts, 6 * ny * kparts);
+            timeit(name, [&] { hipLaunchKernelGGL(march, dim3((6 * ny * kparts + 3) / 4), dim3(256), 0, 0, p, ny, nz, 6, kparts); });
+        }
         for (int wgs : {768})  {
             char name[64];
             snprintf(name, sizeof name, "piped, %d persistent workgroups", wgs);
