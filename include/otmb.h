@@ -76,6 +76,12 @@ int32_t otmb_ctx_synchronize(otmb_ctx *ctx);
  * of the previous upload into its staging slot is NOT copied again -- the caller promises not to have modified it in
  * between.  Off by default (every call uploads everything, like the reference reads everything).                   */
 int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on);
+/* Speed only, never results: the order in which the fill pass of transportmatrix takes its tiles of 256 columns.
+ * rows_per_band = 0: ascending wet rank (i, then j, then k).  R > 0: MARCH order -- the tiles of a band of R grid rows
+ * are taken level after level before the next band starts, so that the levels above / below a tile (the vertical
+ * neighbours of src/matrixbuilding.jl:280-296, :450-477) were read moments ago and are still in the L2 / Infinity Cache
+ * instead of one whole level (124 MB of inputs on a 0.25 degree grid) earlier.  -1 (default): chosen from the grid size. */
+int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
 const char *otmb_version(void);

@@ -54,6 +54,7 @@ SYMBOLS = {
     "otmb_ctx_use_default_stream": (C.c_int32, [_vp]),
     "otmb_ctx_synchronize": (C.c_int32, [_vp]),
     "otmb_ctx_set_reuse_grid": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
     "otmb_last_error": (C.c_char_p, [_vp]),
     "otmb_status_string": (C.c_char_p, [C.c_int32]),
     "otmb_version": (C.c_char_p, []),
@@ -198,6 +199,10 @@ class Context:
     def set_reuse_grid(self, on=True):
         self.check(self._lib.otmb_ctx_set_reuse_grid(self._h, int(bool(on))))
 
+    def set_tile_order(self, rows_per_band):
+        """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = chosen by grid size."""
+        self.check(self._lib.otmb_ctx_set_tile_order(self._h, int(rows_per_band)))
+
     def use_own_stream(self):
         self.check(self._lib.otmb_ctx_set_stream(self._h, _vp(0)))
 
@@ -207,7 +212,7 @@ class Context:
     def timing_enable(self, on=True):
         self.check(self._lib.otmb_ctx_timing_enable(self._h, int(on)))
 
-    def timing_collect(self, n=12):
+    def timing_collect(self, n=16):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()

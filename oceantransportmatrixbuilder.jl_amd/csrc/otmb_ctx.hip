@@ -1,4 +1,6 @@
 // otmb_ctx.hip -- context, error strings, scratch buffers.
+#include <cstdlib>
+
 #include "otmb_common.h"
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail) {
@@ -65,6 +67,7 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     if (hipSetDevice(device_id) != hipSuccess) return OTMB_ERR_HIP;
     otmb_ctx *c = new otmb_ctx();
     c->device = device_id;
+    if (const char *e = getenv("OTMB_MARCH_ROWS")) c->march_rows = atoi(e);  // experiments; otmb_ctx_set_tile_order is the API
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return OTMB_ERR_HIP;
@@ -108,6 +111,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     for (DevBuf &b : ctx->lump)
         if (b.p) (void)hipFree(b.p);
     if (ctx->mask.p) (void)hipFree(ctx->mask.p);
+    if (ctx->order.p) (void)hipFree(ctx->order.p);
     if (ctx->lump_host.p) (void)hipFree(ctx->lump_host.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
@@ -125,6 +129,12 @@ int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *s) {
 int32_t otmb_ctx_use_default_stream(otmb_ctx *ctx) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
     ctx->stream = nullptr;  // HIP's null stream: what torch calls its default stream
+    return OTMB_OK;
+}
+
+int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band) {
+    if (!ctx || rows_per_band < -1) return OTMB_ERR_INVALID_ARG;
+    ctx->march_rows = rows_per_band;
     return OTMB_OK;
 }
 
@@ -173,7 +183,7 @@ const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
                                             "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
-                                            "push_mask_kernel"};
+                                            "push_mask_kernel", "tm_order_kernels"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

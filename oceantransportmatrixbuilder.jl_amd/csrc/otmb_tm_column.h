@@ -48,6 +48,7 @@ struct TmParams {
     int *ticket;           // dynamic tile id (ONEPASS)
     int *flags;
     int *next_state;       // the NEXT asynchronous step's state block, zeroed by this fill (or NULL): no memset between steps
+    const unsigned *order; // fill pass: tile taken by the q-th workgroup slot (march order), or NULL = wet-rank order
 };
 
 // Diagnostic build only (-DOTMB_DBG_STAMPS, tools/stamps.py): s_memtime stamps of the phases of a wave of the fill

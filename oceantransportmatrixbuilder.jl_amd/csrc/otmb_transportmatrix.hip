@@ -26,6 +26,12 @@
 #define TM_WAVES_PER_SIMD 3  // measured: capping at 128 VGPRs (4 waves/SIMD) spills and is 8 % slower
 #endif
 #define TM_MAXROWS 7  // rows per column: A, S, W, SELF, E, N|fold, B
+#ifndef OTMB_MARCH_AUTO_ROWS
+#define OTMB_MARCH_AUTO_ROWS 8  // rows per band of the automatic march order
+#endif
+#ifndef OTMB_MARCH_AUTO_LEVEL_BYTES
+#define OTMB_MARCH_AUTO_LEVEL_BYTES (32ll << 20)  // one level of ten Float64 inputs above this size: march (0.25 degree: 124 MB; 1 degree: 8.6 MB)
+#endif
 #define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     if (MODE != MODE_ONEPASS) {
         const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        if (p.order) tile = p.order[tile];  // march order: the XCD's eighth is a run of (row band, level) buckets
     }
     if (MODE == MODE_ONEPASS) {
         // dynamic tile id: tiles start in ticket order, so every predecessor a tile waits for is already
@@ -643,6 +650,85 @@ __global__ __launch_bounds__(TFIX_THREADS) void tfix_move(const uint8_t *__restr
     }
 }
 
+// ---- march order of the fill pass's tiles (otmb_ctx_set_tile_order) -----------------------------------------------
+// Tiles are 256 consecutive wet columns, i.e. pieces of one level's rows.  In wet-rank order a tile's vertical
+// neighbours (levels k-1 and k+1 of Lwet3D, v3D, ρ) were touched one whole LEVEL of traffic earlier -- 124 MB of inputs
+// plus 300 MB of outputs on a 1440x1080 grid, past every cache -- so they come from HBM three times.  In march order the
+// tiles of a band of R rows are taken level after level: the same lines are needed again a few tiles later and are
+// served by the L2 / Infinity Cache.  Bucket = (band, level); a counting sort of the tiles by bucket.  Speed only.
+__device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 t, int nx, int ny, i64 P, int rows, int nz) {
+    const i64 L = lwet[t * TM_THREADS] - 1;  // (whatever Lwet holds, the key stays inside the bucket table)
+    i64 k = L / P, j = (L - k * P) / nx;
+    k = k < 0 ? 0 : (k >= nz ? nz - 1 : k);
+    j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+    return (unsigned)(j / rows) * (unsigned)nz + (unsigned)k;
+}
+__global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, int nx, int ny, i64 P, int rows, int nz, unsigned *hist) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) atomicAdd(&hist[order_key(lwet, t, nx, ny, P, rows, nz)], 1u);
+}
+__global__ __launch_bounds__(1024) void order_scan(unsigned *hist, i64 nbuckets) {  // in place: exclusive prefix
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (i64 b0 = 0; b0 < nbuckets; b0 += 1024) {
+        const i64 b = b0 + tid;
+        const unsigned mine = (b < nbuckets) ? hist[b] : 0u;
+        unsigned incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        unsigned before = carry;
+        for (int q = 0; q < wid; ++q) before += wave_tot[q];
+        if (b < nbuckets) hist[b] = before + incl - mine;
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+}
+// every tile takes the next free position of its bucket: a bijection whatever the keys are (the order inside a bucket
+// -- a few dozen neighbouring tiles -- is left to the atomics)
+__global__ void order_scatter(const i64 *__restrict__ lwet, i64 ntiles, int nx, int ny, i64 P, int rows, int nz, unsigned *cursor,
+                              unsigned *order) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) order[atomicAdd(&cursor[order_key(lwet, t, nx, ny, P, rows, nz)], 1u)] = (unsigned)t;
+}
+
+// Decide and build the tile order of a fill launch.  Returns the device pointer (or NULL: wet-rank order).
+static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles, const unsigned **out) {
+    *out = nullptr;
+    int rows = ctx->march_rows;
+    if (rows < 0) {
+        // automatic: march once one level of the ten 3-D inputs no longer stays cached between its three uses
+        const i64 level_bytes = a.nx * a.ny * 8 * 10;
+        rows = (level_bytes > OTMB_MARCH_AUTO_LEVEL_BYTES) ? OTMB_MARCH_AUTO_ROWS : 0;
+    }
+    if (rows <= 0 || ntiles < 64 || ntiles >= (1ll << 31)) return OTMB_OK;
+    if (rows > a.ny) rows = (int)a.ny;
+    const i64 nbands = (a.ny + rows - 1) / rows, nbuckets = nbands * a.nz;
+    if (nbuckets >= (1ll << 31)) return OTMB_OK;
+    const size_t ob = ((size_t)ntiles * sizeof(unsigned) + 255) / 256 * 256, bb = ((size_t)nbuckets * sizeof(unsigned) + 255) / 256 * 256;
+    int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->order, ob + bb))) return rc;
+    unsigned *order = (unsigned *)ctx->order.p, *hist = (unsigned *)((char *)ctx->order.p + ob);
+    KernelTimer kt(ctx, K_TM_ORDER);
+    HIP_TRY(ctx, hipMemsetAsync(hist, 0, bb, ctx->stream));
+    const unsigned nb = (unsigned)((ntiles + 255) / 256);
+    hipLaunchKernelGGL(order_hist, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (int)a.nx, (int)a.ny, a.nx * a.ny, rows,
+                       (int)a.nz, hist);
+    hipLaunchKernelGGL(order_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, nbuckets);
+    hipLaunchKernelGGL(order_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (int)a.nx, (int)a.ny, a.nx * a.ny, rows,
+                       (int)a.nz, hist, order);
+    *out = order;
+    return OTMB_OK;
+}
+
 // ---- host side ------------------------------------------------------------------------------
 static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
@@ -861,6 +947,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     p.tcount = (uint8_t *)ctx->tcount.p;
     int *dflags = (int *)ctx->flags.p;
     if (pl.ntiles > 0) {
+        if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, &p.order))) return rc;
         KernelTimer kt(ctx, K_TM_FILL);
         hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     }
@@ -1009,6 +1096,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
             if ((rc = otmb_reserve(ctx, ctx->lookback, (size_t)ntiles * (TM_THREADS / 64) * OTMB_NSTAMP * sizeof(u64)))) return rc;
             p.status = (u64 *)ctx->lookback.p;
 #endif
+            if ((rc = build_tile_order(ctx, *a, ntiles, &p.order))) return rc;
             KernelTimer kt(ctx, K_TM_FILL);
             hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
         }

@@ -2,14 +2,14 @@
 # Memory-system counters of the hot kernels (run on the GPU box via gpurun): address translation, L1 (TCP) stalls,
 # texture addresser (TA), L2 (TCC) stalls towards DRAM.  One rocprofv3 --pmc pass per group; summary by pmc_summary.py.
 # (A pass with TA_* counters -- TA_TA_BUSY_sum etc. -- hung on this pool and was removed; every pass is bounded.)
-# Usage: tools/profile_mem.sh <tag>
+# Usage: tools/profile_mem.sh <tag> [bench args...]
 set -o pipefail
-TAG=${1:-mem}
+TAG=${1:-mem}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline"
+ARGS="--steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end $@"
 i=0
 for set in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_THRASHING_STALL_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
@@ -22,3 +22,4 @@ for set in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSL
   timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_$i.err
   echo "pmc [$set] rc=$?"
 done
+python3 $REPO/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
