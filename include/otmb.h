@@ -226,11 +226,16 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_
                                  int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
 int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);
 /* Several otmb_transportmatrix_dev calls may be enqueued before one otmb_transportmatrix_result (a pipeline over time
- * slices).  Every call keeps its own error flags; result reports the FIRST call that failed -- where the reference
- * would have thrown (src/matrixbuilding.jl:39,61,90,114,233) -- with "(asynchronous step k of n)" appended to
- * otmb_last_error, and the nnz of the last call when none failed.  failed_step: 0-based index of that call among
- * the calls since the previous result, -1 if the last result found no failure.                               */
+ * slices).  Every call keeps its own error flags, its own nnz and its own output arrays: like every transportmatrix call of
+ * the reference returns its own five matrices (src/matrixbuilding.jl:147-149).  result reports the FIRST call that
+ * failed -- where the reference would have thrown (src/matrixbuilding.jl:39,61,90,114,233) -- with "(asynchronous step k
+ * of n)" appended to otmb_last_error; when none failed it returns the nnz of the last call, and EVERY call's T has been
+ * compacted in that call's own arrays if entries of it cancelled.  The outputs of a call are defined until a later call is
+ * handed the same arrays (a caller that keeps one result set, like bench.py, keeps the last call's matrices).
+ * failed_step: 0-based index of the failing call among the calls since the previous result, -1 if the last result found
+ * no failure.  result_step (after result): status and nnz of the k-th of those calls.                              */
 int32_t otmb_transportmatrix_failed_step(otmb_ctx *ctx, int64_t *step);
+int32_t otmb_transportmatrix_result_step(otmb_ctx *ctx, int64_t step, int64_t nnz[5]);
 
 /* Depth-slab partition (multi-GPU).  The wet index is k-slowest (src/matrixbuilding.jl:14-15), so a slab
  * of levels owns a contiguous column range of every matrix.  set_slab (before plan / _dev): the local

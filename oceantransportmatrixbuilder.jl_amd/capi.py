@@ -81,6 +81,7 @@ SYMBOLS = {
     "otmb_facefluxes_slab_flags": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "otmb_facefluxes_pending_flags": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "otmb_transportmatrix_failed_step": (C.c_int32, [_vp, _ip]),
+    "otmb_transportmatrix_result_step": (C.c_int32, [_vp, C.c_int64, C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64]),
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_result": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),

@@ -38,7 +38,6 @@ struct TmParams {
     i64 *colptr[5], *rowval[5];
     double *nzval[5];
     i64 *totals;           // [5] nnz of this launch (one-pass mode)
-    uint8_t *tcount;       // [n_own] rows actually stored in T's column (<= the reserved union count)
     // scan state
     uint32_t *tilesums;    // [ntiles][5]  (COUNT writes)
     const i64 *tileoffs;   // [ntiles][5]  (FILL reads)

@@ -46,7 +46,6 @@ struct TmPlan {
     bool onepass_pending = false;
     i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
-    void *outT[3] = {nullptr, nullptr, nullptr};  // T's colptr/rowval/nzval of the pending one-pass launch
 };
 
 // look-back status word: [63:62] flag (0 empty, 1 tile aggregate, 2 inclusive prefix), [61:0] value.
@@ -387,7 +386,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                         if (((uni >> s) & 1u) && col.tv[s] != 0.0) pT |= 1u << s;
                     }
                     if (pT != uni) raise_flag(p.flags, FLAG_T_CANCEL);
-                    p.tcount[w] = (uint8_t)__popc(pT);
                 }
             }
         }
@@ -521,6 +519,12 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                     my_val[q] = __double_as_longlong(v);
                 }
             }
+            // T after an exact cancellation (rare): the column keeps its reserved (union) width, its entries are left-aligned
+            // and the unused slots carry row 0 -- which is how the compaction (tfix_*) finds a column's real length, for
+            // any step of an asynchronous pipeline, from the step's own output arrays
+            if (m == 0 && (unsigned)__popc(pT) != nU) {
+                for (unsigned e = __popc(pT); e < nU; ++e) { my_row[q0 + e] = 0; my_val[q0 + e] = 0; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -598,6 +602,15 @@ __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i6
 // union pattern.  Compact: per-column actual counts (tcount) -> scan -> move.  One thread per column.
 #define TFIX_THREADS 256
 #define TFIX_PER 4
+__global__ __launch_bounds__(TFIX_THREADS) void tfix_derive(const i64 *__restrict__ colptr, const i64 *__restrict__ rowval, i64 n, i64 nnz_base,
+                                                            uint8_t *__restrict__ tcount) {
+    const i64 c = (i64)blockIdx.x * TFIX_THREADS + threadIdx.x;
+    if (c >= n) return;
+    const i64 lo = colptr[c] - 1 - nnz_base, hi = colptr[c + 1] - 1 - nnz_base;
+    unsigned cnt = 0;
+    for (i64 e = lo; e < hi && e < lo + TM_MAXROWS; ++e) cnt += rowval[e] != 0;  // (rows are 1-based: 0 marks an unused slot)
+    tcount[c] = (uint8_t)cnt;
+}
 __global__ __launch_bounds__(TFIX_THREADS) void tfix_count(const uint8_t *__restrict__ tcount, i64 n, uint32_t *tilesums) {
     __shared__ unsigned part[TFIX_THREADS / 64];
     unsigned x = 0;
@@ -797,27 +810,30 @@ static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a) {
 }
 
 
-// After a fill/one-pass launch has completed: if some T entries cancelled, compact T in place (through
-// temporaries) and correct nnz[0].  The stream is idle on entry.
-static int32_t t_fixup(otmb_ctx *ctx, TmPlan &pl, i64 *colptrT, i64 *rowvalT, double *nzvalT) {
-    const i64 n = pl.args.n_wet;
+// After a fill launch has completed and flagged FLAG_T_CANCEL: compact T in place (through temporaries).  n columns whose
+// reserved (union-pattern) entries number `reserved`; *actual receives the final nnz.  The stream is idle on entry.
+static int32_t t_fixup(otmb_ctx *ctx, i64 n, i64 nnz_base, i64 reserved, i64 *colptrT, i64 *rowvalT, double *nzvalT, i64 *actual_out) {
+    *actual_out = reserved;
     if (n == 0) return OTMB_OK;
     const i64 per = (i64)TFIX_THREADS * TFIX_PER;
     const i64 nt = (n + per - 1) / per;
     int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)n + 16))) return rc;
     if ((rc = otmb_reserve(ctx, ctx->blocksums, (size_t)(nt + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = otmb_reserve(ctx, ctx->blockoffs, (size_t)(nt + 1) * sizeof(i64) + otmb_scan_scratch(nt, 1)))) return rc;
     if ((rc = otmb_reserve(ctx, ctx->tfix[0], (size_t)(n + 1) * sizeof(i64)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->tfix[1], (size_t)(pl.nnz[0] + 1) * sizeof(i64)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->tfix[2], (size_t)(pl.nnz[0] + 1) * sizeof(double)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tfix[1], (size_t)(reserved + 1) * sizeof(i64)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tfix[2], (size_t)(reserved + 1) * sizeof(double)))) return rc;
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS) + 8;
-    const uint8_t *tc = (const uint8_t *)ctx->tcount.p;
-    hipLaunchKernelGGL(tfix_count, dim3((unsigned)nt), dim3(TFIX_THREADS), 0, ctx->stream, tc, n, (uint32_t *)ctx->blocksums.p);
+    uint8_t *tc = (uint8_t *)ctx->tcount.p;
+    hipLaunchKernelGGL(tfix_derive, dim3((unsigned)((n + TFIX_THREADS - 1) / TFIX_THREADS)), dim3(TFIX_THREADS), 0, ctx->stream,
+                       (const i64 *)colptrT, (const i64 *)rowvalT, n, nnz_base, tc);
+    hipLaunchKernelGGL(tfix_count, dim3((unsigned)nt), dim3(TFIX_THREADS), 0, ctx->stream, (const uint8_t *)tc, n, (uint32_t *)ctx->blocksums.p);
     otmb_launch_tilescan(ctx->stream, (const uint32_t *)ctx->blocksums.p, (i64 *)ctx->blockoffs.p, dtot, nt, 1,
                          (i64 *)ctx->blockoffs.p + (nt + 1));
-    hipLaunchKernelGGL(tfix_move, dim3((unsigned)nt), dim3(TFIX_THREADS), 0, ctx->stream, tc, n, (const i64 *)ctx->blockoffs.p,
-                       (const i64 *)colptrT, (const i64 *)rowvalT, (const double *)nzvalT, pl.nnz_base[0],
+    hipLaunchKernelGGL(tfix_move, dim3((unsigned)nt), dim3(TFIX_THREADS), 0, ctx->stream, (const uint8_t *)tc, n, (const i64 *)ctx->blockoffs.p,
+                       (const i64 *)colptrT, (const i64 *)rowvalT, (const double *)nzvalT, nnz_base,
                        (i64 *)ctx->tfix[0].p, (i64 *)ctx->tfix[1].p, (double *)ctx->tfix[2].p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot + 8, dtot, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
@@ -826,10 +842,10 @@ static int32_t t_fixup(otmb_ctx *ctx, TmPlan &pl, i64 *colptrT, i64 *rowvalT, do
     HIP_TRY(ctx, hipMemcpyAsync(colptrT, ctx->tfix[0].p, (size_t)n * sizeof(i64), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(rowvalT, ctx->tfix[1].p, (size_t)actual * sizeof(i64), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(nzvalT, ctx->tfix[2].p, (size_t)actual * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    const i64 last = pl.nnz_base[0] + actual + 1;
+    const i64 last = nnz_base + actual + 1;
     HIP_TRY(ctx, hipMemcpyAsync(colptrT + n, &last, sizeof(i64), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    pl.nnz[0] = actual;
+    *actual_out = actual;
     return OTMB_OK;
 }
 
@@ -840,16 +856,38 @@ static int32_t fetch_ring(otmb_ctx *ctx) {
     return OTMB_OK;
 }
 
-// Fold the completed pending steps [tm_first, tm_next) of the asynchronous protocol into the sticky (status, step) pair:
-// the first failing step wins.  The stream is idle on entry (the steps' state blocks have landed in h_ring).
-static void fold_pending(otmb_ctx *ctx) {
+// Fold the completed pending steps [tm_first, tm_next) of the asynchronous protocol: every step's verdict and nnz go to
+// ctx->tm_hist (otmb_transportmatrix_result_step), the first failing step into the sticky (status, step) pair, and a step
+// whose T had exact cancellations is compacted in ITS OWN output arrays (every otmb_transportmatrix_dev call recorded
+// them) -- unless a later pending step was given the same arrays, which then hold that later step's matrix.
+// The stream is idle on entry (the steps' state blocks have landed in h_ring).
+static int32_t fold_pending(otmb_ctx *ctx) {
+    int32_t ret = OTMB_OK;
     for (i64 s = ctx->tm_first; s < ctx->tm_next; ++s) {
-        if (ctx->tm_sticky) break;
-        const int32_t rc = check_flags(ctx, otmb_ring_tm(ctx->h_ring, s));  // sets ctx->err
-        if (rc) { ctx->tm_sticky = rc; ctx->tm_sticky_step = s; ctx->tm_sticky_msg = ctx->err; }
+        const int *f = otmb_ring_tm(ctx->h_ring, s);
+        const i64 *tot = (const i64 *)(f + OTMB_NFLAGS);
+        otmb_ctx::TmStepResult r;
+        r.status = check_flags(ctx, f);  // sets ctx->err
+        for (int m = 0; m < 5; ++m) r.nnz[m] = tot[m];
+        if (r.status && !ctx->tm_sticky) { ctx->tm_sticky = r.status; ctx->tm_sticky_step = s; ctx->tm_sticky_msg = ctx->err; }
+        const size_t q = (size_t)(s - ctx->tm_first);
+        if (!r.status && f[FLAG_T_CANCEL] && q < ctx->tm_rec.size()) {
+            const otmb_ctx::TmStepRec &rec = ctx->tm_rec[q];
+            bool superseded = false;
+            for (size_t l = q + 1; l < ctx->tm_rec.size(); ++l)
+                superseded |= ctx->tm_rec[l].colptrT == rec.colptrT || ctx->tm_rec[l].rowvalT == rec.rowvalT || ctx->tm_rec[l].nzvalT == rec.nzvalT;
+            if (!superseded && !ret) {
+                i64 actual = r.nnz[0];
+                ret = t_fixup(ctx, rec.n_wet, rec.nnz_base0, r.nnz[0], (i64 *)rec.colptrT, (i64 *)rec.rowvalT, (double *)rec.nzvalT, &actual);
+                r.nnz[0] = actual;
+            }
+        }
+        ctx->tm_hist.push_back(r);
     }
     if (ctx->tm_sticky) ctx->err = ctx->tm_sticky_msg;
+    ctx->tm_rec.clear();
     ctx->tm_first = ctx->tm_next;
+    return ret;
 }
 
 void otmb_tm_plan_free(otmb_ctx *ctx) {
@@ -858,7 +896,8 @@ void otmb_tm_plan_free(otmb_ctx *ctx) {
 }
 
 void otmb_tm_plan_invalidate(otmb_ctx *ctx) {
-    if (ctx->plan) { ctx->plan->valid = false; ctx->plan->onepass_pending = false; }
+    // only the two-phase plan points into the host entry points' staging slots; pending asynchronous steps keep their verdicts
+    if (ctx->plan) ctx->plan->valid = false;
 }
 
 bool otmb_tm_plan_only_t(otmb_ctx *ctx) { return ctx->plan && ctx->plan->args.only_t != 0; }
@@ -943,8 +982,6 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
         p.nzval[m] = wanted ? nzval[m] : nullptr;
     }
     int32_t rc;
-    if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)pl.args.n_wet + 16))) return rc;
-    p.tcount = (uint8_t *)ctx->tcount.p;
     int *dflags = (int *)ctx->flags.p;
     if (pl.ntiles > 0) {
         if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, &p.order))) return rc;
@@ -966,7 +1003,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     pl.valid = false;
     if ((rc = check_flags(ctx))) return rc;
     if (ctx->h_flags[FLAG_T_CANCEL]) {
-        if ((rc = t_fixup(ctx, pl, p.colptr[0], p.rowval[0], p.nzval[0]))) return rc;
+        i64 actual = pl.nnz[0];
+        if ((rc = t_fixup(ctx, pl.args.n_wet, pl.nnz_base[0], pl.nnz[0], p.colptr[0], p.rowval[0], p.nzval[0], &actual))) return rc;
+        pl.nnz[0] = actual;
     }
     return OTMB_OK;
 }
@@ -1032,9 +1071,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         p.nzval[m] = wanted ? nzval[m] : nullptr;
         p.cap[m] = wanted ? capacity[m] : 0;
     }
-    if ((rc = otmb_reserve(ctx, ctx->tcount, (size_t)a->n_wet + 16))) return rc;
-    p.tcount = (uint8_t *)ctx->tcount.p;
-    pl.outT[0] = p.colptr[0]; pl.outT[1] = p.rowval[0]; pl.outT[2] = p.nzval[0];
+    if (ctx->tm_hist_final) { ctx->tm_hist.clear(); ctx->tm_hist_final = false; }  // a new pipeline starts
     // this step's own state block (flag words + totals): a ring slot, so that the verdict on every step of a pipeline
     // of asynchronous calls is still there when otmb_transportmatrix_result finally looks.  A full ring is folded
     // into the sticky (status, step) pair first -- one host synchronisation per OTMB_RING steps.
@@ -1042,7 +1079,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     if (ctx->tm_next - ctx->tm_first >= OTMB_RING - 1) {
         int32_t frc;
         if ((frc = fetch_ring(ctx))) return frc;
-        fold_pending(ctx);
+        if ((frc = fold_pending(ctx))) return frc;
     }
     int *dflags = otmb_ring_tm((int *)ctx->ring.p, ctx->tm_next);
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
@@ -1103,6 +1140,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     }
     HIP_TRY(ctx, hipGetLastError());
     if (p.next_state) ctx->ring_clean |= 1ull << slot_after;
+    ctx->tm_rec.push_back({p.colptr[0], p.rowval[0], p.nzval[0], (i64)a->n_wet, p.nnz_base[0]});
     ctx->tm_next += 1;
     pl.onepass_pending = true;
     return OTMB_OK;
@@ -1115,14 +1153,15 @@ int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]) {
     if ((frc = fetch_ring(ctx))) return frc;
     ctx->plan->onepass_pending = false;
     // every step enqueued since the previous result: the FIRST one that failed is reported (the reference would have
-    // thrown there, src/matrixbuilding.jl:39,61,90,114,233), with its position in the error text
-    const i64 n_steps = ctx->tm_next, last = ctx->tm_next - 1;
-    const int *lastf = otmb_ring_tm(ctx->h_ring, last);
-    fold_pending(ctx);
+    // thrown there, src/matrixbuilding.jl:39,61,90,114,233), with its position in the error text; every step that did
+    // not fail has its own nnz (and its T compacted if entries cancelled): otmb_transportmatrix_result_step
+    const i64 n_steps = ctx->tm_next;
+    frc = fold_pending(ctx);
     const int32_t st = ctx->tm_sticky;
     ctx->tm_failed_step = ctx->tm_sticky_step;
     ctx->tm_sticky = 0; ctx->tm_sticky_step = -1;
     ctx->tm_first = ctx->tm_next = 0;
+    ctx->tm_hist_final = true;
     if (st) {
         if (n_steps > 1) {
             char where[96];
@@ -1131,15 +1170,17 @@ int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]) {
         }
         return st;
     }
-    const i64 *lasttot = (const i64 *)(lastf + OTMB_NFLAGS);
-    for (int m = 0; m < 5; ++m) ctx->plan->nnz[m] = lasttot[m];
-    if (lastf[FLAG_T_CANCEL]) {
-        TmPlan &pl = *ctx->plan;
-        int32_t rc;
-        if ((rc = t_fixup(ctx, pl, (i64 *)pl.outT[0], (i64 *)pl.outT[1], (double *)pl.outT[2]))) return rc;
-    }
-    for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m];
+    if (frc) return frc;
+    if (ctx->tm_hist.empty()) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
+    for (int m = 0; m < 5; ++m) nnz[m] = ctx->plan->nnz[m] = ctx->tm_hist.back().nnz[m];
     return OTMB_OK;
+}
+
+int32_t otmb_transportmatrix_result_step(otmb_ctx *ctx, int64_t step, int64_t nnz[5]) {
+    if (!ctx || !nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (!ctx->tm_hist_final || step < 0 || (size_t)step >= ctx->tm_hist.size()) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "no such asynchronous step");
+    for (int m = 0; m < 5; ++m) nnz[m] = ctx->tm_hist[(size_t)step].nnz[m];
+    return ctx->tm_hist[(size_t)step].status;
 }
 
 }  // extern "C"

@@ -168,12 +168,22 @@ class DeviceAssembler:
             self.push_mask = self._empty(self.G, torch.int16)
         ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
         self._mask_key = None
+        self._note("_ff_seq")
         self.ctx.check(self.lib.otmb_facefluxes_slab_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
                                                          int(umo.dtype == torch.float32), self.wet3d.data_ptr(), float(fill),
                                                          self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
                                                          self.push_mask.data_ptr()))
         self._mask_key = self._phi_key(self.phi)
         return self.phi
+
+    def _note(self, which):
+        """Asynchronous calls of both kinds are numbered in one sequence, so that finish() can tell which of a facefluxes
+        failure (counted among facefluxes calls) and a transportmatrix failure (counted among transportmatrix calls) came
+        FIRST even when the two kinds of call were not issued in pairs."""
+        self._seq = getattr(self, "_seq", 0) + 1
+        if not hasattr(self, which):
+            setattr(self, which, [])
+        getattr(self, which).append(self._seq)
 
     @staticmethod
     def _phi_key(phi):
@@ -189,6 +199,7 @@ class DeviceAssembler:
         u, v, n = (C.c_int32 * cap)(), (C.c_int32 * cap)(), C.c_int32(0)
         self.ctx.check(self.lib.otmb_facefluxes_pending_flags(self.ctx.handle, cap, u, v, C.byref(n)))
         self._ff_pending = 0
+        self._ff_seq_drained, self._ff_seq = getattr(self, "_ff_seq", [])[-n.value:] if n.value else [], []
         for q in range(n.value):
             if not (u[q] and v[q]):
                 return q, n.value
@@ -220,12 +231,17 @@ class DeviceAssembler:
         """Drain the pipeline: the earliest failing step wins; within a step facefluxes' assertion comes first, as in
         the reference (facefluxes runs before transportmatrix)."""
         bad, n = self._first_missing()
+        ff_seq = self._ff_seq_drained
+        tm_seq, self._tm_seq = getattr(self, "_tm_seq", []), []
         err = None
         try:
             out = self.result()
         except capi.OtmbError as e:
             err = e
-        if bad is not None and (err is None or err.step is None or bad <= err.step):
+        ff_first = True
+        if bad is not None and err is not None and err.step is not None and bad < len(ff_seq) and err.step < len(tm_seq):
+            ff_first = ff_seq[bad] < tm_seq[err.step]  # which of the two calls was issued first
+        if bad is not None and (err is None or err.step is None or ff_first):
             where = f" (asynchronous step {bad + 1} of {n})" if n > 1 else ""
             raise capi.OtmbError(8, self.lib.otmb_status_string(8).decode() + where, step=bad)
         if err is not None:
@@ -285,27 +301,36 @@ class DeviceAssembler:
 
     PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold
 
-    def transportmatrix_onepass(self, phi, sync=True):
+    def new_output_set(self):
+        """A set of five CSC output buffers at their upper bound (for transportmatrix_onepass(out=...): a pipeline whose
+        steps each keep their own matrices)."""
+        cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
+        return {m: (self._empty(self.N + 1, torch.int64), self._empty(cap[k], torch.int64),
+                    self._empty(cap[k], torch.float64)) for k, m in enumerate(MATS)}
+
+    def transportmatrix_onepass(self, phi, sync=True, out=None):
         """Asynchronous protocol (otmb_transportmatrix_dev): outputs preallocated at their upper bound, count ->
         scan -> fill enqueued without a host round trip.  With sync=False the nnz/errors are collected later by
-        result()."""
-        if self.out is None or getattr(self, "_out_cap", None) is None:
-            cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
-            self.out = {m: (self._empty(self.N + 1, torch.int64), self._empty(cap[k], torch.int64),
-                            self._empty(cap[k], torch.float64)) for k, m in enumerate(MATS)}
-            self._out_cap = cap
+        result().  out: an output set of new_output_set() (default: this object's one set, overwritten by every call)."""
+        if out is None and (self.out is None or getattr(self, "_out_cap", None) is None):
+            self.out = self.new_output_set()
+            self._out_cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
+        if out is None:
+            out = self.out
         a = self._args(phi)
-        cp = capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
-        rv = capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
-        nz = capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
-        caps = (C.c_int64 * 5)(*self._out_cap)
+        cp = capi.ptr_array(5, [out[m][0].data_ptr() for m in MATS])
+        rv = capi.ptr_array(5, [out[m][1].data_ptr() for m in MATS])
+        nz = capi.ptr_array(5, [out[m][2].data_ptr() for m in MATS])
+        caps = (C.c_int64 * 5)(*[self.N * k + 1 for k in self.PER_COLUMN_MAX])
         self.ctx.check(self.lib.otmb_transportmatrix_dev(self.ctx.handle, C.byref(a), C.byref(cp), C.byref(rv),
                                                          C.byref(nz), C.byref(caps)))
-        return self.result() if sync else self.out
+        self._note("_tm_seq")
+        return self.result() if sync else out
 
     def result(self):
         nnz = (C.c_int64 * 5)()
         rc = self.lib.otmb_transportmatrix_result(self.ctx.handle, C.byref(nnz))
+        self._tm_seq = []
         if rc != capi.OK:
             step = C.c_int64(-1)
             self.lib.otmb_transportmatrix_failed_step(self.ctx.handle, C.byref(step))
@@ -313,6 +338,13 @@ class DeviceAssembler:
                                  step=int(step.value) if step.value >= 0 else None)
         self.nnz = [int(x) for x in nnz]
         return self.out
+
+    def result_step(self, k):
+        """(status, nnz) of the k-th asynchronous call covered by the last result(): every call keeps its own verdict and
+        its own nnz (and its own T, compacted if entries cancelled, when it was given its own output arrays)."""
+        nnz = (C.c_int64 * 5)()
+        rc = self.lib.otmb_transportmatrix_result_step(self.ctx.handle, int(k), C.byref(nnz))
+        return rc, [int(x) for x in nnz]
 
     def step(self, umo, vmo, fill, onepass=True):
         """One pass of the hot path, all device resident: facefluxes -> transportmatrix."""

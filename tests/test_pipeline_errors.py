@@ -165,3 +165,91 @@ def test_hip_slab_pipeline_reports_first_failing_step_on_every_rank(oracle, tmp_
     z = run_ranks(3, "hip", case, tmp_path, fault=fault)
     check_fault_reports(tmp_path, 3, "OtmbError", int(fault.split(":")[1]), "ρ contains NaNs")
     check_against_whole_grid(oracle, z, case)
+
+
+def test_every_asynchronous_step_keeps_its_own_matrices(oracle):
+    """Two asynchronous calls into two output sets; the FIRST one with exact cancellations in T (κ = 0: every diffusive
+    value is an explicit zero that sparse() keeps in the operators and `+` drops from T, src/matrixbuilding.jl:147), the
+    second an ordinary one.  Both must come out as the reference's matrices, each with its own nnz: every transportmatrix
+    call of the reference returns its own five matrices (src/matrixbuilding.jl:147-149)."""
+    g, gm, ref, rtm, asm, umo, vmo = _setup(oracle, "tiny_tripolar")
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    rtm0 = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, 0.0, 0.0, 0.0, True)
+    phi = asm.facefluxes(umo, vmo, 1e20)
+    outs = [asm.new_output_set() for _ in range(3)]
+    kappa = asm.kappa
+    asm.kappa = (0.0, 0.0, 0.0)
+    asm.transportmatrix_onepass(phi, sync=False, out=outs[0])
+    asm.kappa = kappa
+    asm.transportmatrix_onepass(phi, sync=False, out=outs[1])
+    asm.kappa = (0.0, 0.0, 0.0)
+    asm.transportmatrix_onepass(phi, sync=False, out=outs[2])
+    asm.kappa = kappa
+    asm.result()
+    for k, want in enumerate((rtm0, rtm, rtm0)):
+        rc, nnz = asm.result_step(k)
+        assert rc == 0
+        assert nnz == [len(want[m][1]) for m in MATS], (k, nnz)
+        for q, m in enumerate(MATS):
+            cp, rv, nz = (t.cpu().numpy() for t in outs[k][m])
+            assert_csc_equal((cp, rv[:nnz[q]], nz[:nnz[q]]), want[m], f"step {k} {m}")
+    assert len(rtm0["T"][1]) < len(rtm["T"][1])  # the cancellation really happened
+    # one output set reused by every call (what bench.py does): the last call's matrices are what it holds
+    asm.kappa = (0.0, 0.0, 0.0)
+    asm.transportmatrix_onepass(phi, sync=False)
+    asm.kappa = kappa
+    asm.transportmatrix_onepass(phi, sync=False)
+    out = asm.result()
+    for q, m in enumerate(MATS):
+        cp, rv, nz = (t.cpu().numpy() for t in out[m])
+        assert_csc_equal((cp, rv[:asm.nnz[q]], nz[:asm.nnz[q]]), rtm[m], m)
+
+
+def test_a_failed_step_does_not_hide_the_results_of_the_others(oracle):
+    from otmb_amd.capi import OtmbError
+
+    g, gm, ref, rtm, asm, umo, vmo = _setup(oracle, "tiny_rho3d")
+    phi = asm.facefluxes(umo, vmo, 1e20)
+    outs = [asm.new_output_set() for _ in range(3)]
+    L = int(ref["Lwet"][3] - 1)
+    for k in range(3):
+        if k == 1:
+            old = asm.rho[L].clone()
+            asm.rho[L] = float("nan")
+        asm.transportmatrix_onepass(phi, sync=False, out=outs[k])
+        if k == 1:
+            asm.rho[L] = old
+    with pytest.raises(OtmbError, match="ρ contains NaNs") as e:
+        asm.result()
+    assert e.value.step == 1
+    for k in (0, 2):
+        rc, nnz = asm.result_step(k)
+        assert rc == 0 and nnz == [len(rtm[m][1]) for m in MATS]
+        for q, m in enumerate(MATS):
+            cp, rv, nz = (t.cpu().numpy() for t in outs[k][m])
+            assert_csc_equal((cp, rv[:nnz[q]], nz[:nnz[q]]), rtm[m], f"step {k} {m}")
+    assert asm.result_step(1)[0] == 1  # OTMB_ERR_RHO_NAN
+    assert asm.result_step(3)[0] == 11  # no such step
+
+
+def test_failures_of_unpaired_calls_are_ordered_by_issue(oracle):
+    """A facefluxes call that is not part of a step (no transportmatrix after it) shifts the two kinds of index against each
+    other: the failure that was ISSUED first must win (facefluxes call 2 comes after transportmatrix call 0 here)."""
+    import torch
+
+    from otmb_amd.capi import OtmbError
+
+    g, gm, ref, rtm, asm, umo, vmo = _setup(oracle, "tiny_rho3d")
+    L = int(ref["Lwet"][3] - 1)
+    old = asm.rho[L].clone()
+    asm.rho[L] = float("nan")
+    asm.step_async(umo, vmo, 1e20)      # facefluxes call 0 (fine), transportmatrix call 0 (ρ NaN)
+    asm.rho[L] = old
+    asm.facefluxes_async(umo, vmo, 1e20)  # facefluxes call 1, unpaired
+    wet = asm.wet3d.clone()
+    asm.wet3d.fill_(1)
+    asm.facefluxes_async(torch.full_like(umo, float("nan")), vmo, 1e20)  # facefluxes call 2: nothing valid
+    asm.wet3d.copy_(wet)
+    with pytest.raises(OtmbError, match="ρ contains NaNs") as e:
+        asm.finish()
+    assert e.value.step == 0

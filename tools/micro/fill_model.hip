@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 typedef long long i64;
@@ -276,15 +277,18 @@ __global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg,
     }
 }
 
-int main() {
-    const int nx = 360, ny = 300, nz = 50;
-    const i64 P = (i64)nx * ny, G = P * nz, n = 3051515 / 256 * 256, ntiles = n / 256;
+int main(int argc, char **argv) {
+    // default: the 1 degree grid; `fill_model 1440 1080 75 63526216` = the 0.25 degree grid
+    const int nx = argc > 3 ? atoi(argv[1]) : 360, ny = argc > 3 ? atoi(argv[2]) : 300, nz = argc > 3 ? atoi(argv[3]) : 50;
+    const int nseg = (nx + 63) / 64;
+    const i64 P = (i64)nx * ny, G = P * nz, n = (argc > 4 ? atoll(argv[4]) : 3051515) / 256 * 256, ntiles = n / 256;
+    const bool quick = argc > 5;  // fewer variants
     std::vector<i64> lwet(n);
     unsigned long long s = 88172645463325252ull;
     i64 L = 0;
     for (i64 w = 0; w < n; ++w) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-        L += 1 + ((s & 3) == 0) + ((s & 12) == 0) * 2;
+        L += 1 + ((s & 3) == 0) + ((s & 12) == 0) * 2 + (((s >> 8) % 100) < (unsigned long long)(100.0 * ((double)G / n - 1.75) > 0 ? 100.0 * ((double)G / n - 1.75) : 0));
         if (L >= G) L = G - 1;
         lwet[w] = L;
     }
@@ -297,7 +301,7 @@ int main() {
     for (int k = 0; k < N2D; ++k) { double *x; CK(hipMalloc(&x, P * 8)); CK(hipMemset(x, 0, P * 8)); p.b[k] = x; }
     double out_bytes = 0;
     for (int m = 0; m < 5; ++m)
-        for (int h = 0; h < 2; ++h) { CK(hipMalloc(&p.out[2 * m + h], ((i64)6 * ny * nz * 64 * CNT[m] + 256) * 8)); out_bytes += (double)n * CNT[m] * 8; }
+        for (int h = 0; h < 2; ++h) { CK(hipMalloc(&p.out[2 * m + h], ((i64)nseg * ny * nz * 64 * CNT[m] + 256) * 8)); out_bytes += (double)n * CNT[m] * 8; }
     p.n = n; p.G = G; p.P = P; p.nx = nx;
     const double in_bytes = (double)G * 8 * NARR + (double)n * 8;
     hipEvent_t e0, e1;
@@ -320,7 +324,8 @@ int main() {
         p.nfma = nf;
         printf("-- %d rounds of 20 dependent FMAs per cell --\n", nf);
         timeit("plain: loads + math + stores", [&] { hipLaunchKernelGGL((plain<true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
-        timeit("plain: 8 east/west loads fewer", [&] { hipLaunchKernelGGL((plain<true, true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        if (!quick) timeit("plain: 8 east/west loads fewer", [&] { hipLaunchKernelGGL((plain<true, true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        if (!quick) {
         timeit("plain: nontemporal stores", [&] { hipLaunchKernelGGL((plain<true, true, true, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain, 5 workgroups per CU (32 KB LDS)", [&] { hipLaunchKernelGGL((plain_occ<32 * 1024>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain, 4 workgroups per CU (40 KB LDS)", [&] { hipLaunchKernelGGL((plain_occ<40 * 1024>), dim3(ntiles), dim3(256), 0, 0, p); });
@@ -340,13 +345,14 @@ int main() {
         timeit("plain + barrier", [&] { hipLaunchKernelGGL((plain_extras<true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain + barrier + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        }
         timeit("plain: no stores", [&] { hipLaunchKernelGGL((plain<true, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: no loads", [&] { hipLaunchKernelGGL((plain<false, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: math only", [&] { hipLaunchKernelGGL((plain<false, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         for (int kparts : {1, 2, 5, 10, 25}) {
             char name[96];
-            snprintf(name, sizeof name, "march model: dense rows, %d level segments (%d waves)", kparts, 6 * ny * kparts);
-            timeit(name, [&] { hipLaunchKernelGGL(march, dim3((6 * ny * kparts + 3) / 4), dim3(256), 0, 0, p, ny, nz, 6, kparts); });
+            snprintf(name, sizeof name, "march model: dense rows, %d level segments (%d waves)", kparts, nseg * ny * kparts);
+            timeit(name, [&] { hipLaunchKernelGGL(march, dim3((nseg * ny * kparts + 3) / 4), dim3(256), 0, 0, p, ny, nz, nseg, kparts); });
         }
         for (int wgs : {768})  {
             char name[64];

@@ -48,6 +48,47 @@ __global__ __launch_bounds__(256) void calib_write16(d2 *__restrict__ a, i64 n) 
     const i64 stride = (i64)gridDim.x * 256;
     for (i64 q = (i64)blockIdx.x * 256 + threadIdx.x; q < n; q += stride) a[q] = d2{1.0, 2.0};
 }
+// write shapes: one pass, every workgroup writes a contiguous 16 KB block (4 stores of 16 B per lane, 4 KB apart)
+template <bool NT>
+__global__ __launch_bounds__(256) void write16_block(d2 *__restrict__ a, i64 n) {
+    const i64 q0 = (i64)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const i64 q = q0 + r * 256;
+        if (q < n) {
+            if (NT) __builtin_nontemporal_store(d2{1.0, 2.0}, a + q);
+            else a[q] = d2{1.0, 2.0};
+        }
+    }
+}
+__global__ __launch_bounds__(256) void write8_block(double *__restrict__ a, i64 n) {
+    const i64 q0 = (i64)blockIdx.x * 2048 + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const i64 q = q0 + r * 256;
+        if (q < n) a[q] = 1.0;
+    }
+}
+// ten output streams at once: workgroup b writes a 4 KB piece (one store per lane) into each of ten regions of the buffer
+__global__ __launch_bounds__(256) void write16_ten_streams(d2 *__restrict__ a, i64 n) {
+    const i64 per = n / 10;
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q < per) {
+#pragma unroll
+        for (int s = 0; s < 10; ++s) a[s * per + q] = d2{1.0, 2.0};
+    }
+}
+// reads beside writes at a chosen ratio: a workgroup reads RD blocks of 4 KB and writes WR blocks of 4 KB
+template <int RD, int WR>
+__global__ __launch_bounds__(256) void rw_ratio(const d2 *__restrict__ a, d2 *__restrict__ b, i64 nblk) {
+    const i64 blk = blockIdx.x;
+    if (blk >= nblk) return;
+    d2 acc = {0, 0};
+#pragma unroll
+    for (int r = 0; r < RD; ++r) acc += a[(blk * RD + r) * 256 + threadIdx.x];
+#pragma unroll
+    for (int w = 0; w < WR; ++w) b[(blk * WR + w) * 256 + threadIdx.x] = acc;
+}
 __global__ __launch_bounds__(256) void calib_copy16(const d2 *__restrict__ a, d2 *__restrict__ b, i64 n) {
     const i64 stride = (i64)gridDim.x * 256;
     for (i64 q = (i64)blockIdx.x * 256 + threadIdx.x; q < n; q += stride) b[q] = a[q];
@@ -70,7 +111,7 @@ __global__ __launch_bounds__(256) void mix_stream(Mix p, i64 nchunks) {
         const i64 o0 = c * (i64)256;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            if (r == 2 && (threadIdx.x & 3)) continue;
+            if (r == 2 && threadIdx.x >= 64) continue;  // a quarter round: one wave's worth, contiguous
             int e = 0;
 #pragma unroll
             for (int m = 0; m < 5; ++m) {
@@ -133,6 +174,14 @@ int main() {
         CK(hipFree(didx));
     }
     timeit("calib_write16 (16 B/lane stream, 2 GiB)", (double)NB, 10, [&] { hipLaunchKernelGGL(calib_write16, dim3(256 * 16), dim3(256), 0, 0, (d2 *)buf, n16); });
+    timeit("write16_block (one pass, 16 KB contiguous per workgroup)", (double)NB, 10, [&] { hipLaunchKernelGGL((write16_block<false>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, 0, (d2 *)buf, n16); });
+    timeit("write16_block, nontemporal", (double)NB, 10, [&] { hipLaunchKernelGGL((write16_block<true>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, 0, (d2 *)buf, n16); });
+    timeit("write8_block  (one pass, 8 B/lane, 16 KB per workgroup)", (double)NB, 10, [&] { hipLaunchKernelGGL(write8_block, dim3((unsigned)(n8 / 2048)), dim3(256), 0, 0, buf, n8); });
+    timeit("write16_ten_streams (4 KB into each of ten regions)", (double)(n16 / 10 * 10) * 16, 10, [&] { hipLaunchKernelGGL(write16_ten_streams, dim3((unsigned)((n16 / 10 + 255) / 256)), dim3(256), 0, 0, (d2 *)buf, n16); });
+    timeit("rw_ratio<4,4>  (copy, one pass)", 2.0 * (n16 / 1024 * 1024) * 16, 10, [&] { hipLaunchKernelGGL((rw_ratio<4, 4>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, 0, (const d2 *)buf, (d2 *)buf2, n16 / 1024); });
+    timeit("rw_ratio<2,4>  (1 read : 2 written)", 1.5 * (n16 / 1024 * 1024) * 16, 10, [&] { hipLaunchKernelGGL((rw_ratio<2, 4>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, 0, (const d2 *)buf, (d2 *)buf2, n16 / 1024); });
+    timeit("rw_ratio<4,2>  (2 read : 1 written)", 1.5 * (n16 / 1024 * 1024) * 16, 10, [&] { hipLaunchKernelGGL((rw_ratio<4, 2>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, 0, (const d2 *)buf, (d2 *)buf2, n16 / 1024); });
+    timeit("rw_ratio<4,1>  (4 read : 1 written)", 1.25 * (n16 / 1024 * 1024) * 16, 10, [&] { hipLaunchKernelGGL((rw_ratio<4, 1>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, 0, (const d2 *)buf, (d2 *)buf2, n16 / 1024); });
     timeit("calib_copy16  (2 GiB -> 2 GiB)", 2.0 * NB, 10, [&] { hipLaunchKernelGGL(calib_copy16, dim3(256 * 16), dim3(256), 0, 0, (const d2 *)buf, (d2 *)buf2, n16); });
     CK(hipFree(buf)); CK(hipFree(buf2));
 
