@@ -82,6 +82,13 @@ int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on);
  * neighbours of src/matrixbuilding.jl:280-296, :450-477) were read moments ago and are still in the L2 / Infinity Cache
  * instead of one whole level (124 MB of inputs on a 0.25 degree grid) earlier.  -1 (default): chosen from the grid size. */
 int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band);
+/* Speed only, never results: which kernels build the matrices of transportmatrix.  dense = 0: GATHER -- one lane per wet
+ * cell fetches its 6-neighbour stencil from global memory (tiles of 256 columns); dense = 1: DENSE-TILE MARCH -- a wave is
+ * 62 consecutive cells of one grid row and walks down the levels: east / west neighbours are the neighbouring lanes, the
+ * levels above / below stay in registers, every input is read once (land lanes idle); -1 (default): by grid size (the
+ * march from 0.25 degree grids on).  depth_parts > 0: levels per column are cut into that many pieces (more waves,
+ * shorter marches); 0 leaves it unchanged.  Both give the same matrices bit for bit.                           */
+int32_t otmb_ctx_set_formulation(otmb_ctx *ctx, int32_t dense, int32_t depth_parts);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
 const char *otmb_version(void);

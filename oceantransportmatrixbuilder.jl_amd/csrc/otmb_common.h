@@ -28,7 +28,7 @@ struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = null
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_TM_ORDER, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_TM_ORDER, K_DM_COUNT, K_DM_FILL, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 
@@ -44,6 +44,8 @@ struct otmb_ctx {
     DevBuf mask;              // push mask derived by the library when the caller passes none
     DevBuf order;             // tile order of the fill pass (march order: otmb_ctx_set_tile_order) + its bucket scratch
     int march_rows = -1;      // rows per band of the march order; 0 = wet-rank order; -1 = chosen by grid size
+    int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)
+    int dense_kparts = 1;     // dense march: depth pieces per (row, segment)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)
     DevBuf lump_host;         // staging of the host-pointer entry point
     bool lump_valid = false;

@@ -68,6 +68,8 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     otmb_ctx *c = new otmb_ctx();
     c->device = device_id;
     if (const char *e = getenv("OTMB_MARCH_ROWS")) c->march_rows = atoi(e);  // experiments; otmb_ctx_set_tile_order is the API
+    if (const char *e = getenv("OTMB_DENSE")) c->formulation = atoi(e);        // experiments; otmb_ctx_set_formulation is the API
+    if (const char *e = getenv("OTMB_DENSE_KPARTS")) c->dense_kparts = atoi(e);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return OTMB_ERR_HIP;
@@ -138,6 +140,13 @@ int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band) {
     return OTMB_OK;
 }
 
+int32_t otmb_ctx_set_formulation(otmb_ctx *ctx, int32_t dense, int32_t depth_parts) {
+    if (!ctx || dense < -1 || dense > 1 || depth_parts < 0) return OTMB_ERR_INVALID_ARG;
+    ctx->formulation = dense;
+    if (depth_parts > 0) ctx->dense_kparts = depth_parts;
+    return OTMB_OK;
+}
+
 int32_t otmb_ctx_synchronize(otmb_ctx *ctx) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -183,7 +192,7 @@ const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
                                             "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
-                                            "push_mask_kernel", "tm_order_kernels"};
+                                            "push_mask_kernel", "tm_order_kernels", "dm_count_kernel", "dm_fill_kernel"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

@@ -1,0 +1,528 @@
+// otmb_tm_dense.h -- DENSE-TILE MARCH formulation of the counting and fill passes of transportmatrix
+// (src/matrixbuilding.jl:128-150; same columns, same arithmetic, same CSC output as the gather kernels of
+// otmb_transportmatrix.hip -- only WHERE a stencil value comes from differs).
+//
+// The gather kernels give every lane one wet cell and fetch its 58 stencil values from global memory: each value of
+// v3D / ρ / Lwet3D crosses L2 -> L1 five times (as a cell's own and as its south / north / above / below
+// neighbours') and, once a level of the grid no longer fits the caches (0.25 degree: 124 MB), the levels above and
+// below come from HBM again (measured: 15.4 GB fetched for 9.3 GB of inputs).  Here a wave is 62 consecutive cells of
+// ONE grid row (lanes 1..62; lanes 0 and 63 hold the west / east halo cells, wrapped periodically,
+// src/gridtopology.jl:57-58) and MARCHES down the levels:
+//   * east / west neighbours are the neighbouring LANES (DPP wave_shl:1 / wave_shr:1);
+//   * the level above is what the wave held one step ago, the level below what it loaded one step ahead (registers);
+//   * south / north rows are the only neighbour loads (same lines as the sibling waves' own loads: the four waves of
+//     a workgroup are four consecutive rows);
+//   * per level 18 coalesced 512-byte loads serve ~45 wet cells (the gather form: 58 loads per 64), every input value
+//     is read from HBM once, and the 2-D metrics are loaded once per column instead of once per cell.
+// Land lanes idle (27 % of the segment-levels of the 0.25 degree grid are all land and skip everything but their
+// loads; the others hold 72 % wet lanes).  The wet lanes of a wave are consecutive columns of all five matrices, so
+// the output side is the gather kernel's: packed wave scan, per-wave LDS staging, 16-byte stores from scalar bases.
+// Offsets: the counting pass leaves six sums per (level, row, segment) -- in that order, which is the order of the wet
+// rank (src/matrixbuilding.jl:14-15) -- and the tile scan turns them into the absolute position of every wave's run.
+#pragma once
+#include "otmb_tm_column.h"
+
+#define DM_W 62     // columns a wave produces (lanes 1..62)
+#define DM_ROWS 4   // rows (= waves) per workgroup
+#define DM_NF 6     // scan fields per segment-level: T (union), Tadv, TκH, TκVML, TκVdeep, wet cells
+#ifndef DM_WAVES_PER_SIMD
+#define DM_WAVES_PER_SIMD 2
+#endif
+
+struct DmGeom {
+    int nseg;        // segments of DM_W cells per row
+    int nrowgrp;     // groups of DM_ROWS rows
+    int kparts;      // the owned levels are cut into kparts pieces per (row, segment)
+    const int *kown; // [2] first and last level that holds owned wet cells (device; slabs own whole levels)
+};
+
+__device__ __forceinline__ int dpp_next_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, false); }  // lane l <- lane l+1
+__device__ __forceinline__ int dpp_prev_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }  // lane l <- lane l-1
+__device__ __forceinline__ double dpp_next(double x) {
+    return __hiloint2double(dpp_next_i(__double2hiint(x)), dpp_next_i(__double2loint(x)));
+}
+__device__ __forceinline__ double dpp_prev(double x) {
+    return __hiloint2double(dpp_prev_i(__double2hiint(x)), dpp_prev_i(__double2loint(x)));
+}
+__device__ __forceinline__ i64 dpp_next(i64 x) {
+    return (i64)(((u64)(unsigned)dpp_next_i((int)((u64)x >> 32)) << 32) | (unsigned)dpp_next_i((int)(unsigned)(u64)x));
+}
+__device__ __forceinline__ i64 dpp_prev(i64 x) {
+    return (i64)(((u64)(unsigned)dpp_prev_i((int)((u64)x >> 32)) << 32) | (unsigned)dpp_prev_i((int)(unsigned)(u64)x));
+}
+
+// The 58 values of a regular cell's stencil (what fast_column loads), wherever they came from.
+struct Stencil {
+    i64 lE, lW, lS, lN, lA, lB;     // Lwet3D of the six neighbours (unmasked)
+    double gE, gW, gS, gN, gA, gB;  // the flux each neighbour pushes with: ϕwest[E], ϕeast[W], ϕnorth[S], ϕsouth[N], ϕbottom[A], ϕtop[B]
+    double vC, vE, vW, vS, vN, vA, vB;
+    double rC, rE, rW, rS, rN, rA, rB;
+    double tC, tE, tW, tS, tN;
+    double eW_c, eE_c, eS_c, eN_c, dW_c, dE_c, dS_c, dN_c, eE_w, dE_w, eW_e, dW_e, eN_s, dN_s, eS_n, dS_n, ar, mld;
+    double ztk, zta, ztb;
+};
+
+// fast_column's arithmetic on a Stencil: the same expressions in the same order (src/matrixbuilding.jl:193-204,
+// :244-296, :348-415, :426-435, :450-477), so the two formulations agree bit for bit.  Regular cells only.
+__device__ __forceinline__ void column_compute(const TmParams &p, const Stencil &s, int i, int j, int k, i64 c, Column &col) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
+    const i64 xE = s.lE, xW = s.lW, xS = hS ? s.lS : 0, xN = hN ? s.lN : 0, xA = hA ? s.lA : 0, xB = hB ? s.lB : 0;
+    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
+    const double vC = s.vC, rC = s.rC, tC = s.tC;
+
+    // ---- advective pushes towards this cell (:244-296) ----
+    const double fE = wE ? sel_pos(s.gE, up) : 0.0;
+    const double fW = wW ? sel_neg(s.gW, up) : 0.0;
+    const double fS = wS ? sel_neg(s.gS, up) : 0.0;
+    const double fN = wN ? sel_pos(s.gN, up) : 0.0;
+    const double fA = wA ? sel_pos(s.gA, up) : 0.0;
+    const double fB = wB ? sel_neg(s.gB, up) : 0.0;
+    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
+
+    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
+    {
+        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
+        col.bef[S_A] = 0;
+        col.bef[S_S] = 1u << S_A;
+        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
+        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
+        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
+        col.bef[S_FQ] = 0;
+        col.bef[S_N] = lo | bS | bE | bW;
+        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
+    }
+    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
+    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
+
+    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
+    {
+#define ADV1(PHI, RX, VX, OFF, DG)                \
+    const double rb##OFF = ((RX) + rC) / 2;       \
+    const double OFF = FDIV(-(PHI), (rb##OFF * (VX))); \
+    const double DG = FDIV((PHI), (rb##OFF * vC));
+        ADV1(fA, s.rA, s.vA, oA_, dA_)
+        ADV1(-fS, s.rS, s.vS, oS_, dS_)
+        ADV1(-fW, s.rW, s.vW, oW_, dW_)
+        ADV1(fE, s.rE, s.vE, oE_, dE_)
+        ADV1(fN, s.rN, s.vN, oN_, dN_)
+        ADV1(-fB, s.rB, s.vB, oB_, dB_)
+#undef ADV1
+        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
+                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
+        const bool badrho = p.rho_in_fill && isnan(rC);
+        if (bad | badrho) {
+            if (badrho) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+            if (bad) raise_flag(p.flags, FLAG_TADV_NAN);    // :39
+        }
+        double d = NEG0;  // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
+        d += aA ? dA_ : NEG0;
+        d += aS ? dS_ : NEG0;
+        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
+        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
+        d += m1;
+        d += m2;
+        d += aN ? dN_ : NEG0;
+        d += aB ? dB_ : NEG0;
+        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
+        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
+        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
+                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+    }
+    // ---- TκH (:348-415, :426-435) ----
+    {
+#define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
+    const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
+    const double OWN = FDIV((p.kH * a##OWN), ((D_C) * vC));       \
+    const double IN = FDIV((p.kH * a##OWN), ((D_X) * (VX)));
+        H1(s.tW, s.eW_c, s.eE_w, s.dW_c, s.dE_w, s.vW, ownW, inW)
+        H1(s.tE, s.eE_c, s.eW_e, s.dE_c, s.dW_e, s.vE, ownE, inE)
+        H1(s.tS, s.eS_c, s.eN_s, s.dS_c, s.dN_s, s.vS, ownS, inS)
+        H1(s.tN, s.eN_c, s.eS_n, s.dN_c, s.dS_n, s.vN, ownN, inN)
+#undef H1
+        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
+                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
+        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
+        double h = NEG0;  // own pushes in direction order W, E, S, N
+        h += wW ? ownW : NEG0;
+        h += wE ? ownE : NEG0;
+        h += wS ? ownS : NEG0;
+        h += wN ? ownN : NEG0;
+        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
+        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
+        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
+                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
+    }
+    // ---- TκVdeep / TκVML (:450-477) ----
+    {
+        const double ztk = s.ztk, zta = hA ? s.zta : s.ztk, ztb = hB ? s.ztb : s.ztk;
+        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
+        const double nD = p.kDeep * s.ar;
+        const double ownB = FDIV(nD, (dB * vC)), inB = FDIV(nD, (dB * s.vB)), ownA = FDIV(nD, (dA * vC)), inA = FDIV(nD, (dA * s.vA));
+        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
+        double d = NEG0;  // own pushes: bottom then top
+        d += wB ? ownB : NEG0;
+        d += wA ? ownA : NEG0;
+        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
+        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+        const bool omC = ztk < s.mld;  // Ω (:85); NaN compares false
+        const bool mB = wB & omC & (ztb < s.mld), mA = wA & omC & (zta < s.mld);
+        col.pml = 0;
+        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
+        if (mA | mB) {
+            const double nM = p.kML * s.ar;
+            const double mownB = FDIV(nM, (dB * vC)), minB = FDIV(nM, (dB * s.vB)), mownA = FDIV(nM, (dA * vC)), minA = FDIV(nM, (dA * s.vA));
+            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
+            double m = NEG0;
+            m += mB ? mownB : NEG0;
+            m += mA ? mownA : NEG0;
+            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
+            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
+        }
+    }
+}
+
+// lane geometry of a wave: cells i0-1 .. i0+62 of row j, wrapped periodically
+struct DmLane {
+    int i;         // the lane's cell
+    bool active;   // lanes 1..62 inside the row produce columns
+};
+__device__ __forceinline__ DmLane dm_lane(int seg, int lane, int nx) {
+    DmLane d;
+    int il = seg * DM_W - 1 + lane;
+    il %= nx;
+    d.i = il < 0 ? il + nx : il;
+    d.active = (lane >= 1) & (lane <= DM_W) & (seg * DM_W + lane - 1 < nx);
+    return d;
+}
+
+// first / last level with owned wet cells (the slab's own levels; the whole grid otherwise)
+__global__ void dm_kown_kernel(const i64 *__restrict__ lwet, i64 n_own, i64 P, int nz, int *kown) {
+    if (threadIdx.x == 0) {
+        i64 a = n_own > 0 ? (lwet[0] - 1) / P : 0, b = n_own > 0 ? (lwet[n_own - 1] - 1) / P : -1;
+        a = a < 0 ? 0 : (a >= nz ? nz - 1 : a);
+        b = b >= nz ? nz - 1 : b;
+        kown[0] = (int)a;
+        kown[1] = (int)b;
+    }
+}
+
+// ---- counting pass: one wave per (level, row, segment) ------------------------------------------------------------
+// Presence only, from the push mask (2 bytes per cell, see tm_count_kernel): own row + south / north rows + the levels
+// above / below = five 128-byte loads per wave, east / west from the neighbouring lanes.
+__global__ __launch_bounds__(256) void dm_count_kernel(const TmParams p, const DmGeom g) {
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
+    const i64 nsl = (i64)nz * ny * g.nseg;
+    const i64 id = (i64)blockIdx.x * 4 + wid;  // (k * ny + j) * nseg + seg
+    if (id >= nsl) return;
+    const int seg = (int)(id % g.nseg);
+    const i64 r = id / g.nseg;
+    const int j = (int)(r % ny), k = (int)(r / ny);
+    uint32_t *out = p.tilesums + id * DM_NF;
+    if (k < g.kown[0] || k > g.kown[1]) {  // a halo level of a depth slab: neighbours only
+        if (lane < DM_NF) out[lane] = 0;
+        return;
+    }
+    const DmLane dl = dm_lane(seg, lane, nx);
+    const int i = dl.i;
+    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
+    const i64 L = (i64)k * p.P + (i64)j * nx + i;
+    const unsigned sh = p.upwind ? 0u : 8u;
+    const uint16_t *mk = p.mask;
+    unsigned padv = 0, phh = 0, pml = 0, pdp = 0;
+    const unsigned mC = (unsigned)mk[L] >> sh;
+    const bool wet = dl.active && (mC & PM_WET);
+    const bool regular = !(p.topo == OTMB_TRIPOLAR && j == ny - 1);
+    if (regular) {
+        const unsigned mS = (unsigned)mk[hS ? L - nx : L] >> sh, mN = (unsigned)mk[hN ? L + nx : L] >> sh;
+        const unsigned mA = (unsigned)mk[hA ? L - p.P : L] >> sh, mB = (unsigned)mk[hB ? L + p.P : L] >> sh;
+        const unsigned mE = (unsigned)dpp_next_i((int)mC), mW = (unsigned)dpp_prev_i((int)mC);
+        const double mld = p.ml[(i64)j * nx + i];
+        const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
+        const bool wE = mE & PM_WET, wW = mW & PM_WET, wS = hS && (mS & PM_WET), wN = hN && (mN & PM_WET), wA = hA && (mA & PM_WET),
+                   wB = hB && (mB & PM_WET);
+        if (wet) {
+            // own pushes land in wet cells (the reference indexes Lwet3D[C𝑗] unconditionally, :247 etc.); ρ (:233)
+            const bool bad = ((mC & PM_W) && !wW) | ((mC & PM_E) && !wE) | ((mC & PM_S) && !wS) | ((mC & PM_N) && !wN) |
+                             ((mC & PM_B) && !wB) | (hA && (mC & PM_T) && !wA);
+            if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
+            if (!p.rho_in_fill && p.rho && isnan(p.rho[L])) raise_flag(p.flags, FLAG_RHO_NAN);
+            const bool aE = wE && (mE & PM_W), aW = wW && (mW & PM_E), aS = wS && (mS & PM_N), aN = wN && (mN & PM_S);
+            const bool aA = wA && (mA & PM_B), aB = wB && (mB & PM_T);
+            padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
+                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+            phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
+                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
+            pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+            const bool omC = ztk < mld;
+            const bool mlB = wB & omC & (ztb < mld), mlA = wA & omC & (zta < mld);
+            pml = ((unsigned)mlB << S_B) | ((unsigned)mlA << S_A) | ((unsigned)(mlA | mlB) << S_SELF);
+        }
+    } else if (wet) {  // the tripolar seam row: the generic slot logic on the mask (general_presence)
+        const Cell cell = cell_of(L, nx, ny, p.P);
+        general_presence(p, cell, padv, phh, pml, pdp);
+    }
+    u64 x = 0;
+    if (wet) {
+        x = p.only_t ? (u64)__popc(padv | phh | pml | pdp)
+                     : ((u64)__popc(padv | phh | pml | pdp) | ((u64)__popc(padv) << 11) | ((u64)__popc(phh) << 22) |
+                        ((u64)__popc(pml) << 33) | ((u64)__popc(pdp) << 43));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    const unsigned nwet = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(wet));
+    if (lane < DM_NF) {
+        const unsigned f[DM_NF] = {(unsigned)(x & 0x7ff), (unsigned)((x >> 11) & 0x7ff), (unsigned)((x >> 22) & 0x7ff),
+                                   (unsigned)((x >> 33) & 0x3ff), (unsigned)((x >> 43) & 0x3ff), nwet};
+        unsigned v = 0;
+#pragma unroll
+        for (int q = 0; q < DM_NF; ++q)
+            if (q == lane) v = f[q];
+        out[lane] = v;
+    }
+}
+
+// ---- fill pass: one wave per (row, segment, depth part), marching down the levels --------------------------------------
+struct DmOwn {  // a level's own values that its neighbours above / below need too
+    i64 lw;
+    double v, rho, pt, pb;
+};
+struct DmRest {  // the rest of a level's loads
+    double thk, pe, pw;
+    i64 lwS, lwN;
+    double vS, vN, tS, tN, rS, rN, pnS, psN;
+};
+
+__global__ __launch_bounds__(256, DM_WAVES_PER_SIMD) void dm_fill_kernel(const TmParams p, const DmGeom g, const i64 *totals) {
+    __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // per wave: rows, then value bits (as tm_kernel)
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (p.next_state && blockIdx.x == 0 && tid < (int)(OTMB_TM_STATE_BYTES / sizeof(int))) p.next_state[tid] = 0;
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    (void)up;
+    // units are dealt to the XCDs in eighths (see tm_kernel): a unit's sibling rows and segments share an L2
+    i64 unit;
+    {
+        const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
+        unit = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int seg = (int)(unit % g.nseg);
+    const i64 ur = unit / g.nseg;
+    const int rowgrp = (int)(ur % g.nrowgrp), kp = (int)(ur / g.nrowgrp);
+    const int j = rowgrp * DM_ROWS + wid;
+    if (unit == 0 && tid == 0 && totals[5] != p.n_own) raise_flag(p.flags, FLAG_NONCANONICAL);  // Lwet is not the list of wet cells
+    if (j >= ny) return;
+    const int ko0 = g.kown[0], ko1 = g.kown[1] + 1;  // owned levels [ko0, ko1)
+    const int k_lo = ko0 + (int)((i64)(ko1 - ko0) * kp / g.kparts), k_hi = ko0 + (int)((i64)(ko1 - ko0) * (kp + 1) / g.kparts);
+    if (k_lo >= k_hi) return;
+
+    const DmLane dl = dm_lane(seg, lane, nx);
+    const int i = dl.i;
+    const bool hS = j > 0, hN = j + 1 < ny;
+    const unsigned nx8 = (unsigned)nx * 8u;
+    const unsigned o = ((unsigned)j * (unsigned)nx + (unsigned)i) * 8u;  // byte offset inside a level (P < 2^27)
+    const unsigned oS = hS ? o - nx8 : o, oN = hN ? o + nx8 : o;
+    const bool regular = !(p.topo == OTMB_TRIPOLAR && j == ny - 1);
+    const i64 P8 = p.P * 8;
+
+    // ---- per column: the 2-D metrics (:366-411), once for the whole march ----
+    Stencil st;
+    {
+        const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
+                   *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
+        const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
+                   *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
+        st.eW_c = ldd(eWp, o); st.eE_c = ldd(eEp, o); st.eS_c = ldd(eSp, o); st.eN_c = ldd(eNp, o);
+        st.dW_c = ldd(dWp, o); st.dE_c = ldd(dEp, o); st.dS_c = ldd(dSp, o); st.dN_c = ldd(dNp, o);
+        st.eN_s = ldd(eNp, oS); st.dN_s = ldd(dNp, oS);
+        st.eS_n = ldd(eSp, oN); st.dS_n = ldd(dSp, oN);  // oppdir = south away from the seam row (:407)
+        st.ar = ldd((const char *)p.area, o); st.mld = ldd((const char *)p.ml, o);
+        st.eE_w = dpp_prev(st.eE_c); st.dE_w = dpp_prev(st.dE_c);  // west cell's east edge / distance to its east neighbour
+        st.eW_e = dpp_next(st.eW_c); st.dW_e = dpp_next(st.dW_c);
+    }
+
+    const char *lwp = (const char *)p.lw, *vp = (const char *)p.v, *tp = (const char *)p.thk, *rp = (const char *)p.rho;
+    const char *pep = (const char *)p.phi[OTMB_EAST], *pwp = (const char *)p.phi[OTMB_WEST], *pnp = (const char *)p.phi[OTMB_NORTH],
+               *psp = (const char *)p.phi[OTMB_SOUTH], *ptp = (const char *)p.phi[OTMB_TOP], *pbp = (const char *)p.phi[OTMB_BOTTOM];
+    const double rho_s = p.rho_s;
+    auto load_own = [&](int kk) {
+        const int kc = kk < 0 ? 0 : (kk >= nz ? nz - 1 : kk);  // (outside the grid: masked by hA / hB)
+        const i64 b = (i64)kc * P8;
+        DmOwn w;
+        w.lw = ldi(lwp + b, o);
+        w.v = ldd(vp + b, o);
+        w.rho = rp ? ldd(rp + b, o) : rho_s;
+        w.pt = ldd(ptp + b, o);
+        w.pb = ldd(pbp + b, o);
+        return w;
+    };
+    auto load_rest = [&](int kk) {
+        const int kc = kk >= nz ? nz - 1 : kk;
+        const i64 b = (i64)kc * P8;
+        DmRest w;
+        w.thk = ldd(tp + b, o); w.pe = ldd(pep + b, o); w.pw = ldd(pwp + b, o);
+        w.lwS = ldi(lwp + b, oS); w.lwN = ldi(lwp + b, oN);
+        w.vS = ldd(vp + b, oS); w.vN = ldd(vp + b, oN);
+        w.tS = ldd(tp + b, oS); w.tN = ldd(tp + b, oN);
+        w.rS = rp ? ldd(rp + b, oS) : rho_s; w.rN = rp ? ldd(rp + b, oN) : rho_s;
+        w.pnS = ldd(pnp + b, oS); w.psN = ldd(psp + b, oN);
+        return w;
+    };
+
+    // rows and value bits of the wave's entries are staged here (see tm_kernel)
+    i64 *my_row = s_stage + wid * TM_WSTAGE;
+    i64 *my_val = my_row + TM_STAGE;
+    typedef i64 i64x2 __attribute__((ext_vector_type(2)));
+    typedef i64x2 i64x2g __attribute__((aligned(8)));
+
+    DmOwn A = load_own(k_lo - 1), C = load_own(k_lo), B = load_own(k_lo + 1);
+    DmRest R = load_rest(k_lo);
+    for (int k = k_lo; k < k_hi; ++k) {
+        // the next step's loads are in flight while this level is turned into columns and stored
+        const DmOwn B2 = load_own(k + 2);
+        const DmRest R2 = load_rest(k + 1);
+        const i64 id = ((i64)k * ny + j) * g.nseg + seg;
+        const bool wet = dl.active && C.lw != 0;
+        const u64 wetmask = __builtin_amdgcn_ballot_w64(wet);
+        if (wetmask != 0) {
+            const i64 c = C.lw;  // the column's (global) wet rank
+            Column col;
+            col.padv = col.phh = col.pml = col.pdp = 0;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) { col.idx[s] = 0; col.bef[s] = 0; col.adv[s] = 0; col.hh[s] = 0; col.ml[s] = 0; col.dp[s] = 0; col.tv[s] = 0; }
+            // east / west neighbours sit in the neighbouring lanes
+            st.lE = dpp_next(C.lw); st.lW = dpp_prev(C.lw);
+            st.vE = dpp_next(C.v); st.vW = dpp_prev(C.v);
+            st.rE = dpp_next(C.rho); st.rW = dpp_prev(C.rho);
+            st.tE = dpp_next(R.thk); st.tW = dpp_prev(R.thk);
+            st.gE = dpp_next(R.pw);  // the east cell pushes with its west flux (:244)
+            st.gW = dpp_prev(R.pe);  // the west cell with its east flux (:253)
+            if (wet) {
+                if (regular) {
+                    st.lS = R.lwS; st.lN = R.lwN; st.lA = A.lw; st.lB = B.lw;
+                    st.gS = R.pnS; st.gN = R.psN; st.gA = A.pb; st.gB = B.pt;
+                    st.vC = C.v; st.vS = R.vS; st.vN = R.vN; st.vA = A.v; st.vB = B.v;
+                    st.rC = C.rho; st.rS = R.rS; st.rN = R.rN; st.rA = A.rho; st.rB = B.rho;
+                    st.tC = R.thk; st.tS = R.tS; st.tN = R.tN;
+                    st.ztk = p.zt[k]; st.zta = p.zt[k > 0 ? k - 1 : k]; st.ztb = p.zt[k + 1 < nz ? k + 1 : k];
+                    column_compute(p, st, i, j, k, c, col);
+                } else {  // the tripolar seam row (:94): the generic column builder on global memory
+                    const Cell cell = cell_of((i64)k * p.P + (i64)j * nx + i, nx, ny, p.P);
+                    build_column(p, cell, c, col);
+                }
+            }
+            unsigned pT = 0, nU = 0, nA = 0, nH = 0, nM = 0, nD = 0;
+            if (wet) {
+                const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
+                nU = __popc(uni);
+                if (!p.only_t) { nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp); }
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    col.tv[s] = t_value(col, s);
+                    if (((uni >> s) & 1u) && col.tv[s] != 0.0) pT |= 1u << s;
+                }
+                if (pT != uni) raise_flag(p.flags, FLAG_T_CANCEL);
+            }
+            // ---- the wave's run: packed scan T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 ----
+            const u64 mine = (u64)nU | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43);
+            u64 incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u64 y = __shfl_up(incl, d);
+                if (lane >= d) incl += y;
+            }
+            const u64 excl = incl - mine;
+            const u64 wtot = ((u64)__builtin_amdgcn_readlane((unsigned)(incl >> 32), 63) << 32) | __builtin_amdgcn_readlane((unsigned)incl, 63);
+            const unsigned ex[5] = {(unsigned)(excl & 0x7ff), (unsigned)((excl >> 11) & 0x7ff), (unsigned)((excl >> 22) & 0x7ff),
+                                    (unsigned)((excl >> 33) & 0x3ff), (unsigned)((excl >> 43) & 0x3ff)};
+            const unsigned wc[5] = {(unsigned)(wtot & 0x7ff), (unsigned)((wtot >> 11) & 0x7ff), (unsigned)((wtot >> 22) & 0x7ff),
+                                    (unsigned)((wtot >> 33) & 0x3ff), (unsigned)((wtot >> 43) & 0x3ff)};
+            const unsigned cn[5] = {nU, nA, nH, nM, nD};
+            // what the counting pass reserved for this wave (six uniform words) and where its runs start
+            const uint32_t *sums = p.tilesums + id * DM_NF;
+            const i64 *offs = p.tileoffs + id * DM_NF;
+            bool ok = true;
+#pragma unroll
+            for (int m = 0; m < TM_NF; ++m) ok &= sums[m] == wc[m];
+            ok &= sums[5] == (unsigned)__popcll(wetmask);
+            // Lwet3D is the wet rank in linear-index order (makeindices, :14-20): the wave's wet cells are consecutive ranks
+            // and the first follows the cells of all earlier segment-levels
+            const i64 wprefix = offs[5];
+            const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(wetmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wetmask, 0u));
+            const i64 w = wprefix + before;  // the column's index in this launch
+            const bool canonical = !wet || (c == p.wet_base + w + 1 && w < p.n_own);
+            if (!canonical) raise_flag(p.flags, FLAG_NONCANONICAL);
+            if (!ok && lane == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
+            if (ok && __builtin_amdgcn_ballot_w64(!canonical) == 0) {
+                i64 g0[5];
+#pragma unroll
+                for (int m = 0; m < TM_NF; ++m) g0[m] = wave_uniform(offs[m]);
+                if (wet) {
+#pragma unroll
+                    for (int m = 0; m < TM_NF; ++m) {
+                        if (m == 0 || !p.only_t) {
+                            const i64 cp = p.nnz_base[m] + g0[m] + ex[m] + 1;
+                            p.colptr[m][w] = cp;
+                            if (w + 1 == p.n_own) p.colptr[m][p.n_own] = cp + cn[m];  // the closing entry
+                        }
+                    }
+                }
+                const unsigned vslots = (1u << S_A) | (1u << S_SELF) | (1u << S_B);
+                const unsigned ops = p.only_t ? 0u : ~0u;
+                const unsigned pm[5] = {pT, col.padv & ops, col.phh & ops, col.pml & vslots & ops, col.pdp & vslots & ops};
+#pragma unroll
+                for (int m = 0; m < TM_NF; ++m) {
+                    const i64 run0 = g0[m];
+                    i64 *rv = p.rowval[m] + run0;
+                    double *nz_ = p.nzval[m] + run0;
+                    if (wet) {
+                        const unsigned q0 = ex[m];
+#pragma unroll
+                        for (int s = 0; s < NSLOT; ++s) {
+                            if ((pm[m] >> s) & 1u) {
+                                const unsigned q = q0 + __popc(pm[m] & col.bef[s]);
+                                const double v = (m == 0) ? col.tv[s] : (m == 1) ? col.adv[s] : (m == 2) ? col.hh[s] : (m == 3) ? col.ml[s] : col.dp[s];
+                                my_row[q] = col.idx[s];
+                                my_val[q] = __double_as_longlong(v);
+                            }
+                        }
+                        if (m == 0 && (unsigned)__popc(pT) != nU) {  // exact cancellation: row 0 marks the unused reserved slots (tfix_*)
+                            for (unsigned e = __popc(pT); e < nU; ++e) { my_row[q0 + e] = 0; my_val[q0 + e] = 0; }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    const unsigned cnt = wc[m];
+                    bool room = true;
+                    if (p.cap[m] > 0) {
+                        room = run0 + cnt <= p.cap[m];
+                        if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
+                    }
+                    if (room) {
+                        char *rvb = (char *)rv;
+                        char *nzb = (char *)nz_;
+                        for (unsigned base = 0; base < cnt; base += 128) {  // pairs of entries: 16-byte stores at 8-byte alignment
+                            const unsigned u = base + 2 * lane;
+                            if (u + 1 < cnt) {
+                                *(i64x2g *)(rvb + u * 8u) = *(const i64x2 *)(my_row + u);
+                                *(i64x2g *)(nzb + u * 8u) = *(const i64x2 *)(my_val + u);
+                            }
+                        }
+                        if ((lane < 2) & ((cnt & 1u) == 1u)) {  // an odd run's last entry: lane 0 the row, lane 1 the value
+                            const unsigned e = cnt - 1;
+                            i64 *dst = (lane == 0) ? (i64 *)(rvb + e * 8u) : (i64 *)(nzb + e * 8u);
+                            *dst = (lane == 0) ? my_row[e] : my_val[e];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+        // march on: this level becomes the level above
+        A.lw = C.lw; A.v = C.v; A.rho = C.rho; A.pb = C.pb;
+        C = B;
+        B = B2;
+        R = R2;
+    }
+}

@@ -32,12 +32,16 @@
 #ifndef OTMB_MARCH_AUTO_LEVEL_BYTES
 #define OTMB_MARCH_AUTO_LEVEL_BYTES (32ll << 20)  // one level of ten Float64 inputs above this size: march (0.25 degree: 124 MB; 1 degree: 8.6 MB)
 #endif
+#ifndef OTMB_DENSE_AUTO_LEVEL_BYTES
+#define OTMB_DENSE_AUTO_LEVEL_BYTES (32ll << 20)  // automatic choice of the dense-march formulation: one level of ten Float64 inputs above this
+#endif
 #define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
 
 enum { MODE_FILL = 1, MODE_ONEPASS = 2 };
 
+struct DmGeomHost { int nseg = 0, nrowgrp = 0, kparts = 1; i64 nsl = 0; };  // dense-march launch geometry (otmb_tm_dense.h)
 struct TmPlan {
     otmb_tm_args args;  // device pointers
     i64 ntiles = 0;
@@ -46,6 +50,8 @@ struct TmPlan {
     bool onepass_pending = false;
     i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
+    bool dense = false;  // the plan's counting pass was the dense-march one: its fill must be too (same offsets table)
+    DmGeomHost dm;
 };
 
 // look-back status word: [63:62] flag (0 empty, 1 tile aggregate, 2 inclusive prefix), [61:0] value.
@@ -587,6 +593,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #endif
 }
 
+#include "otmb_tm_dense.h"
+
 // closing colptr entry of each matrix: nnz_base + nnz + 1 (values known on the host since the plan)
 __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
     if (threadIdx.x == 0) {
@@ -740,6 +748,49 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
                        (int)a.nz, hist, order);
     *out = order;
     return OTMB_OK;
+}
+
+
+// ---- dense-march formulation (otmb_tm_dense.h): when, and with what geometry --------------------------------------
+// ctx->formulation: 0 gather kernels, 1 dense march, -1 chosen here.  The march pays where a level of the grid is far
+// larger than the caches (the gather form re-reads the levels above / below from HBM) and rows are long enough to fill
+// waves of 62 cells; nx < 3 grids (row-mates that coincide) always take the gather kernels' generic path.
+static bool use_dense(const otmb_ctx *ctx, const otmb_tm_args &a) {
+    if (a.nx < 3 || a.n_wet <= 0) return false;
+    if (ctx->formulation >= 0) return ctx->formulation == 1;
+    return a.nx >= 256 && a.nx * a.ny * 8 * 10 > OTMB_DENSE_AUTO_LEVEL_BYTES;
+}
+static int32_t dense_prepare(otmb_ctx *ctx, const otmb_tm_args &a, DmGeomHost &h, TmParams &p, DmGeom &g) {
+    h.nseg = (int)((a.nx + DM_W - 1) / DM_W);
+    h.nrowgrp = (int)((a.ny + DM_ROWS - 1) / DM_ROWS);
+    h.kparts = ctx->dense_kparts > 0 ? ctx->dense_kparts : 1;
+    if (h.kparts > a.nz) h.kparts = (int)a.nz;
+    h.nsl = a.nz * a.ny * h.nseg;
+    int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(h.nsl + 1) * DM_NF * sizeof(uint32_t)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(h.nsl + 1) * DM_NF * sizeof(i64) + otmb_scan_scratch(h.nsl, DM_NF) + 64))) return rc;
+    p.tilesums = (uint32_t *)ctx->tm_sums.p;
+    p.tileoffs = (const i64 *)ctx->tm_offs.p;
+    g.nseg = h.nseg; g.nrowgrp = h.nrowgrp; g.kparts = h.kparts;
+    // the two level bounds live behind the scan's scratch
+    g.kown = (const int *)((char *)ctx->tm_offs.p + (size_t)(h.nsl + 1) * DM_NF * sizeof(i64) + otmb_scan_scratch(h.nsl, DM_NF));
+    return OTMB_OK;
+}
+static void dense_launch_count(otmb_ctx *ctx, const otmb_tm_args &a, const DmGeomHost &h, const TmParams &p, const DmGeom &g, i64 *dtot) {
+    {
+        KernelTimer kt(ctx, K_DM_COUNT);
+        hipLaunchKernelGGL(dm_kown_kernel, dim3(1), dim3(64), 0, ctx->stream, (const i64 *)a.lwet, (i64)a.n_wet, a.nx * a.ny, (int)a.nz, (int *)g.kown);
+        hipLaunchKernelGGL(dm_count_kernel, dim3((unsigned)((h.nsl + 3) / 4)), dim3(256), 0, ctx->stream, p, g);
+    }
+    {
+        KernelTimer kt(ctx, K_TILESCAN);
+        otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, h.nsl, DM_NF, (i64 *)ctx->tm_offs.p + (h.nsl + 1) * DM_NF);
+    }
+}
+static void dense_launch_fill(otmb_ctx *ctx, const DmGeomHost &h, const TmParams &p, const DmGeom &g, const i64 *dtot) {
+    KernelTimer kt(ctx, K_DM_FILL);
+    const i64 nunits = (i64)h.nseg * h.nrowgrp * h.kparts;
+    hipLaunchKernelGGL(dm_fill_kernel, dim3((unsigned)nunits), dim3(256), 0, ctx->stream, p, g, dtot);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -929,7 +980,13 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
-    if (ntiles > 0) {
+    pl.dense = ntiles > 0 && use_dense(ctx, *a);
+    if (pl.dense) {
+        DmGeom g;
+        if ((rc = dense_prepare(ctx, *a, pl.dm, p, g))) return rc;
+        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
+        dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
+    } else if (ntiles > 0) {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
@@ -983,7 +1040,11 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     }
     int32_t rc;
     int *dflags = (int *)ctx->flags.p;
-    if (pl.ntiles > 0) {
+    if (pl.dense) {
+        DmGeom g;
+        if ((rc = dense_prepare(ctx, pl.args, pl.dm, p, g))) return rc;  // (the buffers of the plan: nothing is reallocated)
+        dense_launch_fill(ctx, pl.dm, p, g, (const i64 *)(dflags + OTMB_NFLAGS));
+    } else if (pl.ntiles > 0) {
         if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, &p.order))) return rc;
         KernelTimer kt(ctx, K_TM_FILL);
         hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
@@ -1048,11 +1109,13 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
 #ifndef OTMB_DEFAULT_LOOKBACK
 #define OTMB_DEFAULT_LOOKBACK 0
 #endif
-    static const bool use_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e ? e[0] == '1' : (OTMB_DEFAULT_LOOKBACK != 0); }();
+    static const bool env_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e ? e[0] == '1' : (OTMB_DEFAULT_LOOKBACK != 0); }();
+    const bool dense = ntiles > 0 && use_dense(ctx, *a);
+    const bool use_lookback = env_lookback && !dense;
     const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);  // look-back words + prefixes (+ ticket)
     if (use_lookback) {
         if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
-    } else {
+    } else if (!dense) {
         if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
         if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
     }
@@ -1101,6 +1164,13 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
                            p.colptr[3], p.colptr[4], (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2], p.nnz_base[3],
                            p.nnz_base[4]);
+    } else if (dense) {
+        DmGeom g;
+        if ((rc = dense_prepare(ctx, *a, pl.dm, p, g))) return rc;
+        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
+        p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
+        dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
+        dense_launch_fill(ctx, pl.dm, p, g, dtot);
     } else if (use_lookback) {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         p.rho_in_fill = 1;  // the one-pass kernel checks ρ where it loads it

@@ -497,7 +497,7 @@ def test_single_kernel_lookback_variant():
     import subprocess
     import sys
 
-    env = dict(os.environ, OTMB_LOOKBACK="1")
+    env = dict(os.environ, OTMB_LOOKBACK="1", OTMB_DENSE="0")  # (the look-back variant belongs to the gather formulation)
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lookback_worker.py")
     r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LOOKBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
