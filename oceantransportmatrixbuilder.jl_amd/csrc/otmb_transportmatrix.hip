@@ -790,7 +790,12 @@ static void dense_launch_count(otmb_ctx *ctx, const otmb_tm_args &a, const DmGeo
 static void dense_launch_fill(otmb_ctx *ctx, const DmGeomHost &h, const TmParams &p, const DmGeom &g, const i64 *dtot) {
     KernelTimer kt(ctx, K_DM_FILL);
     const i64 nunits = (i64)h.nseg * h.nrowgrp * h.kparts;
-    hipLaunchKernelGGL(dm_fill_kernel, dim3((unsigned)nunits), dim3(256), 0, ctx->stream, p, g, dtot);
+    hipLaunchKernelGGL(dm_fill_kernel<false>, dim3((unsigned)nunits), dim3(256), 0, ctx->stream, p, g, dtot);
+    if (p.topo == OTMB_TRIPOLAR) {  // the seam row: one row group, its four waves are depth parts
+        DmGeom gs = g;
+        gs.nrowgrp = 1;
+        hipLaunchKernelGGL(dm_fill_kernel<true>, dim3((unsigned)(h.nseg * h.kparts)), dim3(256), 0, ctx->stream, p, gs, dtot);
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------
