@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--seed", type=int, default=20260501)
+    ap.add_argument("--extra-configs", default="quarterdeg,tenthdeg",
+                    help="after the headline workload (N = 1 only): BASELINE.json configs[2] (0.25 degree, the HBM-roofline run) and configs[4]'s "
+                         "grid (0.1 degree, on ONE GPU) as extra records of the same JSON line; '' = none")
     ap.add_argument("--protocol", default="async", choices=["async", "twophase"],
                     help="async: otmb_transportmatrix_dev (count -> scan -> fill enqueued back to back, outputs preallocated "
                          "at their upper bound); twophase: plan (host learns nnz) then fill, as a caller that sizes its outputs does")
@@ -68,9 +71,35 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
+    # poll every rank: when one dies the others would wait for it in a collective for ever -- stop them (they are this
+    # process's own children) and report; an overall limit bounds the run whatever happens
+    import threading
+
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("OTMB_BENCH_TIMEOUT", "1500"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else ("timeout", 124)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(2)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=5)
+    out = (out_chunks[0] if out_chunks else b"").decode()
     line = next((l for l in out.splitlines() if l.startswith("{")), None)
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} ended with status {failed[1]}; the other ranks were stopped", file=sys.stderr)
+        return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
     if line:
         print(line, flush=True)
     return max(abs(rc) for rc in rcs) or (0 if line else 1)
@@ -166,6 +195,90 @@ def end_to_end(g, gm, asm_N, reps=3):
             "note": "host-pointer C ABI (what a Julia ccall passes): pageable host arrays in, five host CSC matrices out, PCIe both "
                     "ways through the library's pinned staging ring; c_abi_ms: inside otmb_transportmatrix_plan + _fetch (the rest is the "
                     "caller allocating ~1 GB of fresh output arrays); reuse_grid: gridmetrics / indices uploaded once"}
+
+
+def extra_config(workload, args, dev, local_rank):
+    """One more BASELINE.json configuration on this GPU, reported beside the headline (never as `value`): the same step (facefluxes +
+    full transportmatrix, device resident), K' = min(K, 10) steps x 2 repeats after 2 warm-up steps, then one pass with HIP events."""
+    import numpy as np
+    import torch
+
+    from otmb_amd import synthetic, synthetic_device
+
+    rec = {"workload": workload}
+    try:
+        nx, ny, nz, _ = synthetic.PRESETS[workload]
+        need = 8 * nx * ny * nz * 38  # inputs, fluxes, five matrices at their upper bound (asynchronous protocol: 0.25 degree only)
+        free, total = torch.cuda.mem_get_info(dev)
+        if workload == "tenthdeg" and free < 235e9:
+            return dict(rec, skipped=f"needs ~220 GB of HBM on one GPU, {free / 1e9:.0f} GB free")
+        dg = synthetic_device.make_device_grid(workload, dev, seed=args.seed, rho=args.rho)
+        asm = synthetic_device.assembler_for(dg, local_rank)
+        twophase = workload == "tenthdeg"  # (the upper-bound output buffers of the asynchronous protocol do not fit at 0.1 degree)
+
+        def step():
+            if twophase:
+                asm.step(dg.umo, dg.vmo, dg.fill, onepass=False)
+            else:
+                asm.step_async(dg.umo, dg.vmo, dg.fill)
+
+        def sync():
+            if not twophase:
+                asm.finish()
+            asm.ctx.synchronize()
+
+        k = min(args.steps, 10)
+        for _ in range(2):
+            step()
+        sync()
+        per = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sync()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / k)
+        asm.ctx.timing_enable(True)
+        for _ in range(k):
+            step()
+        sync()
+        kt = {n: v[0] / v[1] for n, v in asm.ctx.timing_collect().items()}
+        asm.ctx.timing_enable(False)
+        ms = 1e3 * float(np.median(per))
+        dom = max(kt, key=kt.get)
+        alg = asm.algorithmic_bytes() if dom.startswith(("tm_kernel", "dm_fill")) else asm.facefluxes_bytes()
+        rec.update({
+            "grid": f"{nx}x{ny}x{nz}", "wet_cells": asm.N, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), asm.nnz)),
+            "protocol": "twophase" if twophase else "async", "steps": k, "ms_per_step": ms, "value": asm.N / (ms * 1e-3), "unit": "wet-cells/s",
+            "ms_per_step_min": 1e3 * min(per), "ms_per_step_max": 1e3 * max(per),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg / (kt[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (kt[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_for(workload, dom, args),
+                         "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": kt[dom]},
+            "kernels_ms": {n: round(v, 5) for n, v in kt.items()},
+            "step_gbs": (asm.algorithmic_bytes() + asm.facefluxes_bytes()) / (ms * 1e-3) / 1e9,
+        })
+        del asm, dg
+    except Exception as e:  # an extra record must never cost the headline
+        rec["error"] = f"{type(e).__name__}: {e}"[:300]
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def traffic_for(workload, kernel, args, world=1):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json), valid only for the
+    kernel sources they were measured on (kernel_source_sha16) and for the workload they were measured at."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if world != 1 or args.rho != "array" or tj.get("kernel_source_sha16") != kernel_source_hash():
+            return None
+        return tj.get("workloads", {}).get(workload, {}).get(kernel, {}).get("traffic_bytes")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -285,6 +398,7 @@ def main():
             fill = g.umo.properties["_FillValue"]
 
         class _Single:
+            protocol = "twophase" if (args.protocol == "twophase" or args.workload == "tenthdeg") else "async"
             n_wet_total = asm.N
             ctx = asm.ctx
             pending = False
@@ -360,18 +474,9 @@ def main():
         roof = None
         if kavg:
             dom = max(kavg, key=kavg.get)
-            bytes_alg = runner.algorithmic_bytes() if dom.startswith("tm_kernel") else runner.facefluxes_bytes()
+            bytes_alg = runner.algorithmic_bytes() if dom.startswith(("tm_kernel", "dm_fill")) else runner.facefluxes_bytes()
             achieved = bytes_alg / (kavg[dom] * 1e-3) / 1e9
-            # HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-            # command (profiles/traffic.json) -- valid only for the kernel sources they were measured on
-            traffic = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if (tj.get("workload") == args.workload and world == 1 and args.rho == "array"
-                        and tj.get("kernel_source_sha16") == kernel_source_hash()):
-                    traffic = tj["kernels"].get(dom, {}).get("traffic_bytes")
-            except (OSError, ValueError):
-                pass
+            traffic = traffic_for(args.workload, dom, args, world)
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg,
                     "avg_kernel_ms": kavg[dom]}
@@ -391,7 +496,7 @@ def main():
                 "workload": f"{args.workload}: synthetic ACCESS-ESM1-5-like tripolar grid {shape}"
                             f", facefluxes + full transportmatrix (5 CSC matrices), rho={args.rho}, upwind",
                 "wet_cells": n_total, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), runner.nnz)),
-                "seed": args.seed, "protocol": args.protocol,
+                "seed": args.seed, "protocol": getattr(runner, "protocol", args.protocol),
             },
             "repeats": {"n": args.repeats, "ms_per_step_median": ms_step, "ms_per_step_min": 1e3 * min(per_repeat) / args.steps,
                         "ms_per_step_max": 1e3 * max(per_repeat) / args.steps},
@@ -402,6 +507,12 @@ def main():
         if world == 1 and host_grid is not None and not rehearsal:
             out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
+        if world == 1 and not rehearsal and not force_slab and args.extra_configs:
+            # BASELINE.json configs[2] ("HBM-roofline run") and the grid of configs[4] on this one GPU: extra records of the same line
+            runner = asm = None  # the headline's buffers are released first
+            names = {"quarterdeg": "config3", "tenthdeg": "config5"}
+            for wl in [w for w in args.extra_configs.split(",") if w and w != args.workload]:
+                out[names.get(wl, "config_" + wl)] = extra_config(wl, args, dev, local_rank)
         sys.stdout.flush()
         if saved_stdout_fd is not None:
             os.dup2(saved_stdout_fd, 1)

@@ -95,7 +95,9 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
     Uploads up;
     TRY(upload(ctx, up, ST_UMO, umo, G * es, &du));
     TRY(upload(ctx, up, ST_VMO, vmo, G * es, &dv));
-    TRY(upload(ctx, up, ST_WET, wet3d, G, &dw, true));
+    // wet3D is NOT treated as grid-constant here: callers hand over converted temporaries (the Julia shim's Array{UInt8}(indices.wet3D)),
+    // and a temporary that the allocator puts back at the same address must not be mistaken for the array of the previous call
+    TRY(upload(ctx, up, ST_WET, wet3d, G, &dw));
     double *dphi[6];
     for (int f = 0; f < 6; ++f) {
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");

@@ -77,3 +77,30 @@ def test_plan_is_invalidated_by_other_host_calls(oracle):
     with pytest.raises(OtmbError) as e:
         ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
     assert e.value.name == "NO_PLAN"
+
+
+def test_facefluxes_never_trusts_the_address_of_a_wet_mask(oracle):
+    """reuse_grid is sticky on the context (set by the last transportmatrix(...; reuse_grid=true)), facefluxes makes no
+    promise about its wet mask, and callers hand over converted temporaries that an allocator may place at the address of
+    the previous one: a mask at the SAME host address with OTHER content must be uploaded again."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    shape = (40, 32, 9)
+    g = synthetic.make_grid(*shape, seed=61, rho="array")
+    gm = gridmetrics_of(g)
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, reuse_grid=True)  # the flag is on now
+    wet = np.asfortranarray(np.array(idx.wet3D, copy=True))
+    api.facefluxes(g.umo.data, g.vmo.data, gm, dict(wet3D=wet), FillValue=1e20)  # this address is what the slot remembers
+    g2 = synthetic.make_grid(*shape, seed=62, rho="array")
+    gm2 = gridmetrics_of(g2)
+    ref2 = oracle.makeindices(gm2.v3D)
+    assert not np.array_equal(ref2["wet3D"].astype(bool), wet)
+    wet[...] = ref2["wet3D"].astype(bool)  # another grid's mask, same array object, same address
+    got = api.facefluxes(g2.umo.data, g2.vmo.data, gm2, dict(wet3D=wet), FillValue=1e20)
+    want = oracle.facefluxes(g2.umo.data, g2.vmo.data, ref2["wet3D"], 1e20, gm2.gridtopology.kind)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    api.context(0).set_reuse_grid(False)

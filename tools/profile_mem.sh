@@ -19,7 +19,8 @@ for set in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSL
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum TCP_TCP_LATENCY_sum" \
            "GRBM_GUI_ACTIVE TD_TD_BUSY_sum TD_TC_STALL_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" ; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_$i.err
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_$i.err
   echo "pmc [$set] rc=$?"
 done
-python3 $REPO/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
+python3 $REPO/tools/pmc_summary.py $OUT "tm_kernel,tm_count,facefluxes,dm_" > $OUT/pmc_summary.txt
+rm -rf $OUT/pmc_*/   # (the raw per-dispatch tables are large: only the summary travels back)

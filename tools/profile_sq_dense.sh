@@ -16,3 +16,4 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
 done
 python3 $REPO/tools/pmc_summary.py $OUT "tm_kernel,tm_count,dm_" > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
+rm -rf $OUT/pmc_*/
