@@ -269,6 +269,68 @@ def extra_config(workload, args, dev, local_rank):
     return rec
 
 
+def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend):
+    """BASELINE.json configs[3] beside a multi-rank headline: the FIXED `workload` grid cut into `world` depth slabs (strong scaling),
+    facefluxes chain planes over the communicator, asynchronous pipeline; K' = min(K, 10) steps x 2 repeats between barriers, max over
+    ranks.  Every rank takes part; rank 0 returns the record."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from otmb_amd import dist as odist
+    from otmb_amd import synthetic, synthetic_device
+
+    rec = {"workload": workload, "scaling": "strong", "n_gpus": world}
+    nx, ny, nz, lf = synthetic.PRESETS[workload]
+    counts = synthetic.level_wet_counts(nx, ny, nz, seed=args.seed, land_fraction=lf)
+    k0, k1 = odist.balanced_partition(counts, world)[rank]
+    dg = synthetic_device.make_device_grid((nx, ny, nz), dev, seed=args.seed, land_fraction=lf, rho=args.rho, k0=k0, k1=k1)
+    local = odist.make_local_grid_from_device(dg)
+    if rehearsal:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from slab_checker_backend import OracleSlabBackend
+
+        be = OracleSlabBackend()
+    else:
+        be = odist.HipSlabBackend(local_rank)
+    srun = odist.SlabRunner(be, odist.Comm(), local)
+
+    def barrier():
+        dist.barrier()
+        if not rehearsal:
+            torch.cuda.synchronize()
+
+    k = min(args.steps, 10)
+    for _ in range(2):
+        srun.step_async(dg.umo, dg.vmo, dg.fill)
+    srun.finish()
+    be.sync()
+    per = []
+    for _ in range(2):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            srun.step_async(dg.umo, dg.vmo, dg.fill)
+        srun.finish()
+        be.sync()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per.append(float(t.item()) / k)
+    ms = 1e3 * float(np.median(per))
+    rec.update({"grid": f"{nx}x{ny}x{nz}", "rank0_levels": [int(k0), int(k1)], "wet_cells": int(srun.n_global),
+                "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), (int(x) for x in srun.nnz_global))), "protocol": "async",
+                "steps": k, "ms_per_step": ms, "value": srun.n_global / (ms * 1e-3), "unit": "wet-cells/s",
+                "ms_per_step_min": 1e3 * min(per), "ms_per_step_max": 1e3 * max(per)})
+    del srun, be, dg, local
+    import gc
+
+    gc.collect()
+    if not rehearsal:
+        torch.cuda.empty_cache()
+    return rec
+
+
 def traffic_for(workload, kernel, args, world=1):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json), valid only for the
     kernel sources they were measured on (kernel_source_sha16) and for the workload they were measured at."""
@@ -466,6 +528,15 @@ def main():
         ktimes = runner.ctx.timing_collect()
         runner.ctx.timing_enable(False)
 
+    # N > 1: BASELINE.json configs[3] (the fixed 0.25 degree grid cut into N depth slabs) beside the headline, unless it IS the headline
+    config4 = None
+    c4_workload = os.environ.get("OTMB_BENCH_CONFIG4_WORKLOAD", "quarterdeg")  # (tests rehearse this leg on a small grid)
+    if world > 1 and args.extra_configs and not (args.workload == c4_workload and args.scaling == "strong") and \
+            (not rehearsal or "OTMB_BENCH_CONFIG4_WORKLOAD" in os.environ):
+        try:
+            config4 = slab_config(c4_workload, args, world, rank, dev, local_rank, rehearsal, backend)
+        except Exception as e:  # every rank raises the same pipeline errors (dist.SlabRunner.finish), so nobody is left in a collective
+            config4 = {"workload": c4_workload, "error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         n_total = runner.n_wet_total
@@ -507,6 +578,8 @@ def main():
         if world == 1 and host_grid is not None and not rehearsal:
             out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
+        if config4 is not None:
+            out["config4"] = config4
         if world == 1 and not rehearsal and not force_slab and args.extra_configs:
             # BASELINE.json configs[2] ("HBM-roofline run") and the grid of configs[4] on this one GPU: extra records of the same line
             runner = asm = None  # the headline's buffers are released first

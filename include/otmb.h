@@ -80,14 +80,15 @@ int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on);
  * rows_per_band = 0: ascending wet rank (i, then j, then k).  R > 0: MARCH order -- the tiles of a band of R grid rows
  * are taken level after level before the next band starts, so that the levels above / below a tile (the vertical
  * neighbours of src/matrixbuilding.jl:280-296, :450-477) were read moments ago and are still in the L2 / Infinity Cache
- * instead of one whole level (124 MB of inputs on a 0.25 degree grid) earlier.  -1 (default): chosen from the grid size. */
+ * instead of one whole level (124 MB of inputs on a 0.25 degree grid) earlier.  -1 (default): the library's choice (wet-rank
+ * order: the march order cuts the bytes fetched by 30 % at 0.25 degree but measures 4 % slower).       */
 int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band);
 /* Speed only, never results: which kernels build the matrices of transportmatrix.  dense = 0: GATHER -- one lane per wet
  * cell fetches its 6-neighbour stencil from global memory (tiles of 256 columns); dense = 1: DENSE-TILE MARCH -- a wave is
  * 62 consecutive cells of one grid row and walks down the levels: east / west neighbours are the neighbouring lanes, the
- * levels above / below stay in registers, every input is read once (land lanes idle); -1 (default): by grid size (the
- * march from 0.25 degree grids on).  depth_parts > 0: levels per column are cut into that many pieces (more waves,
- * shorter marches); 0 leaves it unchanged.  Both give the same matrices bit for bit.                           */
+ * levels above / below stay in registers, every input is read once (land lanes idle); -1 (default): the library's choice
+ * (the gather kernels: they measure faster on every grid tried).  depth_parts > 0: levels per column are
+ * cut into that many pieces (more waves, shorter marches); 0 leaves it unchanged.  Same matrices bit for bit.      */
 int32_t otmb_ctx_set_formulation(otmb_ctx *ctx, int32_t dense, int32_t depth_parts);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
@@ -131,6 +132,16 @@ int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo
                                  const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                  int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask);
 int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid);
+/* Speed only.  nofluxboundaries! (src/velocities.jl:161-175) looks at the wet byte of every cell AND of its east, west,
+ * south and north (or fold) neighbours, for every level of every time slice -- all grid constants.  otmb_wetflags_dev folds
+ * the five into one byte per cell (bit 0 the cell, bits 1-4 east, west, south, north; asynchronous; once per grid), and
+ * otmb_facefluxes_flags_dev is otmb_facefluxes_slab_dev reading that array instead of wet3d: five loads per cell and
+ * level instead of nine, the same six ϕ arrays and push mask bit for bit.                                      */
+int32_t otmb_wetflags_dev(otmb_ctx *ctx, const uint8_t *wet3d, int64_t nx, int64_t ny, int64_t nz, int32_t topology,
+                          uint8_t *wetflags);
+int32_t otmb_facefluxes_flags_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                  const uint8_t *wetflags, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                  int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask);
 /* The same two flags for EVERY facefluxes call on this context since the previous call of this function, oldest
  * first (a pipeline of asynchronous steps: the reference asserts per call, src/velocities.jl:199-200, so a field
  * without a single valid value in step 3 of 12 must not be hidden by steps 4-12).  Synchronises.  At most the 64

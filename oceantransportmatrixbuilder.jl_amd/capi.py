@@ -73,6 +73,8 @@ SYMBOLS = {
     "otmb_velocity2fluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_fluxes2velocity": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
+    "otmb_wetflags_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp]),
+    "otmb_facefluxes_flags_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
     "otmb_push_mask_dev": (C.c_int32, [_vp, C.POINTER(_vp * 6), _vp, C.c_int64, C.c_int64, _vp]),
     "otmb_lump_and_spray_plan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp,
                                                   C.c_int64, C.c_int64, C.c_int64, _ip]),

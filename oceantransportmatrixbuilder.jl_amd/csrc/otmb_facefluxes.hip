@@ -20,8 +20,11 @@ __device__ __forceinline__ double ff_replace(double x, double fill) {
 template <typename T>
 struct FfChunk {
     T u[FF_KB], v[FF_KB], uw[FF_KB], vs[FF_KB];
-    unsigned char wc[FF_KB], wE[FF_KB], wW[FF_KB], wS[FF_KB], wN[FF_KB];
+    unsigned char wc[FF_KB], wE[FF_KB], wW[FF_KB], wS[FF_KB], wN[FF_KB];  // (FLAGS: wc holds the cell's five flags, the others are unused)
 };
+// wet flags of a cell and its four horizontal neighbours (otmb_wetflags_dev): the boundary rule of nofluxboundaries!
+// (:161-175) needs five wet bytes per cell and level -- grid constants -- which this byte replaces by one load
+enum { WF_C = 1, WF_E = 2, WF_W = 4, WF_S = 8, WF_N = 16 };
 
 // lane offsets are 32-bit BYTE offsets (8*nx*ny < 2^31, checked on the host) from level bases that are uniform:
 // scalar base + vector offset addressing, no 64-bit address arithmetic per access
@@ -36,7 +39,7 @@ struct FfCol {
     bool hS, hN;
 };
 
-template <typename T>
+template <typename T, bool FLAGS>
 __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo, const T *__restrict__ vmo,
                                         const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0) {
 #pragma unroll
@@ -46,12 +49,15 @@ __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo
         const uint8_t *wl = wet + (i64)k * P;
         c.u[q] = ff_ld(ul, col.s); c.v[q] = ff_ld(vl, col.s);
         c.uw[q] = ff_ld(ul, col.sW); c.vs[q] = ff_ld(vl, col.cS);
-        c.wc[q] = ff_ld(wl, col.s); c.wE[q] = ff_ld(wl, col.sE); c.wW[q] = ff_ld(wl, col.sW); c.wS[q] = ff_ld(wl, col.cS);
-        c.wN[q] = ff_ld(wl, col.cN);
+        c.wc[q] = ff_ld(wl, col.s);
+        if (!FLAGS) {
+            c.wE[q] = ff_ld(wl, col.sE); c.wW[q] = ff_ld(wl, col.sW); c.wS[q] = ff_ld(wl, col.cS);
+            c.wN[q] = ff_ld(wl, col.cN);
+        }
     }
 }
 
-template <typename T>
+template <typename T, bool FLAGS>
 __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
                                           bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
                                           double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
@@ -61,8 +67,10 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
         const int k = k0 - q;
         if (k >= 0) {
             const i64 o = (i64)k * P;
-            const bool wc = c.wc[q] != 0, wE = c.wE[q] != 0, wW = c.wW[q] != 0;
-            const bool wS = col.hS && c.wS[q] != 0, wN = col.hN && c.wN[q] != 0;
+            const unsigned f = c.wc[q];
+            const bool wc = FLAGS ? (f & WF_C) != 0 : c.wc[q] != 0, wE = FLAGS ? (f & WF_E) != 0 : c.wE[q] != 0,
+                       wW = FLAGS ? (f & WF_W) != 0 : c.wW[q] != 0;
+            const bool wS = FLAGS ? (f & WF_S) != 0 : (col.hS && c.wS[q] != 0), wN = FLAGS ? (f & WF_N) != 0 : (col.hN && c.wN[q] != 0);
             double u = (double)c.u[q], v = (double)c.v[q];  // Array{Float64}(umo), :125-126
             // nofluxboundaries!, :167-173
             if (!wc || !wE) u = 0.0;
@@ -91,7 +99,7 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
 // Software pipeline over chunks of FF_KB levels: while chunk A is turned into fluxes and stored, the loads of the
 // next chunk B are already in flight.  A column is one thread and the grid has few columns (1.7 waves per SIMD at
 // 1 degree), so nothing else hides the memory latency of a chunk.
-template <typename T>
+template <typename T, bool FLAGS>
 __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
@@ -115,14 +123,14 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
         double topbelow = top_below ? top_below[s] : 0.0;
         FfChunk<T> A, B;
         int k0 = nz - 1;
-        ff_load(A, umo, vmo, wet, col, P, k0);
+        ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0);
         while (k0 >= 0) {
-            ff_load(B, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB);
+            ff_levels<T, FLAGS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
             k0 -= FF_KB;
             if (k0 < 0) break;
-            ff_load(A, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB);
+            ff_levels<T, FLAGS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
             k0 -= FF_KB;
         }
     }
@@ -132,10 +140,28 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     if (__any(vvalid) && (threadIdx.x & 63) == 0 && uv[1] != gen) atomicExch(&uv[1], gen);
 }
 
+// one thread per cell: the cell's wet byte and those of its east / west / south / north neighbours (periodic in i, closed in
+// j, tripolar fold at j == ny: src/gridtopology.jl:57-65,94) folded into one byte
+__global__ __launch_bounds__(256) void wetflags_kernel(const uint8_t *__restrict__ wet, int nx, int ny, i64 P, i64 G, int topo,
+                                                       uint8_t *__restrict__ flags) {
+    const i64 L = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (L >= G) return;
+    const i64 k = L / P, s = L - k * P;
+    const int j = (int)(s / nx), i = (int)(s - (i64)j * nx);
+    const i64 row = L - i;
+    const bool fold = (j + 1 >= ny) && (topo == OTMB_TRIPOLAR);
+    unsigned f = wet[L] ? WF_C : 0u;
+    if (wet[row + ((i + 1 < nx) ? i + 1 : 0)]) f |= WF_E;
+    if (wet[row + ((i > 0) ? i - 1 : nx - 1)]) f |= WF_W;
+    if (j > 0 && wet[L - nx]) f |= WF_S;
+    if ((j + 1 < ny) ? wet[L + nx] != 0 : (fold && wet[row + (nx - 1 - i)] != 0)) f |= WF_N;
+    flags[L] = (uint8_t)f;
+}
+
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
-                               bool check_missing) {
+                               bool check_missing, bool flags = false) {
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -150,16 +176,13 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
-    if (src_is_f32)
-        hipLaunchKernelGGL(facefluxes_kernel<float>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const float *)umo,
-                           (const float *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
-                           phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen);
-    else
-        hipLaunchKernelGGL(facefluxes_kernel<double>, dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const double *)umo,
-                           (const double *)vmo, wet3d, fill, (int)nx, (int)ny, (int)nz, (int)topology, P,
-                           phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH], phi[OTMB_SOUTH], phi[OTMB_TOP],
-                           phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen);
+#define FF_LAUNCH(T, FL)                                                                                                          \
+    hipLaunchKernelGGL((facefluxes_kernel<T, FL>), dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
+                       fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
+                       phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen)
+    if (src_is_f32) { if (flags) FF_LAUNCH(float, true); else FF_LAUNCH(float, false); }
+    else { if (flags) FF_LAUNCH(double, true); else FF_LAUNCH(double, false); }
+#undef FF_LAUNCH
     }
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
@@ -185,6 +208,27 @@ extern "C" int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, cons
                                             int32_t topology, double *const phi[6], const double *top_below,
                                             uint16_t *push_mask) {
     return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, push_mask, false);
+}
+
+extern "C" int32_t otmb_wetflags_dev(otmb_ctx *ctx, const uint8_t *wet3d, int64_t nx, int64_t ny, int64_t nz, int32_t topology,
+                                     uint8_t *wetflags) {
+    if (!ctx || !wet3d || !wetflags) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);
+    if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 P = nx * ny, G = P * nz;
+    hipLaunchKernelGGL(wetflags_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx->stream, wet3d, (int)nx, (int)ny, P, G,
+                       (int)topology, wetflags);
+    HIP_TRY(ctx, hipGetLastError());
+    return OTMB_OK;
+}
+
+extern "C" int32_t otmb_facefluxes_flags_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                             const uint8_t *wetflags, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                             int32_t topology, double *const phi[6], const double *top_below,
+                                             uint16_t *push_mask) {
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, top_below, push_mask, false, true);
 }
 
 // Push mask of existing ϕ arrays (include/otmb.h): one thread per cell of [first, first + count).

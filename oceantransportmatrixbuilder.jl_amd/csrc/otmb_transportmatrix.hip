@@ -27,13 +27,7 @@
 #endif
 #define TM_MAXROWS 7  // rows per column: A, S, W, SELF, E, N|fold, B
 #ifndef OTMB_MARCH_AUTO_ROWS
-#define OTMB_MARCH_AUTO_ROWS 8  // rows per band of the automatic march order
-#endif
-#ifndef OTMB_MARCH_AUTO_LEVEL_BYTES
-#define OTMB_MARCH_AUTO_LEVEL_BYTES (32ll << 20)  // one level of ten Float64 inputs above this size: march (0.25 degree: 124 MB; 1 degree: 8.6 MB)
-#endif
-#ifndef OTMB_DENSE_AUTO_LEVEL_BYTES
-#define OTMB_DENSE_AUTO_LEVEL_BYTES (32ll << 20)  // automatic choice of the dense-march formulation: one level of ten Float64 inputs above this
+#define OTMB_MARCH_AUTO_ROWS 0  // tile order when the caller does not choose: wet-rank order
 #endif
 #define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
@@ -725,11 +719,7 @@ __global__ void order_scatter(const i64 *__restrict__ lwet, i64 ntiles, int nx, 
 static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles, const unsigned **out) {
     *out = nullptr;
     int rows = ctx->march_rows;
-    if (rows < 0) {
-        // automatic: march once one level of the ten 3-D inputs no longer stays cached between its three uses
-        const i64 level_bytes = a.nx * a.ny * 8 * 10;
-        rows = (level_bytes > OTMB_MARCH_AUTO_LEVEL_BYTES) ? OTMB_MARCH_AUTO_ROWS : 0;
-    }
+    if (rows < 0) rows = OTMB_MARCH_AUTO_ROWS;  // (0: measured -- the march order fetches 30 % fewer bytes at 0.25 degree and is 4 % slower)
     if (rows <= 0 || ntiles < 64 || ntiles >= (1ll << 31)) return OTMB_OK;
     if (rows > a.ny) rows = (int)a.ny;
     const i64 nbands = (a.ny + rows - 1) / rows, nbuckets = nbands * a.nz;
@@ -752,13 +742,16 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
 
 
 // ---- dense-march formulation (otmb_tm_dense.h): when, and with what geometry --------------------------------------
-// ctx->formulation: 0 gather kernels, 1 dense march, -1 chosen here.  The march pays where a level of the grid is far
-// larger than the caches (the gather form re-reads the levels above / below from HBM) and rows are long enough to fill
-// waves of 62 cells; nx < 3 grids (row-mates that coincide) always take the gather kernels' generic path.
+// ctx->formulation: 0 gather kernels, 1 dense march, -1 chosen here -- which today means the gather kernels on every grid:
+// measured on MI355X (profiles/r03/README.md) the march reads every input once (9.3 GB instead of the gather form's 15.4 GB
+// at 0.25 degree) with a third fewer load instructions, but executes 1.6 x the vector instructions (72 % of the lanes of
+// a non-empty wave hold wet cells, plus the march's bookkeeping) at two waves per SIMD (its level-to-level state costs
+// ~90 registers more than a gather tile), and a wave that both loads and stores waits for its previous level's stores at
+// every level (s_waitcnt vmcnt counts loads and stores in one queue): 9.3 ms against 6.4 ms.  It stays as a selectable,
+// bit-identical alternative.  nx < 3 grids (row-mates that coincide) always take the gather kernels' generic path.
 static bool use_dense(const otmb_ctx *ctx, const otmb_tm_args &a) {
     if (a.nx < 3 || a.n_wet <= 0) return false;
-    if (ctx->formulation >= 0) return ctx->formulation == 1;
-    return a.nx >= 256 && a.nx * a.ny * 8 * 10 > OTMB_DENSE_AUTO_LEVEL_BYTES;
+    return ctx->formulation == 1;
 }
 static int32_t dense_prepare(otmb_ctx *ctx, const otmb_tm_args &a, DmGeomHost &h, TmParams &p, DmGeom &g) {
     h.nseg = (int)((a.nx + DM_W - 1) / DM_W);

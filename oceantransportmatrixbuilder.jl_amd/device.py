@@ -149,6 +149,11 @@ class DeviceAssembler:
                                                      self.lwet3d.data_ptr(), self.lwet.data_ptr(),
                                                      self.wet3d.data_ptr(), C.byref(n)))
         self.N = int(n.value)
+        # the five wet bytes nofluxboundaries! reads per cell and level, folded into one (otmb_wetflags_dev): once per grid
+        self.wetflags = torch.empty(self.G, dtype=torch.uint8, device=self.device)
+        self.ctx.check(self.lib.otmb_wetflags_dev(self.ctx.handle, self.wet3d.data_ptr(), self.nx, self.ny, self.nz, self.topology,
+                                                  self.wetflags.data_ptr()))
+        self._wetflags_version = self.wet3d._version
         return self.N
 
     # ---- per time slice -----------------------------------------------------------------------
@@ -169,10 +174,14 @@ class DeviceAssembler:
         ptrs = capi.ptr_array(6, [p.data_ptr() for p in self.phi])
         self._mask_key = None
         self._note("_ff_seq")
-        self.ctx.check(self.lib.otmb_facefluxes_slab_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
-                                                         int(umo.dtype == torch.float32), self.wet3d.data_ptr(), float(fill),
-                                                         self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
-                                                         self.push_mask.data_ptr()))
+        if self.wet3d._version != self._wetflags_version:  # the mask was edited in place (tests do): fold it again
+            self.ctx.check(self.lib.otmb_wetflags_dev(self.ctx.handle, self.wet3d.data_ptr(), self.nx, self.ny, self.nz, self.topology,
+                                                      self.wetflags.data_ptr()))
+            self._wetflags_version = self.wet3d._version
+        self.ctx.check(self.lib.otmb_facefluxes_flags_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
+                                                          int(umo.dtype == torch.float32), self.wetflags.data_ptr(), float(fill),
+                                                          self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
+                                                          self.push_mask.data_ptr()))
         self._mask_key = self._phi_key(self.phi)
         return self.phi
 

@@ -14,7 +14,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def run(rank, world, port, backend_kind, case, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rccl = os.environ.get("OTMB_TEST_RCCL") == "1"  # one GPU per rank, planes over RCCL (xGMI): needs world GPUs on the box
+    if rccl:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import otmb_amd
     from otmb_amd import dist as od, synthetic
 
@@ -26,7 +32,7 @@ def run(rank, world, port, backend_kind, case, outdir):
                                   lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
     local = od.make_local_grid(gm, g.mlotst, g.rho, k0, k1, nz, g.lev)
     if backend_kind == "hip":
-        be = od.HipSlabBackend(0)
+        be = od.HipSlabBackend(rank if rccl else 0)
     else:
         from slab_checker_backend import OracleSlabBackend
 

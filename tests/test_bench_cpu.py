@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("gpus,scaling", [(2, "weak"), (3, "strong")])
 def test_bench_spawns_its_ranks_and_prints_one_json_line(gpus, scaling):
-    env = dict(os.environ, OTMB_BENCH_CHECKER_BACKEND="1")
+    env = dict(os.environ, OTMB_BENCH_CHECKER_BACKEND="1", OTMB_BENCH_CONFIG4_WORKLOAD="small")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "small", "--scaling", scaling,
@@ -27,6 +27,13 @@ def test_bench_spawns_its_ranks_and_prints_one_json_line(gpus, scaling):
     assert f"cut into {gpus} depth slabs" in d["config"]["workload"]
     nz = 10 * gpus if scaling == "weak" else 10
     assert f"36x30x{nz}" in d["config"]["workload"]
+    # the strong-scaled sub-record (BASELINE.json configs[3]; here on the small grid) rides along unless it is the headline itself
+    if scaling == "weak":
+        c4 = d["config4"]
+        assert c4.get("error") is None and c4["scaling"] == "strong" and c4["n_gpus"] == gpus and c4["grid"] == "36x30x10", c4
+        assert c4["wet_cells"] > 0 and c4["ms_per_step"] > 0
+    else:
+        assert "config4" not in d
 
 
 def test_traffic_json_is_keyed_to_the_kernel_sources():

@@ -34,9 +34,9 @@ def whole_grid_reference(oracle, nx, ny, nz, seed, rho, topo):
     return idx, oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
 
 
-def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None):
+def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None, rccl=False):
     port = free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTMB_TEST_ASYNC="1" if async_mode else "0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTMB_TEST_ASYNC="1" if async_mode else "0", OTMB_TEST_RCCL="1" if rccl else "0")
     if fault:
         env["OTMB_TEST_FAULT"] = fault
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), kind,

@@ -19,3 +19,23 @@ def test_hip_slabs_async_pipeline(oracle, tmp_path):
     case = (24, 18, 11, 34, "array", "tripolar")
     z = run_ranks(3, "hip", case, tmp_path, async_mode=True)
     check_against_whole_grid(oracle, z, case)
+
+
+def _gpus():
+    import torch
+
+    return torch.cuda.device_count()  # (does not initialise the GPU in this process)
+
+
+@pytest.mark.parametrize("async_mode", [False, True])
+def test_hip_slabs_over_rccl_one_gpu_per_rank(oracle, tmp_path, async_mode):
+    """BASELINE.json configs[3] in small, as it runs on a multi-GPU node: every rank its own GPU, the facefluxes chain's planes
+    and the setup halos over RCCL (backend "nccl") point-to-point -- skipped on a one-GPU box.  Strong-scaled small grid,
+    compared with the whole-grid oracle bit for bit."""
+    n = _gpus()
+    if n < 2:
+        pytest.skip(f"needs at least 2 GPUs for one rank per GPU over RCCL ({n} visible)")
+    world = min(n, 4)
+    case = (24, 18, 12, 36, "array", "tripolar")
+    z = run_ranks(world, "hip", case, tmp_path, async_mode=async_mode, rccl=True, timeout=600)
+    check_against_whole_grid(oracle, z, case)
