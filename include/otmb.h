@@ -76,6 +76,18 @@ int32_t otmb_ctx_synchronize(otmb_ctx *ctx);
  * of the previous upload into its staging slot is NOT copied again -- the caller promises not to have modified it in
  * between.  Off by default (every call uploads everything, like the reference reads everything).                   */
 int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on);
+/* Host-pointer entry points only.  otmb_facefluxes leaves the six ϕ arrays in the context's device staging; with
+ * reuse_fluxes on, an otmb_transportmatrix_plan that is handed those very host arrays back (same pointers, same size)
+ * does not upload them again (259 MB at 1 degree) -- the caller promises not to have modified them in between, which
+ * is what a script that passes facefluxesfrommasstransport's result straight to transportmatrix does (README.md:65-80).
+ * Off by default.                                                                                                */
+int32_t otmb_ctx_set_reuse_fluxes(otmb_ctx *ctx, int32_t on);
+/* Pinned (page-locked) host memory owned by the context, for the arrays a caller hands to the host-pointer entry points:
+ * a buffer inside such a block is the DMA's own source / target -- no staging copy, no page faults on freshly allocated
+ * output arrays (1 GB of them per transportmatrix at 1 degree).  Julia: unsafe_wrap(Array, ptr, n) + a finalizer calling
+ * otmb_host_free.  Freed blocks are kept by the context and handed out again (up to 4 GiB idle).                  */
+int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out);
+int32_t otmb_host_free(otmb_ctx *ctx, void *p);
 /* Speed only, never results: the order in which the fill pass of transportmatrix takes its tiles of 256 columns.
  * rows_per_band = 0: ascending wet rank (i, then j, then k).  R > 0: MARCH order -- the tiles of a band of R grid rows
  * are taken level after level before the next band starts, so that the levels above / below a tile (the vertical

@@ -93,6 +93,20 @@ def makeindices(v3D, *, device=0):
     return NT(wet3D=wet3d.view(np.bool_), L=v.shape, Lwet=lwet[:N].copy(), N=N, Lwet3D=lwet3d, C=v.shape)
 
 
+PINNED_OUTPUTS = True  # results live in pinned host memory owned by the context (otmb_host_alloc): no staging copy, no page faults
+
+
+def _out_array(ctx, shape, dtype):
+    """Output array of a host-pointer call: pinned memory of the context when it can be had (the library DMAs straight into
+    it; the block returns to the context's pool when the array is garbage collected), ordinary memory otherwise."""
+    if PINNED_OUTPUTS:
+        try:
+            return ctx.pinned_empty(shape, dtype)
+        except capi.OtmbError:
+            pass
+    return np.empty(shape, dtype=dtype, order="F")
+
+
 def facefluxes(umo, vmo, gridmetrics, indices, *, FillValue, device=0):
     """velocities.jl:190-255.  umo/vmo are not modified (the reference mutates its converted copies)."""
     ctx = context(device)
@@ -104,7 +118,7 @@ def facefluxes(umo, vmo, gridmetrics, indices, *, FillValue, device=0):
     v = np.asfortranarray(v, dtype=dt)
     nx, ny, nz = u.shape
     wet = np.asfortranarray(indices["wet3D"]).view(np.uint8)
-    out = {k: np.empty(u.shape, dtype=np.float64, order="F") for k in PHI_ORDER}
+    out = {k: _out_array(ctx, u.shape, np.float64) for k in PHI_ORDER}  # pinned: the DMA writes the results in place
     ptrs = capi.ptr_array(6, [out[k].ctypes.data for k in PHI_ORDER])
     ctx.check(capi.lib().otmb_facefluxes(ctx.handle, u.ctypes.data, v.ctypes.data, int(is32), wet.ctypes.data,
                                          float(FillValue), nx, ny, nz, _topology_kind(gridmetrics), C.byref(ptrs)))
@@ -268,13 +282,15 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
 
 def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None, rho=None, κH=500.0, κVML=0.1,
                     κVdeep=1.0e-5, kappaH=None, kappaVML=None, kappaVdeep=None, Tadv=None, TκH=None, TκVML=None,
-                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, device=0):
+                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, reuse_fluxes=False, device=0):
     """matrixbuilding.jl:128-150 -> NT(T, Tadv, TκH, TκVML, TκVdeep), each a SparseMatrixCSC.
     ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords.
     operators=False (extension; the reference always returns all five): only T is materialised, the other four come
     back as None -- the same T, half the bytes written and a third of the bytes copied back to the host.
     reuse_grid=True (extension): the caller promises that the gridmetrics / indices arrays are the very arrays of the
-    previous call, unmodified (a loop over time slices): they are not copied to the device again (otmb_ctx_set_reuse_grid)."""
+    previous call, unmodified (a loop over time slices): they are not copied to the device again (otmb_ctx_set_reuse_grid).
+    reuse_fluxes=True (extension): ϕ is what facefluxes* returned last on this device, unmodified: its device copy is used
+    (otmb_ctx_set_reuse_fluxes)."""
     phi = ϕ if ϕ is not None else phi
     rho = ρ if ρ is not None else rho
     kH = κH if kappaH is None else kappaH
@@ -292,6 +308,7 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     keep, passthrough = [], []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
     ctx.set_reuse_grid(bool(reuse_grid) and all(passthrough))  # converted temporaries have no identity to rely on
+    ctx.set_reuse_fluxes(bool(reuse_fluxes))
     a.only_t = 0 if operators else 1
     nnz = (C.c_int64 * 5)()
     import time as _time
@@ -300,9 +317,11 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     ctx.check(capi.lib().otmb_transportmatrix_plan(ctx.handle, C.byref(a), C.byref(nnz)))
     last_call_seconds["plan"] = _time.perf_counter() - t0
     N = int(indices["N"])
-    colptr = [np.empty(N + 1, dtype=np.int64) for _ in range(5)]
-    rowval = [np.empty(int(nnz[m]), dtype=np.int64) for m in range(5)]
-    nzval = [np.empty(int(nnz[m]), dtype=np.float64) for m in range(5)]
+    t0 = _time.perf_counter()
+    colptr = [_out_array(ctx, N + 1, np.int64) for _ in range(5)]
+    rowval = [_out_array(ctx, int(nnz[m]), np.int64) for m in range(5)]
+    nzval = [_out_array(ctx, int(nnz[m]), np.float64) for m in range(5)]
+    last_call_seconds["alloc"] = _time.perf_counter() - t0
     cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
     rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
     nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
@@ -310,6 +329,7 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     t0 = _time.perf_counter()
     ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
     last_call_seconds["fetch"] = _time.perf_counter() - t0
+    ctx.set_reuse_fluxes(False)
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
     return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
                  for m, name in enumerate(MATS)})

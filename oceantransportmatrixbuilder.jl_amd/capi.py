@@ -54,6 +54,9 @@ SYMBOLS = {
     "otmb_ctx_use_default_stream": (C.c_int32, [_vp]),
     "otmb_ctx_synchronize": (C.c_int32, [_vp]),
     "otmb_ctx_set_reuse_grid": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_ctx_set_reuse_fluxes": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_host_alloc": (C.c_int32, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "otmb_host_free": (C.c_int32, [_vp, _vp]),
     "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
     "otmb_ctx_set_formulation": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "otmb_last_error": (C.c_char_p, [_vp]),
@@ -162,6 +165,18 @@ def lib():
     return _lib
 
 
+class _PinnedOwner:
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def __del__(self):
+        try:
+            if self.ctx._h.value:
+                self.ctx._lib.otmb_host_free(self.ctx._h, _vp(self.ptr))
+        except Exception:
+            pass
+
+
 class Context:
     """One otmb_ctx bound to a GPU."""
 
@@ -202,6 +217,24 @@ class Context:
 
     def set_reuse_grid(self, on=True):
         self.check(self._lib.otmb_ctx_set_reuse_grid(self._h, int(bool(on))))
+
+    def set_reuse_fluxes(self, on=True):
+        self.check(self._lib.otmb_ctx_set_reuse_fluxes(self._h, int(bool(on))))
+
+    def pinned_empty(self, shape, dtype, order="F"):
+        """numpy array in pinned host memory of this context (otmb_host_alloc): the DMA's own target -- no staging copy and
+        no page faults; the block returns to the context's pool when the array (and every view of it) is gone."""
+        import numpy as np
+
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) if np.ndim(shape) else int(shape)
+        nbytes = max(n * dt.itemsize, 1)
+        ptr = _vp()
+        self.check(self._lib.otmb_host_alloc(self._h, nbytes, C.byref(ptr)))
+        buf = (C.c_char * nbytes).from_address(ptr.value)
+        buf._otmb_owner = _PinnedOwner(self, ptr.value)  # freed when buf dies, i.e. when no array refers to it any more
+        a = np.frombuffer(buf, dtype=dt, count=n)
+        return a.reshape(shape, order=order) if np.ndim(shape) else a
 
     def set_tile_order(self, rows_per_band):
         """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = chosen by grid size."""

@@ -77,6 +77,9 @@ struct otmb_ctx {
     std::vector<DevBuf> stage;
     OtmbXfer *xfer = nullptr;
     bool reuse_grid = false;  // otmb_ctx_set_reuse_grid: grid-constant host arrays are uploaded once (see include/otmb.h)
+    bool reuse_fluxes = false;  // otmb_ctx_set_reuse_fluxes: ϕ that otmb_facefluxes left in the staging slots is not uploaded again
+    struct HostBlock { void *p = nullptr; size_t cap = 0; bool used = false; };
+    std::vector<HostBlock> host_pool;  // pinned host memory handed out by otmb_host_alloc (DMA source / target without staging)
     struct StageKey { const void *host = nullptr; size_t bytes = 0; };
     std::vector<StageKey> stage_key;  // what each staging slot currently holds (host pointer it was uploaded from)
     // optional per-kernel timing with HIP events recorded on the launch stream
@@ -129,6 +132,7 @@ int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const i
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
 void otmb_tm_plan_invalidate(otmb_ctx *ctx);                         // otmb_transportmatrix.hip
 void otmb_xfer_free(otmb_ctx *ctx);                                  // otmb_host.hip
+bool otmb_host_is_pinned(const otmb_ctx *ctx, const void *p, size_t bytes);  // otmb_host.hip: inside a block of otmb_host_alloc
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
 bool otmb_tm_plan_only_t(otmb_ctx *ctx);                              // otmb_transportmatrix.hip
 

@@ -23,18 +23,26 @@ static int32_t stage(otmb_ctx *ctx, int slot, size_t bytes, void **dptr) {
 struct Uploads {
     std::vector<OtmbXferItem> items;
 };
-static int32_t upload(otmb_ctx *ctx, Uploads &up, int slot, const void *h, size_t bytes, const void **dptr, bool grid_constant = false) {
+// kind: 0 = uploaded every call; 1 = grid constant (otmb_ctx_set_reuse_grid); 2 = a face-flux array (otmb_ctx_set_reuse_fluxes:
+// resident when the slot still holds what otmb_facefluxes computed and copied to this very host array)
+static int32_t upload(otmb_ctx *ctx, Uploads &up, int slot, const void *h, size_t bytes, const void **dptr, int kind = 0) {
     void *d = nullptr;
     int32_t rc = stage(ctx, slot, bytes, &d);
     if (rc) return rc;
     if (ctx->stage_key.size() < (size_t)ST_COUNT) ctx->stage_key.resize(ST_COUNT);
     otmb_ctx::StageKey &key = ctx->stage_key[slot];
-    const bool resident = ctx->reuse_grid && grid_constant && key.host == h && key.bytes == bytes && bytes > 0;
+    const bool promised = (kind == 1 && ctx->reuse_grid) || (kind == 2 && ctx->reuse_fluxes);
+    const bool resident = promised && key.host == h && key.bytes == bytes && bytes > 0;
     if (bytes && !resident) up.items.push_back({d, const_cast<void *>(h), bytes});
-    key.host = (ctx->reuse_grid && grid_constant) ? h : nullptr;
+    key.host = (promised || resident) ? h : nullptr;
     key.bytes = bytes;
     *dptr = d;
     return OTMB_OK;
+}
+bool otmb_host_is_pinned(const otmb_ctx *ctx, const void *p, size_t bytes) {
+    for (const auto &b : ctx->host_pool)
+        if (b.used && (const char *)p >= (const char *)b.p && (const char *)p + bytes <= (const char *)b.p + b.cap) return true;
+    return false;
 }
 static int32_t flush(otmb_ctx *ctx, Uploads &up) {
     if (up.items.empty()) return OTMB_OK;
@@ -112,6 +120,9 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
     for (int f = 0; f < 6; ++f) down.push_back({dphi[f], phi[f], G * 8});
     TRY(download(ctx, down));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the staging slots still hold the six arrays: a transportmatrix_plan that is handed these very host arrays back can skip
+    // their upload (otmb_ctx_set_reuse_fluxes: the caller's promise that it has not modified them)
+    for (int f = 0; f < 6; ++f) { ctx->stage_key[ST_PHI0 + f].host = phi[f]; ctx->stage_key[ST_PHI0 + f].bytes = G * 8; }
     return OTMB_OK;
 }
 
@@ -228,19 +239,19 @@ int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t 
     otmb_tm_plan_invalidate(ctx);
     Uploads up;
     // ϕ, ρ and mlotst change from one time slice to the next; gridmetrics and indices do not (otmb_ctx_set_reuse_grid)
-    for (int f = 0; f < 6; ++f) { TRY(upload(ctx, up, ST_PHI0 + f, a->phi[f], G * 8, &p)); d.phi[f] = (const double *)p; }
-    TRY(upload(ctx, up, ST_V, a->v3d, G * 8, &p, true)); d.v3d = (const double *)p;
-    TRY(upload(ctx, up, ST_THK, a->thkcello, G * 8, &p, true)); d.thkcello = (const double *)p;
+    for (int f = 0; f < 6; ++f) { TRY(upload(ctx, up, ST_PHI0 + f, a->phi[f], G * 8, &p, 2)); d.phi[f] = (const double *)p; }
+    TRY(upload(ctx, up, ST_V, a->v3d, G * 8, &p, 1)); d.v3d = (const double *)p;
+    TRY(upload(ctx, up, ST_THK, a->thkcello, G * 8, &p, 1)); d.thkcello = (const double *)p;
     if (a->rho) { TRY(upload(ctx, up, ST_RHO, a->rho, G * 8, &p)); d.rho = (const double *)p; }
-    TRY(upload(ctx, up, ST_LW, a->lwet3d, G * 8, &p, true)); d.lwet3d = (const int64_t *)p;
+    TRY(upload(ctx, up, ST_LW, a->lwet3d, G * 8, &p, 1)); d.lwet3d = (const int64_t *)p;
     if (a->n_wet > 0 && !a->lwet) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "lwet");
-    TRY(upload(ctx, up, ST_LWET, a->lwet, (size_t)(a->n_wet > 0 ? a->n_wet : 0) * 8, &p, true)); d.lwet = (const int64_t *)p;
+    TRY(upload(ctx, up, ST_LWET, a->lwet, (size_t)(a->n_wet > 0 ? a->n_wet : 0) * 8, &p, 1)); d.lwet = (const int64_t *)p;
     for (int k = 0; k < 4; ++k) {
-        TRY(upload(ctx, up, ST_EDGE0 + k, a->edge_length[k], P * 8, &p, true)); d.edge_length[k] = (const double *)p;
-        TRY(upload(ctx, up, ST_DIST0 + k, a->dist_nbr[k], P * 8, &p, true)); d.dist_nbr[k] = (const double *)p;
+        TRY(upload(ctx, up, ST_EDGE0 + k, a->edge_length[k], P * 8, &p, 1)); d.edge_length[k] = (const double *)p;
+        TRY(upload(ctx, up, ST_DIST0 + k, a->dist_nbr[k], P * 8, &p, 1)); d.dist_nbr[k] = (const double *)p;
     }
-    TRY(upload(ctx, up, ST_AREA, a->area2d, P * 8, &p, true)); d.area2d = (const double *)p;
-    TRY(upload(ctx, up, ST_ZT, a->zt, (size_t)a->nz * 8, &p, true)); d.zt = (const double *)p;
+    TRY(upload(ctx, up, ST_AREA, a->area2d, P * 8, &p, 1)); d.area2d = (const double *)p;
+    TRY(upload(ctx, up, ST_ZT, a->zt, (size_t)a->nz * 8, &p, 1)); d.zt = (const double *)p;
     TRY(upload(ctx, up, ST_ML, a->mlotst, P * 8, &p)); d.mlotst = (const double *)p;
     TRY(flush(ctx, up));
     return otmb_transportmatrix_plan_dev(ctx, &d, nnz);
@@ -277,6 +288,57 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     }
     TRY(download(ctx, down));
     return otmb_ctx_synchronize(ctx);
+}
+
+int32_t otmb_ctx_set_reuse_fluxes(otmb_ctx *ctx, int32_t on) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    ctx->reuse_fluxes = on != 0;
+    return OTMB_OK;
+}
+
+// Pinned host memory owned by the context: freed blocks are kept (pinning a gigabyte costs a quarter of a second) and handed
+// out again to the next request they fit.
+int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out) {
+    if (!ctx || !out || bytes < 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_host_alloc");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t want = ((size_t)(bytes > 0 ? bytes : 1) + 4095) & ~(size_t)4095;
+    int best = -1;
+    for (int q = 0; q < (int)ctx->host_pool.size(); ++q) {
+        const auto &b = ctx->host_pool[q];
+        if (!b.used && b.cap >= want && b.cap <= 2 * want + (1u << 20) && (best < 0 || b.cap < ctx->host_pool[best].cap)) best = q;
+    }
+    if (best < 0) {
+        otmb_ctx::HostBlock nb;
+        if (hipHostMalloc(&nb.p, want) != hipSuccess) return otmb_fail(ctx, OTMB_ERR_ALLOC, "hipHostMalloc");
+        nb.cap = want;
+        ctx->host_pool.push_back(nb);
+        best = (int)ctx->host_pool.size() - 1;
+    }
+    ctx->host_pool[best].used = true;
+    *out = ctx->host_pool[best].p;
+    return OTMB_OK;
+}
+
+int32_t otmb_host_free(otmb_ctx *ctx, void *p) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    if (!p) return OTMB_OK;
+    size_t idle = 0;
+    for (auto &b : ctx->host_pool)
+        if (b.p == p && b.used) { b.used = false; p = nullptr; }
+    if (p) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_host_free: not a block of otmb_host_alloc");
+    // keep at most 4 GiB of idle pinned memory
+    for (auto &b : ctx->host_pool) idle += b.used ? 0 : b.cap;
+    for (size_t q = 0; q < ctx->host_pool.size() && idle > ((size_t)4 << 30);) {
+        if (!ctx->host_pool[q].used) {
+            idle -= ctx->host_pool[q].cap;
+            (void)hipHostFree(ctx->host_pool[q].p);
+            ctx->host_pool.erase(ctx->host_pool.begin() + q);
+        } else {
+            ++q;
+        }
+    }
+    return OTMB_OK;
 }
 
 int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on) {

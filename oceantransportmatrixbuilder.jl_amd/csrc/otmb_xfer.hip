@@ -103,7 +103,9 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
     std::vector<Piece> pieces;
     for (int q = 0; q < n; ++q) {
         if (!items[q].bytes) continue;
-        if (items[q].bytes < ((size_t)256 << 10)) {  // small arrays: the runtime's own pageable path is fine
+        // small arrays: the runtime's own pageable path is fine; arrays inside pinned memory of otmb_host_alloc are the DMA's
+        // own source / target: no staging, no host copy
+        if (items[q].bytes < ((size_t)256 << 10) || otmb_host_is_pinned(ctx, items[q].host, items[q].bytes)) {
             HIP_TRY(ctx, to_device ? hipMemcpyAsync(items[q].dev, items[q].host, items[q].bytes, hipMemcpyHostToDevice, ctx->stream)
                                    : hipMemcpyAsync(items[q].host, items[q].dev, items[q].bytes, hipMemcpyDeviceToHost, ctx->stream));
             continue;

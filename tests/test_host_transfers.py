@@ -104,3 +104,55 @@ def test_facefluxes_never_trusts_the_address_of_a_wet_mask(oracle):
     for k in want:
         assert np.array_equal(got[k], want[k]), k
     api.context(0).set_reuse_grid(False)
+
+
+def test_reuse_fluxes_and_pinned_outputs(oracle):
+    """reuse_fluxes: the ϕ arrays facefluxes returned are not uploaded again -- same matrices; ϕ from somewhere else (other
+    addresses) or modified-and-not-promised ϕ is uploaded as ever.  The results live in pinned memory of the context: views
+    keep their block alive, dropped results return it to the pool."""
+    import gc
+
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(90, 80, 20, seed=71, rho="array")
+    gm = gridmetrics_of(g)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    idx = api.makeindices(gm.v3D)
+    ctx = api.context(0)
+    for rnd in range(3):
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+        for k in rphi:
+            assert np.array_equal(phi[k], rphi[k]), k
+        tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, reuse_fluxes=True, reuse_grid=rnd > 0)
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/round {rnd}")
+        keep = tm["T"].nzval[:5].copy()
+        view = tm["T"].nzval[:5]  # a view keeps the pinned block alive after the matrices are dropped
+        del tm, phi
+        gc.collect()
+        assert np.array_equal(view, keep)
+    # the promise is per call: ϕ at other addresses (the oracle's arrays) with reuse_fluxes on is simply uploaded
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, reuse_fluxes=True)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    # ... and without the promise modified fluxes are what counts
+    phi2 = {k: np.array(v, copy=True, order="F") for k, v in phi.items()}
+    phi2["east"] *= 0.5
+    phi2["west"] *= 0.5
+    want = oracle.transportmatrix(phi2, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    phi["east"] *= 0.5  # in place: same addresses as what facefluxes returned
+    phi["west"] *= 0.5
+    tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), want[m], m)
+    # pinned blocks are recycled: a dropped result's block serves the next request of its size
+    a = ctx.pinned_empty(1 << 20, np.float64)
+    addr = a.ctypes.data
+    del a
+    gc.collect()
+    b = ctx.pinned_empty(1 << 20, np.float64)
+    assert b.ctypes.data == addr
