@@ -233,6 +233,11 @@ typedef struct {
     int32_t only_t;              /* extension (0 = the reference's behaviour): non-zero builds T alone -- the four operator
                                   * matrices are still evaluated (T is their sum) but neither counted nor written: their
                                   * nnz come out 0 and their output pointers may be NULL.  Halves the bytes written.      */
+    int32_t ignore_ops;          /* bit m (m = OTMB_TADV .. OTMB_TKVDEEP): the caller already HAS operator m (transportmatrix's
+                                  * Tadv / TκH / TκVML / TκVdeep keywords, src/matrixbuilding.jl:133-143) -- the reference then never
+                                  * builds it, so nothing it alone would have raised is raised: "Tadv contains NaNs.", "ρ contains
+                                  * NaNs" and a flux into land for Tadv, "TκH / TκVML / TκVdeep contains NaNs." for the others.  The
+                                  * matrices of ignored operators and T are still written and are the caller's to discard.       */
 } otmb_tm_args;
 
 /* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).

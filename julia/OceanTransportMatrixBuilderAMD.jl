@@ -10,9 +10,9 @@
 # `using OceanTransportMatrixBuilder` in a TMIP script.
 #
 # NOTE: no Julia toolchain exists in the build image, so this file has never been executed there; it is
-# kept thin and mechanical (argument flattening + ccall) and mirrors, line for line, the Python host
-# layer oceantransportmatrixbuilder.jl_amd/api.py, which IS exercised by the GPU test-suite through the
-# same C entry points.
+# kept thin and mechanical (argument flattening + ccall) and mirrors the Python host layer
+# oceantransportmatrixbuilder.jl_amd/api.py, which IS exercised by the GPU test-suite through the same C entry points in the
+# same order (tests/test_julia_shim_static.py checks struct, prototypes and the call sequences of both layers).
 module OceanTransportMatrixBuilderAMD
 
 using SparseArrays
@@ -86,7 +86,7 @@ function facefluxes(umo, vmo, gridmetrics, indices; FillValue)
     u = Array{T,3}(umo); v = Array{T,3}(vmo)          # velocities.jl:125-126 happens on the device
     nx, ny, nz = size(u)
     wet = Array{UInt8,3}(indices.wet3D)
-    ϕ = [Array{Float64,3}(undef, nx, ny, nz) for _ in 1:6]   # east west north south top bottom
+    ϕ = [pinned(Float64, nx, ny, nz) for _ in 1:6]   # east west north south top bottom (pinned: the DMA's own target)
     ptrs = [pointer(a) for a in ϕ]
     GC.@preserve ϕ check(ccall(sym(:otmb_facefluxes), Int32,
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{UInt8}, Float64, Int64, Int64, Int64, Int32, Ptr{Ptr{Float64}}),
@@ -115,6 +115,31 @@ struct TmArgs
     kappa_h::Float64; kappa_vml::Float64; kappa_vdeep::Float64
     push_mask::Ptr{UInt16}        # device-resident callers only; C_NULL here (host arrays)
     only_t::Int32                 # extension: 1 = materialise T alone
+    ignore_ops::Int32             # bit m: operator m was passed in by the caller -- nothing it alone would raise is raised
+end
+
+# Output arrays live in pinned host memory owned by the library (otmb_host_alloc): the DMA writes them in place -- no staging
+# copy, no page faults on a gigabyte of fresh vectors -- and the block goes back to the library's pool when Julia collects
+# the array.  (SparseMatrixCSC only ever reads these vectors; resize! on a wrapped array would throw.)
+function pinned(::Type{T}, dims...) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall(sym(:otmb_host_alloc), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx[], Int64(max(prod(dims), 1) * sizeof(T)), p))
+    a = unsafe_wrap(Array, Ptr{T}(p[]), dims; own = false)
+    finalizer(_ -> ccall(sym(:otmb_host_free), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx[], p[]), a)
+    return a
+end
+
+# A + B with the library's `+` (otmb_spadd: SparseArrays' map(+): union pattern, exact-zero sums dropped, :147)
+function spadd(A::SparseMatrixCSC{Float64,Int64}, B::SparseMatrixCSC{Float64,Int64})
+    n = size(A, 2)
+    cap = max(1, nnz(A) + nnz(B))
+    Cp = Vector{Int64}(undef, n + 1); Ci = Vector{Int64}(undef, cap); Cx = Vector{Float64}(undef, cap)
+    k = Ref{Int64}(0)
+    check(ccall(sym(:otmb_spadd), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+        ctx[], n, A.colptr, A.rowval, A.nzval, B.colptr, B.rowval, B.nzval, Cp, Ci, Cx, k))
+    resize!(Ci, k[]); resize!(Cx, k[])
+    return SparseMatrixCSC{Float64,Int64}(size(A, 1), n, Cp, Ci, Cx)
 end
 
 const HDIRS = (:west, :east, :south, :north)      # OTMB_DIR_*
@@ -142,29 +167,40 @@ the library writes colptr/rowval/nzval straight into the Julia-owned vectors.
 """
 function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
         κH = 500.0, κVML = 0.1, κVdeep = 1.0e-5,
-        Tadv = nothing, TκH = nothing, TκVML = nothing, TκVdeep = nothing, upwind = true, operators = true, reuse_grid = false)
+        Tadv = nothing, TκH = nothing, TκVML = nothing, TκVdeep = nothing, upwind = true, operators = true, reuse_grid = false,
+        reuse_fluxes = false)
     # operators = false (extension, not in the reference): only T is materialised, the four operators return `nothing`
     # reuse_grid = true (extension): the caller promises that gridmetrics / indices are the arrays of the previous call,
     #   unmodified (a loop over time slices); they are then not copied to the GPU again (otmb_ctx_set_reuse_grid)
+    # reuse_fluxes = true (extension): ϕ is what facefluxes* returned last, unmodified: its device copy is used
     if !(isnothing(Tadv) && isnothing(TκH) && isnothing(TκVML) && isnothing(TκVdeep))
-        # precomputed operators (matrixbuilding.jl:140-143): only the missing ones are built.  The reference never looks at
-        # ϕ and ρ when Tadv is given, so they are replaced by harmless stand-ins for the fused build (no advective flux, a
-        # scalar ρ): no error can come from inputs the reference would not have read.  The adds are SparseArrays' own.
+        # precomputed operators (matrixbuilding.jl:133-147).  The same sequence of C calls as api.py's
+        # _transportmatrix_with_given: one fused build whose errors for the GIVEN operators are switched off (ignore_ops: the
+        # reference never builds them, so it never looks at ϕ / ρ when Tadv is given, nor at mlotst when TκVML is -- harmless
+        # stand-ins take their place), then the three adds of :147 with the library's `+`.
+        given = (Tadv, TκH, TκVML, TκVdeep)
+        ignore = sum(Int32(1) << m for m in 1:4 if !isnothing(given[m]))
         if !isnothing(Tadv)
             z = zeros(size(gridmetrics.v3D))
             ϕ = (east = z, west = z, north = z, south = z, top = z, bottom = z)
             ρ = 1035.0
         end
-        r = transportmatrix(; ϕ, mlotst = something(mlotst, fill(NaN, size(gridmetrics.v3D)[1:2])), gridmetrics, indices, ρ, κH, κVML,
-                            κVdeep, upwind, reuse_grid)
+        r = fused(ϕ, something(mlotst, fill(NaN, size(gridmetrics.v3D)[1:2])), gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, true,
+                  false, false, Int32(ignore))
         A = something(Tadv, r.Tadv); H = something(TκH, r.TκH); M = something(TκVML, r.TκVML); D = something(TκVdeep, r.TκVdeep)
-        return (; T = A + H + M + D, Tadv = A, TκH = H, TκVML = M, TκVdeep = D)
+        return (; T = spadd(spadd(spadd(A, H), M), D), Tadv = A, TκH = H, TκVML = M, TκVdeep = D)
     end
+    return fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0))
+end
+
+# otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch
+function fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32)
     check(ccall(sym(:otmb_ctx_set_reuse_grid), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_grid)))
+    check(ccall(sym(:otmb_ctx_set_reuse_fluxes), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_fluxes)))
     (; v3D, thkcello, edge_length_2D, distance_to_neighbour_2D, area2D, zt, gridtopology) = gridmetrics
     nx, ny, nz = size(v3D)
     N = indices.N
-    ph = [f64(getproperty(ϕ, d)) for d in (:east, :west, :north, :south, :top, :bottom)]
+    ph = [asis(getproperty(ϕ, d)) for d in (:east, :west, :north, :south, :top, :bottom)]   # as they are: reuse_fluxes knows them by address
     v = asis(v3D); thk = asis(thkcello)
     rho3 = ρ isa Number ? Float64[] : f64(ρ)
     lw3 = lwet3d_of(indices, reuse_grid)
@@ -178,21 +214,31 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
             ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0,
             pointer(lw3), pointer(lw), ntuple(i -> pointer(el[i]), 4), ntuple(i -> pointer(dn[i]), 4),
             pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep), Ptr{UInt16}(C_NULL),
-            Int32(operators ? 0 : 1)))
+            Int32(operators ? 0 : 1), ignore_ops))
         check(ccall(sym(:otmb_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), ctx[], a, nnz))
     end
-    colptr = [Vector{Int64}(undef, N + 1) for _ in 1:5]
-    rowval = [Vector{Int64}(undef, nnz[m]) for m in 1:5]
-    nzval = [Vector{Float64}(undef, nnz[m]) for m in 1:5]
+    colptr = [pinned(Int64, N + 1) for _ in 1:5]
+    rowval = [pinned(Int64, nnz[m]) for m in 1:5]
+    nzval = [pinned(Float64, nnz[m]) for m in 1:5]
     final = zeros(Int64, 5)
     cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
     GC.@preserve colptr rowval nzval check(ccall(sym(:otmb_transportmatrix_fetch), Int32,
         (Ptr{Cvoid}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}), ctx[], cp, rv, nz, final))
-    for m in 1:5   # plan's count for T is the union-pattern bound; exact-zero sums are dropped (:147)
-        resize!(rowval[m], final[m]); resize!(nzval[m], final[m])
-    end
-    mats = Any[(operators || m == 1) ? SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], rowval[m], nzval[m]) : nothing for m in 1:5]
+    check(ccall(sym(:otmb_ctx_set_reuse_fluxes), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(0)))
+    # plan's count for T is the union-pattern bound; exact-zero sums are dropped (:147): T's vectors are views of the first final[1] entries
+    trim(x, k) = length(x) == k ? x : unsafe_wrap(Array, pointer(x), k; own = false)
+    mats = Any[(operators || m == 1) ? SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], keepalive(trim(rowval[m], final[m]), rowval[m]),
+                                                                        keepalive(trim(nzval[m], final[m]), nzval[m])) : nothing for m in 1:5]
     return (; T = mats[1], Tadv = mats[2], TκH = mats[3], TκVML = mats[4], TκVdeep = mats[5])
+end
+
+# a trimmed view of a pinned vector must keep the vector (and with it the pinned block) alive: weak keys, so that the entry
+# -- and the parent -- go when the view does
+const KEEP = WeakKeyDict{Any,Any}()
+function keepalive(view, parent)
+    view === parent && return view
+    KEEP[view] = parent
+    return view
 end
 
 """

@@ -298,18 +298,22 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     kVdeep = κVdeep if kappaVdeep is None else kappaVdeep
     given = dict(Tadv=Tadv, TκH=TκH, TκVML=TκVML, TκVdeep=TκVdeep)
     if any(x is not None for x in given.values()):
-        # matrixbuilding.jl:140-143: operators passed in are used as they are and ONLY the missing ones are built (so ϕ,
-        # ρ, mlotst are not even looked at when their operator is given: no error the reference would not raise);
-        # T = ((Tadv + TκH) + TκVML) + TκVdeep is formed with the sparse add (:147).  Everything stays on the device:
-        # the missing operators come from the general path (COO generator -> sparse(), csrc/otmb_coo.hip), the given ones
-        # are uploaded once, the three adds run on the device and only T and the built operators come back.
+        # matrixbuilding.jl:140-143: operators passed in are used as they are; T = ((Tadv + TκH) + TκVML) + TκVdeep (:147)
         return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device)
+    return _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes,
+                                  device, 0)
+
+
+def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes, device,
+                           ignore_ops):
+    """otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch."""
     ctx = context(device)
     keep, passthrough = [], []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
     ctx.set_reuse_grid(bool(reuse_grid) and all(passthrough))  # converted temporaries have no identity to rely on
     ctx.set_reuse_fluxes(bool(reuse_fluxes))
     a.only_t = 0 if operators else 1
+    a.ignore_ops = int(ignore_ops)
     nnz = (C.c_int64 * 5)()
     import time as _time
 
@@ -336,43 +340,29 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
 
 
 def _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, kappa, upwind, device):
-    import torch
-
-    from .device import DeviceAssembler
-
-    asm = DeviceAssembler(device)
+    """transportmatrix with precomputed operators (matrixbuilding.jl:133-147).  The same sequence of C calls as the Julia
+    shim (julia/OceanTransportMatrixBuilderAMD.jl; tests/test_julia_shim_static.py compares the two): one fused build whose
+    errors for the GIVEN operators are switched off (otmb_tm_args.ignore_ops -- the reference never builds them, so it never
+    looks at ϕ / ρ when Tadv is given, nor at mlotst when TκVML is: harmless stand-ins take their place), then the three
+    sparse adds of :147 with the library's `+` (otmb_spadd: union pattern, exact-zero sums dropped)."""
     shape = np.asarray(gridmetrics["v3D"]).shape
-    need_ml = given["TκVML"] is None
-    ml = data_and_props(mlotst)[0] if (need_ml and mlotst is not None) else np.full(shape[:2], np.nan)
-    asm.set_grid(gridmetrics, ml, rho if (given["Tadv"] is None and rho is not None) else 1035.0, *kappa, upwind=upwind)
-    N = asm.N
-    if N != int(indices["N"]):
-        raise ValueError("indices do not belong to gridmetrics.v3D")
-    dphi = None
-    if given["Tadv"] is None:
-        dphi = [asm._t(np.asarray(phi[k])) for k in PHI_ORDER]
-    else:
-        dphi = [torch.zeros(asm.G, dtype=torch.float64, device=asm.device) for _ in range(6)]
-    dev_ops, out = {}, {}
-    for name in MATS[1:]:
-        if given[name] is not None:
-            A = given[name]
-            if A.shape != (N, N):
-                raise ValueError(f"{name} is {A.shape[0]}x{A.shape[1]}, expected {N}x{N}")
-            dev_ops[name] = tuple(torch.from_numpy(np.ascontiguousarray(x, dtype=t)).to(asm.device)
-                                  for x, t in ((A.colptr, np.int64), (A.rowval, np.int64), (A.nzval, np.float64)))
-            out[name] = A
-        else:
-            I, J, V = asm.sparse_entries(name, dphi)
-            dev_ops[name] = asm.sparse(I, J, V, N, N)
-            out[name] = SparseMatrixCSC(N, N, *(t.cpu().numpy() for t in dev_ops[name]))
-    T = asm.spadd(asm.spadd(asm.spadd(dev_ops["Tadv"], dev_ops["TκH"], N), dev_ops["TκVML"], N), dev_ops["TκVdeep"], N)
-    return NT(T=SparseMatrixCSC(N, N, *(t.cpu().numpy() for t in T)), **out)
+    ignore = sum(1 << m for m, name in enumerate(MATS) if m > 0 and given[name] is not None)
+    if given["Tadv"] is not None:
+        z = np.zeros(shape, dtype=np.float64, order="F")
+        phi = {k: z for k in PHI_ORDER}
+        rho = 1035.0
+    if mlotst is None:
+        mlotst = np.full(shape[:2], np.nan)
+    N = int(indices["N"])
+    for name, A in given.items():
+        if A is not None and A.shape != (N, N):
+            raise ValueError(f"{name} is {A.shape[0]}x{A.shape[1]}, expected {N}x{N}")
+    r = _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, *kappa, upwind, True, False, False, device, ignore)
+    ops = [given[name] if given[name] is not None else r[name] for name in MATS[1:]]
+    T = spadd(spadd(spadd(ops[0], ops[1], device=device), ops[2], device=device), ops[3], device=device)
+    return NT(T=T, Tadv=ops[0], TκH=ops[1], TκVML=ops[2], TκVdeep=ops[3])
 
 
-# ---- buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120) -----------------------------
-# One operator at a time, in the reference's own two-step formulation on the device: the COO generator in its emission
-# order, the NaN check, then sparse(𝑖s, 𝑗s, Tvals, N, N) (csrc/otmb_coo.hip).
 def _build_operator(which, *, gridmetrics, indices, phi=None, rho=1035.0, mlotst=None, kappa=(500.0, 0.1, 1.0e-5), upwind=True,
                     device=0):
     import torch

@@ -42,6 +42,7 @@ class TmArgs(C.Structure):
         ("kappa_h", C.c_double), ("kappa_vml", C.c_double), ("kappa_vdeep", C.c_double),
         ("push_mask", C.c_void_p),
         ("only_t", C.c_int32),
+        ("ignore_ops", C.c_int32),
     ]
 
 

@@ -65,7 +65,7 @@ struct otmb_ctx {
     i64 tm_sticky_step = -1;
     std::string tm_sticky_msg;
     i64 tm_failed_step = -1;         // what the last otmb_transportmatrix_result found
-    struct TmStepRec { void *colptrT, *rowvalT, *nzvalT; i64 n_wet, nnz_base0; };
+    struct TmStepRec { void *colptrT, *rowvalT, *nzvalT; i64 n_wet, nnz_base0; int ignore_ops; };
     std::vector<TmStepRec> tm_rec;   // T's output arrays of the pending steps [tm_first, tm_next) (compaction after exact cancellation)
     struct TmStepResult { int32_t status; i64 nnz[5]; };
     std::vector<TmStepResult> tm_hist;  // verdict and nnz of every step since the previous otmb_transportmatrix_result

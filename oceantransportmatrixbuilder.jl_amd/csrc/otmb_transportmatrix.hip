@@ -826,17 +826,19 @@ static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &
     return otmb_launch_push_mask(ctx, a.phi, a.lwet3d, 0, p.G, (uint16_t *)ctx->mask.p);
 }
 
-static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr) {
+// ignore: otmb_tm_args.ignore_ops -- errors that only an operator the caller already has would have raised
+static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr, int ignore = 0) {
     if (!f) f = ctx->h_flags;
+    const bool iA = (ignore >> OTMB_TADV) & 1, iH = (ignore >> OTMB_TKH) & 1, iM = (ignore >> OTMB_TKVML) & 1, iD = (ignore >> OTMB_TKVDEEP) & 1;
     if (f[FLAG_NONCANONICAL]) return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
     if (f[FLAG_LOOKBACK_TIMEOUT]) return otmb_fail(ctx, OTMB_ERR_HIP, "look-back spin limit reached");
     if (f[FLAG_COUNT_MISMATCH]) return otmb_fail(ctx, OTMB_ERR_PUSH_MASK);
-    if (f[FLAG_RHO_NAN]) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // reference order: :233, loop, :39, :61, :90, :114
-    if (f[FLAG_FLUX_INTO_LAND]) return otmb_fail(ctx, OTMB_ERR_FLUX_INTO_LAND);
-    if (f[FLAG_TADV_NAN]) return otmb_fail(ctx, OTMB_ERR_TADV_NAN);
-    if (f[FLAG_TKH_NAN]) return otmb_fail(ctx, OTMB_ERR_TKH_NAN);
-    if (f[FLAG_TKVML_NAN]) return otmb_fail(ctx, OTMB_ERR_TKVML_NAN);
-    if (f[FLAG_TKVDEEP_NAN]) return otmb_fail(ctx, OTMB_ERR_TKVDEEP_NAN);
+    if (f[FLAG_RHO_NAN] && !iA) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // reference order: :233, loop, :39, :61, :90, :114
+    if (f[FLAG_FLUX_INTO_LAND] && !iA) return otmb_fail(ctx, OTMB_ERR_FLUX_INTO_LAND);
+    if (f[FLAG_TADV_NAN] && !iA) return otmb_fail(ctx, OTMB_ERR_TADV_NAN);
+    if (f[FLAG_TKH_NAN] && !iH) return otmb_fail(ctx, OTMB_ERR_TKH_NAN);
+    if (f[FLAG_TKVML_NAN] && !iM) return otmb_fail(ctx, OTMB_ERR_TKVML_NAN);
+    if (f[FLAG_TKVDEEP_NAN] && !iD) return otmb_fail(ctx, OTMB_ERR_TKVDEEP_NAN);
     if (f[FLAG_CAPACITY]) return otmb_fail(ctx, OTMB_ERR_CAPACITY);
     return OTMB_OK;
 }
@@ -854,7 +856,7 @@ static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a) {
     if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst)
         return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null input array");
     if (a->n_wet < 0 || a->n_wet > G || (a->n_wet > 0 && !a->lwet)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "lwet / n_wet");
-    if (!a->rho && a->rho_scalar != a->rho_scalar && a->n_wet > 0) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // :233
+    if (!a->rho && a->rho_scalar != a->rho_scalar && a->n_wet > 0 && !((a->ignore_ops >> OTMB_TADV) & 1)) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // :233
     return OTMB_OK;
 }
 
@@ -916,10 +918,10 @@ static int32_t fold_pending(otmb_ctx *ctx) {
         const int *f = otmb_ring_tm(ctx->h_ring, s);
         const i64 *tot = (const i64 *)(f + OTMB_NFLAGS);
         otmb_ctx::TmStepResult r;
-        r.status = check_flags(ctx, f);  // sets ctx->err
+        const size_t q = (size_t)(s - ctx->tm_first);
+        r.status = check_flags(ctx, f, q < ctx->tm_rec.size() ? ctx->tm_rec[q].ignore_ops : 0);  // sets ctx->err
         for (int m = 0; m < 5; ++m) r.nnz[m] = tot[m];
         if (r.status && !ctx->tm_sticky) { ctx->tm_sticky = r.status; ctx->tm_sticky_step = s; ctx->tm_sticky_msg = ctx->err; }
-        const size_t q = (size_t)(s - ctx->tm_first);
         if (!r.status && f[FLAG_T_CANCEL] && q < ctx->tm_rec.size()) {
             const otmb_ctx::TmStepRec &rec = ctx->tm_rec[q];
             bool superseded = false;
@@ -1000,7 +1002,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = check_flags(ctx))) return rc;
+    if ((rc = check_flags(ctx, nullptr, a->ignore_ops))) return rc;
     for (int m = 0; m < 5; ++m) nnz[m] = pl.nnz[m] = ctx->h_tot[m];
     pl.valid = true;
     return OTMB_OK;
@@ -1060,7 +1062,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     // a plan is consumed by its fill: T's final count may be smaller than the reserved (union) one, so a second fill into
     // buffers sized from otmb_transportmatrix_nnz would overflow them -- plan again instead
     pl.valid = false;
-    if ((rc = check_flags(ctx))) return rc;
+    if ((rc = check_flags(ctx, nullptr, pl.args.ignore_ops))) return rc;
     if (ctx->h_flags[FLAG_T_CANCEL]) {
         i64 actual = pl.nnz[0];
         if ((rc = t_fixup(ctx, pl.args.n_wet, pl.nnz_base[0], pl.nnz[0], p.colptr[0], p.rowval[0], p.nzval[0], &actual))) return rc;
@@ -1208,7 +1210,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     }
     HIP_TRY(ctx, hipGetLastError());
     if (p.next_state) ctx->ring_clean |= 1ull << slot_after;
-    ctx->tm_rec.push_back({p.colptr[0], p.rowval[0], p.nzval[0], (i64)a->n_wet, p.nnz_base[0]});
+    ctx->tm_rec.push_back({p.colptr[0], p.rowval[0], p.nzval[0], (i64)a->n_wet, p.nnz_base[0], (int)a->ignore_ops});
     ctx->tm_next += 1;
     pl.onepass_pending = true;
     return OTMB_OK;

@@ -250,6 +250,15 @@ def test_transportmatrix_with_precomputed_operators(api, oracle):
 
     with pytest.raises(OtmbError, match="ρ contains NaNs"):  # TκH given, Tadv not: ρ is checked (matrixbuilding.jl:233)
         api.transportmatrix(ϕ=rphi, ρ=rho_nan, TκH=base.TκH, **kw2)
+    # a given TκH is never built either: a NaN edge length is not "TκH contains NaNs." -- but it is once TκH must be built
+    gm_nan = dict(gm)
+    gm_nan["edge_length_2D"] = {d: a.copy(order="F") for d, a in gm.edge_length_2D.items()}
+    ii, jj = np.argwhere(wet[:, :, 0] & np.roll(wet[:, :, 0], 1, axis=0))[0]
+    gm_nan["edge_length_2D"]["west"][ii, jj] = np.nan
+    with_h = api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm_nan, indices=idx, TκH=base.TκH)
+    assert_csc_equal(tuple(with_h.T), tuple(base.T), "T with TκH given and a NaN metric that only TκH reads")
+    with pytest.raises(OtmbError, match="TκH contains NaNs."):
+        api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm_nan, indices=idx, TκVdeep=base.TκVdeep)
 
 
 # ---- edge cases: empty, single level, single wet cell ------------------------------------------------

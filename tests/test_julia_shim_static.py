@@ -136,3 +136,55 @@ def test_status_codes_the_shim_maps_exist_in_the_header():
     assert codes["OTMB_ERR_ALL_MISSING"] == "8" and "rc == 8 && throw(AssertionError" in SHIM
     assert codes["OTMB_ERR_INVALID_ARG"] == "11" and "rc == 11 && throw(ArgumentError" in SHIM
     assert codes["OTMB_ERR_ASYMMETRIC_PATTERN"] == "16" and "rc == 16 && throw(ArgumentError" in SHIM
+
+
+def _collapse(seq):
+    out = []
+    for x in seq:
+        if not out or out[-1] != x:
+            out.append(x)
+    return out
+
+
+def _julia_function(name):
+    m = re.search(r"\nfunction " + name + r"\(.*?\n(.*?)\nend\n", SHIM, re.S)
+    assert m, name
+    return m.group(1)
+
+
+def _python_function(src, name):
+    m = re.search(r"\ndef " + name + r"\(.*?(?=\n(?:def |class |[A-Z_]+ = )|\Z)", src, re.S)
+    assert m, name
+    return m.group(0)
+
+
+def test_both_host_layers_make_the_same_c_calls_in_the_same_order():
+    """INTEGRATION.md calls api.py the mirror of the Julia shim: the sequence of C entry points of the fused build and of the
+    precomputed-operator case (src/matrixbuilding.jl:133-147) must be the same in both, so that what the GPU tests execute
+    through api.py is what a Julia caller runs."""
+    api_src = open(os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "api.py"), encoding="utf-8").read()
+    # ---- the fused build
+    jl = _julia_function("fused")
+    jl_calls = [a or "otmb_host_alloc" for a in re.findall(r"sym\(:(otmb_\w+)\)|\bpinned\(", jl)]
+    py = _python_function(api_src, "_transportmatrix_fused")
+    alias = {"set_reuse_grid": "otmb_ctx_set_reuse_grid", "set_reuse_fluxes": "otmb_ctx_set_reuse_fluxes", "_out_array": "otmb_host_alloc"}
+    py_calls = [alias.get(a, a) for a in re.findall(r"\b(otmb_\w+|set_reuse_grid|set_reuse_fluxes|_out_array)\(", py)]
+    want = ["otmb_ctx_set_reuse_grid", "otmb_ctx_set_reuse_fluxes", "otmb_transportmatrix_plan", "otmb_host_alloc",
+            "otmb_transportmatrix_fetch", "otmb_ctx_set_reuse_fluxes"]
+    assert _collapse(jl_calls) == want, jl_calls
+    assert _collapse(py_calls) == want, py_calls
+    # ---- precomputed operators: stand-ins + ignore_ops, ONE fused build, three adds with the library's `+`, left to right
+    jl_tm = _julia_function("transportmatrix")
+    py_given = _python_function(api_src, "_transportmatrix_with_given")
+    for src, fused_name in ((jl_tm, "fused("), (py_given, "_transportmatrix_fused(")):
+        assert src.count(fused_name) >= 1 and "spadd(spadd(spadd(" in src.replace(" ", ""), fused_name
+        assert "ignore" in src and "1035.0" in src
+    assert "1 << m" in py_given and "Int32(1) << m" in jl_tm
+    jl_spadd = _julia_function("spadd")
+    assert re.findall(r"sym\(:(otmb_\w+)\)", jl_spadd) == ["otmb_spadd"]
+    assert re.findall(r"\b(otmb_\w+)\(", _python_function(api_src, "spadd")) == ["otmb_spadd"]
+    # ---- the other entry points: one C call each, the same one
+    for jname, pname, sym_ in (("makeindices", "makeindices", "otmb_makeindices"), ("facefluxes", "facefluxes", "otmb_facefluxes"),
+                               ("lump_and_spray", "lump_and_spray", "otmb_lump_and_spray")):
+        assert sym_ in re.findall(r"sym\(:(otmb_\w+)\)", _julia_function(jname)), jname
+        assert sym_ in re.findall(r"\b(otmb_\w+)\(", _python_function(api_src, pname)), pname
