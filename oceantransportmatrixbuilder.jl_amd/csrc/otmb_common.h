@@ -43,7 +43,11 @@ struct otmb_ctx {
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     DevBuf mask;              // push mask derived by the library when the caller passes none
     DevBuf order;             // tile order of the fill pass (march order: otmb_ctx_set_tile_order) + its bucket scratch
-    int march_rows = -1;      // rows per band of the march order; 0 = wet-rank order; -1 = chosen by grid size
+    int march_rows = -1;      // rows per band of the march order; 0 = wet-rank order; -1 = the library's default
+    struct OrderKey {
+        const void *lwet = nullptr; int64_t n = 0, nx = 0, ny = 0, nz = 0; int rows = 0;
+        bool operator==(const OrderKey &o) const { return lwet == o.lwet && n == o.n && nx == o.nx && ny == o.ny && nz == o.nz && rows == o.rows; }
+    } order_key;              // what ctx->order was built for
     int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)
     int dense_kparts = 1;     // dense march: depth pieces per (row, segment)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)

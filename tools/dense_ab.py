@@ -20,7 +20,7 @@ def build(pairs):
         print(b.build(force=True, extra=flags.split(), name=name))
 
 
-def run(names, workload, dense, kparts, steps):
+def run(names, workload, dense, kparts, steps, rows=0):
     import torch
 
     from otmb_amd import capi, synthetic_device
@@ -33,6 +33,7 @@ def run(names, workload, dense, kparts, steps):
         capi.use_library(path, lenient=True)
         asm = synthetic_device.assembler_for(dg, 0)
         asm.ctx.set_formulation(dense, kparts)
+        asm.ctx.set_tile_order(rows)
         for _ in range(4):
             asm.step_async(dg.umo, dg.vmo, dg.fill)
         asm.finish()
@@ -45,7 +46,7 @@ def run(names, workload, dense, kparts, steps):
         if ref is None:
             ref = chk
         k = {n: round(v[0] / v[1], 4) for n, v in kt.items()}
-        print(json.dumps({"variant": name, "same_results": chk == ref, "kernels_ms": k}), flush=True)
+        print(json.dumps({"variant": name, "rows": rows, "same_results": chk == ref, "kernels_ms": k}), flush=True)
         del asm
         torch.cuda.empty_cache()
 
@@ -58,8 +59,9 @@ if __name__ == "__main__":
     ap.add_argument("--dense", type=int, default=1)
     ap.add_argument("--kparts", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--rows", type=int, default=0)
     a = ap.parse_args()
     if a.build:
         build(a.build)
     if a.run:
-        run(a.run.split(","), a.workload, a.dense, a.kparts, a.steps)
+        run(a.run.split(","), a.workload, a.dense, a.kparts, a.steps, a.rows)

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from a tools/profile.sh run:  python tools/make_traffic_json.py gpurun_out/prof_<tag> profiles/r02/<name>
-Copies the rocprofv3 --stats kernel summary and the PMC summary into profiles/ and writes the per-launch HBM-side bytes of
-the three hot kernels, keyed to the hash of the kernel sources they were measured on (bench.kernel_source_hash)."""
-import csv
-import glob
+"""profiles/traffic.json from tools/profile.sh runs:
+    python tools/make_traffic_json.py profiles/r03 access1deg=gpurun_out/prof_r03_1deg quarterdeg=gpurun_out/prof_r03_qdeg
+Copies each run's rocprofv3 --stats kernel summary, PMC summary and bench line into profiles/<round>/ and writes the per-launch
+HBM-side bytes of the hot kernels per workload, keyed to the hash of the kernel sources they were measured on.
+Calibration (profiles/r03/README.md, tools/micro/stream_mix.hip on known byte counts): on gfx950 every TCC_EA0_RDREQ is a
+128-byte request and FETCH_SIZE tallies it as 64 bytes -- for 8- and 16-byte-per-lane streams and for 8-byte gathers alike --
+so fetch_bytes = 2 x FETCH_SIZE (= 128 x TCC_EA0_RDREQ); WRITE_SIZE is exact (64- and 32-byte requests)."""
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -13,36 +16,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-src, dst = sys.argv[1], sys.argv[2]
-os.makedirs(os.path.dirname(dst), exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    shutil.copy(stats[0], dst + "_kernel_stats.csv")
-shutil.copy(os.path.join(src, "pmc_summary.txt"), dst + "_pmc_summary.txt")
-if os.path.exists(os.path.join(src, "bench_trace.json")):
-    shutil.copy(os.path.join(src, "bench_trace.json"), dst + "_bench_under_rocprof.json")
-agg = {}
-for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            agg.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+dst = sys.argv[1]
+os.makedirs(dst, exist_ok=True)
 names = {"tm_kernel<1>": "tm_kernel<fill>", "tm_count_kernel": "tm_count_kernel", "facefluxes_kernel": "facefluxes_kernel"}
-kernels = {}
-for k, d in agg.items():
-    for pat, name in names.items():
-        if pat in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            fb = 1024 * sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
-            wb = 1024 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
-            kernels[name] = dict(fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb + wb)
 out = {
-    "_comment": "HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in KiB; separate passes; tools/profile.sh = "
-                "`bench.py --steps 10 --warmup 2`).  gfx950 correction: FETCH_SIZE was calibrated at 1.0x for this access pattern (8-byte-per-lane "
-                "loads) on facefluxes_kernel, whose read set is known exactly (umo+vmo+wet3D + neighbour-row re-reads); WRITE_SIZE is exact.  "
-                "kernel_source_sha16 = bench.kernel_source_hash() at the time of the measurement: bench.py reports traffic: null when the "
-                "kernel sources have changed since.",
-    "workload": "access1deg", "source": os.path.relpath(dst + "_pmc_summary.txt", ROOT), "kernel_source_sha16": bench.kernel_source_hash(),
-    "kernels": kernels,
+    "_comment": "HBM-side bytes per launch from rocprofv3 PMC passes (tools/profile.sh = `bench.py --steps 10 --warmup 2`, separate passes for "
+                "FETCH_SIZE and WRITE_SIZE).  gfx950 correction: fetch_bytes = 2 x FETCH_SIZE (every TCC_EA0_RDREQ is a 128-byte request "
+                "tallied as 64 bytes; calibrated on 2 GiB streams of 8 and 16 bytes per lane and on an 8-byte gather, tools/micro/stream_mix.hip, "
+                "profiles/r03/calibration_summary.txt); WRITE_SIZE is exact.  Infinity-Cache hits are counted as fetches.  kernel_source_sha16 = "
+                "bench.kernel_source_hash() at the time of the measurement: bench.py reports traffic: null when the kernel sources have changed since.",
+    "kernel_source_sha16": bench.kernel_source_hash(), "workloads": {},
 }
+for arg in sys.argv[2:]:
+    wl, src = arg.split("=", 1)
+    tag = os.path.join(dst, wl)
+    for f, t in (("kernel_stats.csv", "_kernel_stats.csv"), ("pmc_summary.txt", "_pmc_summary.txt"), ("bench_trace.json", "_bench_under_rocprof.json")):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), tag + t)
+    kern, cur = {}, None
+    for line in open(os.path.join(src, "pmc_summary.txt")):
+        if not line.startswith(" "):
+            cur = line.strip()
+        else:
+            m = re.match(r"\s+(\S+)\s+mean\s+([\d.]+)", line)
+            if m:
+                kern.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+    rec = {}
+    for k, d in kern.items():
+        for pat, name in names.items():
+            if pat in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                fb, wb = 2 * 1024 * d["FETCH_SIZE"], 1024 * d["WRITE_SIZE"]
+                rec[name] = dict(fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb + wb, rdreq_128B=d.get("TCC_EA0_RDREQ_sum"),
+                                 wrreq=d.get("TCC_EA0_WRREQ_sum"), wrreq_64B=d.get("TCC_EA0_WRREQ_64B_sum"))
+    out["workloads"][wl] = rec
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(json.dumps(out["kernels"], indent=1))
+print(json.dumps(out["workloads"], indent=1))
