@@ -462,7 +462,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     if (live) {
 #pragma unroll
         for (int m = 0; m < TM_NF; ++m)
-            if (m == 0 || !p.only_t) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;
+            if (m == 0 || !p.only_t) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;  // (non-temporal here: no gain)
     }
     // the vertical operators only ever hold the rows above, self and below (:438-479): lets the compiler drop
     // the other five slot tests of their staging loops
