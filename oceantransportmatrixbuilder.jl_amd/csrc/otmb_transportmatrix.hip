@@ -676,7 +676,13 @@ __device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 
     i64 k = L / P, j = (L - k * P) / nx;
     k = k < 0 ? 0 : (k >= nz ? nz - 1 : k);
     j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+#ifdef OTMB_MARCH_SOUTH_FIRST
     return (unsigned)(j / rows) * (unsigned)nz + (unsigned)k;
+#else
+    // bands from north to south: the tripolar seam row (generic column builder, several times slower per wave) is then taken at the
+    // START of the first XCD's eighth, not as the tail of the last one
+    return (unsigned)((ny - 1 - j) / rows) * (unsigned)nz + (unsigned)k;
+#endif
 }
 __global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, int nx, int ny, i64 P, int rows, int nz, unsigned *hist) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
