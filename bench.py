@@ -209,6 +209,10 @@ def extra_config(workload, args, dev, local_rank):
 
     rec = {"workload": workload}
     try:
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()  # the previous workload's blocks go back to the driver: this grid gets fresh, contiguous allocations
         nx, ny, nz, _ = synthetic.PRESETS[workload]
         need = 8 * nx * ny * nz * 38  # inputs, fluxes, five matrices at their upper bound (asynchronous protocol: 0.25 degree only)
         free, total = torch.cuda.mem_get_info(dev)
