@@ -127,28 +127,55 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
     const bool fold = (j == ny - 1) && (LNq >= 0);  // north neighbour through the tripolar seam
     const int ifd = nx - 1 - i;
 
-    const i64 xEc = p.lw[LEc], xWc = p.lw[LWc];
-    const i64 xS = (LS >= 0) ? p.lw[LS] : 0, xNq = (LNq >= 0) ? p.lw[LNq] : 0;
-    const i64 xA = (LA >= 0) ? p.lw[LA] : 0, xB = (LB >= 0) ? p.lw[LB] : 0;
+    // Every load of the column is issued up front, unconditionally, with neighbours that do not exist clamped to the cell itself
+    // (their values are never used: the same tests as before decide): one memory round trip instead of the four dependent ones
+    // of a load-test-load chain.  These cells are 1 row in ny, but their waves were the slowest of the pass (3.4 % of it at 1 degree).
+    const i64 cS = (LS >= 0) ? LS : L, cN = (LNq >= 0) ? LNq : L, cA = (LA >= 0) ? LA : L, cB = (LB >= 0) ? LB : L;
+    const i64 s2 = (i64)j * nx + i;
+    const i64 s2W = (i64)j * nx + iw, s2E = (i64)j * nx + ie, s2S = (LS >= 0) ? s2 - nx : s2;
+    const i64 s2N = (LNq >= 0) ? (fold ? (i64)j * nx + ifd : s2 + nx) : s2;
+    const i64 lEc = p.lw[LEc], lWc = p.lw[LWc], lS_ = p.lw[cS], lN_ = p.lw[cN], lA_ = p.lw[cA], lB_ = p.lw[cB];
+    const double *phiN_in = fold ? p.phi[OTMB_NORTH] : p.phi[OTMB_SOUTH];  // through the seam the north neighbour pushes with its NORTH flux
+    const double gEc = p.phi[OTMB_WEST][LEc], gWc = p.phi[OTMB_EAST][LWc], gNq = phiN_in[cN], gS = p.phi[OTMB_NORTH][cS],
+                 gA = p.phi[OTMB_BOTTOM][cA], gB = p.phi[OTMB_TOP][cB];
+    const double qW = p.phi[OTMB_WEST][L], qE = p.phi[OTMB_EAST][L], qS = p.phi[OTMB_SOUTH][L], qN = p.phi[OTMB_NORTH][L],
+                 qB = p.phi[OTMB_BOTTOM][L], qT = p.phi[OTMB_TOP][L];
+    const double vc = p.v[L], vEc = p.v[LEc], vWc = p.v[LWc], vS_ = p.v[cS], vN_ = p.v[cN], vA_ = p.v[cA], vB_ = p.v[cB];
+    const double rc = p.rho ? p.rho[L] : p.rho_s;
+    const double rEc = p.rho ? p.rho[LEc] : p.rho_s, rWc = p.rho ? p.rho[LWc] : p.rho_s, rS_ = p.rho ? p.rho[cS] : p.rho_s,
+                 rN_ = p.rho ? p.rho[cN] : p.rho_s, rA_ = p.rho ? p.rho[cA] : p.rho_s, rB_ = p.rho ? p.rho[cB] : p.rho_s;
+    const double thc = p.thk[L], tEc = p.thk[LEc], tWc = p.thk[LWc], tS_ = p.thk[cS], tN_ = p.thk[cN];
+    const double *edgeNc = fold ? p.edge[OTMB_DIR_NORTH] : p.edge[OTMB_DIR_SOUTH];  // oppdir (:407): the neighbour's facing edge through the seam is its NORTH edge
+    const double *distNc = fold ? p.dist[OTMB_DIR_NORTH] : p.dist[OTMB_DIR_SOUTH];
+    const double eW_c = p.edge[OTMB_DIR_WEST][s2], eE_c = p.edge[OTMB_DIR_EAST][s2], eS_c = p.edge[OTMB_DIR_SOUTH][s2], eN_c = p.edge[OTMB_DIR_NORTH][s2];
+    const double dW_c = p.dist[OTMB_DIR_WEST][s2], dE_c = p.dist[OTMB_DIR_EAST][s2], dS_c = p.dist[OTMB_DIR_SOUTH][s2], dN_c = p.dist[OTMB_DIR_NORTH][s2];
+    const double eE_w = p.edge[OTMB_DIR_EAST][s2W], dE_w = p.dist[OTMB_DIR_EAST][s2W], eW_e = p.edge[OTMB_DIR_WEST][s2E], dW_e = p.dist[OTMB_DIR_WEST][s2E];
+    const double eN_s = p.edge[OTMB_DIR_NORTH][s2S], dN_s = p.dist[OTMB_DIR_NORTH][s2S], eX_n = edgeNc[s2N], dX_n = distNc[s2N];
+    const double ar = p.area[s2], mld = p.ml[s2];
+    const double ztk = p.zt[k], zta_ = p.zt[k > 0 ? k - 1 : k], ztb_ = p.zt[k + 1 < nz ? k + 1 : k];
+
+    const i64 xEc = lEc, xWc = lWc;
+    const i64 xS = (LS >= 0) ? lS_ : 0, xNq = (LNq >= 0) ? lN_ : 0;
+    const i64 xA = (LA >= 0) ? lA_ : 0, xB = (LB >= 0) ? lB_ : 0;
 
     // ---- advective fluxes pushed towards this cell by its neighbours (:244-296) -------------
     // emitter EC pushes its west flux, WC its east flux, N-side its south flux, the fold and
     // S-side cells their north flux, the cell above its bottom flux, the cell below its top flux.
-    const double fEc = xEc ? sel_pos(p.phi[OTMB_WEST][LEc], up) : 0.0;
-    const double fWc = xWc ? sel_neg(p.phi[OTMB_EAST][LWc], up) : 0.0;
-    const double fNq = xNq ? (fold ? sel_neg(p.phi[OTMB_NORTH][LNq], up) : sel_pos(p.phi[OTMB_SOUTH][LNq], up)) : 0.0;
-    const double fS = xS ? sel_neg(p.phi[OTMB_NORTH][LS], up) : 0.0;
-    const double fA = xA ? sel_pos(p.phi[OTMB_BOTTOM][LA], up) : 0.0;
-    const double fB = xB ? sel_neg(p.phi[OTMB_TOP][LB], up) : 0.0;  // emitter has k+1 > 1 (:290)
+    const double fEc = xEc ? sel_pos(gEc, up) : 0.0;
+    const double fWc = xWc ? sel_neg(gWc, up) : 0.0;
+    const double fNq = xNq ? (fold ? sel_neg(gNq, up) : sel_pos(gNq, up)) : 0.0;
+    const double fS = xS ? sel_neg(gS, up) : 0.0;
+    const double fA = xA ? sel_pos(gA, up) : 0.0;
+    const double fB = xB ? sel_neg(gB, up) : 0.0;  // emitter has k+1 > 1 (:290)
     const bool aEc = nonzero(fEc), aWc = nonzero(fWc), aNq = nonzero(fNq), aS = nonzero(fS), aA = nonzero(fA),
                aB = nonzero(fB);
 
     // own pushes (:244-296) must land in a wet cell: the reference indexes Lwet3D[C𝑗] / pushes 𝑗 without
     // testing it, so a non-zero selected flux towards land or `nothing` throws there
     {
-        const double ow = sel_pos(p.phi[OTMB_WEST][L], up), oe = sel_neg(p.phi[OTMB_EAST][L], up);
-        const double os = sel_pos(p.phi[OTMB_SOUTH][L], up), on = sel_neg(p.phi[OTMB_NORTH][L], up);
-        const double ob = sel_pos(p.phi[OTMB_BOTTOM][L], up), ot = (k > 0) ? sel_neg(p.phi[OTMB_TOP][L], up) : 0.0;
+        const double ow = sel_pos(qW, up), oe = sel_neg(qE, up);
+        const double os = sel_pos(qS, up), on = sel_neg(qN, up);
+        const double ob = sel_pos(qB, up), ot = (k > 0) ? sel_neg(qT, up) : 0.0;
         const bool bad = (nonzero(ow) && xWc == 0) || (nonzero(oe) && xEc == 0) || (nonzero(os) && xS == 0) ||
                          (nonzero(on) && xNq == 0) || (nonzero(ob) && xB == 0) || (nonzero(ot) && xA == 0);
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
@@ -184,8 +211,6 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
         col.bef[S_B] = lo | mates | (1u << S_N);
     }
 
-    const double vc = p.v[L];
-    const double rc = p.rho ? p.rho[L] : p.rho_s;
     if (isnan(rc)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
 
     // emission order of the three row-mate emitters: ascending (i of emitter, direction W<E<S<N)
@@ -195,24 +220,24 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
     // ---- Tadv (pushTadvectionvalues!, :193-204): entries (row e, -ϕ/(ρ̄ v_e)), (row c, ϕ/(ρ̄ v_c)) ----
     {
         bool anynan = false;
-#define ADV_VALUES(ACTIVE, LX, PHI, OFF, DG)                          \
+#define ADV_VALUES(ACTIVE, RX, VX, PHI, OFF, DG)                      \
     double OFF = 0.0, DG = 0.0;                                       \
     if (ACTIVE) {                                                     \
-        const double rx_ = p.rho ? p.rho[LX] : p.rho_s;               \
+        const double rx_ = (RX);                                      \
         const double rb_ = (rx_ + rc) / 2;                            \
-        const double mx_ = rb_ * p.v[LX];                             \
+        const double mx_ = rb_ * (VX);                                \
         const double mc_ = rb_ * vc;                                  \
         OFF = -(PHI) / mx_;                                           \
         DG = (PHI) / mc_;                                             \
         anynan |= isnan(OFF) | isnan(DG);                             \
     }
-        ADV_VALUES(aA, LA, fA, oA, dA)
-        ADV_VALUES(aS, LS, -fS, oS, dS)
-        ADV_VALUES(aEc, LEc, fEc, oEc, dEc)
-        ADV_VALUES(aWc, LWc, -fWc, oWc, dWc)
+        ADV_VALUES(aA, rA_, vA_, fA, oA, dA)
+        ADV_VALUES(aS, rS_, vS_, -fS, oS, dS)
+        ADV_VALUES(aEc, rEc, vEc, fEc, oEc, dEc)
+        ADV_VALUES(aWc, rWc, vWc, -fWc, oWc, dWc)
         const double phNq = fold ? -fNq : fNq;
-        ADV_VALUES(aNq, LNq, phNq, oNq, dNq)
-        ADV_VALUES(aB, LB, -fB, oB, dB)
+        ADV_VALUES(aNq, rN_, vN_, phNq, oNq, dNq)
+        ADV_VALUES(aB, rB_, vB_, -fB, oB, dB)
 #undef ADV_VALUES
         if (anynan) raise_flag(p.flags, FLAG_TADV_NAN);  // :39
         if (aA) { acc(col.adv[S_A], col.padv, S_A, oA); acc(col.adv[S_SELF], col.padv, S_SELF, dA); }
@@ -235,28 +260,22 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
     // For each horizontal neighbour X: a = min(thk_c*edge[c->X][c], thk_X*edge[X->c][X]) is shared by
     // c's own push towards X (+Tval on the diagonal) and X's push towards c (-Tval' on row X).
     {
-        const i64 s = (i64)j * nx + i;
-        const double thc = p.thk[L];
         bool anynan = false;
         double ownW = 0, ownE = 0, ownS = 0, ownN = 0, inW = 0, inE = 0, inS = 0, inN = 0;
-#define H_VALUES(WET, LX, SX, DCX, EDGE_XC, DIST_XC, OWN, IN)                      \
+#define H_VALUES(WET, TX, VX, E_C, E_X, D_C, D_X, OWN, IN)                         \
     if (WET) {                                                                     \
-        const i64 sx_ = (SX);                                                      \
-        const double aij_ = thc * p.edge[DCX][s];                                  \
-        const double aji_ = p.thk[LX] * (EDGE_XC)[sx_];                            \
+        const double aij_ = thc * (E_C);                                           \
+        const double aji_ = (TX) * (E_X);                                          \
         const double a_ = jl_min(aij_, aji_);                                      \
-        OWN = (p.kH * a_) / (p.dist[DCX][s] * vc);                                 \
-        IN = (p.kH * a_) / ((DIST_XC)[sx_] * p.v[LX]);                             \
+        OWN = (p.kH * a_) / ((D_C) * vc);                                          \
+        IN = (p.kH * a_) / ((D_X) * (VX));                                         \
         anynan |= isnan(OWN) | isnan(IN);                                          \
     }
-        H_VALUES(xWc != 0, LWc, (i64)j * nx + iw, OTMB_DIR_WEST, p.edge[OTMB_DIR_EAST], p.dist[OTMB_DIR_EAST], ownW, inW)
-        H_VALUES(xEc != 0, LEc, (i64)j * nx + ie, OTMB_DIR_EAST, p.edge[OTMB_DIR_WEST], p.dist[OTMB_DIR_WEST], ownE, inE)
-        H_VALUES(xS != 0, LS, s - nx, OTMB_DIR_SOUTH, p.edge[OTMB_DIR_NORTH], p.dist[OTMB_DIR_NORTH], ownS, inS)
-        // oppdir (:407): through the seam the neighbour's facing edge is its NORTH edge.  Pointer
-        // selects (not p.edge[runtime]) keep the kernel arguments out of scratch memory.
-        const double *edgeNc = fold ? p.edge[OTMB_DIR_NORTH] : p.edge[OTMB_DIR_SOUTH];
-        const double *distNc = fold ? p.dist[OTMB_DIR_NORTH] : p.dist[OTMB_DIR_SOUTH];
-        H_VALUES(xNq != 0, LNq, fold ? (i64)j * nx + ifd : s + nx, OTMB_DIR_NORTH, edgeNc, distNc, ownN, inN)
+        H_VALUES(xWc != 0, tWc, vWc, eW_c, eE_w, dW_c, dE_w, ownW, inW)
+        H_VALUES(xEc != 0, tEc, vEc, eE_c, eW_e, dE_c, dW_e, ownE, inE)
+        H_VALUES(xS != 0, tS_, vS_, eS_c, eN_s, dS_c, dN_s, ownS, inS)
+        // oppdir (:407): through the seam the neighbour's facing edge is its NORTH edge (edgeNc / distNc above)
+        H_VALUES(xNq != 0, tN_, vN_, eN_c, eX_n, dN_c, dX_n, ownN, inN)
 #undef H_VALUES
         if (anynan) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
         // own pushes, direction order W, E, S, N: (c,c,+Tval); the second push (c,X,-Tval) lands in
@@ -282,35 +301,31 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
 
     // ---- TκVML / TκVdeep (:450-477) -------------------------------------------------------------
     {
-        const i64 s = (i64)j * nx + i;
-        const double ar = p.area[s];
-        const double ztk = p.zt[k];
-        const double mld = p.ml[s];
         const bool omc = ztk < mld;  // Ω (:85); NaN (missing) compares false
         bool nanml = false, nandp = false;
         if (xB) {  // from bottom (own push first, B then T)
-            const double ztb = p.zt[k + 1];
+            const double ztb = ztb_;
             const double d = fabs(ztk - ztb);
-            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * p.v[LB]);
+            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * vB_);
             nandp |= isnan(ownD) | isnan(inD);
             acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
             acc(col.dp[S_B], col.pdp, S_B, -inD);
             if (omc && (ztb < mld)) {
-                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * p.v[LB]);
+                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * vB_);
                 nanml |= isnan(ownM) | isnan(inM);
                 acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
                 acc(col.ml[S_B], col.pml, S_B, -inM);
             }
         }
         if (xA) {
-            const double zta = p.zt[k - 1];
+            const double zta = zta_;
             const double d = fabs(ztk - zta);
-            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * p.v[LA]);
+            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * vA_);
             nandp |= isnan(ownD) | isnan(inD);
             acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
             acc(col.dp[S_A], col.pdp, S_A, -inD);
             if (omc && (zta < mld)) {
-                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * p.v[LA]);
+                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * vA_);
                 nanml |= isnan(ownM) | isnan(inM);
                 acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
                 acc(col.ml[S_A], col.pml, S_A, -inM);
