@@ -199,80 +199,36 @@ def end_to_end(g, gm, asm_N, reps=3):
                     "that facefluxes just computed not uploaded again (reuse_fluxes)"}
 
 
-def extra_config(workload, args, dev, local_rank):
-    """One more BASELINE.json configuration on this GPU, reported beside the headline (never as `value`): the same step (facefluxes +
-    full transportmatrix, device resident), K' = min(K, 10) steps x 2 repeats after 2 warm-up steps, then one pass with HIP events."""
-    import numpy as np
-    import torch
-
-    from otmb_amd import synthetic, synthetic_device
-
-    rec = {"workload": workload}
-    try:
-        import gc
-
-        gc.collect()
-        torch.cuda.empty_cache()  # the previous workload's blocks go back to the driver: this grid gets fresh, contiguous allocations
-        nx, ny, nz, _ = synthetic.PRESETS[workload]
-        need = 8 * nx * ny * nz * 38  # inputs, fluxes, five matrices at their upper bound (asynchronous protocol: 0.25 degree only)
-        free, total = torch.cuda.mem_get_info(dev)
-        if workload == "tenthdeg" and free < 235e9:
-            return dict(rec, skipped=f"needs ~220 GB of HBM on one GPU, {free / 1e9:.0f} GB free")
-        dg = synthetic_device.make_device_grid(workload, dev, seed=args.seed, rho=args.rho)
-        asm = synthetic_device.assembler_for(dg, local_rank)
-        twophase = workload == "tenthdeg"  # (the upper-bound output buffers of the asynchronous protocol do not fit at 0.1 degree)
-
-        def step():
-            if twophase:
-                asm.step(dg.umo, dg.vmo, dg.fill, onepass=False)
+def extra_configs_in_children(args):
+    """The other single-GPU BASELINE configurations, each measured by a FRESH process of this same script (`--workload X`) that has the
+    GPU to itself, BEFORE this process touches the GPU: where the allocator places an assembler's arrays moves the fill pass by +-10 %, and
+    allocations made after another workload's blocks were freed measure up to 10 % slower than a fresh process's (profiles/r03/README.md,
+    section 6) -- so every configuration is reported as what `python bench.py --workload X` prints.  Returns {key: record}."""
+    names = {"quarterdeg": "config3", "tenthdeg": "config5"}
+    out = {}
+    for wl in [w for w in args.extra_configs.split(",") if w and w != args.workload]:
+        key = names.get(wl, "config_" + wl)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--extra-configs", "", "--no-cpu-baseline", "--no-end-to-end",
+               "--steps", str(min(args.steps, 10)), "--warmup", "2", "--repeats", "2", "--rho", args.rho, "--seed", str(args.seed)]
+        rec = {"workload": wl}
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("OTMB_BENCH_EXTRA_TIMEOUT", "600")))
+            line = next((l for l in r.stdout.decode().splitlines() if l.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                tail = r.stderr.decode()[-300:].replace("\n", " | ")
+                rec["skipped" if "out of memory" in tail.lower() else "error"] = f"child exited with {r.returncode}: {tail}"
             else:
-                asm.step_async(dg.umo, dg.vmo, dg.fill)
-
-        def sync():
-            if not twophase:
-                asm.finish()
-            asm.ctx.synchronize()
-
-        k = min(args.steps, 10)
-        for _ in range(2):
-            step()
-        sync()
-        per = []
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k):
-                step()
-            sync()
-            torch.cuda.synchronize()
-            per.append((time.perf_counter() - t0) / k)
-        asm.ctx.timing_enable(True)
-        for _ in range(k):
-            step()
-        sync()
-        kt = {n: v[0] / v[1] for n, v in asm.ctx.timing_collect().items()}
-        asm.ctx.timing_enable(False)
-        ms = 1e3 * float(np.median(per))
-        dom = max(kt, key=kt.get)
-        alg = asm.algorithmic_bytes() if dom.startswith(("tm_kernel", "dm_fill")) else asm.facefluxes_bytes()
-        rec.update({
-            "grid": f"{nx}x{ny}x{nz}", "wet_cells": asm.N, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), asm.nnz)),
-            "protocol": "twophase" if twophase else "async", "steps": k, "ms_per_step": ms, "value": asm.N / (ms * 1e-3), "unit": "wet-cells/s",
-            "ms_per_step_min": 1e3 * min(per), "ms_per_step_max": 1e3 * max(per),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg / (kt[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (kt[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_for(workload, dom, args),
-                         "algorithmic_bytes_per_launch": alg, "avg_kernel_ms": kt[dom]},
-            "kernels_ms": {n: round(v, 5) for n, v in kt.items()},
-            "step_gbs": (asm.algorithmic_bytes() + asm.facefluxes_bytes()) / (ms * 1e-3) / 1e9,
-        })
-        del asm, dg
-    except Exception as e:  # an extra record must never cost the headline
-        rec["error"] = f"{type(e).__name__}: {e}"[:300]
-    import gc
-
-    gc.collect()
-    torch.cuda.empty_cache()
-    return rec
+                d = json.loads(line)
+                rec.update({"grid": d["config"]["workload"].split("grid ")[1].split(",")[0], "wet_cells": d["config"]["wet_cells"], "nnz": d["config"]["nnz"],
+                            "protocol": d["config"]["protocol"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
+                            "value": d["value"], "unit": d["unit"], "repeats": d["repeats"], "roofline": d["roofline"], "kernels_ms": d["kernels_ms"],
+                            "step_gbs": d["step_gbs"], "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
+        except subprocess.TimeoutExpired:
+            rec["error"] = "child timed out"
+        except Exception as e:  # an extra record must never cost the headline
+            rec["error"] = f"{type(e).__name__}: {e}"[:300]
+        out[key] = rec
+    return out
 
 
 def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend):
@@ -353,6 +309,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
+    extras = {}
+    if args.gpus == 1 and "RANK" not in os.environ and args.extra_configs and os.environ.get("OTMB_BENCH_CHECKER_BACKEND") != "1":
+        extras = extra_configs_in_children(args)  # (children first: nothing in this process has touched a GPU yet)
 
     import numpy as np
     import torch
@@ -586,12 +545,7 @@ def main():
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
         if config4 is not None:
             out["config4"] = config4
-        if world == 1 and not rehearsal and not force_slab and args.extra_configs:
-            # BASELINE.json configs[2] ("HBM-roofline run") and the grid of configs[4] on this one GPU: extra records of the same line
-            runner = asm = None  # the headline's buffers are released first
-            names = {"quarterdeg": "config3", "tenthdeg": "config5"}
-            for wl in [w for w in args.extra_configs.split(",") if w and w != args.workload]:
-                out[names.get(wl, "config_" + wl)] = extra_config(wl, args, dev, local_rank)
+        out.update(extras)  # BASELINE.json configs[2] ("HBM-roofline run") and the grid of configs[4] on this one GPU
         sys.stdout.flush()
         if saved_stdout_fd is not None:
             os.dup2(saved_stdout_fd, 1)

@@ -145,6 +145,21 @@ __global__ __launch_bounds__(256) void plain(Params p) {
     store_tile<STORES, NT, ALIGNCHUNK>(p, w - lane, lane, r);
 }
 
+// ROWS4: the four waves of a workgroup take four chunks of 64 wet cells that lie in four ADJACENT ROWS at about the same i (chunk
+// ids `stride` apart, stride = wet cells per row / 64) instead of four consecutive chunks: the south / north lines of one wave are
+// the own lines of its neighbour wave -- one L1 miss instead of two.
+__global__ __launch_bounds__(256) void plain_rows4(Params p, int stride, i64 nchunks) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const i64 b = blockIdx.x;
+    const i64 chunk = (b / stride) * (4 * stride) + (b % stride) + (i64)wid * stride;
+    if (chunk >= nchunks) return;
+    const i64 w = chunk * 64 + lane;
+    double v[NVAL], r[20];
+    load_cell<true>(p, w, v);
+    math<true>(p, v, r);
+    store_tile<true>(p, w - lane, lane, r);
+}
+
 // occupancy: the same kernel with LDSB bytes of (unused) LDS per workgroup, i.e. 160 KB / LDSB workgroups of 4 waves per CU
 template <int LDSB>
 __global__ __launch_bounds__(256) void plain_occ(Params p) {
@@ -345,6 +360,13 @@ int main(int argc, char **argv) {
         timeit("plain + barrier", [&] { hipLaunchKernelGGL((plain_extras<true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain + barrier + LDS staging", [&] { hipLaunchKernelGGL((plain_extras<true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
+        }
+        {
+            const int stride = (int)((double)n / ((double)ny * nz) / 64.0 + 0.5);  // chunks per row
+            char name[96];
+            snprintf(name, sizeof name, "plain, waves of a workgroup in 4 adjacent rows (stride %d)", stride);
+            timeit(name, [&] { hipLaunchKernelGGL(plain_rows4, dim3(ntiles + 4 * stride), dim3(256), 0, 0, p, stride, n / 64); });
+            timeit("plain (again)", [&] { hipLaunchKernelGGL((plain<true, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         }
         timeit("plain: no stores", [&] { hipLaunchKernelGGL((plain<true, true, false>), dim3(ntiles), dim3(256), 0, 0, p); });
         timeit("plain: no loads", [&] { hipLaunchKernelGGL((plain<false, true, true>), dim3(ntiles), dim3(256), 0, 0, p); });
