@@ -382,11 +382,10 @@ def main():
             slab = (k0, k1, nzg)
 
             def step(self):
-                if args.protocol == "async":
-                    srun.step_async(umo, vmo, fill)  # only the facefluxes chain's planes couple the ranks
-                    self.pending = True
-                else:
-                    srun.step(umo, vmo, fill)
+                # always the asynchronous pipeline: only the facefluxes chain's planes couple the ranks (the synchronous
+                # SlabRunner.step gathers nnz with two collectives per field: every rank would wait out the chain's skew every step)
+                srun.step_async(umo, vmo, fill)
+                self.pending = True
 
             def sync(self):
                 if self.pending:

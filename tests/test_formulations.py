@@ -1,0 +1,90 @@
+"""The speed-only switches of transportmatrix must never change a result (run with -m gpu): the dense-tile march kernels
+(otmb_ctx_set_formulation) and every tile order of the gather kernels (otmb_ctx_set_tile_order) against the oracle, bit for bit,
+on the cases that stress them -- tripolar seam row, odd nx (a cell that is its own fold neighbour), nx just above the dense kernels'
+minimum, rows longer than one 62-cell segment, depth parts that do not divide the levels, scalar and 3-D ρ, upwind and centred."""
+import numpy as np
+import pytest
+
+from helpers import MATS, assert_csc_equal, gridmetrics_of, randomize_metrics
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [  # (nx, ny, nz, seed, rho, topology)
+    (36, 30, 10, 81, "array", "tripolar"),
+    (37, 11, 7, 82, "scalar", "tripolar"),   # odd nx: the centre cell of the seam row is its own north neighbour
+    (3, 5, 4, 83, "array", "tripolar"),      # the smallest nx the dense kernels take
+    (150, 9, 5, 84, "array", "bipolar"),     # three segments of 62 cells per row, the last one partial
+    (64, 8, 13, 85, "scalar", "tripolar"),   # a row of exactly 64 cells: segment boundary + periodic wrap in one wave
+]
+
+
+def _setup(oracle, case, upwind=True):
+    import torch
+
+    from otmb_amd import synthetic
+    from otmb_amd.device import DeviceAssembler
+
+    nx, ny, nz, seed, rho, topo = case
+    g = synthetic.make_grid(nx, ny, nz, seed=seed, rho=rho, topology=topo)
+    gm = gridmetrics_of(g)
+    if nx % 2 == 1 and topo == "tripolar":  # (the fold-centre cell is its own north neighbour: the real distance is 0)
+        randomize_metrics(gm)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep, upwind=upwind)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    return asm, umo, vmo, rtm
+
+
+def _check(asm, rtm, what):
+    got = asm.result_to_host()
+    for m in MATS:
+        assert_csc_equal(got[m], rtm[m], f"{what}/{m}")
+
+
+@pytest.mark.parametrize("case", GRIDS, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}-{c[4]}-{c[5]}")
+@pytest.mark.parametrize("upwind", [True, False])
+def test_dense_march_kernels_match_the_oracle(oracle, case, upwind):
+    asm, umo, vmo, rtm = _setup(oracle, case, upwind)
+    for parts in (1, 2, 3):
+        asm.ctx.set_formulation(1, parts)
+        asm.step(umo, vmo, 1e20)                      # asynchronous protocol (count -> scan -> fill back to back)
+        _check(asm, rtm, f"dense/{parts} parts/async")
+        asm.step(umo, vmo, 1e20, onepass=False)       # two-phase protocol (plan, then fill)
+        _check(asm, rtm, f"dense/{parts} parts/two-phase")
+    asm.ctx.set_formulation(0)
+    asm.step(umo, vmo, 1e20)
+    _check(asm, rtm, "gather")
+
+
+def test_every_tile_order_gives_the_same_matrices(oracle):
+    asm, umo, vmo, rtm = _setup(oracle, (120, 100, 23, 86, "array", "tripolar"))  # 600 tiles: above the threshold of the march order
+    for rows in (0, 1, 3, 8, 64, 1000, -1):
+        asm.ctx.set_tile_order(rows)
+        asm.step(umo, vmo, 1e20)
+        _check(asm, rtm, f"tile order {rows}")
+        asm.step(umo, vmo, 1e20, onepass=False)
+        _check(asm, rtm, f"tile order {rows}, two-phase")
+
+
+def test_dense_march_reports_the_reference_errors(oracle):
+    from otmb_amd.capi import OtmbError
+
+    asm, umo, vmo, rtm = _setup(oracle, GRIDS[0])
+    asm.ctx.set_formulation(1)
+    L = int(asm.lwet[asm.N // 2].item()) - 1
+    old = asm.rho[L].clone()
+    asm.rho[L] = float("nan")
+    with pytest.raises(OtmbError, match="ρ contains NaNs"):
+        asm.step(umo, vmo, 1e20)
+    asm.rho[L] = old
+    asm.step(umo, vmo, 1e20)
+    _check(asm, rtm, "dense after an error")
+    # exact cancellation in T (κ = 0: explicit zeros stay in the operators, T drops them, src/matrixbuilding.jl:147)
+    asm.kappa = (0.0, 0.0, 0.0)
+    asm.step(umo, vmo, 1e20)
+    got = asm.result_to_host()
+    assert len(got["T"][1]) == len(got["Tadv"][1]) and len(got["TκH"][1]) > 0 and not np.any(got["T"][2] == 0.0)
