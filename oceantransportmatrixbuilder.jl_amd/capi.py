@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libotmb_hip.so")
+LIB_PATH = os.environ.get("OTMB_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libotmb_hip.so")  # (override: A/B of builds in fresh processes, tools/fresh_ab.sh)
 
 OK = 0
 STATUS_NAMES = {

@@ -31,8 +31,12 @@ enum { WF_C = 1, WF_E = 2, WF_W = 4, WF_S = 8, WF_N = 16 };
 template <typename T> __device__ __forceinline__ T ff_ld(const T *base, unsigned idx) {
     return *(const T *)((const char *)base + idx * (unsigned)sizeof(T));
 }
-template <typename T> __device__ __forceinline__ void ff_st(T *base, unsigned idx, T x) {
-    *(T *)((char *)base + idx * (unsigned)sizeof(T)) = x;
+// NT: non-temporal stores.  The six ϕ arrays are read back by transportmatrix: on a 1 degree grid (259 MB) partly out of the Infinity
+// Cache, which ordinary stores favour; on grids whose fluxes are far larger than any cache they only displace what the kernel itself
+// re-reads (the west / south neighbours' rows): 1.63 -> 1.46 ms at 0.25 degree, no change at 1 degree (chosen by size on the host).
+template <bool NT, typename T> __device__ __forceinline__ void ff_st(T *base, unsigned idx, T x) {
+    if (NT) __builtin_nontemporal_store(x, (T *)((char *)base + idx * (unsigned)sizeof(T)));
+    else *(T *)((char *)base + idx * (unsigned)sizeof(T)) = x;
 }
 struct FfCol {
     unsigned s, sE, sW, cS, cN;  // this column and its (clamped) neighbour columns inside a level
@@ -57,7 +61,7 @@ __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo
     }
 }
 
-template <typename T, bool FLAGS>
+template <typename T, bool FLAGS, bool NT>
 __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
                                           bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
                                           double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
@@ -88,9 +92,9 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
             const double so = col.hS ? ff_replace(vs, fill) : 0.0;
             const double b = topbelow;                  // :238-240
             const double t = (((b + w) + so) - e) - n;  // :242
-            ff_st(east + o, col.s, e); ff_st(west + o, col.s, w); ff_st(north + o, col.s, n); ff_st(south + o, col.s, so);
-            ff_st(top + o, col.s, t); ff_st(bottom + o, col.s, b);
-            if (push_mask) ff_st(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
+            ff_st<NT>(east + o, col.s, e); ff_st<NT>(west + o, col.s, w); ff_st<NT>(north + o, col.s, n); ff_st<NT>(south + o, col.s, so);
+            ff_st<NT>(top + o, col.s, t); ff_st<NT>(bottom + o, col.s, b);
+            if (push_mask) ff_st<false>(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
             topbelow = t;
         }
     }
@@ -99,7 +103,7 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
 // Software pipeline over chunks of FF_KB levels: while chunk A is turned into fluxes and stored, the loads of the
 // next chunk B are already in flight.  A column is one thread and the grid has few columns (1.7 waves per SIMD at
 // 1 degree), so nothing else hides the memory latency of a chunk.
-template <typename T, bool FLAGS>
+template <typename T, bool FLAGS, bool NT>
 __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
@@ -126,11 +130,11 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
         ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0);
         while (k0 >= 0) {
             ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels<T, FLAGS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            ff_levels<T, FLAGS, NT>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
             k0 -= FF_KB;
             if (k0 < 0) break;
             ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels<T, FLAGS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            ff_levels<T, FLAGS, NT>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
             k0 -= FF_KB;
         }
     }
@@ -176,12 +180,15 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
-#define FF_LAUNCH(T, FL)                                                                                                          \
-    hipLaunchKernelGGL((facefluxes_kernel<T, FL>), dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
+    const bool nt = (i64)48 * P * nz > (1ll << 30);  // six Float64 arrays beyond a gigabyte: streaming stores
+#define FF_LAUNCH(T, FL, NTS)                                                                                                          \
+    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS>), dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
                        phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen)
-    if (src_is_f32) { if (flags) FF_LAUNCH(float, true); else FF_LAUNCH(float, false); }
-    else { if (flags) FF_LAUNCH(double, true); else FF_LAUNCH(double, false); }
+#define FF_LAUNCH2(T, FL) do { if (nt) FF_LAUNCH(T, FL, true); else FF_LAUNCH(T, FL, false); } while (0)
+    if (src_is_f32) { if (flags) FF_LAUNCH2(float, true); else FF_LAUNCH2(float, false); }
+    else { if (flags) FF_LAUNCH2(double, true); else FF_LAUNCH2(double, false); }
+#undef FF_LAUNCH2
 #undef FF_LAUNCH
     }
     HIP_TRY(ctx, hipGetLastError());

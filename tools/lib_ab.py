@@ -37,6 +37,7 @@ for rep in range(a.reps):
             x = mk(); x.ctx.set_formulation(0); asms.append((name + ("" if stg == "0" else "+stagger" + stg), rep, x))
 rows = [int(r) for r in a.rows.split(",")]
 res = {}
+allk = {}
 for rnd in range(a.rounds):
     order = [(n, rep, x, r) for n, rep, x in asms for r in rows]
     if rnd % 2: order.reverse()
@@ -56,9 +57,13 @@ for rnd in range(a.rounds):
         for _ in range(a.steps): x.step_async(umo, vmo, fill)
         x.finish(); kt = x.ctx.timing_collect(); x.ctx.timing_enable(False)
         res.setdefault((n, r), {}).setdefault(rep, []).append(kt["tm_kernel<fill>"][0] / kt["tm_kernel<fill>"][1])
+        for kk, vv in kt.items():
+            allk.setdefault((n, r), {}).setdefault(kk, []).append(vv[0] / vv[1])
 alg = asms[0][2].algorithmic_bytes()
 for (n, r), d in res.items():
     per = [float(np.median(v)) for v in d.values()]  # per assembler
     m = float(np.mean(per))
     print(json.dumps({"lib": n, "rows": r, "fill_ms_mean_over_assemblers": round(m, 4), "per_assembler": [round(q, 4) for q in per],
-                      "frac_of_8TBs": round(alg / m / 1e9 / 8, 3)}), flush=True)
+                      "frac_of_8TBs": round(alg / m / 1e9 / 8, 3),
+                      "kernels_ms": {kk: round(float(np.mean(vv)), 4) for kk, vv in allk[(n, r)].items()},
+                      "sum_ms": round(float(sum(np.mean(vv) for vv in allk[(n, r)].values())), 4)}), flush=True)

@@ -40,6 +40,17 @@ __global__ __launch_bounds__(256) void calib_read8_onepass(const double *__restr
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     if (q < n && a[q] == 1.2345e300) *sink = 1;
 }
+// non-temporal variants (the fill pass reads its six flux arrays this way): does a streaming load fetch whole 128-byte lines?
+__global__ __launch_bounds__(256) void calib_read8_nt(const double *__restrict__ a, i64 n, double *sink) {
+    const i64 stride = (i64)gridDim.x * 256;
+    double s = 0;
+    for (i64 q = (i64)blockIdx.x * 256 + threadIdx.x; q < n; q += stride) s += __builtin_nontemporal_load(a + q);
+    if (s == 1.2345e300) *sink = s;
+}
+__global__ __launch_bounds__(256) void calib_gather8_nt(const double *__restrict__ a, const i64 *__restrict__ idx, i64 n, double *sink) {
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q < n && __builtin_nontemporal_load(a + idx[q]) == 1.2345e300) *sink = 1;
+}
 __global__ __launch_bounds__(256) void calib_gather8(const double *__restrict__ a, const i64 *__restrict__ idx, i64 n, double *sink) {
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     if (q < n && a[idx[q]] == 1.2345e300) *sink = 1;
@@ -150,6 +161,7 @@ int main() {
     const i64 n8 = NB / 8, n16 = NB / 16;
     timeit("calib_read8   (8 B/lane stream, 2 GiB, grid-stride)", (double)NB, 10, [&] { hipLaunchKernelGGL(calib_read8, dim3(256 * 16), dim3(256), 0, 0, buf, n8, sink); });
     timeit("calib_read16  (16 B/lane stream, 2 GiB, grid-stride)", (double)NB, 10, [&] { hipLaunchKernelGGL(calib_read16, dim3(256 * 16), dim3(256), 0, 0, (const d2 *)buf, n16, sink); });
+    timeit("calib_read8_nt (8 B/lane stream, non-temporal loads)", (double)NB, 10, [&] { hipLaunchKernelGGL(calib_read8_nt, dim3(256 * 16), dim3(256), 0, 0, buf, n8, sink); });
     timeit("calib_read8_onepass (8 B/lane, one element per thread)", (double)NB, 10, [&] { hipLaunchKernelGGL(calib_read8_onepass, dim3((unsigned)(n8 / 256)), dim3(256), 0, 0, buf, n8, sink); });
     // gather through an index list with a wet mask's gaps: 54 % of the cells, runs and holes of random length
     {
@@ -171,6 +183,8 @@ int main() {
         printf("gather: %lld of %lld cells (%.1f %%)\n", (long long)ng, (long long)n8, 100.0 * ng / n8);
         timeit("calib_gather8 (8 B/lane through an index list; bytes = whole buffer + index)", (double)NB + ng * 8.0, 10,
                [&] { hipLaunchKernelGGL(calib_gather8, dim3((unsigned)(ng / 256)), dim3(256), 0, 0, buf, didx, ng, sink); });
+        timeit("calib_gather8_nt (the same gather, non-temporal loads)", (double)NB + ng * 8.0, 10,
+               [&] { hipLaunchKernelGGL(calib_gather8_nt, dim3((unsigned)(ng / 256)), dim3(256), 0, 0, buf, didx, ng, sink); });
         CK(hipFree(didx));
     }
     timeit("calib_write16 (16 B/lane stream, 2 GiB)", (double)NB, 10, [&] { hipLaunchKernelGGL(calib_write16, dim3(256 * 16), dim3(256), 0, 0, (d2 *)buf, n16); });
