@@ -51,6 +51,10 @@ t = t[ok]
 print(f"{wl}: {nw} waves, {ok.sum()} with all stamps")
 names = ["entry->Lwet back", "->stencil loads back", "->arithmetic done", "->offsets known (scan+barrier)", "->stores issued (5 x stage+store)",
          "->stores acked"]
+if "-DOTMB_DBG_STAMPS_ORDER" in extra:  # slot 6 = "tile id known" instead of "stores acked"
+    e = t[:, 6] - t[:, 0]
+    print(f"  entry->tile id known (kernel arguments, tile order) mean {e.mean():9.0f}  median {np.median(e):9.0f}  p90 {np.percentile(e, 90):9.0f}")
+    t[:, 6] = t[:, 5]
 d = np.diff(t[:, :7], axis=1)
 life = t[:, 6] - t[:, 0]
 for q, n in enumerate(names):
