@@ -293,6 +293,29 @@ def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend
     return rec
 
 
+def box_probe(dev):
+    """How fast is THIS box's memory system for the plainest job there is?  A 2 GiB device-to-device copy (torch), after the timed region.  The boxes
+    of the pool differ by up to 15 % on every kernel of this path (profiles/r03/README.md section 6); this number lets a reader tell a slow box
+    from a slow kernel.  Not part of the measurement."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    return {"copy_2GiB_ms": ms, "copy_gbs_read_plus_write": 2 * n * 8 / (ms * 1e-3) / 1e9,
+            "note": "torch device-to-device copy of 2 GiB after the timed region: the box's memory speed, for comparing runs on different boxes"}
+
+
 def traffic_for(workload, kernel, args, world=1):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json), valid only for the
     kernel sources they were measured on (kernel_source_sha16) and for the workload they were measured at."""
@@ -542,6 +565,8 @@ def main():
         if world == 1 and host_grid is not None and not rehearsal:
             out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
+        if world == 1 and not rehearsal and dev.type == "cuda":
+            out["box_probe"] = box_probe(dev)
         if config4 is not None:
             out["config4"] = config4
         out.update(extras)  # BASELINE.json configs[2] ("HBM-roofline run") and the grid of configs[4] on this one GPU
