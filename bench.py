@@ -294,9 +294,9 @@ def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend
 
 
 def box_probe(dev):
-    """How fast is THIS box's memory system for the plainest job there is?  A 2 GiB device-to-device copy (torch), after the timed region.  The boxes
-    of the pool differ by up to 15 % on every kernel of this path (profiles/r03/README.md section 6); this number lets a reader tell a slow box
-    from a slow kernel.  Not part of the measurement."""
+    """How fast is THIS box's memory system for the plainest job there is?  A 2 GiB device-to-device copy (torch), after the timed region: a
+    reference point beside the line's own kernel times (the boxes of the pool differ by up to 15 % on the fill pass, profiles/r03/README.md
+    section 6).  Not part of the measurement."""
     import torch
     n = 1 << 28
     a = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
@@ -313,7 +313,9 @@ def box_probe(dev):
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / reps
     return {"copy_2GiB_ms": ms, "copy_gbs_read_plus_write": 2 * n * 8 / (ms * 1e-3) / 1e9,
-            "note": "torch device-to-device copy of 2 GiB after the timed region: the box's memory speed, for comparing runs on different boxes"}
+            "note": "torch device-to-device copy of 2 GiB after the timed region: this box's plain streaming rate.  (Round 3: the pool's boxes differ by up to 15 % on the "
+                    "fill pass and this rate does not follow it -- 4.63 TB/s on a box with a 0.316 ms fill, 4.98 TB/s on one with 0.360 ms -- the pass is bound by "
+                    "request latency, not by streaming bandwidth: profiles/r03/README.md 5b, 6.)"}
 
 
 def traffic_for(workload, kernel, args, world=1):
