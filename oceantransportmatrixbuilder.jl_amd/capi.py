@@ -238,7 +238,7 @@ class Context:
         return a.reshape(shape, order=order) if np.ndim(shape) else a
 
     def set_tile_order(self, rows_per_band):
-        """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = chosen by grid size."""
+        """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = the library default (bands of 8 rows)."""
         self.check(self._lib.otmb_ctx_set_tile_order(self._h, int(rows_per_band)))
 
     def set_formulation(self, dense, depth_parts=0):
