@@ -70,6 +70,27 @@ def test_every_tile_order_gives_the_same_matrices(oracle):
         _check(asm, rtm, f"tile order {rows}, two-phase")
 
 
+def test_tile_order_is_computed_once_per_grid(oracle):
+    """The march order is a function of the grid: its three kernels run on the first step and again only when the band height changes
+    (otmb_ctx_set_tile_order); the default (-1) is the march order, i.e. they do run."""
+    asm, umo, vmo, rtm = _setup(oracle, (120, 100, 23, 87, "array", "tripolar"))
+    asm.ctx.timing_enable(True)
+    for _ in range(3):
+        asm.step(umo, vmo, 1e20)
+    t = asm.ctx.timing_collect()
+    assert t["tm_order_kernels"][1] == 1, t
+    assert t["tm_kernel<fill>"][1] == 3, t
+    asm.ctx.set_tile_order(5)
+    for _ in range(2):
+        asm.step(umo, vmo, 1e20)
+    t = asm.ctx.timing_collect()
+    assert t["tm_order_kernels"][1] == 1, t
+    _check(asm, rtm, "after the order was rebuilt")
+    asm.ctx.set_tile_order(0)
+    asm.step(umo, vmo, 1e20)
+    assert "tm_order_kernels" not in asm.ctx.timing_collect()
+
+
 def test_dense_march_reports_the_reference_errors(oracle):
     from otmb_amd.capi import OtmbError
 
