@@ -9,6 +9,7 @@ ap.add_argument("--libs", default="default"); ap.add_argument("--rows", default=
 ap.add_argument("--rounds", type=int, default=4); ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--stagger", default="0", help="OTMB_STAGGER values (bytes): the k-th array of an assembler starts k*stagger bytes into its allocation")
 ap.add_argument("--bipolar", action="store_true", help="also time every assembler with the topology flag forced to bipolar (no seam row: what the generic column path costs)")
+ap.add_argument("--only-bipolar", action="store_true", help="time ONLY with the topology flag forced to bipolar (variants that cannot do the seam row)")
 ap.add_argument("--reps", type=int, default=1, help="assemblers per library (the placement of the arrays in HBM moves the fill pass by +-5 %)")
 a = ap.parse_args()
 import numpy as np, torch
@@ -41,7 +42,9 @@ allk = {}
 for rnd in range(a.rounds):
     order = [(n, rep, x, r) for n, rep, x in asms for r in rows]
     if rnd % 2: order.reverse()
-    if a.bipolar:
+    if a.only_bipolar:
+        order = [(n + "+bipolar", rep, x, r, 0) for n, rep, x, r in order]
+    elif a.bipolar:
         order = [(n + tag, rep, x, r, topo) for n, rep, x, r in order for tag, topo in (("", None), ("+bipolar", 0))]
     else:
         order = [(n, rep, x, r, None) for n, rep, x, r in order]
@@ -49,7 +52,7 @@ for rnd in range(a.rounds):
         if not hasattr(x, "_topo0"):
             x._topo0 = x.topology
         x.topology = x._topo0 if topo is None else topo
-        if a.bipolar:
+        if a.bipolar or a.only_bipolar:
             x.makeindices()  # (the folded wet flags depend on the topology)
         x.ctx.set_tile_order(r)
         for _ in range(3): x.step_async(umo, vmo, fill)
