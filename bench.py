@@ -69,7 +69,8 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+        # (the script that was started, not necessarily this file: tests/bench_rehearsal.py wraps main() and must be what the ranks run)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0]), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # poll every rank: when one dies the others would wait for it in a collective for ever -- stop them (they are this
     # process's own children) and report; an overall limit bounds the run whatever happens
@@ -231,7 +232,7 @@ def extra_configs_in_children(args):
     return out
 
 
-def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend):
+def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend, make_backend):
     """BASELINE.json configs[3] beside a multi-rank headline: the FIXED `workload` grid cut into `world` depth slabs (strong scaling),
     facefluxes chain planes over the communicator, asynchronous pipeline; K' = min(K, 10) steps x 2 repeats between barriers, max over
     ranks.  Every rank takes part; rank 0 returns the record."""
@@ -248,13 +249,7 @@ def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend
     k0, k1 = odist.balanced_partition(counts, world)[rank]
     dg = synthetic_device.make_device_grid((nx, ny, nz), dev, seed=args.seed, land_fraction=lf, rho=args.rho, k0=k0, k1=k1)
     local = odist.make_local_grid_from_device(dg)
-    if rehearsal:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from slab_checker_backend import OracleSlabBackend
-
-        be = OracleSlabBackend()
-    else:
-        be = odist.HipSlabBackend(local_rank)
+    be = make_backend(local_rank)
     srun = odist.SlabRunner(be, odist.Comm(), local)
 
     def barrier():
@@ -330,12 +325,21 @@ def traffic_for(workload, kernel, args, world=1):
         return None
 
 
-def main():
+def under_profiler():
+    """A rocprofv3 / rocprof preload has initialised the GPU before this script started: no child processes then (they would inherit the
+    profiler, write their dispatches into the same output directory and mix two grids in one summary)."""
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def main(slab_backend_factory=None, cpu_rehearsal=False):
+    """slab_backend_factory / cpu_rehearsal: a seam for tests/bench_rehearsal.py ONLY (the multi-rank plumbing of this script on a box
+    without GPUs, over gloo, with a backend the TEST side supplies).  Nothing in this file imports from tests/ or oracle/ except the
+    cpu_baseline leg, no environment variable or flag selects another backend: run as `python bench.py` the product library computes."""
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
     extras = {}
-    if args.gpus == 1 and "RANK" not in os.environ and args.extra_configs and os.environ.get("OTMB_BENCH_CHECKER_BACKEND") != "1":
+    if args.gpus == 1 and "RANK" not in os.environ and args.extra_configs and not cpu_rehearsal and not under_profiler():
         extras = extra_configs_in_children(args)  # (children first: nothing in this process has touched a GPU yet)
 
     import numpy as np
@@ -352,9 +356,9 @@ def main():
     # OTMB_FORCE_SLAB=1: take the depth-slab (distributed) code path even with one rank, e.g. under
     # `torchrun --nproc-per-node 1`, to exercise RCCL initialisation and collectives on a one-GPU box
     force_slab = os.environ.get("OTMB_FORCE_SLAB") == "1" and "RANK" in os.environ
-    # OTMB_BENCH_CHECKER_BACKEND=1 (tests only): rehearse the multi-rank orchestration of this script on a box without
-    # GPUs -- gloo, the CPU checker backend of tests/ -- the line it prints is labelled as not being a measurement
-    rehearsal = os.environ.get("OTMB_BENCH_CHECKER_BACKEND") == "1"
+    # rehearsal (tests/bench_rehearsal.py only): the multi-rank orchestration of this script on a box without GPUs -- gloo, a
+    # backend supplied by the test -- the line it prints is labelled as not being a measurement
+    rehearsal = bool(cpu_rehearsal)
     saved_stdout_fd = None
     backend = os.environ.get("OTMB_DIST_BACKEND", "gloo" if rehearsal else "nccl")
     if world > 1 or force_slab:
@@ -377,6 +381,14 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
 
+    def make_backend(lr):
+        if slab_backend_factory is not None:
+            assert rehearsal, "a foreign slab backend is a rehearsal, never a measurement"
+            return slab_backend_factory(lr)
+        from otmb_amd import dist as odist_
+
+        return odist_.HipSlabBackend(lr)
+
     nx, ny, nz, lf = synthetic.PRESETS[args.workload]
     host_grid = None  # (g, gm) when the whole grid also exists on the host (cpu_baseline / end_to_end legs)
     if world > 1 or force_slab:
@@ -390,13 +402,7 @@ def main():
         # every rank generates only its own levels, on its own device
         dg = synthetic_device.make_device_grid((nx, ny, nzg), dev, seed=args.seed, land_fraction=lf, rho=args.rho, k0=k0, k1=k1)
         local = odist.make_local_grid_from_device(dg)
-        if rehearsal:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from slab_checker_backend import OracleSlabBackend
-
-            be = OracleSlabBackend()
-        else:
-            be = odist.HipSlabBackend(local_rank)
+        be = make_backend(local_rank)
         srun = odist.SlabRunner(be, odist.Comm(), local)
         umo, vmo, fill = dg.umo, dg.vmo, dg.fill
 
@@ -523,7 +529,7 @@ def main():
     if world > 1 and args.extra_configs and not (args.workload == c4_workload and args.scaling == "strong") and \
             (not rehearsal or "OTMB_BENCH_CONFIG4_WORKLOAD" in os.environ):
         try:
-            config4 = slab_config(c4_workload, args, world, rank, dev, local_rank, rehearsal, backend)
+            config4 = slab_config(c4_workload, args, world, rank, dev, local_rank, rehearsal, backend, make_backend)
         except Exception as e:  # every rank raises the same pipeline errors (dist.SlabRunner.finish), so nobody is left in a collective
             config4 = {"workload": c4_workload, "error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
@@ -568,7 +574,11 @@ def main():
             out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
         if world == 1 and not rehearsal and dev.type == "cuda":
-            out["box_probe"] = box_probe(dev)
+            try:  # after the timed region and not part of the measurement: it must never cost the line
+                torch.cuda.empty_cache()
+                out["box_probe"] = box_probe(dev)
+            except Exception as e:
+                out["box_probe"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if config4 is not None:
             out["config4"] = config4
         out.update(extras)  # BASELINE.json configs[2] ("HBM-roofline run") and the grid of configs[4] on this one GPU

@@ -48,6 +48,9 @@ struct otmb_ctx {
         const void *lwet = nullptr; int64_t n = 0, nx = 0, ny = 0, nz = 0; int rows = 0;
         bool operator==(const OrderKey &o) const { return lwet == o.lwet && n == o.n && nx == o.nx && ny == o.ny && nz == o.nz && rows == o.rows; }
     } order_key;              // what ctx->order was built for
+    int ff_xcd_chunks = 1;    // facefluxes: XCD x takes the x-th contiguous eighth of the column blocks (0 = blockIdx order; experiments: OTMB_FF_XCD)
+    int count_order = 1;      // counting pass: 0 = blockIdx (wet-rank) order, 1 = XCD-contiguous eighths of wet-rank order, 2 = the fill pass's tile order (OTMB_COUNT_ORDER)
+    int pf_dist = -1;         // fill pass: a workgroup prefetches the Lwet lines of the tile taken pf_dist positions later in its XCD's sequence (0 = off, -1 = default; OTMB_PF_DIST)
     int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)
     int dense_kparts = 1;     // dense march: depth pieces per (row, segment)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)

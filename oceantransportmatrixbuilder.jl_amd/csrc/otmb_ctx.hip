@@ -69,6 +69,9 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     c->device = device_id;
     if (const char *e = getenv("OTMB_MARCH_ROWS")) c->march_rows = atoi(e);  // experiments; otmb_ctx_set_tile_order is the API
     if (const char *e = getenv("OTMB_DENSE")) c->formulation = atoi(e);        // experiments; otmb_ctx_set_formulation is the API
+    if (const char *e = getenv("OTMB_FF_XCD")) c->ff_xcd_chunks = atoi(e);       // experiments (A/B in one library)
+    if (const char *e = getenv("OTMB_COUNT_ORDER")) c->count_order = atoi(e);
+    if (const char *e = getenv("OTMB_PF_DIST")) c->pf_dist = atoi(e);
     if (const char *e = getenv("OTMB_DENSE_KPARTS")) c->dense_kparts = atoi(e);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -126,12 +129,15 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
 
 int32_t otmb_ctx_set_stream(otmb_ctx *ctx, void *s) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    hipStream_t ns = s ? (hipStream_t)s : ctx->own_stream;
+    if (ns != ctx->stream) ctx->order_key = otmb_ctx::OrderKey();  // the cached tile order may still be in flight on the previous stream: build it again here
+    ctx->stream = ns;
     return OTMB_OK;
 }
 
 int32_t otmb_ctx_use_default_stream(otmb_ctx *ctx) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
+    if (ctx->stream != nullptr) ctx->order_key = otmb_ctx::OrderKey();
     ctx->stream = nullptr;  // HIP's null stream: what torch calls its default stream
     return OTMB_OK;
 }

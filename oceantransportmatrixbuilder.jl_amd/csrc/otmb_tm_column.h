@@ -48,13 +48,15 @@ struct TmParams {
     int *flags;
     int *next_state;       // the NEXT asynchronous step's state block, zeroed by this fill (or NULL): no memset between steps
     const unsigned *order; // fill pass: tile taken by the q-th workgroup slot (march order), or NULL = wet-rank order
+    int count_order;       // counting pass: 0 blockIdx order, 1 XCD-contiguous eighths, 2 XCD-contiguous eighths of `order`
+    int pf_dist;           // fill pass: prefetch the Lwet lines of the tile pf_dist positions later in this XCD's sequence (0 = off)
 };
 
 // Diagnostic build only (-DOTMB_DBG_STAMPS, tools/stamps.py): s_memtime stamps of the phases of a wave of the fill
 // pass, kept in SGPR pairs and written by lane 0 at the end to a buffer nothing else reads (p.status).  STAMP(n, WAITVM)
 // with WAITVM drains the wave's vector-memory operations first, so the stamp says when the loads were back.
 #ifdef OTMB_DBG_STAMPS
-#define OTMB_NSTAMP 8
+#define OTMB_NSTAMP 10  // 0-6 s_memtime stamps (shader clock of the wave's XCD), 7 HW_ID | XCC_ID << 32, 8 / 9 s_memrealtime (100 MHz, chip-wide) at entry / end
 struct Stamps { unsigned long long t[OTMB_NSTAMP]; };
 #define STAMP(st, n, WAITVM)                                                                              \
     do {                                                                                                  \

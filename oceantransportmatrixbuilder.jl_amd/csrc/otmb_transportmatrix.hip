@@ -30,6 +30,10 @@
 #define OTMB_MARCH_AUTO_ROWS 8  // tile order when the caller does not choose: march order, bands of 8 rows (with the matrices written by
                                 // non-temporal stores: -8 % against wet-rank order at 1 and at 0.25 degree, R = 2 ... 32 within 1 %)
 #endif
+#ifndef TM_PF_DEFAULT
+#define TM_PF_DEFAULT 96  // index prefetch distance of the fill pass, in tiles of one XCD's sequence: 96 = the workgroups an XCD holds at once
+                          // (3 per CU x 32 CUs), i.e. the tile that starts about one workgroup life later
+#endif
 #define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
@@ -121,9 +125,18 @@ template <int TPB>
 __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, i64 ntiles) {
     __shared__ u64 wave_tot[TPB][TM_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // Tile(s) of this workgroup.  Like the fill pass, XCD x (workgroups are dealt round-robin over the 8 XCDs) takes the x-th
+    // contiguous eighth of the tile sequence, so that the mask lines of the rows south / north and of the levels above / below --
+    // read again by later tiles -- are found in the same L2 (count_order 1: wet-rank sequence, 2: the fill pass's march sequence).
+    i64 blk = blockIdx.x;
+    if (p.count_order) {
+        const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        if (TPB == 1 && p.count_order == 2 && p.order) blk = p.order[blk];
+    }
     u64 mine[TPB];
 #pragma unroll
-    for (int q = 0; q < TPB; ++q) mine[q] = count_cell(p, (i64)blockIdx.x * TPB + q, tid);
+    for (int q = 0; q < TPB; ++q) mine[q] = count_cell(p, blk * TPB + q, tid);
 #pragma unroll
     for (int q = 0; q < TPB; ++q) {  // wave totals (the in-tile offsets are recomputed by the fill pass)
         u64 x = mine[q];
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
     __syncthreads();
     if (tid < TPB * TM_NF) {
         const int q = tid / TM_NF, m = tid - q * TM_NF;
-        const i64 tile = (i64)blockIdx.x * TPB + q;
+        const i64 tile = blk * TPB + q;
         if (tile < ntiles) {
             u64 all = 0;
 #pragma unroll
@@ -242,6 +255,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     for (int q = 0; q < OTMB_NSTAMP; ++q) st.t[q] = 0;
 #endif
     STAMP(st, 0, 0);
+#ifdef OTMB_DBG_STAMPS
+    u64 rt_entry;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
+#endif
     if (p.next_state && blockIdx.x == 0 && tid < (int)(OTMB_TM_STATE_BYTES / sizeof(int))) p.next_state[tid] = 0;
 #ifdef OTMB_STAGGER_UNITS
     // Experiment: the workgroups of the first dispatch round start together and march through their phases (loads,
@@ -257,10 +274,19 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     // the same XCD touched a little earlier, are L2 hits instead of fabric re-reads.  Speed only: any
     // bijection is correct.
     i64 tile = blockIdx.x;
+    i64 pf_tile = -1;  // the tile whose index lines this workgroup prefetches (below)
     if (MODE != MODE_ONEPASS) {
         const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-        if (p.order) tile = p.order[tile];  // march order: the XCD's eighth is a run of (row band, level) buckets
+        const i64 pos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        const bool pf = MODE == MODE_FILL && p.pf_dist > 0 && y + p.pf_dist < q + (x < r ? 1 : 0);  // still inside this XCD's eighth
+        const i64 ppos = pf ? pos + p.pf_dist : pos;
+        tile = pos;
+        i64 pt = ppos;
+        if (p.order) {  // march order: the XCD's eighth is a run of (row band, level) buckets
+            tile = p.order[pos];
+            pt = p.order[ppos];  // (unconditional: both entries in one round trip)
+        }
+        if (pf) pf_tile = pt;
     }
 #ifdef OTMB_DBG_STAMPS_ORDER  // diagnostic (tools/stamps.py): when is the tile id known (kernel arguments + tile order)
     STAMP(st, 6, 1);
@@ -305,6 +331,16 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 Lnext_own = (wcl + 1 < p.n_own) ? Lnext_ld : p.G;
     const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
+    // Prefetch for the workgroup that will follow on this XCD: a tile's first act is a dependent trip to HBM for its 2 KB of Lwet
+    // (read once per launch, so never in a cache: 15 % of a wave's life with nothing else in flight, tools/stamps.py).  The tile
+    // pf_dist positions further down this XCD's sequence starts about one workgroup life from now: touch its lines now (one
+    // load per lane, issued BEHIND the wave's own index loads -- loads return in order), so that its trip ends in this L2.
+    // The value is only compared with a constant no index can take, beside the canonical-indices check.
+    i64 pf_val = 0;
+    if (MODE == MODE_FILL) {
+        const i64 pw = (pf_tile >= 0 ? pf_tile : tile) * TM_THREADS + tid;
+        pf_val = p.lwet[pw < p.n_own ? pw : p.n_own - 1];
+    }
     unsigned pre_sum = 0;
     i64 pre_off = 0;
     if (MODE == MODE_FILL && tid < TM_NF) {
@@ -375,7 +411,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 }
 #endif
             }
-            if (!canonical) {
+            if (!canonical | (pf_val == (i64)0x8000000000000000ll)) {
                 raise_flag(p.flags, FLAG_NONCANONICAL);
             } else {
                 live = true;
@@ -596,7 +632,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     if (MODE == MODE_FILL && p.status && lane == 0) {
         u64 *o = p.status + ((u64)tile * (TM_THREADS / 64) + wid) * OTMB_NSTAMP;
         for (int q = 0; q < 7; ++q) o[q] = st.t[q];
-        o[7] = (u64)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: CU / SIMD / wave slot
+        // HW_REG_HW_ID (4): wave slot / SIMD / CU / SH / SE;  HW_REG_XCC_ID (20): which XCD (each XCD has its own s_memtime base)
+        o[7] = (u64)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+               ((u64)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+        o[8] = rt_entry;
+        u64 rt_end;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_end)::"memory");
+        o[9] = rt_end;
     }
 #endif
 }
@@ -754,8 +796,11 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
         return OTMB_OK;
     }
     int32_t rc;
+    // (a failed or half-enqueued build must not be trusted by the next call: the key is recorded only once all three kernels are
+    // enqueued without an error, on the stream they were enqueued on -- otmb_ctx_set_stream forgets the key, so a fill on another
+    // stream can never read a permutation that is still being built)
+    ctx->order_key = otmb_ctx::OrderKey();
     if ((rc = otmb_reserve(ctx, ctx->order, ob + bb))) return rc;
-    ctx->order_key = key;
     unsigned *order = (unsigned *)ctx->order.p, *hist = (unsigned *)((char *)ctx->order.p + ob);
     KernelTimer kt(ctx, K_TM_ORDER);
     HIP_TRY(ctx, hipMemsetAsync(hist, 0, bb, ctx->stream));
@@ -765,6 +810,8 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
     hipLaunchKernelGGL(order_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, nbuckets);
     hipLaunchKernelGGL(order_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (int)a.nx, (int)a.ny, a.nx * a.ny, rows,
                        (int)a.nz, hist, order);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->order_key = key;
     *out = order;
     return OTMB_OK;
 }
@@ -840,6 +887,8 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.tilesums = (uint32_t *)ctx->tm_sums.p;
     p.tileoffs = (const i64 *)ctx->tm_offs.p;
     p.flags = (int *)ctx->flags.p;
+    p.count_order = ctx->count_order;
+    p.pf_dist = ctx->pf_dist < 0 ? TM_PF_DEFAULT : ctx->pf_dist;
 }
 
 // The counting pass reads the push mask: the caller's (written by facefluxes for exactly these ϕ), or one derived
@@ -1017,6 +1066,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
     } else if (ntiles > 0) {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
+        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, &p.order))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
@@ -1212,6 +1262,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     } else {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
+        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, &p.order))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),

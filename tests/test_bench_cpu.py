@@ -1,6 +1,7 @@
 """bench.py's launcher and multi-rank plumbing on a box without GPUs: `python bench.py --gpus N` (no torchrun) must spawn
 its N ranks itself and print exactly ONE JSON line.  The ranks run the depth-slab orchestration over gloo with the CPU
-checker backend of tests/ (OTMB_BENCH_CHECKER_BACKEND=1) -- the line says that it is a rehearsal, not a measurement."""
+checker backend of tests/, injected by tests/bench_rehearsal.py (bench.py itself cannot select it) -- the line says that it is a
+rehearsal, not a measurement."""
 import json
 import os
 import subprocess
@@ -13,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("gpus,scaling", [(2, "weak"), (3, "strong")])
 def test_bench_spawns_its_ranks_and_prints_one_json_line(gpus, scaling):
-    env = dict(os.environ, OTMB_BENCH_CHECKER_BACKEND="1", OTMB_BENCH_CONFIG4_WORKLOAD="small")
+    env = dict(os.environ, OTMB_BENCH_CONFIG4_WORKLOAD="small")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "small", "--scaling", scaling,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", str(gpus), "--workload", "small", "--scaling", scaling,
                         "--steps", "2", "--warmup", "1", "--repeats", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -45,3 +46,14 @@ def test_traffic_json_is_keyed_to_the_kernel_sources():
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert "kernel_source_sha16" in tj and len(tj["kernel_source_sha16"]) == 16
     assert len(bench.kernel_source_hash()) == 16
+
+
+def test_bench_py_cannot_reach_the_checker():
+    """nothing in bench.py imports from tests/, and the oracle is imported by the cpu_baseline leg alone."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "slab_checker_backend" not in src and "OTMB_BENCH_CHECKER_BACKEND" not in src
+    assert '"tests"' not in src and "'tests'" not in src
+    head, tail = src.split("def cpu_baseline", 1)
+    rest = tail.split("\ndef ", 1)[1]  # everything after the cpu_baseline leg
+    for part in (head, rest):
+        assert "from oracle" not in part and "import oracle" not in part

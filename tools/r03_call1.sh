@@ -33,7 +33,7 @@ python3 $REPO/tools/pmc_summary.py $OUT/calib calib_,mix_stream > $OUT/calib_sum
 cat $OUT/calib_summary.txt
 
 echo "== traffic of the fill pass at 0.25 degree: wet-rank order against march order =="
-ARGS="--workload quarterdeg --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end"
+ARGS="--workload quarterdeg --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end --extra-configs="
 for rows in 0 8; do
   for set in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
     name=$(echo $set | tr ' ' '_' | cut -c1-30)

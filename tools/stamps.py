@@ -2,7 +2,10 @@
 """Where does a wave of the fill pass spend its life?  Diagnostic build (-DOTMB_DBG_STAMPS: s_memtime stamps in SGPRs,
 written by lane 0 of each wave to a buffer of their own; fences around every stamp forbid overlaps the real kernel has,
 so read the SHARES, not the length).   gpurun -- python tools/stamps.py [workload] [extra -D flags]
-Stamps: 0 entry | 1 Lwet back | 2 stencil loads back | 3 arithmetic done | 4 tile offsets known | 5 stores issued | 6 stores acked"""
+Stamps: 0 entry | 1 Lwet back | 2 stencil loads back | 3 arithmetic done | 4 tile offsets known | 5 stores issued | 6 stores acked
+         7 HW_ID | XCC_ID << 32 | 8, 9 s_memrealtime (100 MHz, one clock for the whole chip) at entry / end of the wave
+Round 4: a DISPATCH TIMELINE from words 7-9 -- waves resident per XCD / per CU over the kernel, the share of the kernel spent
+ramping up and draining."""
 import ctypes as C
 import importlib.util
 import os
@@ -16,7 +19,9 @@ spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "oceantran
 b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 wl = sys.argv[1] if len(sys.argv) > 1 else "access1deg"
 extra = sys.argv[2:]
-path = b.build(force=True, extra=["-DOTMB_DBG_STAMPS", *extra], name="stamps")
+path = os.path.join(b.LIBDIR, "libotmb_hip_stamps.so")
+if not (os.environ.get("OTMB_STAMPS_PREBUILT") == "1" and os.path.exists(path)):  # (prebuilt on the CPU box: saves GPU minutes)
+    path = b.build(force=True, extra=["-DOTMB_DBG_STAMPS", *extra], name="stamps")
 import torch
 import otmb_amd
 from otmb_amd import capi, synthetic
@@ -39,13 +44,14 @@ for _ in range(5):
 print({k: round(v[0] / v[1], 4) for k, v in asm.ctx.timing_collect().items()})
 ntiles = (asm.N + 255) // 256
 nw = ntiles * 4
-buf = np.zeros(nw * 8, dtype=np.uint64)
+NST = 10
+buf = np.zeros(nw * NST, dtype=np.uint64)
 fn = capi.lib().otmb_debug_stamps
 fn.restype = C.c_int32
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 rc = fn(asm.ctx.handle, buf.ctypes.data, buf.size)
 assert rc == 0, rc
-t = buf.reshape(nw, 8).astype(np.int64)
+t = buf.reshape(nw, NST).astype(np.int64)
 ok = (t[:, :7] > 0).all(axis=1)
 t = t[ok]
 print(f"{wl}: {nw} waves, {ok.sum()} with all stamps")
@@ -65,6 +71,48 @@ print(f"  kernel span {span} ticks; sum of wave lives / span = {life.sum() / spa
 # start-time profile: how many dispatch rounds
 st = np.sort(t[:, 0] - t[:, 0].min())
 print("  wave start times (ticks) deciles:", [int(x) for x in np.percentile(st, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100])])
-hw = t[:, 7]
-cu_key = (hw >> 8) & 0xfffff  # everything above the wave-slot/SIMD bits: CU, SH, SE, ...
-print("  distinct HW_ID>>8 values:", len(np.unique(cu_key)))
+hw = t[:, 7] & 0xffffffff
+xcc = (t[:, 7] >> 32) & 0xf
+cu_key = ((hw >> 8) & 0xff) | (xcc << 8)  # CU id (4 bits), SH (1), SE (3) inside an XCD, and the XCD
+print("  distinct (XCD, SE, SH, CU) values:", len(np.unique(cu_key)), " XCDs seen:", sorted(int(x) for x in np.unique(xcc)))
+
+# ---- dispatch timeline (s_memrealtime: 100 MHz, the same counter on every XCD) ----
+t0, t1 = t[:, 8], t[:, 9]
+k0, k1 = t0.min(), t1.max()
+span = k1 - k0
+print(f"  timeline: first wave entry -> last wave end = {span} ticks of 10 ns = {span / 100:.1f} us; mean wave life {np.mean(t1 - t0) / 100:.2f} us")
+nb = 64
+edges = np.linspace(k0, k1, nb + 1)
+def resident(sel):
+    # average number of waves resident in each time bin: sum of overlaps / bin width
+    a, b = t0[sel], t1[sel]
+    out = np.zeros(nb)
+    for q in range(nb):
+        lo, hi = edges[q], edges[q + 1]
+        out[q] = np.clip(np.minimum(b, hi) - np.maximum(a, lo), 0, None).sum() / (hi - lo)
+    return out
+allr = resident(np.ones(len(t0), bool))
+steady = np.median(allr[nb // 4: 3 * nb // 4])
+print(f"  waves resident on the chip, {nb} bins over the kernel (steady state = median of the middle half = {steady:.0f} = {steady / 256:.2f} per CU):")
+print("   ", " ".join(f"{x:.0f}" for x in allr))
+ramp = np.argmax(allr >= 0.95 * steady)
+tail = nb - 1 - np.argmax(allr[::-1] >= 0.95 * steady)
+lost = ((steady - allr[:ramp]).clip(0).sum() + (steady - allr[tail + 1:]).clip(0).sum()) / (steady * nb)
+print(f"  ramp: residency reaches 95 % of steady after {ramp}/{nb} bins ({ramp / nb:.1%} of the kernel); drain: falls below 95 % for the last {nb - 1 - tail}/{nb} bins ({(nb - 1 - tail) / nb:.1%})")
+print(f"  wave-slots left empty in ramp + drain = {lost:.1%} of (steady residency x kernel span)")
+for x in sorted(int(v) for v in np.unique(xcc)):
+    sel = xcc == x
+    r = resident(sel)
+    print(f"  XCD {x}: {sel.sum():6d} waves, first entry +{(t0[sel].min() - k0) / 100:6.1f} us, last end {(k1 - t1[sel].max()) / 100:6.1f} us before the kernel's end, "
+          f"steady {np.median(r[nb // 4: 3 * nb // 4]):.0f} waves, mean life {np.mean(t1[sel] - t0[sel]) / 100:.2f} us")
+# per-CU idle tail: for each CU the time between its last wave's end and the kernel's end
+cus = np.unique(cu_key)
+tails = np.array([k1 - t1[cu_key == c].max() for c in cus]) / 100.0
+heads = np.array([t0[cu_key == c].min() - k0 for c in cus]) / 100.0
+print(f"  per CU ({len(cus)}): idle before its first wave mean {heads.mean():.2f} us (max {heads.max():.2f}); idle after its last wave mean {tails.mean():.2f} us "
+      f"(median {np.median(tails):.2f}, max {tails.max():.2f}) = {tails.mean() / (span / 100):.1%} of the kernel")
+# life of a wave against its start time (do late waves -- less contention -- live shorter?)
+order = np.argsort(t0)
+for q in range(8):
+    sl = order[q * len(order) // 8:(q + 1) * len(order) // 8]
+    print(f"  waves starting in octile {q}: mean life {np.mean(t1[sl] - t0[sl]) / 100:6.2f} us")
