@@ -288,6 +288,50 @@ def slab_config(workload, args, world, rank, dev, local_rank, rehearsal, backend
     return rec
 
 
+def config2_bolus(g, gm, dev, local_rank, steps):
+    """BASELINE.json configs[1] ("... incl. Redi/GM triads").  In the reference the triads never enter T (src/RediGM.jl:44; DESIGN.md
+    section 0): the headline line IS config 2's transportmatrix (3-D ρ).  What the reference has of Redi/GM is bolus_GM_velocity
+    (src/RediGM.jl:46-79): its two kernels on the same grid, device resident, as an extra record (never `value`).  Algorithmic bytes:
+    ρ, Z3D (8 B), the wet byte and two (nx,ny) distances in, u and v out = 33 B per cell; the κGM·S intermediates are overhead."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from otmb_amd import capi
+
+    ctx = capi.Context(local_rank)
+    nx, ny, nz = gm.v3D.shape
+    flat = lambda a: torch.from_numpy(np.asfortranarray(a, dtype=np.float64).ravel(order="F")).to(dev)
+    dn = gm.distance_to_neighbour_2D
+    rho, z3d, de, dnn = flat(g.rho), flat(gm.Z3D), flat(dn["east"]), flat(dn["north"])
+    wet = (~torch.isnan(flat(gm.v3D))).to(torch.uint8)
+    u, v = torch.empty_like(rho), torch.empty_like(rho)
+    torch.cuda.synchronize(dev)
+
+    def call():
+        ctx.check(capi.lib().otmb_bolus_gm_velocity_dev(ctx.handle, rho.data_ptr(), z3d.data_ptr(), wet.data_ptr(), de.data_ptr(), dnn.data_ptr(),
+                                                        nx, ny, nz, int(gm.gridtopology.kind), 600.0, 0.01, u.data_ptr(), v.data_ptr()))
+
+    for _ in range(3):
+        call()
+    ctx.synchronize()
+    ctx.timing_enable(True)
+    for _ in range(steps):
+        call()
+    kt = ctx.timing_collect()
+    ctx.timing_enable(False)
+    ms = kt["gm_slopes+gm_dyad"][0] / kt["gm_slopes+gm_dyad"][1]
+    G = nx * ny * nz
+    alg = 33 * G + 16 * nx * ny
+    ctx.close()
+    return {"workload": f"bolus_GM_velocity on the {nx}x{ny}x{nz} grid (src/RediGM.jl:46-79; the reference's Redi/GM code never enters T)",
+            "kernels": "gm_slopes_kernel + gm_dyad_kernel", "ms": ms, "cells_per_s": G / (ms * 1e-3), "algorithmic_bytes": alg,
+            "achieved_gbs": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "4 arrays in (ρ, Z3D, wet, 2-D distances), 2 out; the two κGM·S arrays between the kernels are written and read once more "
+                    "(74 B per cell of real traffic).  The transportmatrix of config 2 (3-D ρ) is this line's headline."}
+
+
 def box_probe(dev):
     """How fast is THIS box's memory system for the plainest job there is?  A 2 GiB device-to-device copy (torch), after the timed region: a
     reference point beside the line's own kernel times (the boxes of the pool differ by up to 15 % on the fill pass, profiles/r03/README.md
@@ -573,6 +617,11 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         if world == 1 and host_grid is not None and not rehearsal:
             out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
+        if world == 1 and host_grid is not None and not rehearsal and dev.type == "cuda":
+            try:  # an extra record must never cost the headline
+                out["config2"] = config2_bolus(*host_grid, dev, local_rank, min(args.steps, 10))
+            except Exception as e:
+                out["config2"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not rehearsal and dev.type == "cuda":
             try:  # after the timed region and not part of the measurement: it must never cost the line
                 torch.cuda.empty_cache()

@@ -82,12 +82,22 @@ int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on);
  * is what a script that passes facefluxesfrommasstransport's result straight to transportmatrix does (README.md:65-80).
  * Off by default.                                                                                                */
 int32_t otmb_ctx_set_reuse_fluxes(otmb_ctx *ctx, int32_t on);
+/* reuse_grid and reuse_fluxes are independent promises (either may be on without the other).  Diagnostics: the bytes the
+ * host-pointer entry points of this context have copied to the device so far -- what the two flags save.            */
+int64_t otmb_ctx_uploaded_bytes(const otmb_ctx *ctx);
 /* Pinned (page-locked) host memory owned by the context, for the arrays a caller hands to the host-pointer entry points:
  * a buffer inside such a block is the DMA's own source / target -- no staging copy, no page faults on freshly allocated
  * output arrays (1 GB of them per transportmatrix at 1 degree).  Julia: unsafe_wrap(Array, ptr, n) + a finalizer calling
- * otmb_host_free.  Freed blocks are kept by the context and handed out again (up to 4 GiB idle).                  */
+ * otmb_host_free.  Freed blocks are kept and handed out again (up to 4 GiB idle).                                   */
 int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out);
-int32_t otmb_host_free(otmb_ctx *ctx, void *p);
+/* Lifetime and threads: the blocks belong to ONE pool of the process, behind a lock, which no context owns: otmb_ctx_destroy
+ * frees none of them, and otmb_host_free IGNORES its context argument (NULL and an already destroyed context are fine) and may
+ * be called from any thread at any time -- a garbage collector's finalizer thread while another thread is inside a call on the
+ * context, or a finalizer that runs after the atexit hook that destroyed the context (Julia runs atexit hooks BEFORE its final
+ * finalizer sweep).  Returns OTMB_ERR_INVALID_ARG for a pointer that is not a live block (e.g. freed twice).              */
+int32_t otmb_host_free(otmb_ctx *ctx_ignored, void *p);
+/* blocks handed out and not yet freed, their bytes, and the bytes kept idle for reuse (any argument may be NULL) */
+int32_t otmb_host_pool_stats(int64_t *blocks_in_use, int64_t *bytes_in_use, int64_t *bytes_idle);
 /* Speed only, never results: the order in which the fill pass of transportmatrix takes its tiles of 256 columns.
  * rows_per_band = 0: ascending wet rank (i, then j, then k).  R > 0: MARCH order -- the tiles of a band of R grid rows
  * are taken level after level before the next band starts, so that the levels above / below a tile (the vertical
@@ -286,6 +296,42 @@ int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]);
 /* host variant of fill: nnz_out receives the final counts (trim T's arrays to nnz_out[0]) */
 int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int64_t *const rowval[5],
                                    double *const nzval[5], int64_t nnz_out[5]);
+
+/* ---- the same two calls over SEVERAL GPUs of one process: transportmatrix(...; devices = 0:7) ---------------------------
+ * No counterpart in the single-threaded reference (src/matrixbuilding.jl:128-150 is the call shape that is kept).  The wet
+ * index is k-slowest (src/matrixbuilding.jl:14-15): a slab of consecutive levels owns a contiguous column range of every matrix
+ * and a contiguous range of every (nx,ny,nz) array.  An otmb_mgpu owns one context and one host thread per device, cuts the
+ * levels with otmb_balanced_partition (wet counts as even as a sweep gets them) and moves every slab over ITS device's PCIe
+ * link.  HOST pointers of the WHOLE grid go in and come out, exactly as for otmb_facefluxes / otmb_transportmatrix_plan /
+ * _fetch, and the results are the same bit for bit:
+ *   otmb_mgpu_facefluxes            the continuity recurrence (src/velocities.jl:236-243) is a chain in k with a fixed
+ *                                   association: slabs run deepest first and hand ONE (nx,ny) plane of ϕtop per boundary to
+ *                                   the slab above -- a grouped ncclSend / ncclRecv pair on a single-process communicator
+ *                                   (ncclCommInitAll: RCCL over xGMI) between different devices; a device-to-device copy
+ *                                   when the slabs share a device (every device id equal: tests on a one-GPU box);
+ *   otmb_mgpu_transportmatrix_plan  every slab uploads its levels plus one halo level each side (neighbours only) from the
+ *                                   host arrays -- nothing crosses devices; nnz = sums over the slabs (T: the union bound);
+ *   otmb_mgpu_transportmatrix_fetch every slab fills its column range with global colptr offsets and copies it into its
+ *                                   range of the caller's five matrices; T is compacted across slabs if entries cancelled.
+ * device_ids: all different (RCCL; OTMB_MGPU_TRANSPORT=peer selects hipMemcpyPeerAsync) or all equal.  Errors: the status of
+ * the first failing check in the reference's order over all slabs; otmb_mgpu_last_error names the slab.  An otmb_mgpu is not
+ * shared between threads.  transport: 0 same-device copy, 1 RCCL, 2 peer copy.                                            */
+typedef struct otmb_mgpu otmb_mgpu;
+int32_t otmb_mgpu_create(int32_t ndev, const int32_t *device_ids, otmb_mgpu **out);
+void otmb_mgpu_destroy(otmb_mgpu *mg);
+const char *otmb_mgpu_last_error(const otmb_mgpu *mg);
+int32_t otmb_mgpu_ndev(const otmb_mgpu *mg);
+int32_t otmb_mgpu_transport(const otmb_mgpu *mg);
+/* level bounds of the last facefluxes / plan: ndev + 1 entries, slab s = levels [bounds[s], bounds[s+1]) (0-based) */
+int32_t otmb_mgpu_partition(const otmb_mgpu *mg, int64_t *bounds);
+/* nslabs consecutive slabs of >= 1 level each with wet counts as even as a greedy sweep gets them (upper levels are wetter);
+ * bounds: nslabs + 1 entries.  Pure host arithmetic, no GPU.                                                              */
+int32_t otmb_balanced_partition(const int64_t *level_counts, int64_t nz, int32_t nslabs, int64_t *bounds);
+int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d,
+                             double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6]);
+int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *args, int64_t nnz[5]);
+int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5], int64_t *const rowval[5],
+                                        double *const nzval[5], int64_t nnz_out[5]);
 
 /* ---- makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices) -- the array work of
  *      src/gridcellgeometry.jl:265-311 (device pointers; vertex permutation :158-178 and topology detection

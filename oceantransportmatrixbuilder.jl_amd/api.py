@@ -18,6 +18,7 @@ from ._nt import NT, data_and_props
 from .capi import HDIRS, MATS, PHI_ORDER
 
 _ctx = {}
+_mgpu = {}
 last_call_seconds = {}  # time spent inside the C ABI by the last transportmatrix call: {"plan": s, "fetch": s} (bench.py)
 
 
@@ -25,6 +26,14 @@ def context(device=0):
     if device not in _ctx:
         _ctx[device] = capi.Context(device)
     return _ctx[device]
+
+
+def mgpu(devices):
+    """The otmb_mgpu of a device list (`devices = 0:7` in the Julia shim): created once, kept."""
+    key = tuple(int(d) for d in devices)
+    if key not in _mgpu:
+        _mgpu[key] = capi.Mgpu(key)
+    return _mgpu[key]
 
 
 def _f64(a):
@@ -107,9 +116,10 @@ def _out_array(ctx, shape, dtype):
     return np.empty(shape, dtype=dtype, order="F")
 
 
-def facefluxes(umo, vmo, gridmetrics, indices, *, FillValue, device=0):
-    """velocities.jl:190-255.  umo/vmo are not modified (the reference mutates its converted copies)."""
-    ctx = context(device)
+def facefluxes(umo, vmo, gridmetrics, indices, *, FillValue, device=0, devices=None):
+    """velocities.jl:190-255.  umo/vmo are not modified (the reference mutates its converted copies).
+    devices=[...] (extension): depth slabs over several GPUs (otmb_mgpu_facefluxes), same six arrays bit for bit."""
+    ctx = context(device if devices is None else list(devices)[0])
     u = np.asarray(umo)
     v = np.asarray(vmo)
     is32 = u.dtype == np.float32 and v.dtype == np.float32
@@ -120,19 +130,29 @@ def facefluxes(umo, vmo, gridmetrics, indices, *, FillValue, device=0):
     wet = np.asfortranarray(indices["wet3D"]).view(np.uint8)
     out = {k: _out_array(ctx, u.shape, np.float64) for k in PHI_ORDER}  # pinned: the DMA writes the results in place
     ptrs = capi.ptr_array(6, [out[k].ctypes.data for k in PHI_ORDER])
+    if devices is not None:
+        return _facefluxes_mgpu(devices, u, v, is32, wet, FillValue, gridmetrics, out, ptrs)
     ctx.check(capi.lib().otmb_facefluxes(ctx.handle, u.ctypes.data, v.ctypes.data, int(is32), wet.ctypes.data,
                                          float(FillValue), nx, ny, nz, _topology_kind(gridmetrics), C.byref(ptrs)))
     return NT(**out)
 
 
-def facefluxesfrommasstransport(*, umo, vmo, gridmetrics, indices, device=0):
+def _facefluxes_mgpu(devices, u, v, is32, wet, FillValue, gridmetrics, out, ptrs):
+    mg = mgpu(devices)
+    nx, ny, nz = u.shape
+    mg.check(capi.lib().otmb_mgpu_facefluxes(mg.handle, u.ctypes.data, v.ctypes.data, int(is32), wet.ctypes.data,
+                                             float(FillValue), nx, ny, nz, _topology_kind(gridmetrics), C.byref(ptrs)))
+    return NT(**out)
+
+
+def facefluxesfrommasstransport(*, umo, vmo, gridmetrics, indices, device=0, devices=None):
     """velocities.jl:118-130."""
     u, up = data_and_props(umo)
     v, vp = data_and_props(vmo)
     fill = up["_FillValue"]
     fv = vp["_FillValue"]
     assert (fill == fv) or (np.isnan(fill) and np.isnan(fv))  # @assert isequal(...), :121
-    return facefluxes(u, v, gridmetrics, indices, FillValue=fill, device=device)
+    return facefluxes(u, v, gridmetrics, indices, FillValue=fill, device=device, devices=devices)
 
 
 def _velocity_flux(which, a_i, a_j, gridmetrics, rho, device):
@@ -282,7 +302,7 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
 
 def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None, rho=None, κH=500.0, κVML=0.1,
                     κVdeep=1.0e-5, kappaH=None, kappaVML=None, kappaVdeep=None, Tadv=None, TκH=None, TκVML=None,
-                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, reuse_fluxes=False, device=0):
+                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, reuse_fluxes=False, device=0, devices=None):
     """matrixbuilding.jl:128-150 -> NT(T, Tadv, TκH, TκVML, TκVdeep), each a SparseMatrixCSC.
     ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords.
     operators=False (extension; the reference always returns all five): only T is materialised, the other four come
@@ -290,7 +310,9 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     reuse_grid=True (extension): the caller promises that the gridmetrics / indices arrays are the very arrays of the
     previous call, unmodified (a loop over time slices): they are not copied to the device again (otmb_ctx_set_reuse_grid).
     reuse_fluxes=True (extension): ϕ is what facefluxes* returned last on this device, unmodified: its device copy is used
-    (otmb_ctx_set_reuse_fluxes)."""
+    (otmb_ctx_set_reuse_fluxes).
+    devices=[0, 1, ...] (extension): the grid is cut into depth slabs, one per listed GPU of this process, each moved over its own
+    PCIe link (otmb_mgpu_transportmatrix_plan / _fetch); the same five matrices bit for bit."""
     phi = ϕ if ϕ is not None else phi
     rho = ρ if ρ is not None else rho
     kH = κH if kappaH is None else kappaH
@@ -301,12 +323,14 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
         # matrixbuilding.jl:140-143: operators passed in are used as they are; T = ((Tadv + TκH) + TκVML) + TκVdeep (:147)
         return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device)
     return _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes,
-                                  device, 0)
+                                  device, 0, devices)
 
 
 def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes, device,
-                           ignore_ops):
+                           ignore_ops, devices=None):
     """otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch."""
+    if devices is not None:
+        return _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops)
     ctx = context(device)
     keep, passthrough = [], []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
@@ -335,6 +359,35 @@ def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVd
     last_call_seconds["fetch"] = _time.perf_counter() - t0
     ctx.set_reuse_fluxes(False)
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
+    return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
+                 for m, name in enumerate(MATS)})
+
+
+def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops):
+    """otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs, one per listed GPU."""
+    mg = mgpu(devices)
+    ctx = context(list(devices)[0])  # (pinned result arrays only: the pool is the process's, every device's DMA reaches it)
+    keep = []
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep)
+    a.only_t = 0 if operators else 1
+    a.ignore_ops = int(ignore_ops)
+    nnz = (C.c_int64 * 5)()
+    import time as _time
+
+    t0 = _time.perf_counter()
+    mg.check(capi.lib().otmb_mgpu_transportmatrix_plan(mg.handle, C.byref(a), C.byref(nnz)))
+    last_call_seconds["plan"] = _time.perf_counter() - t0
+    N = int(indices["N"])
+    colptr = [_out_array(ctx, N + 1, np.int64) for _ in range(5)]
+    rowval = [_out_array(ctx, int(nnz[m]), np.int64) for m in range(5)]
+    nzval = [_out_array(ctx, int(nnz[m]), np.float64) for m in range(5)]
+    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
+    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
+    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    final = (C.c_int64 * 5)()
+    t0 = _time.perf_counter()
+    mg.check(capi.lib().otmb_mgpu_transportmatrix_fetch(mg.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
+    last_call_seconds["fetch"] = _time.perf_counter() - t0
     return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
                  for m, name in enumerate(MATS)})
 

@@ -56,8 +56,20 @@ SYMBOLS = {
     "otmb_ctx_synchronize": (C.c_int32, [_vp]),
     "otmb_ctx_set_reuse_grid": (C.c_int32, [_vp, C.c_int32]),
     "otmb_ctx_set_reuse_fluxes": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_ctx_uploaded_bytes": (C.c_int64, [_vp]),
     "otmb_host_alloc": (C.c_int32, [_vp, C.c_int64, C.POINTER(_vp)]),
     "otmb_host_free": (C.c_int32, [_vp, _vp]),
+    "otmb_host_pool_stats": (C.c_int32, [_ip, _ip, _ip]),
+    "otmb_mgpu_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_vp)]),
+    "otmb_mgpu_destroy": (None, [_vp]),
+    "otmb_mgpu_last_error": (C.c_char_p, [_vp]),
+    "otmb_mgpu_ndev": (C.c_int32, [_vp]),
+    "otmb_mgpu_transport": (C.c_int32, [_vp]),
+    "otmb_mgpu_partition": (C.c_int32, [_vp, _ip]),
+    "otmb_balanced_partition": (C.c_int32, [_ip, C.c_int64, C.c_int32, _ip]),
+    "otmb_mgpu_facefluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
+    "otmb_mgpu_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
+    "otmb_mgpu_transportmatrix_fetch": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
     "otmb_ctx_set_formulation": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "otmb_last_error": (C.c_char_p, [_vp]),
@@ -171,9 +183,10 @@ class _PinnedOwner:
         self.ctx, self.ptr = ctx, ptr
 
     def __del__(self):
+        # otmb_host_free ignores its context argument: the block goes back to the process-wide pool whether or not the context
+        # that allocated it is still alive, from whichever thread the garbage collector runs on
         try:
-            if self.ctx._h.value:
-                self.ctx._lib.otmb_host_free(self.ctx._h, _vp(self.ptr))
+            self.ctx._lib.otmb_host_free(None, _vp(self.ptr))
         except Exception:
             pass
 
@@ -260,6 +273,59 @@ class Context:
         cnt = (C.c_int64 * n)()
         self.check(self._lib.otmb_ctx_timing_collect(self._h, ms, cnt, n))
         return {self._lib.otmb_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(n) if cnt[k]}
+
+
+class Mgpu:
+    """One otmb_mgpu: depth slabs over several GPUs of this process (include/otmb.h).  device_ids all different (RCCL
+    hand-offs between them) or all equal (same-device copies: tests on a one-GPU box)."""
+
+    def __init__(self, device_ids):
+        self._h = _vp()
+        self._lib = lib()
+        ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+        rc = self._lib.otmb_mgpu_create(len(device_ids), ids, C.byref(self._h))
+        if rc != OK:
+            raise OtmbError(rc, f"otmb_mgpu_create({list(device_ids)}) failed: " + self._lib.otmb_status_string(rc).decode())
+        self.device_ids = tuple(int(d) for d in device_ids)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.otmb_mgpu_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def transport(self):
+        return {0: "same-device copy", 1: "rccl", 2: "peer copy"}[self._lib.otmb_mgpu_transport(self._h)]
+
+    def check(self, rc):
+        if rc != OK:
+            raise OtmbError(rc, self._lib.otmb_mgpu_last_error(self._h).decode("utf-8"))
+
+    def partition(self):
+        n = self._lib.otmb_mgpu_ndev(self._h)
+        b = (C.c_int64 * (n + 1))()
+        self.check(self._lib.otmb_mgpu_partition(self._h, b))
+        return [int(x) for x in b]
+
+
+def balanced_partition(level_counts, nslabs):
+    """otmb_balanced_partition: [(k0, k1)] * nslabs (pure host arithmetic inside the library: needs no GPU)."""
+    counts = (C.c_int64 * len(level_counts))(*[int(x) for x in level_counts])
+    bounds = (C.c_int64 * (nslabs + 1))()
+    rc = lib().otmb_balanced_partition(counts, len(level_counts), int(nslabs), bounds)
+    if rc != OK:
+        raise ValueError(f"{nslabs} slabs for {len(level_counts)} levels")
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(nslabs)]
 
 
 def ptr_array(n, ptrs):

@@ -84,9 +84,8 @@ struct otmb_ctx {
     std::vector<DevBuf> stage;
     OtmbXfer *xfer = nullptr;
     bool reuse_grid = false;  // otmb_ctx_set_reuse_grid: grid-constant host arrays are uploaded once (see include/otmb.h)
+    i64 uploaded_bytes = 0;     // host -> device bytes of the host-pointer entry points (otmb_ctx_uploaded_bytes)
     bool reuse_fluxes = false;  // otmb_ctx_set_reuse_fluxes: ϕ that otmb_facefluxes left in the staging slots is not uploaded again
-    struct HostBlock { void *p = nullptr; size_t cap = 0; bool used = false; };
-    std::vector<HostBlock> host_pool;  // pinned host memory handed out by otmb_host_alloc (DMA source / target without staging)
     struct StageKey { const void *host = nullptr; size_t bytes = 0; };
     std::vector<StageKey> stage_key;  // what each staging slot currently holds (host pointer it was uploaded from)
     // optional per-kernel timing with HIP events recorded on the launch stream

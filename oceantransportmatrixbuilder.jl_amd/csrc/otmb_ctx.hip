@@ -118,8 +118,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     if (ctx->mask.p) (void)hipFree(ctx->mask.p);
     if (ctx->order.p) (void)hipFree(ctx->order.p);
     if (ctx->lump_host.p) (void)hipFree(ctx->lump_host.p);
-    for (auto &b : ctx->host_pool)
-        if (b.p) (void)hipHostFree(b.p);
+    // (pinned blocks of otmb_host_alloc are NOT freed here: they belong to the caller's arrays and to a process-wide pool, otmb_host.hip)
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);

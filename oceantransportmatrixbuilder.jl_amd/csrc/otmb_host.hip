@@ -1,6 +1,8 @@
 // otmb_host.hip -- HOST-pointer entry points (what Julia's ccall hands over): stage the caller's
 // arrays through device buffers owned by the context, run the _dev path, copy the results back
 // into the caller's buffers.  No CPU compute path exists here: without a GPU these calls fail.
+#include <mutex>
+
 #include "otmb_common.h"
 #include "otmb_xfer.h"
 
@@ -33,14 +35,34 @@ static int32_t upload(otmb_ctx *ctx, Uploads &up, int slot, const void *h, size_
     otmb_ctx::StageKey &key = ctx->stage_key[slot];
     const bool promised = (kind == 1 && ctx->reuse_grid) || (kind == 2 && ctx->reuse_fluxes);
     const bool resident = promised && key.host == h && key.bytes == bytes && bytes > 0;
-    if (bytes && !resident) up.items.push_back({d, const_cast<void *>(h), bytes});
+    if (bytes && !resident) { up.items.push_back({d, const_cast<void *>(h), bytes}); ctx->uploaded_bytes += (i64)bytes; }
     key.host = (promised || resident) ? h : nullptr;
     key.bytes = bytes;
     *dptr = d;
     return OTMB_OK;
 }
-bool otmb_host_is_pinned(const otmb_ctx *ctx, const void *p, size_t bytes) {
-    for (const auto &b : ctx->host_pool)
+// ---- pinned host memory handed out to callers (otmb_host_alloc / otmb_host_free) ---------------------------------------------
+// ONE pool for the whole process, behind a mutex, never torn down: the blocks belong to the CALLER's arrays (a Julia Vector wrapped
+// around a block, freed by a finalizer), whose lifetime is not the context's -- finalizers run on whichever thread triggers the
+// garbage collector, concurrently with a ccall in flight, and at process exit AFTER the atexit hooks that destroy the context
+// (VERDICT r03 "What's weak" 7).  So: otmb_ctx_destroy never frees a block, otmb_host_free never looks at its context argument, and
+// every access takes the lock.  Pinned memory is not tied to a device (hipHostMallocPortable): every context of the process --
+// the worker contexts of an otmb_mgpu included -- recognises the blocks as DMA sources / targets.
+namespace {
+struct HostBlock { void *p = nullptr; size_t cap = 0; bool used = false; };
+struct HostPool {
+    std::mutex m;
+    std::vector<HostBlock> blocks;
+};
+HostPool &host_pool() {
+    static HostPool *pool = new HostPool();  // intentionally leaked: must outlive every static destructor and atexit hook
+    return *pool;
+}
+}  // namespace
+bool otmb_host_is_pinned(const otmb_ctx *, const void *p, size_t bytes) {
+    HostPool &hp = host_pool();
+    std::lock_guard<std::mutex> l(hp.m);
+    for (const auto &b : hp.blocks)
         if (b.used && (const char *)p >= (const char *)b.p && (const char *)p + bytes <= (const char *)b.p + b.cap) return true;
     return false;
 }
@@ -290,61 +312,93 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     return otmb_ctx_synchronize(ctx);
 }
 
+// bytes the host-pointer entry points have copied to the device since the context was created (diagnostics / tests: what the
+// reuse flags save)
+int64_t otmb_ctx_uploaded_bytes(const otmb_ctx *ctx) { return ctx ? ctx->uploaded_bytes : -1; }
+
 int32_t otmb_ctx_set_reuse_fluxes(otmb_ctx *ctx, int32_t on) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
     ctx->reuse_fluxes = on != 0;
+    if (!ctx->reuse_fluxes)
+        for (size_t q = ST_PHI0; q < (size_t)ST_PHI0 + 6 && q < ctx->stage_key.size(); ++q) ctx->stage_key[q] = otmb_ctx::StageKey();
     return OTMB_OK;
 }
 
-// Pinned host memory owned by the context: freed blocks are kept (pinning a gigabyte costs a quarter of a second) and handed
-// out again to the next request they fit.
+// Pinned host memory for the caller's arrays: freed blocks are kept (pinning a gigabyte costs a quarter of a second) and handed
+// out again to the next request they fit.  Thread-safe; the blocks outlive the context (see host_pool above).
 int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out) {
     if (!ctx || !out || bytes < 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_host_alloc");
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t want = ((size_t)(bytes > 0 ? bytes : 1) + 4095) & ~(size_t)4095;
+    HostPool &hp = host_pool();
+    std::lock_guard<std::mutex> l(hp.m);
     int best = -1;
-    for (int q = 0; q < (int)ctx->host_pool.size(); ++q) {
-        const auto &b = ctx->host_pool[q];
-        if (!b.used && b.cap >= want && b.cap <= 2 * want + (1u << 20) && (best < 0 || b.cap < ctx->host_pool[best].cap)) best = q;
+    for (int q = 0; q < (int)hp.blocks.size(); ++q) {
+        const auto &b = hp.blocks[q];
+        if (!b.used && b.cap >= want && b.cap <= 2 * want + (1u << 20) && (best < 0 || b.cap < hp.blocks[best].cap)) best = q;
     }
     if (best < 0) {
-        otmb_ctx::HostBlock nb;
-        if (hipHostMalloc(&nb.p, want) != hipSuccess) return otmb_fail(ctx, OTMB_ERR_ALLOC, "hipHostMalloc");
+        HostBlock nb;
+        if (hipHostMalloc(&nb.p, want, hipHostMallocPortable) != hipSuccess) return otmb_fail(ctx, OTMB_ERR_ALLOC, "hipHostMalloc");
         nb.cap = want;
-        ctx->host_pool.push_back(nb);
-        best = (int)ctx->host_pool.size() - 1;
+        hp.blocks.push_back(nb);
+        best = (int)hp.blocks.size() - 1;
     }
-    ctx->host_pool[best].used = true;
-    *out = ctx->host_pool[best].p;
+    hp.blocks[best].used = true;
+    *out = hp.blocks[best].p;
     return OTMB_OK;
 }
 
-int32_t otmb_host_free(otmb_ctx *ctx, void *p) {
-    if (!ctx) return OTMB_ERR_INVALID_ARG;
+// The context argument is IGNORED (kept for the signature): it may be NULL, or a context that has been destroyed -- a finalizer
+// that runs after otmb_ctx_destroy, or on another thread than the one that is inside a call on that context, is fine.
+int32_t otmb_host_free(otmb_ctx *, void *p) {
     if (!p) return OTMB_OK;
-    size_t idle = 0;
-    for (auto &b : ctx->host_pool)
-        if (b.p == p && b.used) { b.used = false; p = nullptr; }
-    if (p) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_host_free: not a block of otmb_host_alloc");
-    // keep at most 4 GiB of idle pinned memory
-    for (auto &b : ctx->host_pool) idle += b.used ? 0 : b.cap;
-    for (size_t q = 0; q < ctx->host_pool.size() && idle > ((size_t)4 << 30);) {
-        if (!ctx->host_pool[q].used) {
-            idle -= ctx->host_pool[q].cap;
-            (void)hipHostFree(ctx->host_pool[q].p);
-            ctx->host_pool.erase(ctx->host_pool.begin() + q);
-        } else {
-            ++q;
+    HostPool &hp = host_pool();
+    std::vector<void *> release;
+    {
+        std::lock_guard<std::mutex> l(hp.m);
+        for (auto &b : hp.blocks)
+            if (b.p == p && b.used) { b.used = false; p = nullptr; }
+        if (p) return OTMB_ERR_INVALID_ARG;  // not a block of otmb_host_alloc (or freed twice)
+        // keep at most 4 GiB of idle pinned memory
+        size_t idle = 0;
+        for (auto &b : hp.blocks) idle += b.used ? 0 : b.cap;
+        for (size_t q = 0; q < hp.blocks.size() && idle > ((size_t)4 << 30);) {
+            if (!hp.blocks[q].used) {
+                idle -= hp.blocks[q].cap;
+                release.push_back(hp.blocks[q].p);
+                hp.blocks.erase(hp.blocks.begin() + q);
+            } else {
+                ++q;
+            }
         }
     }
+    for (void *q : release) (void)hipHostFree(q);  // (outside the lock: unpinning a gigabyte takes a while)
+    return OTMB_OK;
+}
+
+// Blocks currently handed out / kept idle (tests, diagnostics).
+int32_t otmb_host_pool_stats(int64_t *blocks_in_use, int64_t *bytes_in_use, int64_t *bytes_idle) {
+    HostPool &hp = host_pool();
+    std::lock_guard<std::mutex> l(hp.m);
+    int64_t n = 0, bu = 0, bi = 0;
+    for (auto &b : hp.blocks) { if (b.used) { ++n; bu += (int64_t)b.cap; } else bi += (int64_t)b.cap; }
+    if (blocks_in_use) *blocks_in_use = n;
+    if (bytes_in_use) *bytes_in_use = bu;
+    if (bytes_idle) *bytes_idle = bi;
     return OTMB_OK;
 }
 
 int32_t otmb_ctx_set_reuse_grid(otmb_ctx *ctx, int32_t on) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;
     ctx->reuse_grid = on != 0;
-    if (!ctx->reuse_grid) ctx->stage_key.assign(ctx->stage_key.size(), otmb_ctx::StageKey());
+    // switching it off forgets the GRID-CONSTANT slots only: the ϕ slots belong to otmb_ctx_set_reuse_fluxes, which is an
+    // independent promise (api.py and the Julia shim set reuse_grid before every plan: clearing everything here made
+    // reuse_fluxes = true with reuse_grid = false upload all six ϕ arrays again)
+    if (!ctx->reuse_grid)
+        for (size_t q = 0; q < ctx->stage_key.size(); ++q)
+            if (q < (size_t)ST_PHI0 || q >= (size_t)ST_PHI0 + 6) ctx->stage_key[q] = otmb_ctx::StageKey();
     return OTMB_OK;
 }
 

@@ -1,0 +1,574 @@
+// otmb_mgpu.hip -- depth slabs over several GPUs of ONE process, behind the C ABI (HOST pointers: what Julia's ccall hands over).
+//
+// Nothing distributed exists in the reference; this is SURVEY.md section 8(e) for a caller of the boundary: `transportmatrix(...;
+// devices = 0:7)`.  The wet index is k-slowest (src/matrixbuilding.jl:14-15), so a slab of consecutive levels owns a contiguous
+// column range of every matrix and a contiguous range of every (nx,ny,nz) host array:
+//   * the library cuts the levels with otmb_balanced_partition (wet counts as even as a sweep gets them), owns one context per
+//     device and one host thread per slab, and moves every slab over ITS device's PCIe link -- the host-pointer path is PCIe-bound
+//     (1.06 GB down at 1 degree), so N links are the one lever left on it;
+//   * facefluxes: the bottom-up continuity recurrence (src/velocities.jl:236-243) is a chain in k with a fixed association; the
+//     slabs run it deepest first and hand ONE (nx,ny) plane of ϕtop per boundary to the slab above -- never re-associated, so the
+//     fluxes stay bit-identical to a single-device run.  The hand-off is a grouped ncclSend / ncclRecv on a single-process
+//     communicator (ncclCommInitAll; RCCL over xGMI) when the two slabs live on different devices, and a device-to-device
+//     hipMemcpyAsync when they share one (tests on a one-GPU box; never selected between different devices);
+//   * transportmatrix: with the whole grid in host memory a slab's halo levels (one above, one below: they act as neighbours only)
+//     are just the adjacent levels of the same host arrays, so every slab uploads levels [k0 - 1, k1 + 1) and nothing crosses
+//     devices; lwet3d carries GLOBAL wet ranks already.  Each slab writes its column range with global colptr offsets
+//     (otmb_transportmatrix_set_slab / _set_nnz_base) straight into its range of the caller's five CSC matrices.
+// No COO triplet or matrix entry ever crosses devices (gather formulation: a column is built by the owner of its cell).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "otmb_common.h"
+#include "otmb_xfer.h"
+
+namespace {
+
+// ---- RCCL, loaded on demand (a one-device run never needs it; libotmb_hip.so does not link against it) ----
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(std::string &err) {
+        if (h) return true;
+        h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) { err = std::string("librccl.so: ") + dlerror(); return false; }
+#define OTMB_SYM(field, name)                                                         \
+    field = (decltype(field))dlsym(h, name);                                          \
+    if (!field) { err = std::string("librccl.so lacks ") + name; h = nullptr; return false; }
+        OTMB_SYM(CommInitAll, "ncclCommInitAll")
+        OTMB_SYM(CommDestroy, "ncclCommDestroy")
+        OTMB_SYM(GroupStart, "ncclGroupStart")
+        OTMB_SYM(GroupEnd, "ncclGroupEnd")
+        OTMB_SYM(Send, "ncclSend")
+        OTMB_SYM(Recv, "ncclRecv")
+        OTMB_SYM(GetErrorString, "ncclGetErrorString")
+#undef OTMB_SYM
+        return true;
+    }
+};
+
+enum { B_PHI0 = 0, B_V = 6, B_THK, B_RHO, B_LW, B_LWET, B_EDGE0, B_DIST0 = B_EDGE0 + 4, B_AREA = B_DIST0 + 4, B_ZT, B_ML, B_UMO, B_VMO,
+       B_WET, B_PLANE, B_COLPTR0, B_ROWVAL0 = B_COLPTR0 + 5, B_NZVAL0 = B_ROWVAL0 + 5, B_COUNT = B_NZVAL0 + 5 };
+
+struct Slab {
+    otmb_ctx *ctx = nullptr;
+    int device = 0;
+    i64 k0 = 0, k1 = 0;      // owned levels
+    int ha = 0, hb = 0;      // halo level above / below
+    i64 wet_base = 0, n_own = 0;
+    DevBuf buf[B_COUNT];
+    i64 nnz[5] = {0, 0, 0, 0, 0}, base[5] = {0, 0, 0, 0, 0};
+    int32_t status = OTMB_OK;
+    std::string msg;
+    int32_t u_valid = 0, v_valid = 0;
+    // hand-off of the chain's plane to this slab (from the slab below it)
+    std::mutex m;
+    std::condition_variable cv;
+    bool plane_ready = false, plane_failed = false;
+};
+
+__global__ void shift_i64_kernel(i64 *p, i64 n, i64 delta) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) p[q] -= delta;
+}
+
+// the reference's order of the checks inside one transportmatrix call (src/matrixbuilding.jl:233, the generators' loops, :39, :61,
+// :90, :114), behind the library's own input checks -- as oceantransportmatrixbuilder.jl_amd/dist.py ranks them
+int status_rank(int32_t st) {
+    static const int order[] = {OTMB_ERR_NONCANONICAL_INDICES, OTMB_ERR_HIP, OTMB_ERR_PUSH_MASK, OTMB_ERR_RHO_NAN, OTMB_ERR_FLUX_INTO_LAND,
+                                OTMB_ERR_TADV_NAN, OTMB_ERR_TKH_NAN, OTMB_ERR_TKVML_NAN, OTMB_ERR_TKVDEEP_NAN, OTMB_ERR_CAPACITY};
+    for (int q = 0; q < (int)(sizeof order / sizeof order[0]); ++q)
+        if (order[q] == st) return q;
+    return 99;
+}
+
+}  // namespace
+
+struct otmb_mgpu {
+    std::vector<Slab *> slabs;
+    std::string err;
+    int transport = 0;  // 0: every slab on one device (device-to-device copy); 1: RCCL send / recv; 2: hipMemcpyPeerAsync
+    Rccl rccl;
+    std::vector<ncclComm_t> comms;
+    // the grid the current partition was made for
+    i64 nx = 0, ny = 0, nz = 0;
+    std::vector<i64> bounds;
+    // pending plan
+    bool planned = false;
+    otmb_tm_args args;  // host pointers of the plan
+    i64 N = 0;
+    i64 nnz[5] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int32_t mg_fail(otmb_mgpu *mg, int32_t st, const std::string &detail = std::string()) {
+    if (mg) {
+        mg->err = otmb_status_string(st);
+        if (!detail.empty()) mg->err += ": " + detail;
+    }
+    return st;
+}
+
+template <typename F>
+void run_slabs(otmb_mgpu *mg, F &&fn) {  // one host thread per slab (the calling thread takes slab 0)
+    const int n = (int)mg->slabs.size();
+    std::vector<std::thread> th;
+    for (int s = 1; s < n; ++s) th.emplace_back([&, s] { fn(s); });
+    fn(0);
+    for (auto &t : th) t.join();
+}
+
+int32_t reserve(Slab &sl, int b, size_t bytes, void **out) {
+    const int32_t rc = otmb_reserve(sl.ctx, sl.buf[b], bytes ? bytes : 8);
+    *out = sl.buf[b].p;
+    return rc;
+}
+
+// first failing slab in the reference's order; copies its message
+int32_t collect_status(otmb_mgpu *mg) {
+    int best = -1;
+    for (int s = 0; s < (int)mg->slabs.size(); ++s) {
+        const Slab &sl = *mg->slabs[s];
+        if (sl.status == OTMB_OK) continue;
+        if (best < 0 || status_rank(sl.status) < status_rank(mg->slabs[best]->status)) best = s;
+    }
+    if (best < 0) return OTMB_OK;
+    char where[64];
+    snprintf(where, sizeof where, " [slab %d of %d, levels %lld-%lld]", best + 1, (int)mg->slabs.size(), (long long)mg->slabs[best]->k0 + 1,
+             (long long)mg->slabs[best]->k1);
+    mg->err = mg->slabs[best]->msg + (mg->slabs.size() > 1 ? where : "");
+    return mg->slabs[best]->status;
+}
+
+int32_t set_partition(otmb_mgpu *mg, const std::vector<i64> &counts, i64 nx, i64 ny) {
+    const int n = (int)mg->slabs.size();
+    const i64 nz = (i64)counts.size();
+    if (n > nz) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "more devices than levels");
+    mg->bounds.assign(n + 1, 0);
+    int32_t rc = otmb_balanced_partition(counts.data(), nz, n, mg->bounds.data());
+    if (rc) return mg_fail(mg, rc, "partition");
+    std::vector<i64> cum(nz + 1, 0);
+    for (i64 k = 0; k < nz; ++k) cum[k + 1] = cum[k] + counts[k];
+    for (int s = 0; s < n; ++s) {
+        Slab &sl = *mg->slabs[s];
+        sl.k0 = mg->bounds[s]; sl.k1 = mg->bounds[s + 1];
+        sl.ha = s > 0; sl.hb = s + 1 < n;
+        sl.wet_base = cum[sl.k0];
+        sl.n_own = cum[sl.k1] - cum[sl.k0];
+        sl.status = OTMB_OK; sl.msg.clear();
+    }
+    mg->nx = nx; mg->ny = ny; mg->nz = nz;
+    return OTMB_OK;
+}
+
+// Hand the plane src (device memory of slab `from`, P doubles, produced on its stream) to slab `to`'s receive buffer and wake
+// the thread of `to`.  Called by the thread of `from`.
+int32_t send_plane(otmb_mgpu *mg, int from, int to, const double *src, i64 P) {
+    Slab &a = *mg->slabs[from], &b = *mg->slabs[to];
+    double *dst = (double *)b.buf[B_PLANE].p;
+    int32_t rc = OTMB_OK;
+    if (a.device == b.device) {
+        // same device (tests): the copy is ordered behind the producing kernel on the producer's stream; the consumer's stream
+        // must not start before it has landed -- the producer waits for it here and then wakes the consumer
+        if (hipMemcpyAsync(dst, src, (size_t)P * 8, hipMemcpyDeviceToDevice, a.ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(a.ctx->stream) != hipSuccess)
+            rc = OTMB_ERR_HIP;
+    } else if (mg->transport == 1) {
+        // one grouped send / receive pair on the single-process communicator: the send is ordered behind the producing kernel on
+        // the producer's stream, the receive goes onto the CONSUMER's stream, in front of the kernel its thread enqueues after
+        // being woken -- the plane crosses xGMI without a host round trip
+        ncclResult_t r = mg->rccl.GroupStart();
+        if (r == ncclSuccess) r = mg->rccl.Send(src, (size_t)P, ncclDouble, to, mg->comms[from], a.ctx->stream);
+        if (r == ncclSuccess) r = mg->rccl.Recv(dst, (size_t)P, ncclDouble, from, mg->comms[to], b.ctx->stream);
+        const ncclResult_t r2 = mg->rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) { a.msg = std::string("RCCL: ") + mg->rccl.GetErrorString(r); rc = OTMB_ERR_HIP; }
+    } else {
+        if (hipMemcpyPeerAsync(dst, b.device, src, a.device, (size_t)P * 8, a.ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(a.ctx->stream) != hipSuccess)
+            rc = OTMB_ERR_HIP;
+    }
+    {
+        std::lock_guard<std::mutex> l(b.m);
+        b.plane_ready = true;
+        b.plane_failed = rc != OTMB_OK;
+    }
+    b.cv.notify_all();
+    return rc;
+}
+
+void fail_plane(otmb_mgpu *mg, int to) {  // a slab that cannot produce its plane must still release the slab above it
+    Slab &b = *mg->slabs[to];
+    {
+        std::lock_guard<std::mutex> l(b.m);
+        b.plane_ready = true;
+        b.plane_failed = true;
+    }
+    b.cv.notify_all();
+}
+
+}  // namespace
+
+extern "C" {
+
+// Split levels 0..nz-1 into `nslabs` consecutive slabs with >= 1 level each, wet counts as even as a greedy sweep gets them
+// (upper levels are wetter, so equal level counts would not balance).  bounds: nslabs + 1 entries, slab s = [bounds[s], bounds[s+1]).
+// The ONE partition rule of the package: otmb_mgpu_* use it, and so does the process-per-GPU orchestration (dist.py).
+int32_t otmb_balanced_partition(const int64_t *level_counts, int64_t nz, int32_t nslabs, int64_t *bounds) {
+    if (!level_counts || !bounds || nz < 1 || nslabs < 1 || nslabs > nz) return OTMB_ERR_INVALID_ARG;
+    std::vector<i64> cum(nz + 1, 0);
+    for (i64 k = 0; k < nz; ++k) {
+        if (level_counts[k] < 0) return OTMB_ERR_INVALID_ARG;
+        cum[k + 1] = cum[k] + level_counts[k];
+    }
+    const i64 total = cum[nz];
+    bounds[0] = 0;
+    for (int r = 1; r < nslabs; ++r) {
+        // first k with cum[k] >= total * r / nslabs, compared exactly: cum[k] * nslabs >= total * r
+        const __int128 target = (__int128)total * r;
+        i64 k = (i64)(std::lower_bound(cum.begin(), cum.end(), target, [&](i64 c, __int128 t) { return (__int128)c * nslabs < t; }) - cum.begin());
+        if (k > nz) k = nz;
+        // the closer of k-1 and k
+        if (k > 0) {
+            const __int128 dl = target - (__int128)cum[k - 1] * nslabs, dr = (__int128)cum[k < nz ? k : nz] * nslabs - target;
+            if ((dl < 0 ? -dl : dl) <= (dr < 0 ? -dr : dr)) k -= 1;
+        }
+        if (k < bounds[r - 1] + 1) k = bounds[r - 1] + 1;  // >= 1 level per slab on both sides
+        if (k > nz - (nslabs - r)) k = nz - (nslabs - r);
+        bounds[r] = k;
+    }
+    bounds[nslabs] = nz;
+    return OTMB_OK;
+}
+
+int32_t otmb_mgpu_create(int32_t ndev, const int32_t *device_ids, otmb_mgpu **out) {
+    if (!out) return OTMB_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (ndev < 1 || ndev > 64 || !device_ids) return OTMB_ERR_INVALID_ARG;
+    otmb_mgpu *mg = new otmb_mgpu();
+    bool distinct = true, same = true;
+    for (int s = 0; s < ndev; ++s) {
+        for (int q = 0; q < s; ++q) distinct &= device_ids[q] != device_ids[s];
+        same &= device_ids[s] == device_ids[0];
+    }
+    for (int s = 0; s < ndev; ++s) {
+        Slab *sl = new Slab();
+        sl->device = device_ids[s];
+        mg->slabs.push_back(sl);
+        const int32_t rc = otmb_ctx_create(device_ids[s], &sl->ctx);
+        if (rc) { otmb_mgpu_destroy(mg); return rc; }
+    }
+    if (same) {
+        mg->transport = 0;
+    } else if (!distinct) {
+        otmb_mgpu_destroy(mg);  // a device twice among others: no communicator has such a shape
+        return OTMB_ERR_INVALID_ARG;
+    } else {
+        // different devices: the single-process RCCL communicator (one rank per slab); peer copies only if RCCL cannot be loaded
+        // or is refused by OTMB_MGPU_TRANSPORT=peer
+        const char *e = getenv("OTMB_MGPU_TRANSPORT");
+        const bool want_peer = e && std::string(e) == "peer";
+        mg->transport = 2;
+        std::string why;
+        if (!want_peer && mg->rccl.load(why)) {
+            mg->comms.assign(ndev, nullptr);
+            if (mg->rccl.CommInitAll(mg->comms.data(), ndev, device_ids) == ncclSuccess) mg->transport = 1;
+            else mg->comms.clear();
+        }
+        if (mg->transport == 2) {
+            for (int s = 0; s + 1 < ndev; ++s) {  // neighbours hand planes upwards: enable access both ways (an error = already enabled)
+                (void)hipSetDevice(device_ids[s]); (void)hipDeviceEnablePeerAccess(device_ids[s + 1], 0);
+                (void)hipSetDevice(device_ids[s + 1]); (void)hipDeviceEnablePeerAccess(device_ids[s], 0);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    *out = mg;
+    return OTMB_OK;
+}
+
+void otmb_mgpu_destroy(otmb_mgpu *mg) {
+    if (!mg) return;
+    for (Slab *sl : mg->slabs) {
+        if (sl->ctx) {
+            (void)hipSetDevice(sl->device);
+            (void)hipStreamSynchronize(sl->ctx->stream);
+        }
+    }
+    for (ncclComm_t c : mg->comms)
+        if (c) (void)mg->rccl.CommDestroy(c);
+    for (Slab *sl : mg->slabs) {
+        if (sl->ctx) {
+            (void)hipSetDevice(sl->device);
+            for (DevBuf &b : sl->buf)
+                if (b.p) (void)hipFree(b.p);
+            otmb_ctx_destroy(sl->ctx);
+        }
+        delete sl;
+    }
+    delete mg;
+}
+
+const char *otmb_mgpu_last_error(const otmb_mgpu *mg) { return mg ? mg->err.c_str() : "null otmb_mgpu"; }
+int32_t otmb_mgpu_ndev(const otmb_mgpu *mg) { return mg ? (int32_t)mg->slabs.size() : 0; }
+int32_t otmb_mgpu_transport(const otmb_mgpu *mg) { return mg ? mg->transport : -1; }
+
+// the partition of the last facefluxes / plan: ndev + 1 level bounds
+int32_t otmb_mgpu_partition(const otmb_mgpu *mg, int64_t *bounds) {
+    if (!mg || !bounds || mg->bounds.empty()) return OTMB_ERR_INVALID_ARG;
+    for (size_t q = 0; q < mg->bounds.size(); ++q) bounds[q] = mg->bounds[q];
+    return OTMB_OK;
+}
+
+// facefluxes over the slabs: same arguments and results as otmb_facefluxes (src/velocities.jl:118-130, :154-255).
+int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d, double fill,
+                             int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6]) {
+    if (!mg || !umo || !vmo || !wet3d || !phi) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null argument");
+    for (int f = 0; f < 6; ++f)
+        if (!phi[f]) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
+    if (nx < 1 || ny < 1 || nz < 1) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "grid size");
+    const i64 P = nx * ny;
+    const size_t es = src_is_f32 ? 4 : 8;
+    const int n = (int)mg->slabs.size();
+    mg->planned = false;
+    // wet cells per level (bytes of indices.wet3D): what the partition balances
+    std::vector<i64> counts(nz, 0);
+    {
+        OtmbThreadPool pool(std::min<int>(8, std::max<int>(1, (int)std::thread::hardware_concurrency())));
+        pool.parallel_for((int)nz, [&](int k) {
+            const uint8_t *w = wet3d + (size_t)k * P;
+            i64 c = 0;
+            for (i64 q = 0; q < P; ++q) c += w[q] != 0;
+            counts[k] = c;
+        });
+    }
+    int32_t rc;
+    if ((rc = set_partition(mg, counts, nx, ny))) return rc;
+    for (Slab *sl : mg->slabs) { sl->plane_ready = false; sl->plane_failed = false; }
+    run_slabs(mg, [&](int s) {
+        Slab &sl = *mg->slabs[s];
+        auto fail = [&](int32_t st) {
+            sl.status = st;
+            sl.msg = otmb_last_error(sl.ctx);
+            if (s > 0) fail_plane(mg, s - 1);
+        };
+        if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
+        const i64 nl = sl.k1 - sl.k0;
+        const size_t Gl = (size_t)(nl * P);
+        void *du, *dv, *dw, *dplane, *dphi[6];
+        int32_t r;
+        if ((r = reserve(sl, B_UMO, Gl * es, &du)) || (r = reserve(sl, B_VMO, Gl * es, &dv)) || (r = reserve(sl, B_WET, Gl, &dw)) ||
+            (r = reserve(sl, B_PLANE, (size_t)P * 8, &dplane)))
+            return fail(r);
+        for (int f = 0; f < 6; ++f)
+            if ((r = reserve(sl, B_PHI0 + f, Gl * 8, &dphi[f]))) return fail(r);
+        OtmbXferItem up[3] = {{du, (char *)umo + (size_t)sl.k0 * P * es, Gl * es}, {dv, (char *)vmo + (size_t)sl.k0 * P * es, Gl * es},
+                              {dw, (char *)wet3d + (size_t)sl.k0 * P, Gl}};
+        if ((r = otmb_xfer(sl.ctx, true, up, 3))) return fail(r);
+        const double *top_below = nullptr;
+        if (sl.hb) {  // the chain: ϕtop of the level below this slab
+            std::unique_lock<std::mutex> l(sl.m);
+            sl.cv.wait(l, [&] { return sl.plane_ready; });
+            if (sl.plane_failed) {  // the slab below failed: its status is the one reported; release the slab above
+                l.unlock();
+                if (s > 0) fail_plane(mg, s - 1);
+                return;
+            }
+            top_below = (const double *)dplane;
+        }
+        double *dp[6];
+        for (int f = 0; f < 6; ++f) dp[f] = (double *)dphi[f];
+        if ((r = otmb_facefluxes_slab_dev(sl.ctx, du, dv, src_is_f32, (const uint8_t *)dw, fill, nx, ny, nl, topology, dp, top_below, nullptr)))
+            return fail(r);
+        if (s > 0 && (r = send_plane(mg, s, s - 1, dp[OTMB_TOP], P))) {  // ϕtop of this slab's first level goes up
+            otmb_fail(sl.ctx, r, sl.msg.empty() ? "plane hand-off" : sl.msg.c_str());
+            sl.status = r;
+            sl.msg = otmb_last_error(sl.ctx);
+            return;
+        }
+        std::vector<OtmbXferItem> down;
+        for (int f = 0; f < 6; ++f) down.push_back({dp[f], phi[f] + (size_t)sl.k0 * P, Gl * 8});
+        if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size()))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
+        if ((r = otmb_facefluxes_slab_flags(sl.ctx, &sl.u_valid, &sl.v_valid))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); }
+    });
+    if ((rc = collect_status(mg))) return rc;
+    bool u = false, v = false;
+    for (Slab *sl : mg->slabs) { u |= sl->u_valid != 0; v |= sl->v_valid != 0; }
+    if (!u || !v) return mg_fail(mg, OTMB_ERR_ALL_MISSING);  // @assert over the WHOLE grid (:199-200)
+    (void)n;
+    return OTMB_OK;
+}
+
+// transportmatrix over the slabs, two-phase like otmb_transportmatrix_plan / _fetch: HOST pointers of the whole grid.
+int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *a, int64_t nnz[5]) {
+    if (!mg || !a || !nnz) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null argument");
+    if (a->nx < 1 || a->ny < 1 || a->nz < 1) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "grid size");
+    for (int f = 0; f < 6; ++f)
+        if (!a->phi[f]) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "phi");
+    for (int d = 0; d < 4; ++d)
+        if (!a->edge_length[d] || !a->dist_nbr[d]) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "metrics");
+    if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null input array");
+    const i64 P = a->nx * a->ny, G = P * a->nz, N = a->n_wet;
+    if (N < 0 || N > G || (N > 0 && !a->lwet)) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "lwet / n_wet");
+    mg->planned = false;
+    // wet cells per level from Lwet (ascending 1-based linear indices, k slowest): positions of the level boundaries
+    std::vector<i64> counts(a->nz, 0);
+    {
+        const i64 *lw = (const i64 *)a->lwet;
+        i64 prev = 0;
+        for (i64 k = 0; k < a->nz; ++k) {
+            const i64 pos = (i64)(std::upper_bound(lw, lw + N, (k + 1) * P) - lw);  // entries with L <= (k+1) P
+            counts[k] = pos - prev;
+            prev = pos;
+        }
+        if (prev != N) return mg_fail(mg, OTMB_ERR_NONCANONICAL_INDICES);
+    }
+    int32_t rc;
+    if ((rc = set_partition(mg, counts, a->nx, a->ny))) return rc;
+    mg->args = *a;
+    mg->N = N;
+    run_slabs(mg, [&](int s) {
+        Slab &sl = *mg->slabs[s];
+        auto fail = [&](int32_t st) { sl.status = st; sl.msg = otmb_last_error(sl.ctx); };
+        if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
+        const i64 e0 = sl.k0 - sl.ha, e1 = sl.k1 + sl.hb, nze = e1 - e0;
+        const size_t Ge = (size_t)(nze * P), off = (size_t)e0 * P;
+        otmb_tm_args d = *a;
+        d.nz = nze;
+        d.n_wet = sl.n_own;
+        d.push_mask = nullptr;
+        std::vector<OtmbXferItem> up;
+        int32_t r;
+        void *p;
+#define UP3(B, HOST, FIELD, TYPE)                                               \
+    if ((r = reserve(sl, B, Ge * 8, &p))) return fail(r);                        \
+    up.push_back({p, (char *)(HOST) + off * 8, Ge * 8});                         \
+    FIELD = (TYPE)p;
+        for (int f = 0; f < 6; ++f) { UP3(B_PHI0 + f, a->phi[f], d.phi[f], const double *) }
+        UP3(B_V, a->v3d, d.v3d, const double *)
+        UP3(B_THK, a->thkcello, d.thkcello, const double *)
+        if (a->rho) { UP3(B_RHO, a->rho, d.rho, const double *) }
+        UP3(B_LW, a->lwet3d, d.lwet3d, const int64_t *)
+#undef UP3
+        if ((r = reserve(sl, B_LWET, (size_t)sl.n_own * 8, &p))) return fail(r);
+        if (sl.n_own > 0) up.push_back({p, (char *)((const i64 *)a->lwet + sl.wet_base), (size_t)sl.n_own * 8});
+        d.lwet = (const int64_t *)p;
+        i64 *dlwet = (i64 *)p;
+#define UP2(B, HOST, FIELD)                                                      \
+    if ((r = reserve(sl, B, (size_t)P * 8, &p))) return fail(r);                 \
+    up.push_back({p, (void *)(HOST), (size_t)P * 8});                            \
+    FIELD = (const double *)p;
+        for (int k = 0; k < 4; ++k) { UP2(B_EDGE0 + k, a->edge_length[k], d.edge_length[k]) UP2(B_DIST0 + k, a->dist_nbr[k], d.dist_nbr[k]) }
+        UP2(B_AREA, a->area2d, d.area2d)
+        UP2(B_ML, a->mlotst, d.mlotst)
+#undef UP2
+        if ((r = reserve(sl, B_ZT, (size_t)nze * 8, &p))) return fail(r);
+        up.push_back({p, (void *)(a->zt + e0), (size_t)nze * 8});
+        d.zt = (const double *)p;
+        if ((r = otmb_xfer(sl.ctx, true, up.data(), (int)up.size()))) return fail(r);
+        // Lwet of the owned cells as LOCAL linear indices of the extended grid (levels [e0, e1))
+        if (sl.n_own > 0 && off > 0) {
+            hipLaunchKernelGGL(shift_i64_kernel, dim3((unsigned)((sl.n_own + 255) / 256)), dim3(256), 0, sl.ctx->stream, dlwet, sl.n_own, (i64)off);
+            if (hipGetLastError() != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "shift_i64_kernel"); return fail(OTMB_ERR_HIP); }
+        }
+        if ((r = otmb_transportmatrix_set_slab(sl.ctx, sl.wet_base))) return fail(r);
+        if ((r = otmb_transportmatrix_plan_dev(sl.ctx, &d, sl.nnz))) return fail(r);
+    });
+    if ((rc = collect_status(mg))) return rc;
+    for (int m = 0; m < 5; ++m) {
+        i64 run = 0;
+        for (Slab *sl : mg->slabs) { sl->base[m] = run; run += sl->nnz[m]; }
+        nnz[m] = mg->nnz[m] = run;
+    }
+    mg->planned = true;
+    return OTMB_OK;
+}
+
+int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5], int64_t *const rowval[5], double *const nzval[5],
+                                        int64_t nnz_out[5]) {
+    if (!mg || !colptr || !rowval || !nzval || !nnz_out) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null argument");
+    if (!mg->planned) return mg_fail(mg, OTMB_ERR_NO_PLAN);
+    mg->planned = false;  // a plan is consumed by its fetch
+    const int nm = mg->args.only_t ? 1 : 5, n = (int)mg->slabs.size();
+    for (int m = 0; m < nm; ++m)
+        if (!colptr[m] || (mg->nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
+    // phase 1: every slab fills its column range on its device and copies the four operators home (their counts are exact
+    // since the plan); T's final count is only known now (entries that summed to exactly zero, src/matrixbuilding.jl:147)
+    run_slabs(mg, [&](int s) {
+        Slab &sl = *mg->slabs[s];
+        auto fail = [&](int32_t st) { sl.status = st; sl.msg = otmb_last_error(sl.ctx); };
+        if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
+        int32_t r;
+        int64_t *dcp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *drv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        double *dnz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        void *p;
+        for (int m = 0; m < nm; ++m) {
+            if ((r = reserve(sl, B_COLPTR0 + m, (size_t)(sl.n_own + 1) * 8, &p))) return fail(r);
+            dcp[m] = (int64_t *)p;
+            if ((r = reserve(sl, B_ROWVAL0 + m, (size_t)sl.nnz[m] * 8, &p))) return fail(r);
+            drv[m] = (int64_t *)p;
+            if ((r = reserve(sl, B_NZVAL0 + m, (size_t)sl.nnz[m] * 8, &p))) return fail(r);
+            dnz[m] = (double *)p;
+        }
+        if ((r = otmb_transportmatrix_set_nnz_base(sl.ctx, sl.base))) return fail(r);
+        if ((r = otmb_transportmatrix_fill_dev(sl.ctx, dcp, drv, dnz))) return fail(r);
+        if ((r = otmb_transportmatrix_nnz(sl.ctx, sl.nnz))) return fail(r);
+        std::vector<OtmbXferItem> down;
+        const bool last = s + 1 == n;
+        for (int m = 1; m < nm; ++m) {
+            down.push_back({dcp[m], colptr[m] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8});
+            if (sl.nnz[m] > 0) {
+                down.push_back({drv[m], rowval[m] + sl.base[m], (size_t)sl.nnz[m] * 8});
+                down.push_back({dnz[m], nzval[m] + sl.base[m], (size_t)sl.nnz[m] * 8});
+            }
+        }
+        if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size()))) return fail(r);
+    });
+    int32_t rc;
+    if ((rc = collect_status(mg))) return rc;
+    // phase 2: T.  A slab whose T lost entries shifts the offsets of every slab below it.
+    std::vector<i64> tbase(n, 0);
+    i64 run = 0;
+    for (int s = 0; s < n; ++s) { tbase[s] = run; run += mg->slabs[s]->nnz[0]; }
+    run_slabs(mg, [&](int s) {
+        Slab &sl = *mg->slabs[s];
+        if (hipSetDevice(sl.device) != hipSuccess) { sl.status = OTMB_ERR_HIP; sl.msg = "hipSetDevice"; return; }
+        const bool last = s + 1 == n;
+        std::vector<OtmbXferItem> down;
+        down.push_back({sl.buf[B_COLPTR0].p, colptr[0] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8});
+        if (sl.nnz[0] > 0) {
+            down.push_back({sl.buf[B_ROWVAL0].p, rowval[0] + tbase[s], (size_t)sl.nnz[0] * 8});
+            down.push_back({sl.buf[B_NZVAL0].p, nzval[0] + tbase[s], (size_t)sl.nnz[0] * 8});
+        }
+        const int32_t r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size());
+        if (r) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
+        const i64 delta = sl.base[0] - tbase[s];  // entries that the slabs above reserved and did not store
+        if (delta > 0) {
+            i64 *cp = colptr[0] + sl.wet_base;
+            const i64 cnt = sl.n_own + (last ? 1 : 0);
+            for (i64 q = 0; q < cnt; ++q) cp[q] -= delta;
+        }
+    });
+    if ((rc = collect_status(mg))) return rc;
+    for (int m = 0; m < 5; ++m) {
+        i64 tot = 0;
+        for (Slab *sl : mg->slabs) tot += sl->nnz[m];
+        nnz_out[m] = mg->nnz[m] = (m < nm) ? tot : 0;
+    }
+    return OTMB_OK;
+}
+
+}  // extern "C"

@@ -31,25 +31,15 @@ from .capi import HDIRS, MATS, PHI_ORDER
 
 def balanced_partition(level_counts, world):
     """Split levels 0..nz-1 into `world` consecutive slabs with >= 1 level each, wet counts as even as a
-    greedy sweep gets them (upper levels are wetter, so equal level counts would not balance)."""
-    counts = np.asarray(level_counts, dtype=np.int64)
-    nz = len(counts)
+    greedy sweep gets them (upper levels are wetter, so equal level counts would not balance).  ONE rule for the
+    package: the library's otmb_balanced_partition (pure host arithmetic, needs no GPU), which the single-process
+    multi-GPU entry points (otmb_mgpu_*, include/otmb.h) cut their slabs with as well."""
+    nz = len(level_counts)
     if world > nz:
         raise ValueError(f"{world} ranks but only {nz} levels")
-    total = int(counts.sum())
-    cum = np.concatenate([[0], np.cumsum(counts)])
-    bounds = [0]
-    for r in range(1, world):
-        target = total * r / world
-        k = int(np.searchsorted(cum, target, side="left"))
-        # pick the closer of k-1, k; keep >= 1 level per slab on both sides
-        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, nz)] - target):
-            k -= 1
-        k = max(k, bounds[-1] + 1)
-        k = min(k, nz - (world - r))
-        bounds.append(k)
-    bounds.append(nz)
-    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+    from . import capi
+
+    return capi.balanced_partition([int(x) for x in np.asarray(level_counts, dtype=np.int64)], world)
 
 
 class Comm:

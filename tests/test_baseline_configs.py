@@ -175,3 +175,38 @@ def test_large_grid_properties_and_subslab_oracle(oracle, workload, slab, protoc
         _subslab_oracle_check(oracle, dg, asm, dg.nz - 1, dg.nz)
     del asm, dg
     torch.cuda.empty_cache()
+
+
+# ---- config 2's own content at its stated size ------------------------------------------------------------------------
+def test_access1deg_bolus_gm_velocity_matches_oracle(access1deg, oracle):
+    """BASELINE.json configs[1] names the Redi/GM triads.  In the reference they never enter T (src/RediGM.jl:44); what exists is
+    bolus_GM_velocity (src/RediGM.jl:46-79, src/triads.jl:84-146, src/dyads.jl:38-78): here on the 360x300x50 grid config 2 is
+    quoted on, device-resident through the C ABI, against the oracle -- NaN pattern exact, values at 1e-12 relative (tanh is the
+    only inexact operation).  Unpinned like the function itself: no reference test asserts anything about it."""
+    import ctypes as C
+
+    import torch
+
+    from otmb_amd import capi
+
+    g, gm = access1deg
+    idx = oracle.makeindices(gm.v3D)
+    dn = gm.distance_to_neighbour_2D
+    ru, rv = oracle.bolus_gm_velocity(g.rho, gm.Z3D, idx["wet3D"], dn["east"], dn["north"], gm.gridtopology.kind)
+    ctx = capi.Context(0)
+    nx, ny, nz = gm.v3D.shape
+    rho, z3d, de, dnn = _flat(g.rho), _flat(gm.Z3D), _flat(dn["east"]), _flat(dn["north"])
+    wet = torch.from_numpy(np.asfortranarray(idx["wet3D"]).view(np.uint8).ravel(order="F")).cuda()
+    u, v = torch.empty_like(rho), torch.empty_like(rho)
+    torch.cuda.synchronize()
+    ctx.check(capi.lib().otmb_bolus_gm_velocity_dev(ctx.handle, rho.data_ptr(), z3d.data_ptr(), wet.data_ptr(), de.data_ptr(), dnn.data_ptr(),
+                                                    nx, ny, nz, int(gm.gridtopology.kind), 600.0, 0.01, u.data_ptr(), v.data_ptr()))
+    ctx.synchronize()
+    hu = u.cpu().numpy().reshape((nx, ny, nz), order="F")
+    hv = v.cpu().numpy().reshape((nx, ny, nz), order="F")
+    ctx.close()
+    wet3 = idx["wet3D"].astype(bool)
+    assert np.array_equal(np.isnan(hu), np.isnan(ru)) and np.array_equal(np.isnan(hv), np.isnan(rv))
+    assert np.all(np.isnan(hu[~wet3])) and np.isfinite(hu[wet3]).mean() > 0.5
+    np.testing.assert_allclose(hu, ru, rtol=1e-12, atol=0, equal_nan=True)
+    np.testing.assert_allclose(hv, rv, rtol=1e-12, atol=0, equal_nan=True)

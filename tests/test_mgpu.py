@@ -1,0 +1,194 @@
+"""Depth slabs over several GPUs of ONE process, behind the C ABI (otmb_mgpu_*, include/otmb.h): what a Julia
+caller reaches with `transportmatrix(...; devices = 0:7)`.  On a one-GPU box N contexts share GPU 0 and the facefluxes chain's
+planes are handed over by device-to-device copies; with every slab on its own GPU the same code hands them over with grouped
+ncclSend / ncclRecv on a single-process RCCL communicator (the last test: skipped below 2 GPUs).  Whole-grid oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import MATS, assert_csc_equal, gridmetrics_of
+
+
+def _py_partition(level_counts, world):
+    """The rule as rounds 1-3 had it in dist.py (floating-point target); the library restates it in exact integer arithmetic."""
+    counts = np.asarray(level_counts, dtype=np.int64)
+    nz = len(counts)
+    total = int(counts.sum())
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(cum, target, side="left"))
+        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, nz)] - target):
+            k -= 1
+        k = max(k, bounds[-1] + 1)
+        k = min(k, nz - (world - r))
+        bounds.append(k)
+    bounds.append(nz)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def test_balanced_partition_is_host_arithmetic_and_matches_the_rule():
+    """No GPU: the library cuts levels into slabs (>= 1 level each, consecutive, covering) as the Python rule did."""
+    from otmb_amd import capi, dist
+
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        nz = int(rng.integers(1, 80))
+        world = int(rng.integers(1, min(nz, 9) + 1))
+        counts = np.sort(rng.integers(0, 100000, nz))[::-1] if trial % 2 else rng.integers(0, 50, nz)
+        got = capi.balanced_partition(counts, world)
+        assert got[0][0] == 0 and got[-1][1] == nz and all(a < b for a, b in got)
+        assert all(got[r][1] == got[r + 1][0] for r in range(world - 1))
+        if counts.sum() * world < 2 ** 52:  # where the floating-point target is exact enough to compare
+            assert got == _py_partition(counts, world), (counts, world)
+        assert dist.balanced_partition(counts, world) == got
+    with pytest.raises(ValueError):
+        capi.balanced_partition([1, 2], 3)
+
+
+def _reference(oracle, g, gm, upwind=True, kappa=None):
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    kH, kML, kD = kappa if kappa is not None else (g.kappaH, g.kappaVML, g.kappaVdeep)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, kH, kML, kD, upwind)
+    return ref, rphi, rtm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev,rho,upwind", [(1, "array", True), (2, "array", True), (3, "scalar", False), (8, "array", True)])
+def test_mgpu_on_one_gpu_matches_whole_grid_oracle(oracle, ndev, rho, upwind):
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(24, 18, 11, seed=33 + ndev, rho=rho)
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm, upwind)
+    devices = [0] * ndev
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+    for k in rphi:
+        same = (phi[k] == rphi[k]) & (np.signbit(phi[k]) == np.signbit(rphi[k]))
+        assert same.all(), (k, np.argwhere(~same)[:3])
+    mg = api.mgpu(devices)
+    assert mg.transport == "same-device copy"
+    bounds = mg.partition()
+    assert bounds[0] == 0 and bounds[-1] == 11 and len(bounds) == ndev + 1 and all(a < b for a, b in zip(bounds, bounds[1:]))
+    for operators in (True, False):
+        tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, upwind=upwind, devices=devices,
+                                 operators=operators)
+        for m in MATS if operators else MATS[:1]:
+            assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/ndev={ndev}")
+            assert tm[m].colptr[-1] == len(tm[m].rowval) + 1
+
+
+@pytest.mark.gpu
+def test_mgpu_compacts_T_across_slabs_when_entries_cancel(oracle):
+    """κ = 0: every diffusive value is an explicit 0.0 -- kept in the operators, dropped from T (src/matrixbuilding.jl:147) -- so
+    EVERY slab's T is shorter than its planned (union) bound and every slab below the first must shift its offsets."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(20, 16, 9, seed=41, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm, True, (0.0, 0.0, 0.0))
+    idx = api.makeindices(gm.v3D)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=0.0, κVML=0.0, κVdeep=0.0, devices=[0, 0, 0])
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    assert tm["T"].nnz == tm["Tadv"].nnz < tm["TκH"].nnz + tm["Tadv"].nnz
+
+
+@pytest.mark.gpu
+def test_mgpu_reports_the_reference_error_of_the_failing_slab(oracle):
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+    from otmb_amd.capi import OtmbError
+
+    g = synthetic.make_grid(24, 18, 11, seed=36, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    devices = [0, 0, 0]
+    kw = dict(mlotst=g.mlotst, gridmetrics=gm, indices=idx, devices=devices)
+    # a NaN density in a cell of the deepest wet level: the LAST slab's check (src/matrixbuilding.jl:233)
+    rho = g.rho.copy(order="F")
+    rho.ravel(order="F")[ref["Lwet"][-1] - 1] = np.nan
+    with pytest.raises(OtmbError, match="ρ contains NaNs") as e:
+        api.transportmatrix(ϕ=rphi, ρ=rho, **kw)
+    assert "slab 3 of 3" in str(e.value)
+    # a NaN edge length (TκH, :61) and a NaN density in different slabs: the reference checks ρ first
+    gm2 = dict(gm)
+    gm2["edge_length_2D"] = {d: a.copy(order="F") for d, a in gm.edge_length_2D.items()}
+    wet0 = ref["wet3D"].astype(bool)[:, :, 0]
+    ii, jj = np.argwhere(wet0 & np.roll(wet0, 1, axis=0))[0]
+    gm2["edge_length_2D"]["west"][ii, jj] = np.nan
+    with pytest.raises(OtmbError, match="TκH contains NaNs."):
+        api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm2, indices=idx, devices=devices)
+    with pytest.raises(OtmbError, match="ρ contains NaNs"):
+        api.transportmatrix(ϕ=rphi, ρ=rho, mlotst=g.mlotst, gridmetrics=gm2, indices=idx, devices=devices)
+    # facefluxes: a field without a single valid value is an assertion over the WHOLE grid (src/velocities.jl:199-200)
+    with pytest.raises(OtmbError, match="AssertionError"):
+        api.facefluxes(np.full(g.umo.data.shape, np.nan), g.vmo.data, gm, idx, FillValue=1e20, devices=devices)
+    # valid values in ONE slab only are enough
+    u = np.full(g.umo.data.shape, 1e20, order="F")
+    u[:, :, -1] = g.umo.data[:, :, -1]
+    got = api.facefluxes(u, g.vmo.data, gm, idx, FillValue=1e20, devices=devices)
+    want = oracle.facefluxes(u, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    # and the object is usable after every one of these errors
+    tm = api.transportmatrix(ϕ=rphi, ρ=g.rho, **kw)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    # more devices than levels, a device twice among others
+    with pytest.raises(OtmbError):
+        api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm, indices=idx, devices=[0] * 12)
+
+
+@pytest.mark.gpu
+def test_mgpu_at_the_headline_grid_matches_the_single_device_path():
+    """BASELINE.json configs[0/1]'s grid (360x300x50) cut into 4 slabs on GPU 0 against the single-context host path of the same
+    library: identical bytes (the single-context path is compared with the oracle on this grid by tests/test_baseline_configs.py)."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    nx, ny, nz, lf = synthetic.PRESETS["access1deg"]
+    g = synthetic.make_grid(nx, ny, nz, seed=20260501, land_fraction=lf, rho="array")
+    gm = gridmetrics_of(g)
+    idx = api.makeindices(gm.v3D)
+    phi1 = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    phi4 = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=[0, 0, 0, 0])
+    for k in phi1:
+        assert np.array_equal(phi1[k].view(np.int64), phi4[k].view(np.int64)), k
+    tm1 = api.transportmatrix(ϕ=phi1, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho)
+    tm4 = api.transportmatrix(ϕ=phi4, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=[0, 0, 0, 0])
+    for m in MATS:
+        assert_csc_equal(tuple(tm4[m]), tuple(tm1[m]), m)
+
+
+@pytest.mark.gpu
+def test_mgpu_over_rccl_one_gpu_per_slab(oracle):
+    """Every slab on its own GPU: the chain's planes cross xGMI as grouped ncclSend / ncclRecv pairs on the single-process
+    communicator.  Skipped on a one-GPU box."""
+    import torch
+
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"needs at least 2 GPUs ({n} visible)")
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    devices = list(range(min(n, 8)))
+    g = synthetic.make_grid(24, 18, 12, seed=37, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+    assert api.mgpu(devices).transport == "rccl"
+    for k in rphi:
+        assert np.array_equal(phi[k], rphi[k]), k
+    tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
