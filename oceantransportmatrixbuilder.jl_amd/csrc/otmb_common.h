@@ -45,12 +45,13 @@ struct otmb_ctx {
     DevBuf order;             // tile order of the fill pass (march order: otmb_ctx_set_tile_order) + its bucket scratch
     int march_rows = -1;      // rows per band of the march order; 0 = wet-rank order; -1 = the library's default
     struct OrderKey {
-        const void *lwet = nullptr; int64_t n = 0, nx = 0, ny = 0, nz = 0; int rows = 0;
-        bool operator==(const OrderKey &o) const { return lwet == o.lwet && n == o.n && nx == o.nx && ny == o.ny && nz == o.nz && rows == o.rows; }
+        const void *lwet = nullptr; int64_t n = 0, nx = 0, ny = 0, nz = 0; int rows = 0, topo = -1;
+        bool operator==(const OrderKey &o) const { return lwet == o.lwet && n == o.n && nx == o.nx && ny == o.ny && nz == o.nz && rows == o.rows && topo == o.topo; }
     } order_key;              // what ctx->order was built for
+    int deal_heavy = 1;         // 0: the heavy tiles stay in the first XCD's share (experiments: OTMB_DEAL_HEAVY)
+    unsigned order_nheavy = 0;  // the order's first entries are this many heavy tiles (tripolar seam row), dealt over the XCDs
     int ff_xcd_chunks = 1;    // facefluxes: XCD x takes the x-th contiguous eighth of the column blocks (0 = blockIdx order; experiments: OTMB_FF_XCD)
-    int count_order = 1;      // counting pass: 0 = blockIdx (wet-rank) order, 1 = XCD-contiguous eighths of wet-rank order, 2 = the fill pass's tile order (OTMB_COUNT_ORDER)
-    int pf_dist = -1;         // fill pass: a workgroup prefetches the Lwet lines of the tile taken pf_dist positions later in its XCD's sequence (0 = off, -1 = default; OTMB_PF_DIST)
+    int count_order = 0;      // counting pass: 0 = blockIdx (wet-rank) order (default: measured fastest), 1 = XCD-contiguous eighths of wet-rank order, 2 = of the fill pass's tile order (OTMB_COUNT_ORDER)
     int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)
     int dense_kparts = 1;     // dense march: depth pieces per (row, segment)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)

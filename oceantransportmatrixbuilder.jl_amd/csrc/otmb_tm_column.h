@@ -49,8 +49,35 @@ struct TmParams {
     int *next_state;       // the NEXT asynchronous step's state block, zeroed by this fill (or NULL): no memset between steps
     const unsigned *order; // fill pass: tile taken by the q-th workgroup slot (march order), or NULL = wet-rank order
     int count_order;       // counting pass: 0 blockIdx order, 1 XCD-contiguous eighths, 2 XCD-contiguous eighths of `order`
-    int pf_dist;           // fill pass: prefetch the Lwet lines of the tile pf_dist positions later in this XCD's sequence (0 = off)
+    unsigned nt_order;     // number of tiles (the fill pass's grid may be a few workgroups larger: xcd_position)
+    unsigned nheavy;       // `order` starts with this many HEAVY tiles (tripolar seam row: generic column builder), dealt over the XCDs
 };
+
+// Which position of the tile sequence does workgroup b take?  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2):
+// XCD x = b % 8 takes (1) every eighth of the sequence's first `nh` positions -- the HEAVY tiles, whose waves live about twice as
+// long (tripolar seam row: generic column builder); left in one XCD's share they made that XCD finish 10-20 us after the other
+// seven (profiles/r04: dispatch timeline), 5 % of a 1 degree fill pass with seven eighths of the chip idle -- and then (2) the x-th
+// contiguous eighth of the remaining positions, so that a tile's south / north rows and the levels above / below, which the same
+// XCD touched a little earlier, are L2 hits instead of fabric re-reads.  Returns false for the (at most 15) workgroups of the
+// rounded-up grid that have nothing to do.  Speed only: every position is taken exactly once whatever nh is.
+__device__ __forceinline__ bool xcd_position(unsigned b, unsigned nt, unsigned nh, unsigned &pos) {
+    const unsigned x = b % 8u, y = b / 8u;
+    const unsigned hx = (nh + 7u - x) / 8u;  // heavy positions x, x + 8, ... below nh
+    const unsigned R = nt - nh, q = R / 8u, r = R % 8u;
+    const unsigned rx = q + (x < r ? 1u : 0u), rstart = (x < r) ? x * (q + 1u) : r * (q + 1u) + (x - r) * q;
+    if (y >= hx + rx) return false;
+    pos = (y < hx) ? x + 8u * y : nh + rstart + (y - hx);
+    return true;
+}
+// grid size of a launch that maps its workgroups with xcd_position
+static inline unsigned xcd_grid(unsigned nt, unsigned nh) {
+    unsigned m = 0;
+    for (unsigned x = 0; x < 8; ++x) {
+        const unsigned hx = (nh + 7u - x) / 8u, R = nt - nh, c = hx + R / 8u + (x < R % 8u ? 1u : 0u);
+        m = c > m ? c : m;
+    }
+    return 8u * m;
+}
 
 // Diagnostic build only (-DOTMB_DBG_STAMPS, tools/stamps.py): s_memtime stamps of the phases of a wave of the fill
 // pass, kept in SGPR pairs and written by lane 0 at the end to a buffer nothing else reads (p.status).  STAMP(n, WAITVM)

@@ -30,10 +30,6 @@
 #define OTMB_MARCH_AUTO_ROWS 8  // tile order when the caller does not choose: march order, bands of 8 rows (with the matrices written by
                                 // non-temporal stores: -8 % against wet-rank order at 1 and at 0.25 degree, R = 2 ... 32 within 1 %)
 #endif
-#ifndef TM_PF_DEFAULT
-#define TM_PF_DEFAULT 96  // index prefetch distance of the fill pass, in tiles of one XCD's sequence: 96 = the workgroups an XCD holds at once
-                          // (3 per CU x 32 CUs), i.e. the tile that starts about one workgroup life later
-#endif
 #define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
@@ -130,9 +126,10 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
     // read again by later tiles -- are found in the same L2 (count_order 1: wet-rank sequence, 2: the fill pass's march sequence).
     i64 blk = blockIdx.x;
     if (p.count_order) {
-        const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
-        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-        if (TPB == 1 && p.count_order == 2 && p.order) blk = p.order[blk];
+        unsigned pos;
+        if (!xcd_position(blockIdx.x, gridDim.x, 0u, pos)) return;
+        blk = pos;
+        if (TPB == 1 && p.count_order == 2 && p.order) blk = p.order[pos];
     }
     u64 mine[TPB];
 #pragma unroll
@@ -274,19 +271,11 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     // the same XCD touched a little earlier, are L2 hits instead of fabric re-reads.  Speed only: any
     // bijection is correct.
     i64 tile = blockIdx.x;
-    i64 pf_tile = -1;  // the tile whose index lines this workgroup prefetches (below)
     if (MODE != MODE_ONEPASS) {
-        const i64 nt = gridDim.x, q = nt / 8, r = nt % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
-        const i64 pos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-        const bool pf = MODE == MODE_FILL && p.pf_dist > 0 && y + p.pf_dist < q + (x < r ? 1 : 0);  // still inside this XCD's eighth
-        const i64 ppos = pf ? pos + p.pf_dist : pos;
+        unsigned pos;
+        if (!xcd_position(blockIdx.x, p.nt_order, p.nheavy, pos)) return;  // (the whole workgroup: no barrier has been reached)
         tile = pos;
-        i64 pt = ppos;
-        if (p.order) {  // march order: the XCD's eighth is a run of (row band, level) buckets
-            tile = p.order[pos];
-            pt = p.order[ppos];  // (unconditional: both entries in one round trip)
-        }
-        if (pf) pf_tile = pt;
+        if (p.order) tile = p.order[pos];  // march order: heavy tiles first, then the XCD's eighth is a run of (row band, level) buckets
     }
 #ifdef OTMB_DBG_STAMPS_ORDER  // diagnostic (tools/stamps.py): when is the tile id known (kernel arguments + tile order)
     STAMP(st, 6, 1);
@@ -331,16 +320,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 Lnext_own = (wcl + 1 < p.n_own) ? Lnext_ld : p.G;
     const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
-    // Prefetch for the workgroup that will follow on this XCD: a tile's first act is a dependent trip to HBM for its 2 KB of Lwet
-    // (read once per launch, so never in a cache: 15 % of a wave's life with nothing else in flight, tools/stamps.py).  The tile
-    // pf_dist positions further down this XCD's sequence starts about one workgroup life from now: touch its lines now (one
-    // load per lane, issued BEHIND the wave's own index loads -- loads return in order), so that its trip ends in this L2.
-    // The value is only compared with a constant no index can take, beside the canonical-indices check.
-    i64 pf_val = 0;
-    if (MODE == MODE_FILL) {
-        const i64 pw = (pf_tile >= 0 ? pf_tile : tile) * TM_THREADS + tid;
-        pf_val = p.lwet[pw < p.n_own ? pw : p.n_own - 1];
-    }
     unsigned pre_sum = 0;
     i64 pre_off = 0;
     if (MODE == MODE_FILL && tid < TM_NF) {
@@ -411,7 +390,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 }
 #endif
             }
-            if (!canonical | (pf_val == (i64)0x8000000000000000ll)) {
+            if (!canonical) {
                 raise_flag(p.flags, FLAG_NONCANONICAL);
             } else {
                 live = true;
@@ -727,22 +706,30 @@ __global__ __launch_bounds__(TFIX_THREADS) void tfix_move(const uint8_t *__restr
 // plus 300 MB of outputs on a 1440x1080 grid, past every cache -- so they come from HBM three times.  In march order the
 // tiles of a band of R rows are taken level after level: the same lines are needed again a few tiles later and are
 // served by the L2 / Infinity Cache.  Bucket = (band, level); a counting sort of the tiles by bucket.  Speed only.
-__device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 t, int nx, int ny, i64 P, int rows, int nz) {
+__device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 t, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo) {
     const i64 L = lwet[t * TM_THREADS] - 1;  // (whatever Lwet holds, the key stays inside the bucket table)
     i64 k = L / P, j = (L - k * P) / nx;
     k = k < 0 ? 0 : (k >= nz ? nz - 1 : k);
     j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+    // HEAVY tiles -- bucket 0, the front of the sequence, dealt over the XCDs by xcd_position: tiles with cells on the tripolar
+    // seam row (generic column builder, waves live about twice as long).  Lwet ascends, so the tile's cells lie between its
+    // first and its last entry in (level, row) order: it touches row ny - 1 iff it starts there, ends there or runs into the next level.
+    if (topo == OTMB_TRIPOLAR && nx >= 3) {
+        const i64 wl = (t * TM_THREADS + TM_THREADS - 1 < n) ? t * TM_THREADS + TM_THREADS - 1 : n - 1;
+        const i64 L1 = lwet[wl] - 1;
+        i64 k1 = L1 / P, j1 = (L1 - k1 * P) / nx;
+        if (j == ny - 1 || j1 == ny - 1 || k1 > k) return 0u;
+    }
 #ifdef OTMB_MARCH_SOUTH_FIRST
-    return (unsigned)(j / rows) * (unsigned)nz + (unsigned)k;
+    return 1u + (unsigned)(j / rows) * (unsigned)nz + (unsigned)k;
 #else
-    // bands from north to south: the tripolar seam row (generic column builder, several times slower per wave) is then taken at the
-    // START of the first XCD's eighth, not as the tail of the last one
-    return (unsigned)((ny - 1 - j) / rows) * (unsigned)nz + (unsigned)k;
+    // bands from north to south
+    return 1u + (unsigned)((ny - 1 - j) / rows) * (unsigned)nz + (unsigned)k;
 #endif
 }
-__global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, int nx, int ny, i64 P, int rows, int nz, unsigned *hist) {
+__global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, unsigned *hist) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ntiles) atomicAdd(&hist[order_key(lwet, t, nx, ny, P, rows, nz)], 1u);
+    if (t < ntiles) atomicAdd(&hist[order_key(lwet, t, n, nx, ny, P, rows, nz, topo)], 1u);
 }
 __global__ __launch_bounds__(1024) void order_scan(unsigned *hist, i64 nbuckets) {  // in place: exclusive prefix
     __shared__ unsigned wave_tot[16];
@@ -771,28 +758,31 @@ __global__ __launch_bounds__(1024) void order_scan(unsigned *hist, i64 nbuckets)
 }
 // every tile takes the next free position of its bucket: a bijection whatever the keys are (the order inside a bucket
 // -- a few dozen neighbouring tiles -- is left to the atomics)
-__global__ void order_scatter(const i64 *__restrict__ lwet, i64 ntiles, int nx, int ny, i64 P, int rows, int nz, unsigned *cursor,
+__global__ void order_scatter(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, unsigned *cursor,
                               unsigned *order) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ntiles) order[atomicAdd(&cursor[order_key(lwet, t, nx, ny, P, rows, nz)], 1u)] = (unsigned)t;
+    if (t < ntiles) order[atomicAdd(&cursor[order_key(lwet, t, n, nx, ny, P, rows, nz, topo)], 1u)] = (unsigned)t;
 }
 
 // Decide and build the tile order of a fill launch.  Returns the device pointer (or NULL: wet-rank order).
-static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles, const unsigned **out) {
-    *out = nullptr;
+static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles, TmParams &p) {
+    p.order = nullptr;
+    p.nt_order = (unsigned)ntiles;
+    p.nheavy = 0;
     int rows = ctx->march_rows;
     if (rows < 0) rows = OTMB_MARCH_AUTO_ROWS;
-    if (rows <= 0 || ntiles < 64 || ntiles >= (1ll << 31)) return OTMB_OK;
+    if (rows <= 0 || ntiles < 64 || ntiles >= (1ll << 31) - 16) return OTMB_OK;
     if (rows > a.ny) rows = (int)a.ny;
-    const i64 nbands = (a.ny + rows - 1) / rows, nbuckets = nbands * a.nz;
+    const i64 nbands = (a.ny + rows - 1) / rows, nbuckets = nbands * a.nz + 1;
     if (nbuckets >= (1ll << 31)) return OTMB_OK;
     const size_t ob = ((size_t)ntiles * sizeof(unsigned) + 255) / 256 * 256, bb = ((size_t)nbuckets * sizeof(unsigned) + 255) / 256 * 256;
     // the order is a function of the grid alone: computed once per (Lwet array, shape, band height) and kept.  (Any permutation of
     // the tiles is correct, so an Lwet array rewritten in place can only cost speed.)
     otmb_ctx::OrderKey key;
-    key.lwet = a.lwet; key.n = a.n_wet; key.nx = a.nx; key.ny = a.ny; key.nz = a.nz; key.rows = rows;
+    key.lwet = a.lwet; key.n = a.n_wet; key.nx = a.nx; key.ny = a.ny; key.nz = a.nz; key.rows = rows; key.topo = a.topology;
     if (ctx->order.p && ctx->order.cap >= ob + bb && ctx->order_key == key) {
-        *out = (const unsigned *)ctx->order.p;
+        p.order = (const unsigned *)ctx->order.p;
+        p.nheavy = ctx->deal_heavy ? ctx->order_nheavy : 0u;
         return OTMB_OK;
     }
     int32_t rc;
@@ -802,17 +792,26 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
     ctx->order_key = otmb_ctx::OrderKey();
     if ((rc = otmb_reserve(ctx, ctx->order, ob + bb))) return rc;
     unsigned *order = (unsigned *)ctx->order.p, *hist = (unsigned *)((char *)ctx->order.p + ob);
-    KernelTimer kt(ctx, K_TM_ORDER);
-    HIP_TRY(ctx, hipMemsetAsync(hist, 0, bb, ctx->stream));
-    const unsigned nb = (unsigned)((ntiles + 255) / 256);
-    hipLaunchKernelGGL(order_hist, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (int)a.nx, (int)a.ny, a.nx * a.ny, rows,
-                       (int)a.nz, hist);
-    hipLaunchKernelGGL(order_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, nbuckets);
-    hipLaunchKernelGGL(order_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (int)a.nx, (int)a.ny, a.nx * a.ny, rows,
-                       (int)a.nz, hist, order);
+    {
+        KernelTimer kt(ctx, K_TM_ORDER);
+        HIP_TRY(ctx, hipMemsetAsync(hist, 0, bb, ctx->stream));
+        const unsigned nb = (unsigned)((ntiles + 255) / 256);
+        hipLaunchKernelGGL(order_hist, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (i64)a.n_wet, (int)a.nx, (int)a.ny, a.nx * a.ny,
+                           rows, (int)a.nz, (int)a.topology, hist);
+        hipLaunchKernelGGL(order_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, nbuckets);
+        // the number of heavy tiles = the exclusive prefix at bucket 1: the host needs it (grid size, kernel argument), once per grid
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot + 14, hist + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        hipLaunchKernelGGL(order_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (i64)a.n_wet, (int)a.nx, (int)a.ny, a.nx * a.ny,
+                           rows, (int)a.nz, (int)a.topology, hist, order);
+    }
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned nh = *(const unsigned *)(ctx->h_tot + 14);
+    if (nh > (unsigned)ntiles) nh = 0;  // (cannot happen; any value <= ntiles is a correct mapping)
+    ctx->order_nheavy = nh;
     ctx->order_key = key;
-    *out = order;
+    p.order = order;
+    p.nheavy = ctx->deal_heavy ? nh : 0u;
     return OTMB_OK;
 }
 
@@ -888,7 +887,8 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.tileoffs = (const i64 *)ctx->tm_offs.p;
     p.flags = (int *)ctx->flags.p;
     p.count_order = ctx->count_order;
-    p.pf_dist = ctx->pf_dist < 0 ? TM_PF_DEFAULT : ctx->pf_dist;
+    p.nt_order = (unsigned)((a.n_wet + TM_THREADS - 1) / TM_THREADS);
+    p.nheavy = 0;
 }
 
 // The counting pass reads the push mask: the caller's (written by facefluxes for exactly these ϕ), or one derived
@@ -1066,7 +1066,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
     } else if (ntiles > 0) {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
-        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, &p.order))) return rc;
+        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
@@ -1124,9 +1124,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
         if ((rc = dense_prepare(ctx, pl.args, pl.dm, p, g))) return rc;  // (the buffers of the plan: nothing is reallocated)
         dense_launch_fill(ctx, pl.dm, p, g, (const i64 *)(dflags + OTMB_NFLAGS));
     } else if (pl.ntiles > 0) {
-        if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, &p.order))) return rc;
+        if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, p))) return rc;
         KernelTimer kt(ctx, K_TM_FILL);
-        hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)pl.ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
     }
     if (pl.ntiles == 0) {  // (otherwise the fill kernel's last tile writes the closing colptr entries)
         KernelTimer kt(ctx, K_TM_FINISH);
@@ -1262,7 +1262,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     } else {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
-        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, &p.order))) return rc;
+        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
         {
             KernelTimer kt(ctx, K_TM_COUNT);
             hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
@@ -1283,9 +1283,9 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
             if ((rc = otmb_reserve(ctx, ctx->lookback, (size_t)ntiles * (TM_THREADS / 64) * OTMB_NSTAMP * sizeof(u64)))) return rc;
             p.status = (u64 *)ctx->lookback.p;
 #endif
-            if ((rc = build_tile_order(ctx, *a, ntiles, &p.order))) return rc;
+            if ((rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
             KernelTimer kt(ctx, K_TM_FILL);
-            hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
+            hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

@@ -76,6 +76,25 @@ xcc = (t[:, 7] >> 32) & 0xf
 cu_key = ((hw >> 8) & 0xff) | (xcc << 8)  # CU id (4 bits), SH (1), SE (3) inside an XCD, and the XCD
 print("  distinct (XCD, SE, SH, CU) values:", len(np.unique(cu_key)), " XCDs seen:", sorted(int(x) for x in np.unique(xcc)))
 
+# ---- heavy tiles (tripolar seam row: generic column builder) against the rest ----
+try:
+    lw = asm.lwet[: asm.N].cpu().numpy() - 1
+    P_ = nx * ny
+    first = lw[0::256][:ntiles]
+    last = lw[np.minimum(np.arange(ntiles) * 256 + 255, asm.N - 1)]
+    k0_, j0_ = first // P_, (first % P_) // nx
+    k1_, j1_ = last // P_, (last % P_) // nx
+    heavy_tile = (j0_ == ny - 1) | (j1_ == ny - 1) | (k1_ > k0_)
+    tile_of_wave = (np.arange(nw) // 4)[ok]
+    hv = heavy_tile[tile_of_wave]
+    lf = (t[:, 9] - t[:, 8]) / 100.0
+    print(f"  heavy tiles (cells on the seam row): {int(heavy_tile.sum())} of {ntiles}; wave life heavy {lf[hv].mean():.2f} us (max {lf[hv].max():.2f}), "
+          f"regular {lf[~hv].mean():.2f} us -> weight {lf[hv].mean() / lf[~hv].mean():.2f}")
+    xh = ((t[:, 7] >> 32) & 0xf)[hv]
+    print("  heavy waves per XCD:", {int(x): int((xh == x).sum()) for x in np.unique(xh)})
+except Exception as e:  # diagnostics only
+    print("  (heavy-tile statistics unavailable:", repr(e), ")")
+
 # ---- dispatch timeline (s_memrealtime: 100 MHz, the same counter on every XCD) ----
 t0, t1 = t[:, 8], t[:, 9]
 k0, k1 = t0.min(), t1.max()
