@@ -144,6 +144,33 @@ __device__ __forceinline__ void raise_flag(int *flags, int f) {
     if (flags[f] == 0) atomicExch(&flags[f], 1);
 }
 
+// ---- THE value expressions of the three generators: one copy, used by the generic column builder (build_column) and by the
+// regular-cell arithmetic (column_compute) that both the gather kernel (fast_column) and the dense-march kernel call. -------------
+#ifdef OTMB_DBG_MULDIV  // timing experiment only: what the 28 divisions of a column cost (wrong values)
+#define FDIV(a, b) ((a) * (b))
+#else
+#define FDIV(a, b) ((a) / (b))
+#endif
+// pushTadvectionvalues! (src/matrixbuilding.jl:193-204): ρ̄ = (ρx + ρc) / 2; row x: -ϕ / (ρ̄ vx); diagonal: ϕ / (ρ̄ vc)
+__device__ __forceinline__ void adv_pair(double phi, double rx, double rc, double vx, double vc, double &off, double &dg) {
+    const double rb = (rx + rc) / 2;
+    off = FDIV(-phi, (rb * vx));
+    dg = FDIV(phi, (rb * vc));
+}
+// pushTmixingvalues! for a horizontal neighbour (:348-415, :426-435): a = min(thk_c e_c, thk_x e_x) shared by the cell's own push
+// (+Tval on the diagonal) and the neighbour's push towards the cell (-Tval' on row x)
+__device__ __forceinline__ void h_pair(double kH, double tc, double e_c, double tx, double e_x, double d_c, double vc, double d_x, double vx,
+                                       double &own, double &in) {
+    const double a = jl_min(tc * e_c, tx * e_x);
+    own = FDIV((kH * a), (d_c * vc));
+    in = FDIV((kH * a), (d_x * vx));
+}
+// the same for a vertical neighbour (:450-477): a = area2D, d = |zt[k] - zt[k']|
+__device__ __forceinline__ void v_pair(double kar, double d, double vc, double vx, double &own, double &in) {
+    own = FDIV(kar, (d * vc));
+    in = FDIV(kar, (d * vx));
+}
+
 // Build the column of wet cell `cell` (c = own wet rank > 0): generic path, any topology corner case.
 __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell, i64 c, Column &col) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
@@ -252,12 +279,7 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
 #define ADV_VALUES(ACTIVE, RX, VX, PHI, OFF, DG)                      \
     double OFF = 0.0, DG = 0.0;                                       \
     if (ACTIVE) {                                                     \
-        const double rx_ = (RX);                                      \
-        const double rb_ = (rx_ + rc) / 2;                            \
-        const double mx_ = rb_ * (VX);                                \
-        const double mc_ = rb_ * vc;                                  \
-        OFF = -(PHI) / mx_;                                           \
-        DG = (PHI) / mc_;                                             \
+        adv_pair((PHI), (RX), rc, (VX), vc, OFF, DG);                 \
         anynan |= isnan(OFF) | isnan(DG);                             \
     }
         ADV_VALUES(aA, rA_, vA_, fA, oA, dA)
@@ -293,11 +315,7 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
         double ownW = 0, ownE = 0, ownS = 0, ownN = 0, inW = 0, inE = 0, inS = 0, inN = 0;
 #define H_VALUES(WET, TX, VX, E_C, E_X, D_C, D_X, OWN, IN)                         \
     if (WET) {                                                                     \
-        const double aij_ = thc * (E_C);                                           \
-        const double aji_ = (TX) * (E_X);                                          \
-        const double a_ = jl_min(aij_, aji_);                                      \
-        OWN = (p.kH * a_) / ((D_C) * vc);                                          \
-        IN = (p.kH * a_) / ((D_X) * (VX));                                         \
+        h_pair(p.kH, thc, (E_C), (TX), (E_X), (D_C), vc, (D_X), (VX), OWN, IN);     \
         anynan |= isnan(OWN) | isnan(IN);                                          \
     }
         H_VALUES(xWc != 0, tWc, vWc, eW_c, eE_w, dW_c, dE_w, ownW, inW)
@@ -335,12 +353,14 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
         if (xB) {  // from bottom (own push first, B then T)
             const double ztb = ztb_;
             const double d = fabs(ztk - ztb);
-            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * vB_);
+            double ownD, inD;
+            v_pair(p.kDeep * ar, d, vc, vB_, ownD, inD);
             nandp |= isnan(ownD) | isnan(inD);
             acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
             acc(col.dp[S_B], col.pdp, S_B, -inD);
             if (omc && (ztb < mld)) {
-                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * vB_);
+                double ownM, inM;
+                v_pair(p.kML * ar, d, vc, vB_, ownM, inM);
                 nanml |= isnan(ownM) | isnan(inM);
                 acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
                 acc(col.ml[S_B], col.pml, S_B, -inM);
@@ -349,12 +369,14 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
         if (xA) {
             const double zta = zta_;
             const double d = fabs(ztk - zta);
-            const double ownD = (p.kDeep * ar) / (d * vc), inD = (p.kDeep * ar) / (d * vA_);
+            double ownD, inD;
+            v_pair(p.kDeep * ar, d, vc, vA_, ownD, inD);
             nandp |= isnan(ownD) | isnan(inD);
             acc(col.dp[S_SELF], col.pdp, S_SELF, ownD);
             acc(col.dp[S_A], col.pdp, S_A, -inD);
             if (omc && (zta < mld)) {
-                const double ownM = (p.kML * ar) / (d * vc), inM = (p.kML * ar) / (d * vA_);
+                double ownM, inM;
+                v_pair(p.kML * ar, d, vc, vA_, ownM, inM);
                 nanml |= isnan(ownM) | isnan(inM);
                 acc(col.ml[S_SELF], col.pml, S_SELF, ownM);
                 acc(col.ml[S_A], col.pml, S_A, -inM);
@@ -362,6 +384,142 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
         }
         if (nanml) raise_flag(p.flags, FLAG_TKVML_NAN);    // :90
         if (nandp) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
+    }
+}
+
+// The 58 values of a regular cell's stencil (what fast_column loads), wherever they came from.
+struct Stencil {
+    i64 lE, lW, lS, lN, lA, lB;     // Lwet3D of the six neighbours (unmasked)
+    double gE, gW, gS, gN, gA, gB;  // the flux each neighbour pushes with: ϕwest[E], ϕeast[W], ϕnorth[S], ϕsouth[N], ϕbottom[A], ϕtop[B]
+    double vC, vE, vW, vS, vN, vA, vB;
+    double rC, rE, rW, rS, rN, rA, rB;
+    double tC, tE, tW, tS, tN;
+    double eW_c, eE_c, eS_c, eN_c, dW_c, dE_c, dS_c, dN_c, eE_w, dE_w, eW_e, dW_e, eN_s, dN_s, eS_n, dS_n, ar, mld;
+    double ztk, zta, ztb;
+};
+
+// The regular-cell arithmetic on a Stencil -- THE one copy of it (src/matrixbuilding.jl:193-204, :244-296, :348-415, :426-435,
+// :450-477): fast_column (gather kernel) fills the Stencil with loads, the dense-march kernel with registers / DPP / row loads.
+// Accumulators start at -0.0: (-0.0) + x == x bit for bit for every x, which is exactly sparse()'s "first touch copies, later
+// ones add" without tracking the first touch.  RHOCHECK: the ρ-NaN check (:233) shares the (rarely taken) branch of the Tadv NaN
+// check when the fill pass does it (p.rho_in_fill): a separate branch right after the loads splits the scheduling region and
+// cost 6 % of the kernel (collecting ALL error checks into one branch at the end measured 2 % slower than this).
+#define NEG0 (-0.0)
+template <bool RHOCHECK>
+__device__ __forceinline__ void column_compute(const TmParams &p, const Stencil &s, int i, int j, int k, i64 c, Column &col) {
+    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
+    const i64 xE = s.lE, xW = s.lW, xS = hS ? s.lS : 0, xN = hN ? s.lN : 0, xA = hA ? s.lA : 0, xB = hB ? s.lB : 0;
+    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
+    const double vC = s.vC, rC = s.rC, tC = s.tC;
+
+    // ---- advective pushes towards this cell (:244-296) ----
+    const double fE = wE ? sel_pos(s.gE, up) : 0.0;  // east cell pushes its west flux
+    const double fW = wW ? sel_neg(s.gW, up) : 0.0;  // west cell pushes its east flux
+    const double fS = wS ? sel_neg(s.gS, up) : 0.0;  // south cell pushes its north flux
+    const double fN = wN ? sel_pos(s.gN, up) : 0.0;  // north cell pushes its south flux
+    const double fA = wA ? sel_pos(s.gA, up) : 0.0;  // cell above pushes its bottom flux
+    const double fB = wB ? sel_neg(s.gB, up) : 0.0;  // cell below pushes its top flux (its k > 1, :290)
+    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
+
+    // row order of the column: A, S, row-mates by i, N, B.  Row-mates: W, SELF, E -- except at the
+    // periodic wrap (i == 0: SELF, E, W(nx-1);  i == nx-1: E(0), W, SELF)
+    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
+    {
+        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
+        col.bef[S_A] = 0;
+        col.bef[S_S] = 1u << S_A;
+        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
+        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
+        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
+        col.bef[S_FQ] = 0;
+        col.bef[S_N] = lo | bS | bE | bW;
+        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
+    }
+    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
+    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
+
+    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
+    {
+        double oA_, dA_, oS_, dS_, oW_, dW_, oE_, dE_, oN_, dN_, oB_, dB_;
+        adv_pair(fA, s.rA, rC, s.vA, vC, oA_, dA_);
+        adv_pair(-fS, s.rS, rC, s.vS, vC, oS_, dS_);
+        adv_pair(-fW, s.rW, rC, s.vW, vC, oW_, dW_);
+        adv_pair(fE, s.rE, rC, s.vE, vC, oE_, dE_);
+        adv_pair(fN, s.rN, rC, s.vN, vC, oN_, dN_);
+        adv_pair(-fB, s.rB, rC, s.vB, vC, oB_, dB_);
+        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
+                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
+        const bool badrho = RHOCHECK && p.rho_in_fill && isnan(rC);
+        if (bad | badrho) {
+            if (badrho) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+            if (bad) raise_flag(p.flags, FLAG_TADV_NAN);    // :39
+        }
+        // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
+        double d = NEG0;
+        d += aA ? dA_ : NEG0;
+        d += aS ? dS_ : NEG0;
+        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
+        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
+        d += m1;
+        d += m2;
+        d += aN ? dN_ : NEG0;
+        d += aB ? dB_ : NEG0;
+        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
+        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
+        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
+                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
+    }
+    // ---- TκH (:348-415, :426-435); oppdir = south away from the seam row (:407) ----
+    {
+        double ownW, inW, ownE, inE, ownS, inS, ownN, inN;
+        h_pair(p.kH, tC, s.eW_c, s.tW, s.eE_w, s.dW_c, vC, s.dE_w, s.vW, ownW, inW);
+        h_pair(p.kH, tC, s.eE_c, s.tE, s.eW_e, s.dE_c, vC, s.dW_e, s.vE, ownE, inE);
+        h_pair(p.kH, tC, s.eS_c, s.tS, s.eN_s, s.dS_c, vC, s.dN_s, s.vS, ownS, inS);
+        h_pair(p.kH, tC, s.eN_c, s.tN, s.eS_n, s.dN_c, vC, s.dS_n, s.vN, ownN, inN);
+        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
+                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
+        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
+        double h = NEG0;  // own pushes in direction order W, E, S, N
+        h += wW ? ownW : NEG0;
+        h += wE ? ownE : NEG0;
+        h += wS ? ownS : NEG0;
+        h += wN ? ownN : NEG0;
+        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
+        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
+        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
+                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
+    }
+    // ---- TκVdeep / TκVML (:450-477) ----
+    {
+        const double ztk = s.ztk, zta = hA ? s.zta : s.ztk, ztb = hB ? s.ztb : s.ztk;
+        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
+        const double nD = p.kDeep * s.ar;
+        double ownB, inB, ownA, inA;
+        v_pair(nD, dB, vC, s.vB, ownB, inB);
+        v_pair(nD, dA, vC, s.vA, ownA, inA);
+        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
+        double d = NEG0;  // own pushes: bottom then top
+        d += wB ? ownB : NEG0;
+        d += wA ? ownA : NEG0;
+        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
+        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
+        const bool omC = ztk < s.mld;  // Ω (:85); NaN compares false
+        const bool mB = wB & omC & (ztb < s.mld), mA = wA & omC & (zta < s.mld);
+        col.pml = 0;
+        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
+        if (mA | mB) {
+            const double nM = p.kML * s.ar;
+            double mownB, minB, mownA, minA;
+            v_pair(nM, dB, vC, s.vB, mownB, minB);
+            v_pair(nM, dA, vC, s.vA, mownA, minA);
+            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
+            double m = NEG0;
+            m += mB ? mownB : NEG0;
+            m += mA ? mownA : NEG0;
+            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
+            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
+        }
     }
 }
 
@@ -384,13 +542,6 @@ __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return 
 __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return ldd(b, byteoff); }
 #endif
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
-#define NEG0 (-0.0)
-#ifdef OTMB_DBG_MULDIV  // timing experiment only: what the 28 divisions of a column cost (wrong values)
-#define FDIV(a, b) ((a) * (b))
-#else
-#define FDIV(a, b) ((a) / (b))
-#endif
-
 // CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
 // The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
 // Returns whether Lwet3D holds c at the cell itself (the canonical-indices check, loaded with the stencil).
@@ -479,18 +630,8 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
 
     STAMP(st, 2, 1);  // every stencil load is back
     if (!tb.rho) rC = rE = rW = rS = rN = rA = rB = p.rho_s;
-    const i64 xE = lE, xW = lW, xS = hS ? lS : 0, xN = hN ? lN : 0, xA = hA ? lA : 0, xB = hB ? lB : 0;
-    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
-
-    // ---- advective pushes towards this cell (:244-296) ----
-    const double fE = wE ? sel_pos(gE0, up) : 0.0;  // east cell pushes its west flux
-    const double fW = wW ? sel_neg(gW0, up) : 0.0;  // west cell pushes its east flux
-    const double fS = wS ? sel_neg(gS0, up) : 0.0;  // south cell pushes its north flux
-    const double fN = wN ? sel_pos(gN0, up) : 0.0;  // north cell pushes its south flux
-    const double fA = wA ? sel_pos(gA0, up) : 0.0;  // cell above pushes its bottom flux
-    const double fB = wB ? sel_neg(gB0, up) : 0.0;  // cell below pushes its top flux (its k > 1, :290)
-    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
-    if (CHECKS) {  // own pushes must land in a wet cell (see build_column)
+    if (CHECKS) {  // own pushes must land in a wet cell (see build_column); ρ (:233)
+        const bool wE = lE != 0, wW = lW != 0, wS = hS && lS != 0, wN = hN && lN != 0, wA = hA && lA != 0, wB = hB && lB != 0;
         const double ow = sel_pos(qW0, up), oe = sel_neg(qE0, up), os = sel_pos(qS0, up), on = sel_neg(qN0, up);
         const double ob = sel_pos(qB0, up), ot = hA ? sel_neg(qT0, up) : 0.0;
         const bool bad = (nonzero(ow) & !wW) | (nonzero(oe) & !wE) | (nonzero(os) & !wS) | (nonzero(on) & !wN) |
@@ -498,112 +639,17 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
         if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
     }
-
-    // row order of the column: A, S, row-mates by i, N, B.  Row-mates: W, SELF, E -- except at the
-    // periodic wrap (i == 0: SELF, E, W(nx-1);  i == nx-1: E(0), W, SELF)
-    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
-    {
-        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
-        col.bef[S_A] = 0;
-        col.bef[S_S] = 1u << S_A;
-        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
-        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
-        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
-        col.bef[S_FQ] = 0;
-        col.bef[S_N] = lo | bS | bE | bW;
-        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
-    }
-    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
-    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
-
-    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
-    {
-#define ADV1(PHI, RX, VX, OFF, DG)                \
-    const double rb##OFF = ((RX) + rC) / 2;       \
-    const double OFF = FDIV(-(PHI), (rb##OFF * (VX))); \
-    const double DG = FDIV((PHI), (rb##OFF * vC));
-        ADV1(fA, rA, vA, oA_, dA_)
-        ADV1(-fS, rS, vS, oS_, dS_)
-        ADV1(-fW, rW, vW, oW_, dW_)
-        ADV1(fE, rE, vE, oE_, dE_)
-        ADV1(fN, rN, vN, oN_, dN_)
-        ADV1(-fB, rB, vB, oB_, dB_)
-#undef ADV1
-        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
-                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
-        // the ρ check of the asynchronous protocol shares this (rarely taken) branch: a separate one right after the
-        // loads splits the scheduling region and cost 6 % of the kernel (collecting ALL error checks into one branch
-        // at the end measured 2 % slower than this)
-        const bool badrho = !CHECKS && p.rho_in_fill && isnan(rC);
-        if (bad | badrho) {
-            if (badrho) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
-            if (bad) raise_flag(p.flags, FLAG_TADV_NAN);    // :39
-        }
-        // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
-        double d = NEG0;
-        d += aA ? dA_ : NEG0;
-        d += aS ? dS_ : NEG0;
-        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
-        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
-        d += m1;
-        d += m2;
-        d += aN ? dN_ : NEG0;
-        d += aB ? dB_ : NEG0;
-        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
-        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
-        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
-                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
-    }
-    // ---- TκH (:348-415, :426-435) ----
-    {
-#define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
-    const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
-    const double OWN = FDIV((p.kH * a##OWN), ((D_C) * vC));       \
-    const double IN = FDIV((p.kH * a##OWN), ((D_X) * (VX)));
-        H1(tW, eW_c, eE_w, dW_c, dE_w, vW, ownW, inW)
-        H1(tE, eE_c, eW_e, dE_c, dW_e, vE, ownE, inE)
-        H1(tS, eS_c, eN_s, dS_c, dN_s, vS, ownS, inS)
-        H1(tN, eN_c, eS_n, dN_c, dS_n, vN, ownN, inN)
-#undef H1
-        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
-                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
-        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
-        double h = NEG0;  // own pushes in direction order W, E, S, N
-        h += wW ? ownW : NEG0;
-        h += wE ? ownE : NEG0;
-        h += wS ? ownS : NEG0;
-        h += wN ? ownN : NEG0;
-        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
-        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
-        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
-                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
-    }
-    // ---- TκVdeep / TκVML (:450-477) ----
-    {
-        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
-        const double nD = p.kDeep * ar;
-        const double ownB = FDIV(nD, (dB * vC)), inB = FDIV(nD, (dB * vB)), ownA = FDIV(nD, (dA * vC)), inA = FDIV(nD, (dA * vA));
-        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
-        double d = NEG0;  // own pushes: bottom then top
-        d += wB ? ownB : NEG0;
-        d += wA ? ownA : NEG0;
-        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
-        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
-        const bool omC = ztk < mld;  // Ω (:85); NaN compares false
-        const bool mB = wB & omC & (ztb < mld), mA = wA & omC & (zta < mld);
-        col.pml = 0;
-        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
-        if (mA | mB) {
-            const double nM = p.kML * ar;
-            const double mownB = FDIV(nM, (dB * vC)), minB = FDIV(nM, (dB * vB)), mownA = FDIV(nM, (dA * vC)), minA = FDIV(nM, (dA * vA));
-            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
-            double m = NEG0;
-            m += mB ? mownB : NEG0;
-            m += mA ? mownA : NEG0;
-            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
-            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
-        }
-    }
+    // the stencil as values, then THE arithmetic (column_compute: shared with the dense-march kernel)
+    Stencil s;
+    s.lE = lE; s.lW = lW; s.lS = lS; s.lN = lN; s.lA = lA; s.lB = lB;
+    s.gE = gE0; s.gW = gW0; s.gS = gS0; s.gN = gN0; s.gA = gA0; s.gB = gB0;
+    s.vC = vC; s.vE = vE; s.vW = vW; s.vS = vS; s.vN = vN; s.vA = vA; s.vB = vB;
+    s.rC = rC; s.rE = rE; s.rW = rW; s.rS = rS; s.rN = rN; s.rA = rA; s.rB = rB;
+    s.tC = tC; s.tE = tE; s.tW = tW; s.tS = tS; s.tN = tN;
+    s.eW_c = eW_c; s.eE_c = eE_c; s.eS_c = eS_c; s.eN_c = eN_c; s.dW_c = dW_c; s.dE_c = dE_c; s.dS_c = dS_c; s.dN_c = dN_c;
+    s.eE_w = eE_w; s.dE_w = dE_w; s.eW_e = eW_e; s.dW_e = dW_e; s.eN_s = eN_s; s.dN_s = dN_s; s.eS_n = eS_n; s.dS_n = dS_n;
+    s.ar = ar; s.mld = mld; s.ztk = ztk; s.zta = zta; s.ztb = ztb;
+    column_compute<!CHECKS>(p, s, i, j, k, c, col);
     return lC == c;
 }
 

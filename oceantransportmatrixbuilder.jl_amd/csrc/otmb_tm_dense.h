@@ -68,136 +68,7 @@ __device__ __forceinline__ i64 dpp_prev(i64 x) {
     return (i64)(((u64)(unsigned)dpp_prev_i((int)((u64)x >> 32)) << 32) | (unsigned)dpp_prev_i((int)(unsigned)(u64)x));
 }
 
-// The 58 values of a regular cell's stencil (what fast_column loads), wherever they came from.
-struct Stencil {
-    i64 lE, lW, lS, lN, lA, lB;     // Lwet3D of the six neighbours (unmasked)
-    double gE, gW, gS, gN, gA, gB;  // the flux each neighbour pushes with: ϕwest[E], ϕeast[W], ϕnorth[S], ϕsouth[N], ϕbottom[A], ϕtop[B]
-    double vC, vE, vW, vS, vN, vA, vB;
-    double rC, rE, rW, rS, rN, rA, rB;
-    double tC, tE, tW, tS, tN;
-    double eW_c, eE_c, eS_c, eN_c, dW_c, dE_c, dS_c, dN_c, eE_w, dE_w, eW_e, dW_e, eN_s, dN_s, eS_n, dS_n, ar, mld;
-    double ztk, zta, ztb;
-};
-
-// fast_column's arithmetic on a Stencil: the same expressions in the same order (src/matrixbuilding.jl:193-204,
-// :244-296, :348-415, :426-435, :450-477), so the two formulations agree bit for bit.  Regular cells only.
-__device__ __forceinline__ void column_compute(const TmParams &p, const Stencil &s, int i, int j, int k, i64 c, Column &col) {
-    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
-    const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
-    const i64 xE = s.lE, xW = s.lW, xS = hS ? s.lS : 0, xN = hN ? s.lN : 0, xA = hA ? s.lA : 0, xB = hB ? s.lB : 0;
-    const bool wE = xE != 0, wW = xW != 0, wS = xS != 0, wN = xN != 0, wA = xA != 0, wB = xB != 0;
-    const double vC = s.vC, rC = s.rC, tC = s.tC;
-
-    // ---- advective pushes towards this cell (:244-296) ----
-    const double fE = wE ? sel_pos(s.gE, up) : 0.0;
-    const double fW = wW ? sel_neg(s.gW, up) : 0.0;
-    const double fS = wS ? sel_neg(s.gS, up) : 0.0;
-    const double fN = wN ? sel_pos(s.gN, up) : 0.0;
-    const double fA = wA ? sel_pos(s.gA, up) : 0.0;
-    const double fB = wB ? sel_neg(s.gB, up) : 0.0;
-    const bool aE = nonzero(fE), aW = nonzero(fW), aS = nonzero(fS), aN = nonzero(fN), aA = nonzero(fA), aB = nonzero(fB);
-
-    const bool wrap0 = (i == 0), wrap1 = (i == nx - 1), swapWE = wrap0 | wrap1;
-    {
-        const unsigned lo = (1u << S_A) | (1u << S_S), bS = 1u << S_SELF, bE = 1u << S_EC, bW = 1u << S_WC;
-        col.bef[S_A] = 0;
-        col.bef[S_S] = 1u << S_A;
-        col.bef[S_WC] = lo | (wrap0 ? (bS | bE) : (wrap1 ? bE : 0u));
-        col.bef[S_SELF] = lo | (wrap0 ? 0u : (wrap1 ? (bE | bW) : bW));
-        col.bef[S_EC] = lo | (wrap0 ? bS : (wrap1 ? 0u : (bW | bS)));
-        col.bef[S_FQ] = 0;
-        col.bef[S_N] = lo | bS | bE | bW;
-        col.bef[S_B] = lo | bS | bE | bW | (1u << S_N);
-    }
-    col.idx[S_A] = xA; col.idx[S_S] = xS; col.idx[S_SELF] = c; col.idx[S_EC] = xE; col.idx[S_WC] = xW;
-    col.idx[S_FQ] = 0; col.idx[S_N] = xN; col.idx[S_B] = xB;
-
-    // ---- Tadv (pushTadvectionvalues!, :193-204) ----
-    {
-#define ADV1(PHI, RX, VX, OFF, DG)                \
-    const double rb##OFF = ((RX) + rC) / 2;       \
-    const double OFF = FDIV(-(PHI), (rb##OFF * (VX))); \
-    const double DG = FDIV((PHI), (rb##OFF * vC));
-        ADV1(fA, s.rA, s.vA, oA_, dA_)
-        ADV1(-fS, s.rS, s.vS, oS_, dS_)
-        ADV1(-fW, s.rW, s.vW, oW_, dW_)
-        ADV1(fE, s.rE, s.vE, oE_, dE_)
-        ADV1(fN, s.rN, s.vN, oN_, dN_)
-        ADV1(-fB, s.rB, s.vB, oB_, dB_)
-#undef ADV1
-        const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
-                         (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
-        const bool badrho = p.rho_in_fill && isnan(rC);
-        if (bad | badrho) {
-            if (badrho) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
-            if (bad) raise_flag(p.flags, FLAG_TADV_NAN);    // :39
-        }
-        double d = NEG0;  // diagonal: contributions in ascending emitter index = A, S, row-mates by i, N, B
-        d += aA ? dA_ : NEG0;
-        d += aS ? dS_ : NEG0;
-        const double m1 = swapWE ? (aE ? dE_ : NEG0) : (aW ? dW_ : NEG0);
-        const double m2 = swapWE ? (aW ? dW_ : NEG0) : (aE ? dE_ : NEG0);
-        d += m1;
-        d += m2;
-        d += aN ? dN_ : NEG0;
-        d += aB ? dB_ : NEG0;
-        col.adv[S_A] = oA_; col.adv[S_S] = oS_; col.adv[S_WC] = oW_; col.adv[S_EC] = oE_; col.adv[S_N] = oN_;
-        col.adv[S_B] = oB_; col.adv[S_SELF] = d; col.adv[S_FQ] = 0;
-        col.padv = ((unsigned)aA << S_A) | ((unsigned)aS << S_S) | ((unsigned)aW << S_WC) | ((unsigned)aE << S_EC) |
-                   ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
-    }
-    // ---- TκH (:348-415, :426-435) ----
-    {
-#define H1(TX, E_C, E_X, D_C, D_X, VX, OWN, IN)              \
-    const double a##OWN = jl_min(tC * (E_C), (TX) * (E_X));  \
-    const double OWN = FDIV((p.kH * a##OWN), ((D_C) * vC));       \
-    const double IN = FDIV((p.kH * a##OWN), ((D_X) * (VX)));
-        H1(s.tW, s.eW_c, s.eE_w, s.dW_c, s.dE_w, s.vW, ownW, inW)
-        H1(s.tE, s.eE_c, s.eW_e, s.dE_c, s.dW_e, s.vE, ownE, inE)
-        H1(s.tS, s.eS_c, s.eN_s, s.dS_c, s.dN_s, s.vS, ownS, inS)
-        H1(s.tN, s.eN_c, s.eS_n, s.dN_c, s.dS_n, s.vN, ownN, inN)
-#undef H1
-        const bool bad = (wW & (isnan(ownW) | isnan(inW))) | (wE & (isnan(ownE) | isnan(inE))) |
-                         (wS & (isnan(ownS) | isnan(inS))) | (wN & (isnan(ownN) | isnan(inN)));
-        if (bad) raise_flag(p.flags, FLAG_TKH_NAN);  // :61
-        double h = NEG0;  // own pushes in direction order W, E, S, N
-        h += wW ? ownW : NEG0;
-        h += wE ? ownE : NEG0;
-        h += wS ? ownS : NEG0;
-        h += wN ? ownN : NEG0;
-        col.hh[S_SELF] = h; col.hh[S_WC] = -inW; col.hh[S_EC] = -inE; col.hh[S_S] = -inS; col.hh[S_N] = -inN;
-        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
-        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) |
-                  ((unsigned)(wW | wE | wS | wN) << S_SELF);
-    }
-    // ---- TκVdeep / TκVML (:450-477) ----
-    {
-        const double ztk = s.ztk, zta = hA ? s.zta : s.ztk, ztb = hB ? s.ztb : s.ztk;
-        const double dB = fabs(ztk - ztb), dA = fabs(ztk - zta);
-        const double nD = p.kDeep * s.ar;
-        const double ownB = FDIV(nD, (dB * vC)), inB = FDIV(nD, (dB * s.vB)), ownA = FDIV(nD, (dA * vC)), inA = FDIV(nD, (dA * s.vA));
-        if ((wB & (isnan(ownB) | isnan(inB))) | (wA & (isnan(ownA) | isnan(inA)))) raise_flag(p.flags, FLAG_TKVDEEP_NAN);  // :114
-        double d = NEG0;  // own pushes: bottom then top
-        d += wB ? ownB : NEG0;
-        d += wA ? ownA : NEG0;
-        col.dp[S_SELF] = d; col.dp[S_B] = -inB; col.dp[S_A] = -inA;
-        col.pdp = ((unsigned)wB << S_B) | ((unsigned)wA << S_A) | ((unsigned)(wA | wB) << S_SELF);
-        const bool omC = ztk < s.mld;  // Ω (:85); NaN compares false
-        const bool mB = wB & omC & (ztb < s.mld), mA = wA & omC & (zta < s.mld);
-        col.pml = 0;
-        col.ml[S_SELF] = 0; col.ml[S_A] = 0; col.ml[S_B] = 0;
-        if (mA | mB) {
-            const double nM = p.kML * s.ar;
-            const double mownB = FDIV(nM, (dB * vC)), minB = FDIV(nM, (dB * s.vB)), mownA = FDIV(nM, (dA * vC)), minA = FDIV(nM, (dA * s.vA));
-            if ((mB & (isnan(mownB) | isnan(minB))) | (mA & (isnan(mownA) | isnan(minA)))) raise_flag(p.flags, FLAG_TKVML_NAN);  // :90
-            double m = NEG0;
-            m += mB ? mownB : NEG0;
-            m += mA ? mownA : NEG0;
-            col.ml[S_SELF] = m; col.ml[S_B] = -minB; col.ml[S_A] = -minA;
-            col.pml = ((unsigned)mB << S_B) | ((unsigned)mA << S_A) | ((unsigned)(mA | mB) << S_SELF);
-        }
-    }
-}
+// (Stencil and column_compute -- the regular-cell arithmetic, ONE copy shared with the gather kernel -- live in otmb_tm_column.h)
 
 // lane geometry of a wave: cells i0-1 .. i0+62 of row j, wrapped periodically
 struct DmLane {
@@ -471,7 +342,7 @@ __global__ __launch_bounds__(256, DM_WAVES_PER_SIMD) void dm_fill_kernel(const T
                     st.tC = R.thk; st.tS = R.tS; st.tN = R.tN;
                     dm_cf64 *zt = (dm_cf64 *)p.zt;
                     st.ztk = zt[k]; st.zta = zt[k > 0 ? k - 1 : k]; st.ztb = zt[k + 1 < nz ? k + 1 : k];
-                    column_compute(p, st, i, j, k, c, col);
+                    column_compute<true>(p, st, i, j, k, c, col);
                 } else {  // the tripolar seam row (:94): the generic column builder on global memory
                     const Cell cell = cell_of((i64)k * p.P + (i64)j * nx + i, nx, ny, p.P);
                     build_column(p, cell, c, col);
