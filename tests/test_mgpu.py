@@ -128,9 +128,19 @@ def test_mgpu_reports_the_reference_error_of_the_failing_slab(oracle):
         api.transportmatrix(ϕ=rphi, ρ=g.rho, mlotst=g.mlotst, gridmetrics=gm2, indices=idx, devices=devices)
     with pytest.raises(OtmbError, match="ρ contains NaNs"):
         api.transportmatrix(ϕ=rphi, ρ=rho, mlotst=g.mlotst, gridmetrics=gm2, indices=idx, devices=devices)
-    # facefluxes: a field without a single valid value is an assertion over the WHOLE grid (src/velocities.jl:199-200)
+    # facefluxes: a field without a single valid value is an assertion over the WHOLE grid (src/velocities.jl:199-200; on an
+    # all-wet grid: next to land nofluxboundaries! has already written zeros, which count as values, as in the reference)
+    allwet = dict(wet3D=np.ones((4, 3, 6), np.bool_))
+    topo = dict(gridtopology=dict(kind=1))
     with pytest.raises(OtmbError, match="AssertionError"):
-        api.facefluxes(np.full(g.umo.data.shape, np.nan), g.vmo.data, gm, idx, FillValue=1e20, devices=devices)
+        api.facefluxes(np.full((4, 3, 6), np.nan), np.ones((4, 3, 6)), topo, allwet, FillValue=1e20, devices=devices)
+    # ... and ONE slab with values is enough: u valid on the deepest level only (the last slab's)
+    u1 = np.full((4, 3, 6), np.nan, order="F")
+    u1[:, :, -1] = 2.0
+    got1 = api.facefluxes(u1, np.ones((4, 3, 6)), topo, allwet, FillValue=1e20, devices=devices)
+    want1 = oracle.facefluxes(u1, np.ones((4, 3, 6)), allwet["wet3D"], 1e20, 1)
+    for k in want1:
+        assert np.array_equal(got1[k], want1[k]), k
     # valid values in ONE slab only are enough
     u = np.full(g.umo.data.shape, 1e20, order="F")
     u[:, :, -1] = g.umo.data[:, :, -1]

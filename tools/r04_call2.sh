@@ -10,9 +10,9 @@ stop() { echo "STOP: $1 (rc=$2)"; exit 1; }
 guard() { rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then stop "$1" $rc; fi; }
 
 echo "== gpu tests =="
-timeout -k 10 700 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?
-tail -5 $OUT/pytest_gpu.log
-[ $rc -eq 0 ] || stop "gpu tests" $rc
+timeout -k 10 800 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; rc=$?
+tail -8 $OUT/pytest_gpu.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then stop "gpu tests" $rc; fi   # (a failing test is reported; the measurements below still run)
 
 BARGS="--extra-configs= --no-cpu-baseline --no-end-to-end --steps 10 --warmup 3 --repeats 3"
 fresh() {  # fresh <workload> <tag> ENV...
