@@ -12,8 +12,8 @@
 //        ONEPASS                    (device-resident callers with known capacity): decoupled look-back
 //                                   over per-tile status words, so inputs are read once and outputs
 //                                   written once -- the algorithmic HBM traffic;
-//   4. entries are staged through LDS and streamed out with fully coalesced 8-byte-per-lane stores
-//      (a column's entries are contiguous, a tile's columns are contiguous).
+//   4. entries are staged through LDS, per wave, and streamed out with 16-byte-per-lane non-temporal stores from scalar run
+//      bases (a column's entries are contiguous, a wave's 64 columns are one contiguous run in each matrix).
 #include <cstdlib>
 
 #include "otmb_tm_column.h"

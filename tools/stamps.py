@@ -29,18 +29,27 @@ from otmb_amd.device import DeviceAssembler
 
 capi.use_library(path, lenient=True)
 nx, ny, nz, lf = synthetic.PRESETS[wl]
-g = synthetic.make_grid(nx, ny, nz, land_fraction=lf, rho="array")
-gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
-                              lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
-asm = DeviceAssembler(0)
-asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
-umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
-vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
-for _ in range(5):
-    asm.step(umo, vmo, 1e20)
+if wl in ("quarterdeg", "tenthdeg"):  # generated on the device
+    from otmb_amd import synthetic_device
+    dg = synthetic_device.make_device_grid(wl, torch.device("cuda", 0), seed=20260501, rho="array")
+    asm = synthetic_device.assembler_for(dg, 0)
+    umo, vmo, fill_ = dg.umo, dg.vmo, dg.fill
+else:
+    g = synthetic.make_grid(nx, ny, nz, land_fraction=lf, rho="array")
+    gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
+                                  lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep)
+    umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).cuda()
+    vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).cuda()
+    fill_ = 1e20
+for _ in range(3):
+    asm.step_async(umo, vmo, fill_)
+asm.finish()
 asm.ctx.timing_enable(True)
-for _ in range(5):
-    asm.step(umo, vmo, 1e20)
+for _ in range(3):
+    asm.step_async(umo, vmo, fill_)
+asm.finish()
 print({k: round(v[0] / v[1], 4) for k, v in asm.ctx.timing_collect().items()})
 ntiles = (asm.N + 255) // 256
 nw = ntiles * 4
@@ -78,10 +87,10 @@ print("  distinct (XCD, SE, SH, CU) values:", len(np.unique(cu_key)), " XCDs see
 
 # ---- heavy tiles (tripolar seam row: generic column builder) against the rest ----
 try:
-    lw = asm.lwet[: asm.N].cpu().numpy() - 1
+    lwt = asm.lwet[: asm.N]
     P_ = nx * ny
-    first = lw[0::256][:ntiles]
-    last = lw[np.minimum(np.arange(ntiles) * 256 + 255, asm.N - 1)]
+    first = lwt[0::256][:ntiles].cpu().numpy() - 1
+    last = lwt[torch.clamp(torch.arange(ntiles, device=lwt.device) * 256 + 255, max=asm.N - 1)].cpu().numpy() - 1
     k0_, j0_ = first // P_, (first % P_) // nx
     k1_, j1_ = last // P_, (last % P_) // nx
     heavy_tile = (j0_ == ny - 1) | (j1_ == ny - 1) | (k1_ > k0_)
@@ -94,6 +103,31 @@ try:
     print("  heavy waves per XCD:", {int(x): int((xh == x).sum()) for x in np.unique(xh)})
 except Exception as e:  # diagnostics only
     print("  (heavy-tile statistics unavailable:", repr(e), ")")
+
+# ---- what makes a tile expensive?  life of a tile (mean of its waves) against the span of grid cells its 256 wet cells cover ----
+try:
+    lfw = np.full(nw, np.nan); lfw[ok] = (t[:, 9] - t[:, 8]) / 100.0
+    tile_life = np.nanmean(lfw.reshape(ntiles, 4), axis=1)
+    span = (last - first + 1) / 256.0
+    rows_touched = (k1_ * ny + j1_) - (k0_ * ny + j0_) + 1
+    good = np.isfinite(tile_life) & ~heavy_tile
+    qs = np.quantile(span[good], [0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0])
+    print("  regular tiles: span of grid cells / 256 quantiles (0, 25, 50, 75, 90, 99, 100 %):", [round(float(x), 2) for x in qs])
+    for lo, hi in zip(qs[:-1], qs[1:]):
+        sel = good & (span >= lo) & (span <= hi)
+        if sel.sum():
+            print(f"    span {lo:6.2f}-{hi:6.2f}: {int(sel.sum()):7d} tiles, rows touched {rows_touched[sel].mean():5.1f}, tile life {tile_life[sel].mean():6.2f} us")
+    A = np.stack([np.ones(good.sum()), span[good], rows_touched[good]], axis=1)
+    coef, *_ = np.linalg.lstsq(A, tile_life[good], rcond=None)
+    pred = A @ coef
+    r2 = 1 - ((tile_life[good] - pred) ** 2).sum() / ((tile_life[good] - tile_life[good].mean()) ** 2).sum()
+    print(f"  least squares: life = {coef[0]:.2f} + {coef[1]:.3f} x span/256 + {coef[2]:.3f} x rows  (R^2 = {r2:.3f})")
+    # per XCD share under the current order: sum of tile lives
+    xw = np.full(nw, -1); xw[ok] = (t[:, 7] >> 32) & 0xf
+    xt = xw.reshape(ntiles, 4).max(axis=1)
+    print("  sum of tile lives per XCD (us):", {int(x): round(float(np.nansum(tile_life[xt == x])), 0) for x in range(8)})
+except Exception as e:
+    print("  (tile cost statistics unavailable:", repr(e), ")")
 
 # ---- dispatch timeline (s_memrealtime: 100 MHz, the same counter on every XCD) ----
 t0, t1 = t[:, 8], t[:, 9]
