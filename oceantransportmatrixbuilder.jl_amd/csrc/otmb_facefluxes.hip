@@ -103,8 +103,13 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
 // Software pipeline over chunks of FF_KB levels: while chunk A is turned into fluxes and stored, the loads of the
 // next chunk B are already in flight.  A column is one thread and the grid has few columns (1.7 waves per SIMD at
 // 1 degree), so nothing else hides the memory latency of a chunk.
-template <typename T, bool FLAGS, bool NT>
-__global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
+// ROWS: 1 = a workgroup is one wave, 64 consecutive columns of the (nx, ny) plane in linear order; 4 = a workgroup is four waves
+// over the SAME 64 values of i in four consecutive rows j: a wave's south row (vmo[s - nx]) is then the row of the wave next to it
+// in the same workgroup, marching through the same levels at the same time -- an L1 hit (or a ride on the fill already in flight)
+// instead of one more request to the L2 (4 of the ~14 read requests per level and wave).  Large grids only: the last chunk of a row
+// is partly idle (nx = 1440: 2 % more waves), and a grid with fewer waves than the chip has slots wants them spread singly.
+template <typename T, bool FLAGS, bool NT, int ROWS>
+__global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
@@ -119,10 +124,23 @@ __global__ __launch_bounds__(FF_THREADS) void facefluxes_kernel(
         const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
         cb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
-    const unsigned s = cb * FF_THREADS + threadIdx.x;
+    unsigned s, i, j;
+    bool inside;
+    if (ROWS == 1) {
+        s = cb * FF_THREADS + threadIdx.x;
+        j = s / (unsigned)nx;
+        i = s - j * (unsigned)nx;
+        inside = s < (unsigned)P;
+    } else {
+        const unsigned nchunk = ((unsigned)nx + FF_THREADS - 1) / FF_THREADS, grp = cb / nchunk, chunk = cb - grp * nchunk;
+        i = chunk * FF_THREADS + (threadIdx.x & (FF_THREADS - 1));
+        j = grp * ROWS + threadIdx.x / FF_THREADS;
+        inside = i < (unsigned)nx && j < (unsigned)ny;
+        s = j * (unsigned)nx + i;
+    }
     bool uvalid = false, vvalid = false;
-    if (s < (unsigned)P) {
-        const unsigned j = s / (unsigned)nx, i = s - j * (unsigned)nx, row = j * (unsigned)nx;
+    if (inside) {
+        const unsigned row = j * (unsigned)nx;
         FfCol col;
         col.s = s;
         col.sE = row + ((i + 1 < (unsigned)nx) ? i + 1 : 0);  // i₊₁, gridtopology.jl:57
@@ -187,15 +205,19 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     if (ctx->ff_gen == 0x7fffffff) { ctx->ff_gen = 0; ctx->ff_first = 1; }
     ctx->ff_gen += 1;
     int *dflags = otmb_ring_ff((int *)ctx->ring.p, ctx->ff_gen);
-    const unsigned nb = (unsigned)((P + FF_THREADS - 1) / FF_THREADS);
+    // four-row workgroups on grids with many more waves than the chip has slots (otmb_ctx: ff_rows = 0 lets the size decide)
+    const int rows = ctx->ff_rows > 0 ? (ctx->ff_rows >= 4 ? 4 : 1) : ((P >= (1ll << 19) && nx >= 2 * FF_THREADS) ? 4 : 1);
+    const unsigned nb = rows == 1 ? (unsigned)((P + FF_THREADS - 1) / FF_THREADS)
+                                  : (unsigned)(((nx + FF_THREADS - 1) / FF_THREADS) * ((ny + rows - 1) / rows));
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
     const bool nt = (i64)48 * P * nz > (1ll << 30);  // six Float64 arrays beyond a gigabyte: streaming stores
-#define FF_LAUNCH(T, FL, NTS)                                                                                                          \
-    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS>), dim3(nb), dim3(FF_THREADS), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
+#define FF_LAUNCH(T, FL, NTS, R)                                                                                                       \
+    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
                        phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks)
-#define FF_LAUNCH2(T, FL) do { if (nt) FF_LAUNCH(T, FL, true); else FF_LAUNCH(T, FL, false); } while (0)
+#define FF_LAUNCH2(T, FL) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4); else FF_LAUNCH(T, FL, false, 4); } \
+                               else { if (nt) FF_LAUNCH(T, FL, true, 1); else FF_LAUNCH(T, FL, false, 1); } } while (0)
     if (src_is_f32) { if (flags) FF_LAUNCH2(float, true); else FF_LAUNCH2(float, false); }
     else { if (flags) FF_LAUNCH2(double, true); else FF_LAUNCH2(double, false); }
 #undef FF_LAUNCH2
