@@ -109,3 +109,38 @@ def test_dense_march_reports_the_reference_errors(oracle):
     asm.step(umo, vmo, 1e20)
     got = asm.result_to_host()
     assert len(got["T"][1]) == len(got["Tadv"][1]) and len(got["TκH"][1]) > 0 and not np.any(got["T"][2] == 0.0)
+
+
+@pytest.mark.parametrize("env", [
+    dict(OTMB_FF_XCD="0", OTMB_COUNT_ORDER="0", OTMB_DEAL_HEAVY="0", OTMB_FF_ROWS="1"),   # rounds 1-3: blockIdx order everywhere
+    dict(OTMB_FF_XCD="1", OTMB_COUNT_ORDER="1", OTMB_DEAL_HEAVY="1", OTMB_FF_ROWS="4"),
+    dict(OTMB_FF_XCD="1", OTMB_COUNT_ORDER="2", OTMB_DEAL_HEAVY="0", OTMB_FF_ROWS="4"),
+    dict(OTMB_FF_XCD="0", OTMB_COUNT_ORDER="2", OTMB_DEAL_HEAVY="1", OTMB_FF_ROWS="1"),
+], ids=lambda e: "-".join(f"{k[5:].lower()}{v}" for k, v in e.items()))
+def test_work_mappings_never_change_a_result(oracle, monkeypatch, env):
+    """Round 4's speed-only mappings (a context reads them from the environment when it is created): facefluxes and the counting
+    pass in XCD-contiguous eighths, the counting pass in the fill pass's tile order, the heavy (seam-row) tiles of the fill pass dealt
+    over the XCDs, four-row facefluxes workgroups -- every combination gives the oracle's matrices and face fluxes bit for bit, in
+    both protocols, on a tripolar grid with 600 tiles (above the threshold of the tile order) whose rows are not a multiple of 64 cells."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = (120, 100, 23, 88, "array", "tripolar")
+    asm, umo, vmo, rtm = _setup(oracle, case)
+    for rows in (-1, 3):
+        asm.ctx.set_tile_order(rows)
+        asm.step(umo, vmo, 1e20)
+        _check(asm, rtm, f"{env}/order {rows}/async")
+        asm.step(umo, vmo, 1e20, onepass=False)
+        _check(asm, rtm, f"{env}/order {rows}/two-phase")
+    # the face fluxes themselves (four-row workgroups, XCD chunks): against the oracle on the same grid
+    from otmb_amd import synthetic
+
+    nx, ny, nz, seed, rho, topo = case
+    g = synthetic.make_grid(nx, ny, nz, seed=seed, rho=rho, topology=topo)
+    gm = gridmetrics_of(g)
+    ref = oracle.makeindices(gm.v3D)
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], 1e20, gm.gridtopology.kind)
+    for k, name in enumerate(("east", "west", "north", "south", "top", "bottom")):
+        got = asm.phi[k].cpu().numpy().reshape((nx, ny, nz), order="F")
+        same = (got == rphi[name]) & (np.signbit(got) == np.signbit(rphi[name]))
+        assert same.all(), (env, name)
