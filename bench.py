@@ -433,6 +433,14 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
 
         return odist_.HipSlabBackend(lr)
 
+    # One arena for everything the run allocates: a block of the workload's whole footprint is reserved and handed back to
+    # torch's caching allocator BEFORE anything else is allocated, so that every array of the run is carved out of one device
+    # allocation (one contiguous range of addresses) instead of one hipMalloc per array (placement: profiles/r04/README.md section 7).
+    arena_gb = float(os.environ.get("OTMB_BENCH_ARENA_GB", "0"))
+    if arena_gb > 0 and not rehearsal:
+        _arena = torch.empty(int(arena_gb * 2 ** 30), dtype=torch.uint8, device=dev)
+        del _arena
+
     nx, ny, nz, lf = synthetic.PRESETS[args.workload]
     host_grid = None  # (g, gm) when the whole grid also exists on the host (cpu_baseline / end_to_end legs)
     if world > 1 or force_slab:
