@@ -31,6 +31,10 @@ class DeviceAssembler:
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.lib = capi.lib()
         self.out = None
+        arena_gb = float(os.environ.get("OTMB_ARENA_GB", "0"))
+        if arena_gb > 0:  # (see _empty)
+            _arena = torch.empty(int(arena_gb * 2 ** 30), dtype=torch.uint8, device=self.device)
+            del _arena
 
     def _t(self, a, dtype=np.float64):
         h = torch.from_numpy(_flat(a, dtype))
@@ -39,13 +43,23 @@ class DeviceAssembler:
         return d
 
     def _empty(self, n, dtype):
-        """Device array of n elements.  OTMB_STAGGER=<bytes> (experiment, tools/placement_study.py) starts the k-th
-        array k*stagger bytes into its allocation, so that equal offsets in different arrays do not share the low
-        address bits."""
+        """Device array of n elements.  Placement experiments (profiles/r04/README.md section 8; tools/placement_search.sh):
+        OTMB_ARENA_GB=<GB> reserves one block when the assembler is created and hands it back to torch's caching allocator, so
+        that every later array is carved out of that ONE device allocation, back to back; OTMB_ARENA_ALIGN=<bytes> rounds every
+        array's size up to a multiple (array starts on that grid), OTMB_ARENA_PAD=<bytes> leaves a gap behind every array.
+        OTMB_STAGGER=<bytes> (round 3, tools/placement_study.py) starts the k-th array k*stagger bytes into its allocation."""
         stagger = int(os.environ.get("OTMB_STAGGER", "0"))
+        align = int(os.environ.get("OTMB_ARENA_ALIGN", "0"))
+        gap = int(os.environ.get("OTMB_ARENA_PAD", "0"))
+        item = torch.empty(0, dtype=dtype).element_size()
+        if align > 0 or gap > 0:
+            nbytes = max(n * item, 1)
+            if align > 0:
+                nbytes = (nbytes + align - 1) // align * align
+            raw = torch.empty(nbytes + gap, dtype=torch.uint8, device=self.device)
+            return raw[: n * item].view(dtype)
         if stagger <= 0:
             return torch.empty(n, dtype=dtype, device=self.device)
-        item = torch.empty(0, dtype=dtype).element_size()
         self._nalloc = getattr(self, "_nalloc", 0) + 1
         pad = (self._nalloc * stagger) % (1 << 21)
         pad -= pad % 256
