@@ -32,7 +32,7 @@ class DeviceAssembler:
         self.lib = capi.lib()
         self.out = None
         arena_gb = float(os.environ.get("OTMB_ARENA_GB", "0"))
-        if arena_gb > 0:  # (see _empty)
+        if arena_gb > 0 and os.environ.get("OTMB_ARENA_WHEN", "start") == "start":  # (see _empty)
             _arena = torch.empty(int(arena_gb * 2 ** 30), dtype=torch.uint8, device=self.device)
             del _arena
 
@@ -328,6 +328,10 @@ class DeviceAssembler:
         """A set of five CSC output buffers at their upper bound (for transportmatrix_onepass(out=...): a pipeline whose
         steps each keep their own matrices)."""
         cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
+        if os.environ.get("OTMB_ARENA_WHEN") == "outputs" and float(os.environ.get("OTMB_ARENA_GB", "0")) > 0 and not getattr(self, "_arena_done", False):
+            self._arena_done = True  # experiment: only the OUTPUT arrays are carved out of one allocation
+            _arena = torch.empty(int(float(os.environ["OTMB_ARENA_GB"]) * 2 ** 30), dtype=torch.uint8, device=self.device)
+            del _arena
         return {m: (self._empty(self.N + 1, torch.int64), self._empty(cap[k], torch.int64),
                     self._empty(cap[k], torch.float64)) for k, m in enumerate(MATS)}
 
