@@ -98,15 +98,6 @@ int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out);
 int32_t otmb_host_free(otmb_ctx *ctx_ignored, void *p);
 /* blocks handed out and not yet freed, their bytes, and the bytes kept idle for reuse (any argument may be NULL) */
 int32_t otmb_host_pool_stats(int64_t *blocks_in_use, int64_t *bytes_in_use, int64_t *bytes_idle);
-/* Device memory laid out for this chip's HBM (device-resident callers: the arrays the hot kernels stream through).  On MI355X a
- * bandwidth-bound kernel runs 15-20 % slower over arrays carved out of ONE large allocation than over arrays backed by small
- * physical pieces (tools/micro/placement_mix.hip, profiles/r04/README.md section 8): otmb_dev_alloc gives every array its own virtual
- * range mapped from 2 MiB physical handles (32 MiB beyond 1 GiB; hipMemCreate / hipMemMap; plain hipMalloc where that is unavailable).
- * Contents are undefined.  otmb_dev_free ignores its context argument and may be called from any thread (a garbage collector's
- * finalizer); the caller makes sure no kernel still uses the block.  otmb_dev_alloc_mode: 1 small handles, 0 hipMalloc, -1 not yet known. */
-int32_t otmb_dev_alloc(otmb_ctx *ctx, int64_t bytes, void **out);
-int32_t otmb_dev_free(otmb_ctx *ctx_ignored, void *p);
-int32_t otmb_dev_alloc_mode(void);
 /* Speed only, never results: the order in which the fill pass of transportmatrix takes its tiles of 256 columns.
  * rows_per_band = 0: ascending wet rank (i, then j, then k).  R > 0: MARCH order -- the tiles of a band of R grid rows
  * are taken level after level before the next band starts, so that the levels above / below a tile (the vertical

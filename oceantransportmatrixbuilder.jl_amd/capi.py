@@ -60,9 +60,6 @@ SYMBOLS = {
     "otmb_host_alloc": (C.c_int32, [_vp, C.c_int64, C.POINTER(_vp)]),
     "otmb_host_free": (C.c_int32, [_vp, _vp]),
     "otmb_host_pool_stats": (C.c_int32, [_ip, _ip, _ip]),
-    "otmb_dev_alloc": (C.c_int32, [_vp, C.c_int64, C.POINTER(_vp)]),
-    "otmb_dev_free": (C.c_int32, [_vp, _vp]),
-    "otmb_dev_alloc_mode": (C.c_int32, []),
     "otmb_mgpu_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(_vp)]),
     "otmb_mgpu_destroy": (None, [_vp]),
     "otmb_mgpu_last_error": (C.c_char_p, [_vp]),
@@ -194,24 +191,6 @@ class _PinnedOwner:
             pass
 
 
-class _DevBlock:
-    """A block of otmb_dev_alloc seen through __cuda_array_interface__ (what torch.as_tensor takes without a copy); the block goes
-    back when the last tensor that views it is gone."""
-
-    _TYPESTR = {"float64": "<f8", "float32": "<f4", "int64": "<i8", "int32": "<i4", "int16": "<i2", "uint8": "|u1", "uint16": "<u2"}
-
-    def __init__(self, lib_, ptr, n, dtype_name):
-        self._lib, self._ptr = lib_, ptr
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": self._TYPESTR[dtype_name], "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-    def __del__(self):
-        try:
-            self._lib.otmb_dev_free(None, _vp(self._ptr))
-        except Exception:
-            pass
-
-
 class Context:
     """One otmb_ctx bound to a GPU."""
 
@@ -270,20 +249,6 @@ class Context:
         buf._otmb_owner = _PinnedOwner(self, ptr.value)  # freed when buf dies, i.e. when no array refers to it any more
         a = np.frombuffer(buf, dtype=dt, count=n)
         return a.reshape(shape, order=order) if np.ndim(shape) else a
-
-    def dev_empty(self, n, dtype):
-        """torch tensor of n elements in device memory of otmb_dev_alloc: its own virtual range mapped from small physical
-        handles -- the backing a bandwidth-bound kernel streams through fastest on this chip (include/otmb.h).  Uninitialised."""
-        import torch
-
-        name = str(dtype).replace("torch.", "")
-        item = torch.empty(0, dtype=dtype).element_size()
-        if n <= 0:
-            return torch.empty(0, dtype=dtype, device=torch.device("cuda", self.device))
-        ptr = _vp()
-        self.check(self._lib.otmb_dev_alloc(self._h, int(n) * item, C.byref(ptr)))
-        block = _DevBlock(self._lib, ptr.value, n, name)
-        return torch.as_tensor(block, device=torch.device("cuda", self.device))  # (zero-copy; the tensor keeps `block` alive)
 
     def set_tile_order(self, rows_per_band):
         """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = the library default (bands of 8 rows)."""

@@ -59,10 +59,6 @@ class DeviceAssembler:
             raw = torch.empty(nbytes + gap, dtype=torch.uint8, device=self.device)
             return raw[: n * item].view(dtype)
         if stagger <= 0:
-            # the library's placement-aware device memory (otmb_dev_alloc: own virtual range, small physical handles): what the hot
-            # kernels stream through fastest on this chip; OTMB_DEV_ARRAYS=torch takes torch's allocator instead (experiments)
-            if os.environ.get("OTMB_DEV_ARRAYS", "otmb") != "torch":
-                return self.ctx.dev_empty(n, dtype)
             return torch.empty(n, dtype=dtype, device=self.device)
         self._nalloc = getattr(self, "_nalloc", 0) + 1
         pad = (self._nalloc * stagger) % (1 << 21)
