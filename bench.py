@@ -384,7 +384,26 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         sys.exit(spawn_ranks(args))
     extras = {}
     if args.gpus == 1 and "RANK" not in os.environ and args.extra_configs and not cpu_rehearsal and not under_profiler():
-        extras = extra_configs_in_children(args)  # (children first: nothing in this process has touched a GPU yet)
+        # Every configuration of the line is measured by a FRESH process that has the GPU to itself, the HEADLINE FIRST: a process that
+        # starts after the 0.25 / 0.1 degree runs have allocated and freed 35 / 220 GB measures the same kernels 2-3 % slower
+        # (profiles/r04/README.md section 7: 0.3775 against 0.3658 ms on one box; round 3 ran the headline last).  This process only
+        # launches the others -- it never touches the GPU -- and prints the headline child's line with the extra records merged in.
+        cmd = [sys.executable, os.path.abspath(sys.argv[0]), *[a for a in sys.argv[1:]], "--extra-configs", ""]
+        head = None
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=float(os.environ.get("OTMB_BENCH_TIMEOUT", "1500")))
+            line = next((l for l in r.stdout.decode().splitlines() if l.startswith("{")), None)
+            if r.returncode == 0 and line is not None:
+                head = json.loads(line)
+        except (subprocess.TimeoutExpired, OSError, ValueError):
+            head = None
+        if head is not None:
+            head.update(extra_configs_in_children(args))
+            head["measured_by"] = "fresh processes, one per configuration, headline first: " + " ".join(cmd[1:])
+            print(json.dumps(head), flush=True)
+            return
+        # (the headline child failed: measure it here, as rounds 1-3 did, so that the failure is visible in this process's output)
+        extras = extra_configs_in_children(args)
 
     import numpy as np
     import torch
