@@ -327,6 +327,13 @@ int32_t otmb_mgpu_partition(const otmb_mgpu *mg, int64_t *bounds);
 /* nslabs consecutive slabs of >= 1 level each with wet counts as even as a greedy sweep gets them (upper levels are wetter);
  * bounds: nslabs + 1 entries.  Pure host arithmetic, no GPU.                                                              */
 int32_t otmb_balanced_partition(const int64_t *level_counts, int64_t nz, int32_t nslabs, int64_t *bounds);
+/* The two promises of otmb_ctx_set_reuse_grid / otmb_ctx_set_reuse_fluxes, for the slabs (independent, both off by default): grid-constant
+ * host arrays that are the very arrays of the previous plan (same pointers, same cut) are not uploaded again; ϕ that otmb_mgpu_facefluxes
+ * computed and copied to these very host arrays is used where it is -- every slab keeps its levels on its device in the layout the plan
+ * wants, with the one flux each halo level pushes into an owned cell filled in (ϕbottom above = the slab's first ϕtop,
+ * src/velocities.jl:240; ϕtop below = the plane received from the slab below).  otmb_mgpu_uploaded_bytes: host -> device bytes so far. */
+int32_t otmb_mgpu_set_reuse(otmb_mgpu *mg, int32_t reuse_grid, int32_t reuse_fluxes);
+int64_t otmb_mgpu_uploaded_bytes(const otmb_mgpu *mg);
 int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d,
                              double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6]);
 int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *args, int64_t nnz[5]);

@@ -293,7 +293,8 @@ end
 # otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch
 function fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
                usepinned::Bool, devices)
-    devices === nothing || return fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, ignore_ops, usepinned, devices)
+    devices === nothing || return fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes,
+                                              ignore_ops, usepinned, devices)
     lock(CALL_LOCK) do
         check(ccall(sym(:otmb_ctx_set_reuse_grid), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_grid)))
         check(ccall(sym(:otmb_ctx_set_reuse_fluxes), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_fluxes)))
@@ -313,11 +314,13 @@ function fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind
     end
 end
 
-# otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs, one per listed GPU
-function fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, ignore_ops::Int32, usepinned::Bool, devices)
+# otmb_mgpu_set_reuse -> otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs, one per listed GPU
+function fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
+                    usepinned::Bool, devices)
     lock(CALL_LOCK) do
         mg = mgpu_of(devices)
-        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, false, ignore_ops)
+        check_mgpu(mg, ccall(sym(:otmb_mgpu_set_reuse), Int32, (Ptr{Cvoid}, Int32, Int32), mg, Int32(reuse_grid), Int32(reuse_fluxes)))
+        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops)
         N = indices.N
         nnz = zeros(Int64, 5)
         GC.@preserve keep check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), mg, Ref(a), nnz))

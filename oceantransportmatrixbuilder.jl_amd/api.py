@@ -330,7 +330,8 @@ def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVd
                            ignore_ops, devices=None):
     """otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch."""
     if devices is not None:
-        return _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops)
+        return _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
+                                     reuse_grid, reuse_fluxes)
     ctx = context(device)
     keep, passthrough = [], []
     a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
@@ -363,12 +364,15 @@ def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVd
                  for m, name in enumerate(MATS)})
 
 
-def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops):
-    """otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs, one per listed GPU."""
+def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
+                          reuse_grid=False, reuse_fluxes=False):
+    """otmb_mgpu_set_reuse -> otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs,
+    one per listed GPU."""
     mg = mgpu(devices)
     ctx = context(list(devices)[0])  # (pinned result arrays only: the pool is the process's, every device's DMA reaches it)
-    keep = []
-    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep)
+    keep, passthrough = [], []
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
+    mg.check(capi.lib().otmb_mgpu_set_reuse(mg.handle, int(bool(reuse_grid) and all(passthrough)), int(bool(reuse_fluxes))))
     a.only_t = 0 if operators else 1
     a.ignore_ops = int(ignore_ops)
     nnz = (C.c_int64 * 5)()

@@ -66,6 +66,8 @@ SYMBOLS = {
     "otmb_mgpu_ndev": (C.c_int32, [_vp]),
     "otmb_mgpu_transport": (C.c_int32, [_vp]),
     "otmb_mgpu_partition": (C.c_int32, [_vp, _ip]),
+    "otmb_mgpu_set_reuse": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
+    "otmb_mgpu_uploaded_bytes": (C.c_int64, [_vp]),
     "otmb_balanced_partition": (C.c_int32, [_ip, C.c_int64, C.c_int32, _ip]),
     "otmb_mgpu_facefluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
     "otmb_mgpu_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
@@ -310,6 +312,12 @@ class Mgpu:
     def check(self, rc):
         if rc != OK:
             raise OtmbError(rc, self._lib.otmb_mgpu_last_error(self._h).decode("utf-8"))
+
+    def set_reuse(self, grid=False, fluxes=False):
+        self.check(self._lib.otmb_mgpu_set_reuse(self._h, int(bool(grid)), int(bool(fluxes))))
+
+    def uploaded_bytes(self):
+        return int(self._lib.otmb_mgpu_uploaded_bytes(self._h))
 
     def partition(self):
         n = self._lib.otmb_mgpu_ndev(self._h)

@@ -73,6 +73,12 @@ struct Slab {
     int32_t status = OTMB_OK;
     std::string msg;
     int32_t u_valid = 0, v_valid = 0;
+    // what the staging buffers hold (otmb_mgpu_set_reuse): the host array a buffer was uploaded from, its bytes and the first level
+    struct Key { const void *host = nullptr; size_t bytes = 0; i64 e0 = -1; };
+    Key key[B_COUNT];
+    bool phi_resident = false;       // B_PHI0.. hold what otmb_mgpu_facefluxes computed for levels [k0 - ha, k1 + hb) ...
+    const void *phi_host[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and copied to these host arrays
+    i64 uploaded = 0;                // bytes copied to this slab's device so far
     // hand-off of the chain's plane to this slab (from the slab below it)
     std::mutex m;
     std::condition_variable cv;
@@ -105,6 +111,7 @@ struct otmb_mgpu {
     // the grid the current partition was made for
     i64 nx = 0, ny = 0, nz = 0;
     std::vector<i64> bounds;
+    bool reuse_grid = false, reuse_fluxes = false;  // otmb_mgpu_set_reuse
     // pending plan
     bool planned = false;
     otmb_tm_args args;  // host pointers of the plan
@@ -157,9 +164,15 @@ int32_t set_partition(otmb_mgpu *mg, const std::vector<i64> &counts, i64 nx, i64
     const int n = (int)mg->slabs.size();
     const i64 nz = (i64)counts.size();
     if (n > nz) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "more devices than levels");
-    mg->bounds.assign(n + 1, 0);
-    int32_t rc = otmb_balanced_partition(counts.data(), nz, n, mg->bounds.data());
+    std::vector<i64> nb(n + 1, 0);
+    int32_t rc = otmb_balanced_partition(counts.data(), nz, n, nb.data());
     if (rc) return mg_fail(mg, rc, "partition");
+    if (nb != mg->bounds || nx != mg->nx || ny != mg->ny || nz != mg->nz)  // another grid or another cut: nothing staged is still valid
+        for (Slab *sl : mg->slabs) {
+            for (auto &k : sl->key) k = Slab::Key();
+            sl->phi_resident = false;
+        }
+    mg->bounds = nb;
     std::vector<i64> cum(nz + 1, 0);
     for (i64 k = 0; k < nz; ++k) cum[k + 1] = cum[k] + counts[k];
     for (int s = 0; s < n; ++s) {
@@ -326,6 +339,27 @@ const char *otmb_mgpu_last_error(const otmb_mgpu *mg) { return mg ? mg->err.c_st
 int32_t otmb_mgpu_ndev(const otmb_mgpu *mg) { return mg ? (int32_t)mg->slabs.size() : 0; }
 int32_t otmb_mgpu_transport(const otmb_mgpu *mg) { return mg ? mg->transport : -1; }
 
+// The two promises of otmb_ctx_set_reuse_grid / _set_reuse_fluxes for the slabs (independent; both off by default): grid-constant host
+// arrays that are the very arrays of the previous plan are not uploaded again; ϕ that otmb_mgpu_facefluxes computed and copied to
+// these very host arrays is used where it is, on the devices.
+int32_t otmb_mgpu_set_reuse(otmb_mgpu *mg, int32_t grid, int32_t fluxes) {
+    if (!mg) return OTMB_ERR_INVALID_ARG;
+    mg->reuse_grid = grid != 0;
+    mg->reuse_fluxes = fluxes != 0;
+    for (Slab *sl : mg->slabs) {
+        if (!mg->reuse_grid)
+            for (int b = B_V; b < B_UMO; ++b) sl->key[b] = Slab::Key();
+    }
+    return OTMB_OK;
+}
+// bytes copied host -> device over all slabs since the object was created (diagnostics / tests)
+int64_t otmb_mgpu_uploaded_bytes(const otmb_mgpu *mg) {
+    if (!mg) return -1;
+    i64 t = 0;
+    for (const Slab *sl : mg->slabs) t += sl->uploaded;
+    return t;
+}
+
 // the partition of the last facefluxes / plan: ndev + 1 level bounds
 int32_t otmb_mgpu_partition(const otmb_mgpu *mg, int64_t *bounds) {
     if (!mg || !bounds || mg->bounds.empty()) return OTMB_ERR_INVALID_ARG;
@@ -367,17 +401,27 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
         };
         if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
         const i64 nl = sl.k1 - sl.k0;
-        const size_t Gl = (size_t)(nl * P);
+        const size_t Gl = (size_t)(nl * P), Ge = (size_t)((nl + sl.ha + sl.hb) * P);
         void *du, *dv, *dw, *dplane, *dphi[6];
         int32_t r;
+        sl.phi_resident = false;
         if ((r = reserve(sl, B_UMO, Gl * es, &du)) || (r = reserve(sl, B_VMO, Gl * es, &dv)) || (r = reserve(sl, B_WET, Gl, &dw)) ||
             (r = reserve(sl, B_PLANE, (size_t)P * 8, &dplane)))
             return fail(r);
-        for (int f = 0; f < 6; ++f)
-            if ((r = reserve(sl, B_PHI0 + f, Gl * 8, &dphi[f]))) return fail(r);
+        // the six ϕ arrays are kept in the layout otmb_mgpu_transportmatrix_plan wants (levels [k0 - ha, k1 + hb)): the owned levels are
+        // computed in place behind the halo plane above; with otmb_mgpu_set_reuse(…, fluxes) the plan then uploads no ϕ at all
+        for (int f = 0; f < 6; ++f) {
+            void *q;
+            if ((r = reserve(sl, B_PHI0 + f, Ge * 8, &q))) return fail(r);
+            sl.key[B_PHI0 + f] = Slab::Key();
+            if (sl.ha && hipMemsetAsync(q, 0, (size_t)P * 8, sl.ctx->stream) != hipSuccess) return fail(OTMB_ERR_HIP);
+            if (sl.hb && hipMemsetAsync((char *)q + (Ge - (size_t)P) * 8, 0, (size_t)P * 8, sl.ctx->stream) != hipSuccess) return fail(OTMB_ERR_HIP);
+            dphi[f] = (char *)q + (size_t)sl.ha * P * 8;
+        }
         OtmbXferItem up[3] = {{du, (char *)umo + (size_t)sl.k0 * P * es, Gl * es}, {dv, (char *)vmo + (size_t)sl.k0 * P * es, Gl * es},
                               {dw, (char *)wet3d + (size_t)sl.k0 * P, Gl}};
         if ((r = otmb_xfer(sl.ctx, true, up, 3))) return fail(r);
+        sl.uploaded += (i64)(2 * Gl * es + Gl);
         const double *top_below = nullptr;
         if (sl.hb) {  // the chain: ϕtop of the level below this slab
             std::unique_lock<std::mutex> l(sl.m);
@@ -399,10 +443,19 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
             sl.msg = otmb_last_error(sl.ctx);
             return;
         }
+        // the halo levels act as neighbours only; the one flux each of them pushes into an owned cell: the halo above pushes its ϕbottom =
+        // this slab's first ϕtop (src/velocities.jl:240), the halo below its ϕtop = the plane received from the slab below
+        bool halo_ok = true;
+        if (sl.ha) halo_ok &= hipMemcpyAsync((char *)dp[OTMB_BOTTOM] - (size_t)P * 8, dp[OTMB_TOP], (size_t)P * 8, hipMemcpyDeviceToDevice, sl.ctx->stream) == hipSuccess;
+        if (sl.hb) halo_ok &= hipMemcpyAsync((char *)dp[OTMB_TOP] + Gl * 8, dplane, (size_t)P * 8, hipMemcpyDeviceToDevice, sl.ctx->stream) == hipSuccess;
         std::vector<OtmbXferItem> down;
         for (int f = 0; f < 6; ++f) down.push_back({dp[f], phi[f] + (size_t)sl.k0 * P, Gl * 8});
         if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size()))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
-        if ((r = otmb_facefluxes_slab_flags(sl.ctx, &sl.u_valid, &sl.v_valid))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); }
+        if ((r = otmb_facefluxes_slab_flags(sl.ctx, &sl.u_valid, &sl.v_valid))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
+        if (halo_ok) {
+            sl.phi_resident = true;
+            for (int f = 0; f < 6; ++f) sl.phi_host[f] = phi[f];
+        }
     });
     if ((rc = collect_status(mg))) return rc;
     bool u = false, v = false;
@@ -453,34 +506,65 @@ int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *a, int
         std::vector<OtmbXferItem> up;
         int32_t r;
         void *p;
-#define UP3(B, HOST, FIELD, TYPE)                                               \
-    if ((r = reserve(sl, B, Ge * 8, &p))) return fail(r);                        \
-    up.push_back({p, (char *)(HOST) + off * 8, Ge * 8});                         \
-    FIELD = (TYPE)p;
-        for (int f = 0; f < 6; ++f) { UP3(B_PHI0 + f, a->phi[f], d.phi[f], const double *) }
-        UP3(B_V, a->v3d, d.v3d, const double *)
-        UP3(B_THK, a->thkcello, d.thkcello, const double *)
-        if (a->rho) { UP3(B_RHO, a->rho, d.rho, const double *) }
-        UP3(B_LW, a->lwet3d, d.lwet3d, const int64_t *)
-#undef UP3
-        if ((r = reserve(sl, B_LWET, (size_t)sl.n_own * 8, &p))) return fail(r);
-        if (sl.n_own > 0) up.push_back({p, (char *)((const i64 *)a->lwet + sl.wet_base), (size_t)sl.n_own * 8});
+        // One staged array: uploaded unless the slot still holds this very host array (pointer, bytes, first level) and the caller has
+        // promised not to have modified it (otmb_mgpu_set_reuse).  KIND 1: grid constant; 2: a face-flux array; 0: every call.
+        auto put = [&](int B, const void *host, size_t bytes, int kind, void **out) -> int32_t {
+            const void *before = sl.buf[B].p;
+            int32_t rr = reserve(sl, B, bytes, out);
+            if (rr) return rr;
+            Slab::Key &k = sl.key[B];
+            if (sl.buf[B].p != before) k = Slab::Key();  // the buffer was (re)allocated: whatever it held is gone
+            const bool promised = (kind == 1 && mg->reuse_grid) || (kind == 2 && mg->reuse_fluxes);
+            const bool resident = promised && k.host == host && k.bytes == bytes && k.e0 == e0 && bytes > 0;
+            if (!resident && bytes) { up.push_back({*out, const_cast<void *>(host), bytes}); sl.uploaded += (i64)bytes; }
+            k.host = (promised || resident) ? host : nullptr;
+            k.bytes = bytes;
+            k.e0 = e0;
+            return resident ? -1 : OTMB_OK;  // (-1: nothing was queued)
+        };
+        // ϕ: what otmb_mgpu_facefluxes left on this device (already in the extended layout, halo fluxes filled in) is used when the
+        // caller hands back the host arrays facefluxes wrote (reuse_fluxes); otherwise the levels [e0, e1) of the host arrays go up
+        bool phi_here = mg->reuse_fluxes && sl.phi_resident && sl.buf[B_PHI0].cap >= Ge * 8;
+        for (int f = 0; f < 6 && phi_here; ++f) phi_here = sl.phi_host[f] == (const void *)a->phi[f] && sl.buf[B_PHI0 + f].p;
+        for (int f = 0; f < 6; ++f) {
+            if (phi_here) {
+                d.phi[f] = (const double *)sl.buf[B_PHI0 + f].p;
+            } else {
+                if ((r = put(B_PHI0 + f, (const char *)a->phi[f] + off * 8, Ge * 8, 0, &p)) > 0) return fail(r);
+                d.phi[f] = (const double *)p;
+            }
+        }
+        if (!phi_here) sl.phi_resident = false;
+        if ((r = put(B_V, (const char *)a->v3d + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
+        d.v3d = (const double *)p;
+        if ((r = put(B_THK, (const char *)a->thkcello + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
+        d.thkcello = (const double *)p;
+        if (a->rho) {
+            if ((r = put(B_RHO, (const char *)a->rho + off * 8, Ge * 8, 0, &p)) > 0) return fail(r);
+            d.rho = (const double *)p;
+        }
+        if ((r = put(B_LW, (const char *)a->lwet3d + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
+        d.lwet3d = (const int64_t *)p;
+        const int32_t lw_rc = put(B_LWET, (const char *)((const i64 *)a->lwet + sl.wet_base), (size_t)sl.n_own * 8, 1, &p);
+        if (lw_rc > 0) return fail(lw_rc);
         d.lwet = (const int64_t *)p;
         i64 *dlwet = (i64 *)p;
-#define UP2(B, HOST, FIELD)                                                      \
-    if ((r = reserve(sl, B, (size_t)P * 8, &p))) return fail(r);                 \
-    up.push_back({p, (void *)(HOST), (size_t)P * 8});                            \
-    FIELD = (const double *)p;
-        for (int k = 0; k < 4; ++k) { UP2(B_EDGE0 + k, a->edge_length[k], d.edge_length[k]) UP2(B_DIST0 + k, a->dist_nbr[k], d.dist_nbr[k]) }
-        UP2(B_AREA, a->area2d, d.area2d)
-        UP2(B_ML, a->mlotst, d.mlotst)
-#undef UP2
-        if ((r = reserve(sl, B_ZT, (size_t)nze * 8, &p))) return fail(r);
-        up.push_back({p, (void *)(a->zt + e0), (size_t)nze * 8});
+        const bool lwet_fresh = lw_rc == OTMB_OK;  // (a resident Lwet has been shifted to local indices already)
+        for (int k = 0; k < 4; ++k) {
+            if ((r = put(B_EDGE0 + k, a->edge_length[k], (size_t)P * 8, 1, &p)) > 0) return fail(r);
+            d.edge_length[k] = (const double *)p;
+            if ((r = put(B_DIST0 + k, a->dist_nbr[k], (size_t)P * 8, 1, &p)) > 0) return fail(r);
+            d.dist_nbr[k] = (const double *)p;
+        }
+        if ((r = put(B_AREA, a->area2d, (size_t)P * 8, 1, &p)) > 0) return fail(r);
+        d.area2d = (const double *)p;
+        if ((r = put(B_ML, a->mlotst, (size_t)P * 8, 0, &p)) > 0) return fail(r);
+        d.mlotst = (const double *)p;
+        if ((r = put(B_ZT, a->zt + e0, (size_t)nze * 8, 1, &p)) > 0) return fail(r);
         d.zt = (const double *)p;
-        if ((r = otmb_xfer(sl.ctx, true, up.data(), (int)up.size()))) return fail(r);
+        if (!up.empty() && (r = otmb_xfer(sl.ctx, true, up.data(), (int)up.size()))) return fail(r);
         // Lwet of the owned cells as LOCAL linear indices of the extended grid (levels [e0, e1))
-        if (sl.n_own > 0 && off > 0) {
+        if (lwet_fresh && sl.n_own > 0 && off > 0) {
             hipLaunchKernelGGL(shift_i64_kernel, dim3((unsigned)((sl.n_own + 255) / 256)), dim3(256), 0, sl.ctx->stream, dlwet, sl.n_own, (i64)off);
             if (hipGetLastError() != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "shift_i64_kernel"); return fail(OTMB_ERR_HIP); }
         }

@@ -176,7 +176,7 @@ def test_both_host_layers_make_the_same_c_calls_in_the_same_order():
     # ---- the same build over several GPUs (devices = ...): plan -> result arrays -> fetch on the otmb_mgpu object
     jl_m = [a or "otmb_host_alloc" for a in re.findall(r"sym\(:(otmb_\w+)\)|\boutarray\(", _julia_function("fused_mgpu"))]
     py_m = [alias.get(a, a) for a in re.findall(r"\b(otmb_\w+|_out_array)\(", _python_function(api_src, "_transportmatrix_mgpu"))]
-    want_m = ["otmb_mgpu_transportmatrix_plan", "otmb_host_alloc", "otmb_mgpu_transportmatrix_fetch"]
+    want_m = ["otmb_mgpu_set_reuse", "otmb_mgpu_transportmatrix_plan", "otmb_host_alloc", "otmb_mgpu_transportmatrix_fetch"]
     assert _collapse(jl_m) == want_m, jl_m
     assert _collapse(py_m) == want_m, py_m
     assert "fused_mgpu(" in jl and "_transportmatrix_mgpu(" in py  # both single-device builds hand a device list over to it

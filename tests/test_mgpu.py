@@ -202,3 +202,48 @@ def test_mgpu_over_rccl_one_gpu_per_slab(oracle):
     tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices)
     for m in MATS:
         assert_csc_equal(tuple(tm[m]), rtm[m], m)
+
+
+@pytest.mark.gpu
+def test_mgpu_reuse_flags_keep_grid_and_fluxes_on_the_devices(oracle):
+    """otmb_mgpu_set_reuse: with reuse_fluxes the ϕ that otmb_mgpu_facefluxes left on the devices (owned levels + the one flux each halo
+    level pushes into an owned cell) is used in place; with reuse_grid the grid constants are uploaded once.  Same matrices bit for bit,
+    fewer bytes up -- and nothing stale: other ϕ arrays, or modified host ϕ WITHOUT the promise, are uploaded."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(28, 20, 13, seed=45, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    devices = [0, 0, 0, 0]
+    idx = api.makeindices(gm.v3D)
+    mg = api.mgpu(devices)
+
+    def run(fresh_phi=True, **kw):
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices) if fresh_phi else run.phi
+        run.phi = phi
+        b0 = mg.uploaded_bytes()
+        tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices, **kw)
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/{kw}")
+        return mg.uploaded_bytes() - b0
+
+    full = run()
+    assert run(reuse_fluxes=True) < full                      # six ϕ arrays (with their halo levels) stay where they are
+    first = run(reuse_grid=True)
+    again = run(reuse_grid=True)
+    assert again < first == full                              # the first call with the promise still uploads the grid
+    both = run(reuse_grid=True, reuse_fluxes=True)
+    assert both < again and both < run(reuse_fluxes=True)
+    nx, ny, nz = gm.v3D.shape
+    P = nx * ny
+    nze = nz + 2 * (len(devices) - 1)                        # every inner boundary adds a halo level on both sides
+    assert both == nze * P * 8 + len(devices) * P * 8         # ρ (extended levels) and mlotst per slab: what changes between time slices
+    # the promise is about THESE host arrays: ϕ from elsewhere (the oracle's, equal in value) is uploaded
+    run.phi = rphi
+    assert run(fresh_phi=False, reuse_fluxes=True) > both
+    # no promise, modified host ϕ: the modification is what is assembled
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+    z = {k: np.zeros_like(v) for k, v in phi.items()}
+    tm0 = api.transportmatrix(ϕ=z, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices)
+    assert tm0["Tadv"].nnz == 0 and tm0["TκH"].nnz == rtm["TκH"][1].size
