@@ -321,7 +321,7 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     given = dict(Tadv=Tadv, TκH=TκH, TκVML=TκVML, TκVdeep=TκVdeep)
     if any(x is not None for x in given.values()):
         # matrixbuilding.jl:140-143: operators passed in are used as they are; T = ((Tadv + TκH) + TκVML) + TκVdeep (:147)
-        return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device)
+        return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device, devices)
     return _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes,
                                   device, 0, devices)
 
@@ -396,7 +396,7 @@ def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVde
                  for m, name in enumerate(MATS)})
 
 
-def _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, kappa, upwind, device):
+def _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, kappa, upwind, device, devices=None):
     """transportmatrix with precomputed operators (matrixbuilding.jl:133-147).  The same sequence of C calls as the Julia
     shim (julia/OceanTransportMatrixBuilderAMD.jl; tests/test_julia_shim_static.py compares the two): one fused build whose
     errors for the GIVEN operators are switched off (otmb_tm_args.ignore_ops -- the reference never builds them, so it never
@@ -414,7 +414,9 @@ def _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, k
     for name, A in given.items():
         if A is not None and A.shape != (N, N):
             raise ValueError(f"{name} is {A.shape[0]}x{A.shape[1]}, expected {N}x{N}")
-    r = _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, *kappa, upwind, True, False, False, device, ignore)
+    r = _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, *kappa, upwind, True, False, False, device, ignore, devices)
+    if devices is not None:
+        device = list(devices)[0]  # (the three adds run on the first listed device)
     ops = [given[name] if given[name] is not None else r[name] for name in MATS[1:]]
     T = spadd(spadd(spadd(ops[0], ops[1], device=device), ops[2], device=device), ops[3], device=device)
     return NT(T=T, Tadv=ops[0], TκH=ops[1], TκVML=ops[2], TκVdeep=ops[3])

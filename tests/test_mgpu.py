@@ -247,3 +247,34 @@ def test_mgpu_reuse_flags_keep_grid_and_fluxes_on_the_devices(oracle):
     z = {k: np.zeros_like(v) for k, v in phi.items()}
     tm0 = api.transportmatrix(ϕ=z, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices)
     assert tm0["Tadv"].nnz == 0 and tm0["TκH"].nnz == rtm["TκH"][1].size
+
+
+@pytest.mark.gpu
+def test_mgpu_with_precomputed_operators(oracle):
+    """transportmatrix(…; Tadv = …, devices = …) (src/matrixbuilding.jl:133-147): ignore_ops travels to every slab -- a NaN in ρ or a flux
+    into land is no error when Tadv is handed in -- and T is the three sparse adds of the given and the built operators."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+    from otmb_amd.capi import OtmbError
+
+    g = synthetic.make_grid(20, 16, 9, seed=47, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    devices = [0, 0, 0]
+    kw = dict(mlotst=g.mlotst, gridmetrics=gm, indices=idx, devices=devices)
+    base = api.transportmatrix(ϕ=rphi, ρ=g.rho, **kw)
+    rho_nan = g.rho.copy(order="F")
+    rho_nan.ravel(order="F")[ref["Lwet"][-1] - 1] = np.nan
+    bad_phi = {k: v.copy(order="F") for k, v in rphi.items()}
+    wet = ref["wet3D"].astype(bool)
+    i, j, k = np.argwhere(wet & ~np.roll(wet, 1, axis=0))[-1]
+    bad_phi["west"][i, j, k] = 5.0
+    with_adv = api.transportmatrix(ϕ=bad_phi, ρ=rho_nan, Tadv=base.Tadv, **kw)
+    assert with_adv.Tadv is base.Tadv
+    for m in MATS:
+        assert_csc_equal(tuple(with_adv[m]), rtm[m], m)
+    with pytest.raises(OtmbError, match="ρ contains NaNs"):
+        api.transportmatrix(ϕ=rphi, ρ=rho_nan, TκH=base.TκH, **kw)
+    with pytest.raises(OtmbError, match="flux into a land cell"):
+        api.transportmatrix(ϕ=bad_phi, ρ=g.rho, TκH=base.TκH, **kw)
