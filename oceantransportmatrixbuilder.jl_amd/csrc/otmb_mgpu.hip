@@ -283,6 +283,9 @@ int32_t otmb_mgpu_create(int32_t ndev, const int32_t *device_ids, otmb_mgpu **ou
         mg->slabs.push_back(sl);
         const int32_t rc = otmb_ctx_create(device_ids[s], &sl->ctx);
         if (rc) { otmb_mgpu_destroy(mg); return rc; }
+        // every slab has its own transfer engine (pinned ring + host copy threads); together they get the machine's cores, not eight each
+        const int hw = (int)std::thread::hardware_concurrency();
+        sl->ctx->xfer_threads = std::max(1, std::min(8, (hw > 0 ? hw : 8) / ndev));
     }
     if (same) {
         mg->transport = 0;

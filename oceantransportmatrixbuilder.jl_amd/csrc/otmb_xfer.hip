@@ -76,7 +76,7 @@ static int32_t xfer_init(otmb_ctx *ctx) {
             delete x;
             return otmb_fail(ctx, OTMB_ERR_HIP, "hipEventCreate");
         }
-    int nt = 8;
+    int nt = ctx->xfer_threads > 0 ? ctx->xfer_threads : 8;
     if (const char *e = getenv("OTMB_XFER_THREADS")) nt = atoi(e);
     const int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && nt > hw) nt = hw;
