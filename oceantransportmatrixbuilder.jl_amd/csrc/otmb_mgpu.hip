@@ -287,7 +287,18 @@ int32_t otmb_mgpu_create(int32_t ndev, const int32_t *device_ids, otmb_mgpu **ou
         const int hw = (int)std::thread::hardware_concurrency();
         sl->ctx->xfer_threads = std::max(1, std::min(8, (hw > 0 ? hw : 8) / ndev));
     }
-    if (same) {
+    const char *tenv = getenv("OTMB_MGPU_TRANSPORT");
+    if (same && ndev == 1 && tenv && std::string(tenv) == "rccl") {
+        // (tests on a one-GPU box: load librccl.so and bring up a one-rank communicator, so that at least the loading and the
+        // initialisation of the RCCL transport have run somewhere; a single slab never hands a plane over)
+        std::string why;
+        if (mg->rccl.load(why)) {
+            mg->comms.assign(1, nullptr);
+            if (mg->rccl.CommInitAll(mg->comms.data(), 1, device_ids) == ncclSuccess) mg->transport = 1;
+            else mg->comms.clear();
+        }
+        if (mg->transport != 1) { mg->err = "RCCL: " + why; }
+    } else if (same) {
         mg->transport = 0;
     } else if (!distinct) {
         otmb_mgpu_destroy(mg);  // a device twice among others: no communicator has such a shape

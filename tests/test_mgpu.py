@@ -324,3 +324,28 @@ def test_mgpu_sweep_of_grids_topologies_and_input_types(oracle, case):
         tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices, reuse_grid=reuse, reuse_fluxes=reuse)
         for m in MATS:
             assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/reuse={reuse}")
+
+
+@pytest.mark.gpu
+def test_rccl_transport_loads_and_initialises_on_one_gpu(oracle, monkeypatch):
+    """The RCCL transport cannot carry a plane on a one-GPU box, but its loading path can run: OTMB_MGPU_TRANSPORT=rccl makes a
+    one-device otmb_mgpu dlopen librccl.so, resolve its seven entry points and bring up (and later destroy) a one-rank communicator."""
+    import otmb_amd.api as api
+    from otmb_amd import capi, synthetic
+
+    monkeypatch.setenv("OTMB_MGPU_TRANSPORT", "rccl")
+    mg = capi.Mgpu([0])
+    try:
+        assert mg.transport == "rccl", capi.lib().otmb_mgpu_last_error(mg.handle)
+        g = synthetic.make_grid(12, 10, 6, seed=3, rho="array")
+        gm = gridmetrics_of(g)
+        ref, rphi, rtm = _reference(oracle, g, gm)
+        api._mgpu[(0,)] = mg
+        idx = api.makeindices(gm.v3D)
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=[0])
+        tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=[0])
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    finally:
+        api._mgpu.pop((0,), None)
+        mg.close()
