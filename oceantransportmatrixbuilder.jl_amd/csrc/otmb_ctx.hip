@@ -71,6 +71,7 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     if (const char *e = getenv("OTMB_DENSE")) c->formulation = atoi(e);        // experiments; otmb_ctx_set_formulation is the API
     if (const char *e = getenv("OTMB_FF_XCD")) c->ff_xcd_chunks = atoi(e);       // experiments (A/B in one library)
     if (const char *e = getenv("OTMB_FF_ROWS")) c->ff_rows = atoi(e);
+    if (const char *e = getenv("OTMB_FF_LDS_SOUTH")) c->ff_lds_south = atoi(e);
     if (const char *e = getenv("OTMB_COUNT_ORDER")) c->count_order = atoi(e);
     if (const char *e = getenv("OTMB_DEAL_HEAVY")) c->deal_heavy = atoi(e);
     if (const char *e = getenv("OTMB_DENSE_KPARTS")) c->dense_kparts = atoi(e);

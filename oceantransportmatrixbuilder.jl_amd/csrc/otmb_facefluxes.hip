@@ -43,16 +43,18 @@ struct FfCol {
     bool hS, hN;
 };
 
+// load_vs (wave-uniform): false when the wave's south row comes from the neighbouring wave through LDS (ff_south_from_lds)
 template <typename T, bool FLAGS>
 __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo, const T *__restrict__ vmo,
-                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0) {
+                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0, bool load_vs = true) {
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = (k0 - q >= 0) ? k0 - q : 0;  // clamped: loads are unconditional, the level is skipped later
         const T *ul = umo + (i64)k * P, *vl = vmo + (i64)k * P;
         const uint8_t *wl = wet + (i64)k * P;
         c.u[q] = ff_ld(ul, col.s); c.v[q] = ff_ld(vl, col.s);
-        c.uw[q] = ff_ld(ul, col.sW); c.vs[q] = ff_ld(vl, col.cS);
+        c.uw[q] = ff_ld(ul, col.sW);
+        if (load_vs) c.vs[q] = ff_ld(vl, col.cS);
         c.wc[q] = ff_ld(wl, col.s);
         if (!FLAGS) {
             c.wE[q] = ff_ld(wl, col.sE); c.wW[q] = ff_ld(wl, col.sW); c.wS[q] = ff_ld(wl, col.cS);
@@ -65,11 +67,11 @@ template <typename T, bool FLAGS, bool NT>
 __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
                                           bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
                                           double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
-                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask) {
+                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask, bool active = true) {
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = k0 - q;
-        if (k >= 0) {
+        if (k >= 0 && active) {  // (active: lanes beyond the row / rows beyond the grid of a four-row workgroup march along for the barriers only)
             const i64 o = (i64)k * P;
             const unsigned f = c.wc[q];
             const bool wc = FLAGS ? (f & WF_C) != 0 : c.wc[q] != 0, wE = FLAGS ? (f & WF_E) != 0 : c.wE[q] != 0,
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen, int xcd_chunks) {
+    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen, int xcd_chunks, int lds_south) {
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  In blockIdx order a wave's south row
     // (vmo[s - nx], nx / 64 blocks back) and the west cell of its first lane (the previous block) belong to workgroups of OTHER XCDs:
     // every XCD's L2 then fetches vmo twice and a quarter of umo again (profiles/r03: 3.27 GB fetched for 1.98 GB of inputs at
@@ -139,7 +141,51 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
         s = j * (unsigned)nx + i;
     }
     bool uvalid = false, vvalid = false;
-    if (inside) {
+    if (ROWS > 1 && lds_south) {
+        // Four-row workgroups, south row through LDS: wave r's south row IS wave r-1's own row, so every wave posts the vmo values of
+        // its chunk in LDS and takes its south values from the wave below it -- no load at all for three waves out of four (the L1 kept
+        // missing on them: the waves drift apart by more than it holds; profiles/r04/README.md section 4).  Every wave takes part in
+        // the workgroup barriers, so lanes beyond the row and rows beyond the grid march along on clamped addresses and store nothing.
+        __shared__ T s_v[2][ROWS][FF_KB][FF_THREADS];
+        const unsigned lane = threadIdx.x & (FF_THREADS - 1), r = threadIdx.x / FF_THREADS;
+        const unsigned ic = (i < (unsigned)nx) ? i : (unsigned)nx - 1, jc = (j < (unsigned)ny) ? j : (unsigned)ny - 1;
+        const unsigned sc = jc * (unsigned)nx + ic, row = jc * (unsigned)nx;
+        FfCol col;
+        col.s = sc;
+        col.sE = row + ((ic + 1 < (unsigned)nx) ? ic + 1 : 0);
+        col.sW = row + ((ic > 0) ? ic - 1 : nx - 1);
+        col.hS = jc > 0;
+        const bool fold = (jc + 1 >= (unsigned)ny) && (topo == OTMB_TRIPOLAR);
+        col.hN = (jc + 1 < (unsigned)ny) || fold;
+        col.cS = col.hS ? sc - nx : sc;
+        col.cN = (jc + 1 < (unsigned)ny) ? sc + nx : (fold ? row + (nx - 1 - ic) : sc);
+        double topbelow = top_below ? top_below[sc] : 0.0;
+        const bool own_vs = r == 0;  // (wave-uniform) the first row of the workgroup has its south row in another workgroup
+        FfChunk<T> A, B;
+        int k0 = nz - 1, buf = 0;
+        auto south_from_lds = [&](FfChunk<T> &c) {
+#pragma unroll
+            for (int q = 0; q < FF_KB; ++q) s_v[buf][r][q][lane] = c.v[q];
+            __syncthreads();
+            if (!own_vs) {
+#pragma unroll
+                for (int q = 0; q < FF_KB; ++q) c.vs[q] = s_v[buf][r - 1][q][lane];
+            }
+            buf ^= 1;  // (the next chunk writes the other half: one barrier per chunk is enough, see the ordering argument in DESIGN.md 3.2)
+        };
+        ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0, own_vs);
+        while (k0 >= 0) {
+            ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs);
+            south_from_lds(A);
+            ff_levels<T, FLAGS, NT>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside);
+            k0 -= FF_KB;
+            if (k0 < 0) break;
+            ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs);
+            south_from_lds(B);
+            ff_levels<T, FLAGS, NT>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside);
+            k0 -= FF_KB;
+        }
+    } else if (inside) {
         const unsigned row = j * (unsigned)nx;
         FfCol col;
         col.s = s;
@@ -215,7 +261,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
 #define FF_LAUNCH(T, FL, NTS, R)                                                                                                       \
     hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
-                       phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks)
+                       phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks, ctx->ff_lds_south)
 #define FF_LAUNCH2(T, FL) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4); else FF_LAUNCH(T, FL, false, 4); } \
                                else { if (nt) FF_LAUNCH(T, FL, true, 1); else FF_LAUNCH(T, FL, false, 1); } } while (0)
     if (src_is_f32) { if (flags) FF_LAUNCH2(float, true); else FF_LAUNCH2(float, false); }
