@@ -43,25 +43,17 @@ struct FfCol {
     bool hS, hN;
 };
 
-// lane l <- lane l - 1 (DPP wave_shr:1), for the west neighbour's value inside a wave
-__device__ __forceinline__ int ff_dpp_prev_i(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ double ff_dpp_prev(double x) { return __hiloint2double(ff_dpp_prev_i(__double2hiint(x)), ff_dpp_prev_i(__double2loint(x))); }
-__device__ __forceinline__ float ff_dpp_prev(float x) { return __int_as_float(ff_dpp_prev_i(__float_as_int(x))); }
-
-// load_vs (wave-uniform): false when the wave's south row comes from the neighbouring wave through LDS (south_from_lds);
-// uw_lane0: the west neighbour's umo is loaded by lane 0 only (the other lanes take it from the lane to their left, ff_dpp_prev)
+// load_vs (wave-uniform): false when the wave's south row comes from the neighbouring wave through LDS (ff_south_from_lds)
 template <typename T, bool FLAGS>
 __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo, const T *__restrict__ vmo,
-                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0, bool load_vs = true,
-                                        bool uw_lane0 = false) {
+                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0, bool load_vs = true) {
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = (k0 - q >= 0) ? k0 - q : 0;  // clamped: loads are unconditional, the level is skipped later
         const T *ul = umo + (i64)k * P, *vl = vmo + (i64)k * P;
         const uint8_t *wl = wet + (i64)k * P;
         c.u[q] = ff_ld(ul, col.s); c.v[q] = ff_ld(vl, col.s);
-        if (!uw_lane0) c.uw[q] = ff_ld(ul, col.sW);
-        else if ((threadIdx.x & (FF_THREADS - 1)) == 0) c.uw[q] = ff_ld(ul, col.sW);  // (one lane: the cell left of the wave, or the periodic wrap)
+        c.uw[q] = ff_ld(ul, col.sW);
         if (load_vs) c.vs[q] = ff_ld(vl, col.cS);
         c.wc[q] = ff_ld(wl, col.s);
         if (!FLAGS) {
@@ -171,15 +163,7 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
         const bool own_vs = r == 0;  // (wave-uniform) the first row of the workgroup has its south row in another workgroup
         FfChunk<T> A, B;
         int k0 = nz - 1, buf = 0;
-        const bool uwl = lds_south > 1;  // (experiment switch: OTMB_FF_LDS_SOUTH=2 adds the west neighbour by DPP)
         auto south_from_lds = [&](FfChunk<T> &c) {
-            if (uwl) {
-#pragma unroll
-                for (int q = 0; q < FF_KB; ++q) {  // west neighbour = the lane to the left (lanes run along i inside one row; lane 0 loaded its own)
-                    const T left = ff_dpp_prev(c.u[q]);
-                    if (lane != 0) c.uw[q] = left;
-                }
-            }
 #pragma unroll
             for (int q = 0; q < FF_KB; ++q) s_v[buf][r][q][lane] = c.v[q];
             __syncthreads();
@@ -189,14 +173,14 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
             }
             buf ^= 1;  // (the next chunk writes the other half: one barrier per chunk is enough, see the ordering argument in DESIGN.md 3.2)
         };
-        ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0, own_vs, uwl);
+        ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0, own_vs);
         while (k0 >= 0) {
-            ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, uwl);
+            ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs);
             south_from_lds(A);
             ff_levels<T, FLAGS, NT>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside);
             k0 -= FF_KB;
             if (k0 < 0) break;
-            ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, uwl);
+            ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs);
             south_from_lds(B);
             ff_levels<T, FLAGS, NT>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside);
             k0 -= FF_KB;
