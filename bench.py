@@ -351,7 +351,17 @@ def box_probe(dev):
     e1.record()
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / reps
-    return {"copy_2GiB_ms": ms, "copy_gbs_read_plus_write": 2 * n * 8 / (ms * 1e-3) / 1e9,
+    smi = None
+    try:  # clocks / power / temperature right after the run (boxes of the pool differ by 15 % on the same kernels: something to correlate with)
+        r = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--showpower", "--showtemp", "--showmemuse", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        j = json.loads(r.stdout.decode() or "{}")
+        card = next(iter(j.values())) if j else {}
+        keep = ("sclk", "mclk", "fclk", "socclk", "Power", "Temperature", "junction", "memory", "GPU Memory Allocated")
+        smi = {k: v for k, v in card.items() if any(t.lower() in k.lower() for t in keep)}
+    except Exception as e:
+        smi = {"error": f"{type(e).__name__}: {e}"[:120]}
+    return {"copy_2GiB_ms": ms, "copy_gbs_read_plus_write": 2 * n * 8 / (ms * 1e-3) / 1e9, "rocm_smi": smi,
             "note": "torch device-to-device copy of 2 GiB after the timed region: this box's plain streaming rate.  (Round 3: the pool's boxes differ by up to 15 % on the "
                     "fill pass and this rate does not follow it -- 4.63 TB/s on a box with a 0.316 ms fill, 4.98 TB/s on one with 0.360 ms -- the pass is bound by "
                     "request latency, not by streaming bandwidth: profiles/r03/README.md 5b, 6.)"}
