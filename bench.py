@@ -353,6 +353,10 @@ def box_probe(dev):
     ms = e0.elapsed_time(e1) / reps
     smi = None
     try:  # clocks / power / temperature right after the run (boxes of the pool differ by 15 % on the same kernels: something to correlate with)
+        if under_profiler():
+            # rocm-smi is an `env python3` script: under a profiler preload every hop of that chain is a process whose GPU the preload has
+            # already initialised replacing itself with another program -- the GPU boxes refuse exactly that (profiles/r04, call 21)
+            raise RuntimeError("skipped under a profiler preload")
         r = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--showpower", "--showtemp", "--showmemuse", "--json"],
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
         j = json.loads(r.stdout.decode() or "{}")

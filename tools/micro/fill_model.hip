@@ -292,6 +292,150 @@ __global__ __launch_bounds__(256) void march(Params p, int ny, int nz, int nseg,
     }
 }
 
+// 3-D block model (round 4): a workgroup owns 64 consecutive i x J rows x K levels.  Phase 1: the rows of the block and of its halo
+// (south / north rows, levels above / below; no corners) of the four stencil arrays, and the (J + 2) rows of the ten 2-D arrays, come in
+// by coalesced row loads -- every line ONCE per block -- and are parked in LDS.  Phase 2 (after one barrier): a wave per (row, level),
+// a lane per cell; the stencil is read from LDS, only the six flux arrays (read at one point per cell: nothing to share) come from
+// global memory; wet lanes store a contiguous run per (row, level) like the march model.  wetpct % of the lanes hold a wet cell.
+// Requests per wet cell against the gather kernel's 3.6 (1 degree) / 3.15 (0.25 degree): J = K = 4 -> 2.4 / 1.9.
+template <int J, int K, int UNR>
+__global__ __launch_bounds__(256) void block_lds(Params p, int ny, int nz, int nseg, int njg, int nkg, unsigned wetpct, int xcd) {
+    constexpr int W = 66, NR3 = (J + 2) * (K + 2), NR2 = J + 2;
+    extern __shared__ double lds[];
+    double *s3 = lds;                      // [4][NR3][W]
+    double *s2 = lds + 4 * NR3 * W;        // [N2D][NR2][W]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned b = blockIdx.x;
+    if (xcd) {  // XCD x takes the x-th contiguous eighth of the blocks
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8, y = b / 8;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int kg = (int)(b % nkg), seg = (int)((b / nkg) % nseg), jg = (int)(b / nkg / nseg);
+    if (jg >= njg) return;
+    const int i0 = seg * 64, j0 = jg * J, k0 = kg * K;
+    // ---- phase 1: row loads, UNR rows of a wave in flight at a time ----
+    constexpr int NROWS = 4 * NR3 + N2D * NR2;
+    for (int base = wid; base < NROWS; base += 4 * UNR) {
+        double x0[UNR], x1[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = base + 4 * u;
+            x0[u] = 0; x1[u] = 0;
+            if (r < 4 * NR3) {
+                const int a = r / NR3, q = r % NR3, jj = q % (J + 2), kk = q / (J + 2);
+                const bool corner = (jj == 0 || jj == J + 1) && (kk == 0 || kk == K + 1);
+                int j = j0 + jj - 1, k = k0 + kk - 1;
+                j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+                k = k < 0 ? 0 : (k >= nz ? nz - 1 : k);
+                const double *row = p.a[a] + ((i64)k * ny + j) * p.nx;
+                int i = i0 - 1 + lane; i = i < 0 ? 0 : (i >= p.nx ? p.nx - 1 : i);
+                int i2 = i0 + 63 + lane; i2 = i2 >= p.nx ? p.nx - 1 : i2;
+                if (!corner) { x0[u] = row[i]; if (lane < 2) x1[u] = row[i2]; }
+            } else if (r < NROWS) {
+                const int q = r - 4 * NR3, a = q / NR2, jj = q % NR2;
+                int j = j0 + jj - 1; j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+                const double *row = p.b[a] + (i64)j * p.nx;
+                int i = i0 - 1 + lane; i = i < 0 ? 0 : (i >= p.nx ? p.nx - 1 : i);
+                int i2 = i0 + 63 + lane; i2 = i2 >= p.nx ? p.nx - 1 : i2;
+                x0[u] = row[i]; if (lane < 2) x1[u] = row[i2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = base + 4 * u;
+            if (r < NROWS) {
+                double *dst = (r < 4 * NR3) ? s3 + (i64)r * W : s2 + (i64)(r - 4 * NR3) * W;
+                dst[lane] = x0[u];
+                if (lane < 2) dst[64 + lane] = x1[u];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: a wave per (row, level) of the block ----
+    for (int rl = wid; rl < J * K; rl += 4) {
+        const int jj = rl % J, kk = rl / J, j = j0 + jj, k = k0 + kk, i = i0 + lane;
+        if (j >= ny || k >= nz) continue;  // (wave-uniform)
+        const bool in = i < p.nx;
+        const i64 s = (i64)j * p.nx + (in ? i : p.nx - 1), L = (i64)k * p.P + s;
+        double v[NVAL];
+        int q = 0;
+        const int c3 = ((kk + 1) * (J + 2) + (jj + 1)) * W + lane + 1;
+        const int o3[7] = {0, 1, -1, W, -W, (J + 2) * W, -(J + 2) * W};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                if (a == 3 && o >= 5) continue;
+                v[q++] = s3[a * NR3 * W + c3 + o3[o]];
+            }
+        }
+        const i64 off[7] = {0, 1, -1, p.nx, -(i64)p.nx, p.P, -p.P};
+#pragma unroll
+        for (int a = 4; a < NARR; ++a) {
+            i64 x = L + off[a - 3];
+            x = x < 0 ? L : (x >= p.G ? L : x);
+            v[q++] = __builtin_nontemporal_load(p.a[a] + x);
+        }
+        const int c2 = (jj + 1) * W + lane + 1;
+#pragma unroll
+        for (int a = 0; a < N2D; ++a) v[q++] = s2[a * NR2 * W + c2];
+        const int o2[4] = {1, -1, W, -W};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[q++] = s2[a * NR2 * W + c2 + o2[o]];
+        }
+        double r[20];
+        math<true>(p, v, r);
+        unsigned h = (unsigned)(L * 2654435761u);
+        h = h * 1664525u + 1013904223u;
+        const bool wet = in && ((h >> 16) % 100u) < wetpct;
+        // compacted run of the wave's wet cells: position of a wet lane = number of wet lanes below it
+        const unsigned long long m = __ballot(wet);
+        const int cnt = __popcll(m);
+        const int pos = __popcll(m & ((1ull << lane) - 1ull));
+        const i64 runbase = (((i64)seg * ny + j) * nz + k) * 64;
+        // (model: every lane writes its own entries at its compacted position, 16 bytes per lane and store, like store_tile)
+        int e0 = 0;
+#pragma unroll
+        for (int mm = 0; mm < 5; ++mm) {
+            const int nent = cnt * CNT[mm];
+#pragma unroll
+            for (int c = 0; c < CNT[mm]; c += 2) {
+                const int first = c * 64 + lane * 2;
+                if (first < nent) {
+                    d2 x = {r[e0 + c] + pos, r[e0 + (c + 1 < CNT[mm] ? c + 1 : c)]};
+                    const i64 ent = runbase * CNT[mm] + first;
+                    __builtin_nontemporal_store(x, (d2 *)(p.out[2 * mm] + ent));
+                    __builtin_nontemporal_store(x, (d2 *)(p.out[2 * mm + 1] + ent));
+                }
+            }
+            e0 += CNT[mm];
+        }
+    }
+}
+
+template <int J, int K, int UNR>
+static void run_block(const char *tag, Params p, int ny, int nz, int nseg, unsigned wetpct, hipEvent_t e0, hipEvent_t e1) {
+    const int njg = (ny + J - 1) / J, nkg = (nz + K - 1) / K;
+    const size_t ldsb = (size_t)(4 * (J + 2) * (K + 2) + N2D * (J + 2)) * 66 * 8;
+    (void)hipFuncSetAttribute((const void *)block_lds<J, K, UNR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    for (int xcd = 0; xcd < 2; ++xcd) {
+        auto launch = [&] { hipLaunchKernelGGL((block_lds<J, K, UNR>), dim3((unsigned)(nseg * njg * nkg)), dim3(256), ldsb, 0, p, ny, nz, nseg, njg, nkg, wetpct, xcd); };
+        for (int r = 0; r < 10; ++r) launch();
+        (void)hipDeviceSynchronize();
+        hipError_t err = hipGetLastError();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 30; ++r) launch();
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("block model %s: %d rows x %d levels, %d rows in flight per wave, LDS %zu KB, %s, wet %u %%: %.4f ms%s\n", tag, J, K, UNR, ldsb / 1024,
+               xcd ? "XCD eighths" : "blockIdx order", wetpct, ms / 30, err == hipSuccess ? "" : "  (LAUNCH ERROR)");
+    }
+}
+
 int main(int argc, char **argv) {
     // default: the 1 degree grid; `fill_model 1440 1080 75 63526216` = the 0.25 degree grid
     const int nx = argc > 3 ? atoi(argv[1]) : 360, ny = argc > 3 ? atoi(argv[2]) : 300, nz = argc > 3 ? atoi(argv[3]) : 50;
@@ -375,6 +519,18 @@ int main(int argc, char **argv) {
             char name[96];
             snprintf(name, sizeof name, "march model: dense rows, %d level segments (%d waves)", kparts, nseg * ny * kparts);
             timeit(name, [&] { hipLaunchKernelGGL(march, dim3((nseg * ny * kparts + 3) / 4), dim3(256), 0, 0, p, ny, nz, nseg, kparts); });
+        }
+        {
+            const unsigned wetpct = (unsigned)(100.0 * (double)n / (double)G + 0.5);
+            run_block<4, 4, 8>("a", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<3, 3, 8>("b", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<2, 4, 8>("c", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<4, 2, 8>("d", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<2, 2, 8>("e", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<8, 2, 8>("f", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<3, 3, 4>("g", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block<3, 3, 12>("h", p, ny, nz, nseg, wetpct, e0, e1);
+            timeit("plain: nontemporal stores (again)", [&] { hipLaunchKernelGGL((plain<true, true, true, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         }
         for (int wgs : {768})  {
             char name[64];
