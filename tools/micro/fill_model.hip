@@ -415,6 +415,151 @@ __global__ __launch_bounds__(256) void block_lds(Params p, int ny, int nz, int n
     }
 }
 
+// The same block, pipelined as well as a single workgroup can be: phase 1 is ONE burst of asynchronous `global_load_lds_dwordx4` row loads
+// (34 lanes x 16 bytes = the 64 cells of the segment + 2 halo cells on either side, from an even index so that the 16 bytes are aligned;
+// no VGPR staging, every row of the wave in flight at once), the flux loads of all the wave's (row, level)s are issued before the barrier
+// too, and phase 2 touches global memory only to store.  Only two of the ten 2-D arrays carry halo rows (as in the real stencil).
+template <int J, int K>
+__global__ __launch_bounds__(256) void block_async(Params p, int ny, int nz, int nseg, int njg, int nkg, unsigned wetpct, int xcd) {
+    constexpr int W = 68, NR3 = (J + 2) * (K + 2), NR2 = 2 * (J + 2) + (N2D - 2) * J, ITER = (J * K + 3) / 4;
+    extern __shared__ double lds[];
+    double *s3 = lds;                  // [4][NR3][W]
+    double *s2 = lds + 4 * NR3 * W;    // arrays 0, 1: [J + 2][W] each; arrays 2 ..: [J][W] each
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned b = blockIdx.x;
+    if (xcd) {
+        const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8, y = b / 8;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int kg = (int)(b % nkg), seg = (int)((b / nkg) % nseg), jg = (int)(b / nkg / nseg);
+    if (jg >= njg) return;
+    const int i0 = seg * 64, j0 = jg * J, k0 = kg * K;
+    // the 16-byte piece of a row this lane fetches: cells i0 - 2 + 2 * lane, +1 (clamped into the row; lanes >= 34 idle)
+    int ia = i0 - 2 + 2 * lane;
+    ia = ia < 0 ? 0 : (ia > p.nx - 2 ? p.nx - 2 : ia);
+    constexpr int NROWS = 4 * NR3 + NR2;
+    for (int r = wid; r < NROWS; r += 4) {  // (wave-uniform trip count and row)
+        const double *row;
+        double *dst;
+        bool skip = false;
+        if (r < 4 * NR3) {
+            const int a = r / NR3, q = r % NR3, jj = q % (J + 2), kk = q / (J + 2);
+            skip = (jj == 0 || jj == J + 1) && (kk == 0 || kk == K + 1);
+            int j = j0 + jj - 1, k = k0 + kk - 1;
+            j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+            k = k < 0 ? 0 : (k >= nz ? nz - 1 : k);
+            row = p.a[a] + ((i64)k * ny + j) * p.nx;
+            dst = s3 + (i64)r * W;
+        } else {
+            const int q = r - 4 * NR3;
+            int a, jj;
+            if (q < 2 * (J + 2)) { a = q / (J + 2); jj = q % (J + 2) - 1; } else { a = 2 + (q - 2 * (J + 2)) / J; jj = (q - 2 * (J + 2)) % J; }
+            int j = j0 + jj; j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
+            row = p.b[a] + (i64)j * p.nx;
+            dst = s2 + (i64)q * W;
+        }
+        if (!skip && lane < 34)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row + ia), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+    // flux loads of every (row, level) of this wave
+    double phi[ITER][6];
+    const i64 off[7] = {0, 1, -1, p.nx, -(i64)p.nx, p.P, -p.P};
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int rl = wid + 4 * it, jj = rl % J, kk = rl / J;
+        int j = j0 + jj, k = k0 + kk, i = i0 + lane;
+        j = j >= ny ? ny - 1 : j; k = k >= nz ? nz - 1 : k; i = i >= p.nx ? p.nx - 1 : i;
+        const i64 L = (i64)k * p.P + (i64)j * p.nx + i;
+#pragma unroll
+        for (int a = 4; a < NARR; ++a) {
+            i64 x = L + off[a - 3];
+            x = x < 0 ? L : (x >= p.G ? L : x);
+            phi[it][a - 4] = __builtin_nontemporal_load(p.a[a] + x);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int rl = wid + 4 * it;
+        if (rl >= J * K) break;
+        const int jj = rl % J, kk = rl / J, j = j0 + jj, k = k0 + kk, i = i0 + lane;
+        if (j >= ny || k >= nz) continue;
+        const bool in = i < p.nx;
+        const i64 L = (i64)k * p.P + (i64)j * p.nx + (in ? i : p.nx - 1);
+        double v[NVAL];
+        int q = 0;
+        const int c3 = ((kk + 1) * (J + 2) + (jj + 1)) * W + lane + 2;
+        const int o3[7] = {0, 1, -1, W, -W, (J + 2) * W, -(J + 2) * W};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                if (a == 3 && o >= 5) continue;
+                v[q++] = s3[a * NR3 * W + c3 + o3[o]];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[q++] = phi[it][a];
+        const int ch = (jj + 1) * W + lane + 2;  // arrays with halo rows
+        const int cn = jj * W + lane + 2;        // arrays without
+#pragma unroll
+        for (int a = 0; a < N2D; ++a) v[q++] = (a < 2) ? s2[a * (J + 2) * W + ch] : s2[(2 * (J + 2) + (a - 2) * J) * W + cn];
+        const int o2[4] = {1, -1, W, -W};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[q++] = s2[a * (J + 2) * W + ch + o2[o]];
+        }
+        double r[20];
+        math<true>(p, v, r);
+        unsigned h = (unsigned)(L * 2654435761u);
+        h = h * 1664525u + 1013904223u;
+        const bool wet = in && ((h >> 16) % 100u) < wetpct;
+        const unsigned long long m = __ballot(wet);
+        const int cnt = __popcll(m);
+        const int pos = __popcll(m & ((1ull << lane) - 1ull));
+        const i64 runbase = (((i64)seg * ny + j) * nz + k) * 64;
+        int e0 = 0;
+#pragma unroll
+        for (int mm = 0; mm < 5; ++mm) {
+            const int nent = cnt * CNT[mm];
+#pragma unroll
+            for (int c = 0; c < CNT[mm]; c += 2) {
+                const int first = c * 64 + lane * 2;
+                if (first < nent) {
+                    d2 x = {r[e0 + c] + pos, r[e0 + (c + 1 < CNT[mm] ? c + 1 : c)]};
+                    const i64 ent = runbase * CNT[mm] + first;
+                    __builtin_nontemporal_store(x, (d2 *)(p.out[2 * mm] + ent));
+                    __builtin_nontemporal_store(x, (d2 *)(p.out[2 * mm + 1] + ent));
+                }
+            }
+            e0 += CNT[mm];
+        }
+    }
+}
+
+template <int J, int K>
+static void run_block_async(Params p, int ny, int nz, int nseg, unsigned wetpct, hipEvent_t e0, hipEvent_t e1) {
+    const int njg = (ny + J - 1) / J, nkg = (nz + K - 1) / K;
+    const size_t ldsb = (size_t)(4 * (J + 2) * (K + 2) + 2 * (J + 2) + (N2D - 2) * J) * 68 * 8;
+    (void)hipFuncSetAttribute((const void *)block_async<J, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    for (int xcd = 1; xcd < 2; ++xcd) {
+        auto launch = [&] { hipLaunchKernelGGL((block_async<J, K>), dim3((unsigned)(nseg * njg * nkg)), dim3(256), ldsb, 0, p, ny, nz, nseg, njg, nkg, wetpct, xcd); };
+        for (int r = 0; r < 10; ++r) launch();
+        (void)hipDeviceSynchronize();
+        hipError_t err = hipGetLastError();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 30; ++r) launch();
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("block model, asynchronous row loads: %d rows x %d levels, LDS %zu KB (%d workgroups per CU), XCD eighths, wet %u %%: %.4f ms%s\n", J, K, ldsb / 1024,
+               (int)(160 * 1024 / ldsb), wetpct, ms / 30, err == hipSuccess ? "" : "  (LAUNCH ERROR)");
+    }
+}
+
 template <int J, int K, int UNR>
 static void run_block(const char *tag, Params p, int ny, int nz, int nseg, unsigned wetpct, hipEvent_t e0, hipEvent_t e1) {
     const int njg = (ny + J - 1) / J, nkg = (nz + K - 1) / K;
@@ -530,6 +675,12 @@ int main(int argc, char **argv) {
             run_block<8, 2, 8>("f", p, ny, nz, nseg, wetpct, e0, e1);
             run_block<3, 3, 4>("g", p, ny, nz, nseg, wetpct, e0, e1);
             run_block<3, 3, 12>("h", p, ny, nz, nseg, wetpct, e0, e1);
+            run_block_async<3, 3>(p, ny, nz, nseg, wetpct, e0, e1);
+            run_block_async<2, 2>(p, ny, nz, nseg, wetpct, e0, e1);
+            run_block_async<2, 3>(p, ny, nz, nseg, wetpct, e0, e1);
+            run_block_async<3, 2>(p, ny, nz, nseg, wetpct, e0, e1);
+            run_block_async<4, 2>(p, ny, nz, nseg, wetpct, e0, e1);
+            run_block_async<4, 4>(p, ny, nz, nseg, wetpct, e0, e1);
             timeit("plain: nontemporal stores (again)", [&] { hipLaunchKernelGGL((plain<true, true, true, false, true>), dim3(ntiles), dim3(256), 0, 0, p); });
         }
         for (int wgs : {768})  {
