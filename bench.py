@@ -655,6 +655,8 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             "kernels_ms": {k: round(v, 5) for k, v in kavg.items()},
             "step_gbs": None if rehearsal else (runner.algorithmic_bytes() + runner.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
         }
+        if world > 1 or force_slab:
+            out["config"]["ranks_over"] = backend  # the depth-slab path: "nccl" = RCCL (one rank per GPU)
         if world == 1 and host_grid is not None and not rehearsal:
             out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)

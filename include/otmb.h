@@ -103,7 +103,11 @@ int32_t otmb_host_pool_stats(int64_t *blocks_in_use, int64_t *bytes_in_use, int6
  * are taken level after level before the next band starts, so that the levels above / below a tile (the vertical
  * neighbours of src/matrixbuilding.jl:280-296, :450-477) were read moments ago and are still in the L2 / Infinity Cache
  * instead of one whole level (124 MB of inputs on a 0.25 degree grid) earlier.  -1 (default): the library's choice (bands of
- * 8 rows: with the matrices written by non-temporal stores, 8 % faster than wet-rank order at 1 and at 0.25 degree).   */
+ * 8 rows: with the matrices written by non-temporal stores, 8 % faster than wet-rank order at 1 and at 0.25 degree).
+ * On grids whose rows are longer than 1536 cells a band is further cut into equal blocks of columns (3 x 1200 on a 3600-cell
+ * row): what an XCD's L2 keeps from one level to the next is rows x columns cells -- HBM fetch of the fill pass on the 0.1 degree
+ * grid 70 -> 48 GB, its time unchanged (profiles/r04/README.md section 10).  Environment, read when a context is created, for
+ * experiments only: OTMB_MARCH_ROWS, OTMB_MARCH_COLS (0 = whole rows).                                                       */
 int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band);
 /* Speed only, never results: which kernels build the matrices of transportmatrix.  dense = 0: GATHER -- one lane per wet
  * cell fetches its 6-neighbour stencil from global memory (tiles of 256 columns); dense = 1: DENSE-TILE MARCH -- a wave is

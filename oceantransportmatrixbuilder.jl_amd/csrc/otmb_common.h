@@ -44,9 +44,10 @@ struct otmb_ctx {
     DevBuf mask;              // push mask derived by the library when the caller passes none
     DevBuf order;             // tile order of the fill pass (march order: otmb_ctx_set_tile_order) + its bucket scratch
     int march_rows = -1;      // rows per band of the march order; 0 = wet-rank order; -1 = the library's default
+    int march_cols = -1;      // columns (i) per block of a band; 0 = whole rows; -1 = the library's default (experiments: OTMB_MARCH_COLS)
     struct OrderKey {
-        const void *lwet = nullptr; int64_t n = 0, nx = 0, ny = 0, nz = 0; int rows = 0, topo = -1;
-        bool operator==(const OrderKey &o) const { return lwet == o.lwet && n == o.n && nx == o.nx && ny == o.ny && nz == o.nz && rows == o.rows && topo == o.topo; }
+        const void *lwet = nullptr; int64_t n = 0, nx = 0, ny = 0, nz = 0; int rows = 0, topo = -1, cols = 0;
+        bool operator==(const OrderKey &o) const { return lwet == o.lwet && n == o.n && nx == o.nx && ny == o.ny && nz == o.nz && rows == o.rows && topo == o.topo && cols == o.cols; }
     } order_key;              // what ctx->order was built for
     int deal_heavy = 1;         // 0: the heavy tiles stay in the first XCD's share (experiments: OTMB_DEAL_HEAVY)
     unsigned order_nheavy = 0;  // the order's first entries are this many heavy tiles (tripolar seam row), dealt over the XCDs

@@ -68,6 +68,7 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     otmb_ctx *c = new otmb_ctx();
     c->device = device_id;
     if (const char *e = getenv("OTMB_MARCH_ROWS")) c->march_rows = atoi(e);  // experiments; otmb_ctx_set_tile_order is the API
+    if (const char *e = getenv("OTMB_MARCH_COLS")) c->march_cols = atoi(e);  // experiments
     if (const char *e = getenv("OTMB_DENSE")) c->formulation = atoi(e);        // experiments; otmb_ctx_set_formulation is the API
     if (const char *e = getenv("OTMB_FF_XCD")) c->ff_xcd_chunks = atoi(e);       // experiments (A/B in one library)
     if (const char *e = getenv("OTMB_FF_ROWS")) c->ff_rows = atoi(e);

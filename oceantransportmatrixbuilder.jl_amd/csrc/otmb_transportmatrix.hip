@@ -30,6 +30,11 @@
 #define OTMB_MARCH_AUTO_ROWS 8  // tile order when the caller does not choose: march order, bands of 8 rows (with the matrices written by
                                 // non-temporal stores: -8 % against wet-rank order at 1 and at 0.25 degree, R = 2 ... 32 within 1 %)
 #endif
+#ifndef OTMB_MARCH_AUTO_COLS
+#define OTMB_MARCH_AUTO_COLS 1536  // ... and, on grids with longer rows, blocks of at most this many columns (i) of a band: what an XCD's L2 (4 MB) has to keep
+                                   // from one level of a block to the next is rows x columns cells of Lwet3D / v3D / rho; with whole rows of 3600 cells
+                                   // (0.1 degree) every line above / below came from HBM again (fetch 70 GB for 49 GB of touched inputs, profiles/r04 section 10)
+#endif
 #define TM_INFILL_GROUPS 64  // up to this many scan groups the fill pass adds the group bases itself
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
@@ -705,10 +710,14 @@ __global__ __launch_bounds__(TFIX_THREADS) void tfix_move(const uint8_t *__restr
 // neighbours (levels k-1 and k+1 of Lwet3D, v3D, ρ) were touched one whole LEVEL of traffic earlier -- 124 MB of inputs
 // plus 300 MB of outputs on a 1440x1080 grid, past every cache -- so they come from HBM three times.  In march order the
 // tiles of a band of R rows are taken level after level: the same lines are needed again a few tiles later and are
-// served by the L2 / Infinity Cache.  Bucket = (band, level); a counting sort of the tiles by bucket.  Speed only.
-__device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 t, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo) {
+// served by the L2 / Infinity Cache.  Bucket = (band, block of columns, level) -- one block per band unless the rows are longer than
+// OTMB_MARCH_AUTO_COLS cells; a tile belongs to the block its first cell lies in -- ; a counting sort of the tiles by bucket.  Speed only.
+__device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 t, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, int cols) {
     const i64 L = lwet[t * TM_THREADS] - 1;  // (whatever Lwet holds, the key stays inside the bucket table)
     i64 k = L / P, j = (L - k * P) / nx;
+    i64 ic = (L - k * P - j * nx) / cols;
+    const i64 nblk = (nx + cols - 1) / cols;
+    ic = ic < 0 ? 0 : (ic >= nblk ? nblk - 1 : ic);
     k = k < 0 ? 0 : (k >= nz ? nz - 1 : k);
     j = j < 0 ? 0 : (j >= ny ? ny - 1 : j);
     // HEAVY tiles -- bucket 0, the front of the sequence, dealt over the XCDs by xcd_position: tiles with cells on the tripolar
@@ -721,15 +730,15 @@ __device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 
         if (j == ny - 1 || j1 == ny - 1 || k1 > k) return 0u;
     }
 #ifdef OTMB_MARCH_SOUTH_FIRST
-    return 1u + (unsigned)(j / rows) * (unsigned)nz + (unsigned)k;
+    return 1u + ((unsigned)(j / rows) * (unsigned)nblk + (unsigned)ic) * (unsigned)nz + (unsigned)k;
 #else
     // bands from north to south
-    return 1u + (unsigned)((ny - 1 - j) / rows) * (unsigned)nz + (unsigned)k;
+    return 1u + ((unsigned)((ny - 1 - j) / rows) * (unsigned)nblk + (unsigned)ic) * (unsigned)nz + (unsigned)k;
 #endif
 }
-__global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, unsigned *hist) {
+__global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, int cols, unsigned *hist) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ntiles) atomicAdd(&hist[order_key(lwet, t, n, nx, ny, P, rows, nz, topo)], 1u);
+    if (t < ntiles) atomicAdd(&hist[order_key(lwet, t, n, nx, ny, P, rows, nz, topo, cols)], 1u);
 }
 __global__ __launch_bounds__(1024) void order_scan(unsigned *hist, i64 nbuckets) {  // in place: exclusive prefix
     __shared__ unsigned wave_tot[16];
@@ -758,10 +767,10 @@ __global__ __launch_bounds__(1024) void order_scan(unsigned *hist, i64 nbuckets)
 }
 // every tile takes the next free position of its bucket: a bijection whatever the keys are (the order inside a bucket
 // -- a few dozen neighbouring tiles -- is left to the atomics)
-__global__ void order_scatter(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, unsigned *cursor,
-                              unsigned *order) {
+__global__ void order_scatter(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, int cols,
+                              unsigned *cursor, unsigned *order) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ntiles) order[atomicAdd(&cursor[order_key(lwet, t, n, nx, ny, P, rows, nz, topo)], 1u)] = (unsigned)t;
+    if (t < ntiles) order[atomicAdd(&cursor[order_key(lwet, t, n, nx, ny, P, rows, nz, topo, cols)], 1u)] = (unsigned)t;
 }
 
 // Decide and build the tile order of a fill launch.  Returns the device pointer (or NULL: wet-rank order).
@@ -773,13 +782,19 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
     if (rows < 0) rows = OTMB_MARCH_AUTO_ROWS;
     if (rows <= 0 || ntiles < 64 || ntiles >= (1ll << 31) - 16) return OTMB_OK;
     if (rows > a.ny) rows = (int)a.ny;
-    const i64 nbands = (a.ny + rows - 1) / rows, nbuckets = nbands * a.nz + 1;
+    // blocks of columns: equal pieces of a row, none longer than the limit (whole rows when they are short enough)
+    int cols = ctx->march_cols;
+    if (cols < 0) cols = OTMB_MARCH_AUTO_COLS;
+    if (cols <= 0 || cols >= a.nx) cols = (int)a.nx;
+    else { const i64 nb_ = (a.nx + cols - 1) / cols; cols = (int)((a.nx + nb_ - 1) / nb_); }
+    const i64 nblk = (a.nx + cols - 1) / cols;
+    const i64 nbands = (a.ny + rows - 1) / rows, nbuckets = nbands * nblk * a.nz + 1;
     if (nbuckets >= (1ll << 31)) return OTMB_OK;
     const size_t ob = ((size_t)ntiles * sizeof(unsigned) + 255) / 256 * 256, bb = ((size_t)nbuckets * sizeof(unsigned) + 255) / 256 * 256;
     // the order is a function of the grid alone: computed once per (Lwet array, shape, band height) and kept.  (Any permutation of
     // the tiles is correct, so an Lwet array rewritten in place can only cost speed.)
     otmb_ctx::OrderKey key;
-    key.lwet = a.lwet; key.n = a.n_wet; key.nx = a.nx; key.ny = a.ny; key.nz = a.nz; key.rows = rows; key.topo = a.topology;
+    key.lwet = a.lwet; key.n = a.n_wet; key.nx = a.nx; key.ny = a.ny; key.nz = a.nz; key.rows = rows; key.topo = a.topology; key.cols = cols;
     if (ctx->order.p && ctx->order.cap >= ob + bb && ctx->order_key == key) {
         p.order = (const unsigned *)ctx->order.p;
         p.nheavy = ctx->deal_heavy ? ctx->order_nheavy : 0u;
@@ -797,12 +812,12 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
         HIP_TRY(ctx, hipMemsetAsync(hist, 0, bb, ctx->stream));
         const unsigned nb = (unsigned)((ntiles + 255) / 256);
         hipLaunchKernelGGL(order_hist, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (i64)a.n_wet, (int)a.nx, (int)a.ny, a.nx * a.ny,
-                           rows, (int)a.nz, (int)a.topology, hist);
+                           rows, (int)a.nz, (int)a.topology, cols, hist);
         hipLaunchKernelGGL(order_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, nbuckets);
         // the number of heavy tiles = the exclusive prefix at bucket 1: the host needs it (grid size, kernel argument), once per grid
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_tot + 14, hist + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         hipLaunchKernelGGL(order_scatter, dim3(nb), dim3(256), 0, ctx->stream, (const i64 *)a.lwet, ntiles, (i64)a.n_wet, (int)a.nx, (int)a.ny, a.nx * a.ny,
-                           rows, (int)a.nz, (int)a.topology, hist, order);
+                           rows, (int)a.nz, (int)a.topology, cols, hist, order);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -70,6 +70,21 @@ def test_every_tile_order_gives_the_same_matrices(oracle):
         _check(asm, rtm, f"tile order {rows}, two-phase")
 
 
+
+@pytest.mark.parametrize("cols", ["0", "1", "17", "50", "64", "119", "120", "100000"])
+def test_march_order_in_blocks_of_columns_gives_the_same_matrices(oracle, monkeypatch, cols):
+    """Round 4: on grids with long rows the march order's buckets are (band, block of columns, level) (OTMB_MARCH_AUTO_COLS; a context
+    reads OTMB_MARCH_COLS when it is created).  Any block width -- narrower than a tile, not a divisor of nx, wider than the row --
+    is a permutation of the tiles and gives the oracle's matrices bit for bit, in both protocols."""
+    monkeypatch.setenv("OTMB_MARCH_COLS", cols)
+    asm, umo, vmo, rtm = _setup(oracle, (120, 100, 23, 89, "array", "tripolar"))
+    for rows in (-1, 3):
+        asm.ctx.set_tile_order(rows)
+        asm.step(umo, vmo, 1e20)
+        _check(asm, rtm, f"cols {cols}/order {rows}/async")
+        asm.step(umo, vmo, 1e20, onepass=False)
+        _check(asm, rtm, f"cols {cols}/order {rows}/two-phase")
+
 def test_tile_order_is_computed_once_per_grid(oracle):
     """The march order is a function of the grid: its three kernels run on the first step and again only when the band height changes
     (otmb_ctx_set_tile_order); the default (-1) is the march order, i.e. they do run."""
