@@ -43,6 +43,23 @@ __global__ __launch_bounds__(256) void writes(d2 *__restrict__ buf, size_t n, in
         for (int u = 0; u < UNR; ++u) __builtin_nontemporal_store(x, buf + ((e0 + (size_t)u * 256) & (n - 1)));
     }
 }
+// write sweep: NS streams (regions `gap` elements apart, each written front to back by all workgroups together, like the fill pass's ten
+// output arrays), UNR stores of 16 bytes in flight per thread and stream piece, plain or non-temporal
+template <bool NT, int UNR, int NS>
+__global__ __launch_bounds__(256) void writes_sweep(d2 *__restrict__ buf, size_t n_per_stream, size_t gap, int passes) {
+    for (int q = 0; q < passes; ++q) {
+        const size_t e0 = (((size_t)q * gridDim.x + blockIdx.x) * UNR) * 256 + threadIdx.x;
+        const d2 x = {(double)q, (double)e0};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                d2 *dst = buf + (size_t)s * gap + ((e0 + (size_t)u * 256) & (n_per_stream - 1));
+                if (NT) __builtin_nontemporal_store(x, dst); else *dst = x;
+            }
+        }
+    }
+}
 // which XCD / CU does each workgroup run on?  HW_REG_HW_ID (4): cu_id [11:8], sh_id [12], se_id [15:13]; HW_REG_XCC_ID (20)
 __global__ void probe(unsigned *out) {
     if (threadIdx.x == 0) {
@@ -84,6 +101,34 @@ int main(int argc, char **argv) {
     { std::vector<uint32_t> m(nw, 0u); for (int c = 0; c < ncu / 2; ++c) m[c / 32] |= 1u << (c % 32); masks.push_back({"lower half of the CU ids", m}); }
     { std::vector<uint32_t> m(nw, 0x11111111u); masks.push_back({"every fourth CU id", m}); }
 
+    if (only == 100) {  // write sweep on all CUs: total 8 GiB written per launch over a 8 GiB buffer (far beyond L2 + Infinity Cache)
+        char *wb;
+        const size_t tot = (size_t)8 << 30;
+        CK(hipMalloc(&wb, tot));
+        CK(hipMemset(wb, 0, tot));
+        auto run = [&](const char *name, int nblk, int unr, int ns, auto launch) {
+            for (int r = 0; r < 2; ++r) launch();
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(e0, 0);
+            const int REP = 5;
+            for (int r = 0; r < REP; ++r) launch();
+            (void)hipEventRecord(e1, 0);
+            (void)hipDeviceSynchronize();
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("  writes %-14s %5d workgroups, %2d stores in flight x %2d streams: %8.3f ms  %6.2f TB/s\n", name, nblk, unr, ns, ms / REP, (double)tot / (ms * 1e-3 / REP) / 1e12);
+        };
+#define SWEEP(NT, UNR, NS, NBLK) { const size_t nps = tot / 16 / NS; const int passes = (int)(nps / ((size_t)(NBLK) * 256 * UNR)); \
+        run(NT ? "non-temporal" : "plain", NBLK, UNR, NS, [&] { hipLaunchKernelGGL((writes_sweep<NT, UNR, NS>), dim3(NBLK), dim3(256), 0, 0, (d2 *)wb, nps, nps, passes); }); }
+        for (int nblk : {ncu * 2, ncu * 4, ncu * 8, ncu * 16}) {
+            SWEEP(true, 8, 1, nblk) SWEEP(false, 8, 1, nblk)
+        }
+        SWEEP(true, 2, 1, ncu * 8) SWEEP(false, 2, 1, ncu * 8) SWEEP(true, 16, 1, ncu * 8) SWEEP(false, 16, 1, ncu * 8)
+        SWEEP(true, 4, 2, ncu * 8) SWEEP(false, 4, 2, ncu * 8) SWEEP(true, 2, 8, ncu * 8) SWEEP(false, 2, 8, ncu * 8)
+        SWEEP(true, 1, 16, ncu * 8) SWEEP(false, 1, 16, ncu * 8) SWEEP(true, 4, 8, ncu * 4) SWEEP(false, 4, 8, ncu * 4)
+        SWEEP(true, 2, 8, ncu * 3) SWEEP(false, 2, 8, ncu * 3)
+        return 0;
+    }
     for (size_t mi = 0; mi < masks.size(); ++mi) {
         auto &mk = masks[mi];
         if (only >= 0 && (int)mi != only) continue;
