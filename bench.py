@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--extra-configs", default="quarterdeg,tenthdeg",
                     help="after the headline workload (N = 1 only): BASELINE.json configs[2] (0.25 degree, the HBM-roofline run) and configs[4]'s "
                          "grid (0.1 degree, on ONE GPU) as extra records of the same JSON line; '' = none")
+    ap.add_argument("--placement-candidates", type=int, default=4,
+                    help="set-up, N = 1 only: DeviceAssembler.choose_placement -- the flux arrays and the output matrices are allocated this many times, "
+                         "facefluxes / the fill pass timed on each, the fastest kept (profiles/r04/README.md section 12); 1 = off")
     ap.add_argument("--protocol", default="async", choices=["async", "twophase"],
                     help="async: otmb_transportmatrix_dev (count -> scan -> fill enqueued back to back, outputs preallocated "
                          "at their upper bound); twophase: plan (host learns nnz) then fill, as a caller that sizes its outputs does")
@@ -210,7 +213,8 @@ def extra_configs_in_children(args):
     for wl in [w for w in args.extra_configs.split(",") if w and w != args.workload]:
         key = names.get(wl, "config_" + wl)
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--extra-configs", "", "--no-cpu-baseline", "--no-end-to-end",
-               "--steps", str(min(args.steps, 10)), "--warmup", "2", "--repeats", "2", "--rho", args.rho, "--seed", str(args.seed)]
+               "--steps", str(min(args.steps, 10)), "--warmup", "2", "--repeats", "2", "--rho", args.rho, "--seed", str(args.seed),
+               "--placement-candidates", str(args.placement_candidates)]
         rec = {"workload": wl}
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=float(os.environ.get("OTMB_BENCH_EXTRA_TIMEOUT", "600")))
@@ -223,7 +227,7 @@ def extra_configs_in_children(args):
                 rec.update({"grid": d["config"]["workload"].split("grid ")[1].split(",")[0], "wet_cells": d["config"]["wet_cells"], "nnz": d["config"]["nnz"],
                             "protocol": d["config"]["protocol"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
                             "value": d["value"], "unit": d["unit"], "repeats": d["repeats"], "roofline": d["roofline"], "kernels_ms": d["kernels_ms"],
-                            "step_gbs": d["step_gbs"], "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
+                            "step_gbs": d["step_gbs"], "placement": d.get("placement"), "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
         except subprocess.TimeoutExpired:
             rec["error"] = "child timed out"
         except Exception as e:  # an extra record must never cost the headline
@@ -476,6 +480,7 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
 
     nx, ny, nz, lf = synthetic.PRESETS[args.workload]
     host_grid = None  # (g, gm) when the whole grid also exists on the host (cpu_baseline / end_to_end legs)
+    placement = None  # DeviceAssembler.choose_placement's record (single-GPU, asynchronous protocol)
     if world > 1 or force_slab:
         from otmb_amd import dist as odist
         from otmb_amd import synthetic_device
@@ -538,6 +543,12 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             umo = torch.from_numpy(np.asfortranarray(g.umo.data).ravel(order="F")).to(dev)
             vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
             fill = g.umo.properties["_FillValue"]
+
+        if args.placement_candidates > 1 and args.protocol == "async" and args.workload != "tenthdeg":
+            try:  # set-up, outside the timed region; never results (tests/test_device_api.py)
+                placement = asm.choose_placement(umo, vmo, fill, candidates=args.placement_candidates)
+            except Exception as e:
+                placement = {"error": f"{type(e).__name__}: {e}"[:200]}
 
         class _Single:
             protocol = "twophase" if (args.protocol == "twophase" or args.workload == "tenthdeg") else "async"
@@ -655,6 +666,8 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             "kernels_ms": {k: round(v, 5) for k, v in kavg.items()},
             "step_gbs": None if rehearsal else (runner.algorithmic_bytes() + runner.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
         }
+        if world == 1 and not force_slab and not rehearsal:
+            out["placement"] = placement
         if world > 1 or force_slab:
             out["config"]["ranks_over"] = backend  # the depth-slab path: "nccl" = RCCL (one rank per GPU)
         if world == 1 and host_grid is not None and not rehearsal:

@@ -335,6 +335,61 @@ class DeviceAssembler:
         return {m: (self._empty(self.N + 1, torch.int64), self._empty(cap[k], torch.int64),
                     self._empty(cap[k], torch.float64)) for k, m in enumerate(MATS)}
 
+    def choose_placement(self, umo, vmo, fill, candidates=4, reps=3, budget_fraction=0.6, min_output_bytes=4 << 30):
+        """Set-up time only, never results: pick WHERE this assembler's flux arrays and output matrices live.
+        On MI355X the time of the two write-heavy passes depends reproducibly on which device allocations their arrays were given -- inside one
+        process the fill pass ran 5.86 ... 6.57 ms (another box: 5.97 ... 7.35 ms) on eight output sets whose virtual layout is identical, every set
+        repeating to 0.1 % (profiles/r04/README.md section 12): it is the physical backing of the ~30 concurrently streamed arrays that differs, and
+        no per-buffer probe sees it (single streams differ by <= 4 %).  So: allocate `candidates` flux sets and time facefluxes on each, keep the fastest;
+        then `candidates` output sets (new_output_set()) and time the fill pass on each with the kept fluxes, keep the fastest; free the rest.
+        Nothing is chosen when the candidates would not fit in `budget_fraction` of the free device memory (the 0.1 degree grid), nor on grids whose
+        output set is smaller than `min_output_bytes` (1 degree: the candidates differ by 1-2 % there, nothing to choose).  Returns a record of every
+        candidate's time (bench.py prints it)."""
+        rec = {"candidates": int(candidates), "facefluxes_ms": [], "fill_ms": [], "chosen": None}
+        if candidates < 2:
+            return rec
+        free_b, _ = torch.cuda.mem_get_info(self.device)
+        phi_bytes = self.G * (6 * 8 + 2)
+        out_bytes = sum((self.N * k + 1) * 16 + (self.N + 1) * 8 for k in self.PER_COLUMN_MAX)
+        if out_bytes < min_output_bytes:
+            rec["skipped"] = "small grid: placements differ by 1-2 %"
+            return rec
+        if candidates * (phi_bytes + out_bytes) > budget_fraction * free_b:
+            rec["skipped"] = "candidates do not fit"
+            return rec
+
+        def timed(kernel, launch):
+            for _ in range(2):
+                launch()
+            self.ctx.synchronize()
+            self.ctx.timing_enable(True)
+            for _ in range(reps):
+                launch()
+            self.ctx.synchronize()
+            t = self.ctx.timing_collect()
+            self.ctx.timing_enable(False)
+            return t[kernel][0] / t[kernel][1]
+
+        phis = [([self._empty(self.G, torch.float64) for _ in range(6)], self._empty(self.G, torch.int16)) for _ in range(candidates)]
+        for p, m in phis:
+            self.phi, self.push_mask = p, m
+            rec["facefluxes_ms"].append(timed("facefluxes_kernel", lambda: self.facefluxes_async(umo, vmo, fill)))
+        self.finish_facefluxes()
+        kp = int(np.argmin(rec["facefluxes_ms"]))
+        self.phi, self.push_mask = phis[kp]
+        del phis, p, m
+        phi = self.facefluxes(umo, vmo, fill)
+        outs = [self.new_output_set() for _ in range(candidates)]
+        for o in outs:
+            rec["fill_ms"].append(timed("tm_kernel<fill>", lambda: self.transportmatrix_onepass(phi, sync=False, out=o)))
+            self.result()
+        ko = int(np.argmin(rec["fill_ms"]))
+        self.out, self._out_cap = outs[ko], [self.N * k + 1 for k in self.PER_COLUMN_MAX]
+        del outs, o
+        torch.cuda.empty_cache()  # the candidates that were not kept go back to the driver
+        rec["chosen"] = [kp, ko]
+        return rec
+
     def transportmatrix_onepass(self, phi, sync=True, out=None):
         """Asynchronous protocol (otmb_transportmatrix_dev): outputs preallocated at their upper bound, count ->
         scan -> fill enqueued without a host round trip.  With sync=False the nnz/errors are collected later by

@@ -85,6 +85,26 @@ def test_march_order_in_blocks_of_columns_gives_the_same_matrices(oracle, monkey
         asm.step(umo, vmo, 1e20, onepass=False)
         _check(asm, rtm, f"cols {cols}/order {rows}/two-phase")
 
+
+def test_choose_placement_never_changes_a_result(oracle):
+    """DeviceAssembler.choose_placement (set-up: which allocations the flux arrays and the matrices live in, chosen by timing) keeps the fastest of
+    its candidates and leaves every result as it was, in both protocols; a candidate count that cannot fit is skipped, not an error."""
+    asm, umo, vmo, rtm = _setup(oracle, (120, 100, 23, 90, "array", "tripolar"))
+    assert "skipped" in asm.choose_placement(umo, vmo, 1e20, candidates=3)  # (a small grid: nothing to choose by default)
+    rec = asm.choose_placement(umo, vmo, 1e20, candidates=3, reps=2, min_output_bytes=0)
+    assert rec["chosen"] is not None and len(rec["fill_ms"]) == 3 and len(rec["facefluxes_ms"]) == 3, rec
+    assert rec["chosen"] == [int(np.argmin(rec["facefluxes_ms"])), int(np.argmin(rec["fill_ms"]))]
+    asm.step(umo, vmo, 1e20)
+    _check(asm, rtm, "after choose_placement/async")
+    asm.step(umo, vmo, 1e20, onepass=False)
+    _check(asm, rtm, "after choose_placement/two-phase")
+    for _ in range(3):
+        asm.step_async(umo, vmo, 1e20)
+    asm.finish()
+    _check(asm, rtm, "after choose_placement/pipeline")
+    assert asm.choose_placement(umo, vmo, 1e20, candidates=1, min_output_bytes=0)["chosen"] is None
+    assert "skipped" in asm.choose_placement(umo, vmo, 1e20, candidates=10 ** 9, min_output_bytes=0)
+
 def test_tile_order_is_computed_once_per_grid(oracle):
     """The march order is a function of the grid: its three kernels run on the first step and again only when the band height changes
     (otmb_ctx_set_tile_order); the default (-1) is the march order, i.e. they do run."""
