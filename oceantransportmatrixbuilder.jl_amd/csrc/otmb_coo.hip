@@ -141,10 +141,35 @@ __global__ __launch_bounds__(256) void sp_keys_kernel(const i64 *__restrict__ I,
         if (!ok && *bad == 0) atomicAdd((unsigned long long *)bad, 1ull);
     }
 }
+// colptr over runs of EMPTY columns: the head that follows a run owns it.  Short runs it writes itself; a long one (a matrix whose entries sit in a
+// few columns -- TκVML lives in the mixed layer only: one thread used to walk two million empty columns, 26 ms of a 27 ms call) goes to a list of
+// (first column, last column, value) pieces of at most SP_GAP_PIECE columns that sp_fill_gaps_kernel fills with whole workgroups.
+#define SP_GAP_SELF 16
+#define SP_GAP_PIECE 65536
+struct SpGap { i64 lo, hi, val; };
+__device__ __forceinline__ void sp_colptr_run(i64 lo, i64 hi, i64 val, i64 *__restrict__ colptr, unsigned long long *__restrict__ ngaps, SpGap *__restrict__ gaps) {
+    if (hi - lo < SP_GAP_SELF) {
+        for (i64 c = lo; c <= hi; ++c) colptr[c - 1] = val;
+        return;
+    }
+    for (i64 a = lo; a <= hi; a += SP_GAP_PIECE) {
+        const i64 b = (a + SP_GAP_PIECE - 1 < hi) ? a + SP_GAP_PIECE - 1 : hi;
+        const unsigned long long slot = atomicAdd(ngaps, 1ull);
+        gaps[slot].lo = a; gaps[slot].hi = b; gaps[slot].val = val;
+    }
+}
+__global__ __launch_bounds__(256) void sp_fill_gaps_kernel(const unsigned long long *__restrict__ ngaps, const SpGap *__restrict__ gaps, i64 *__restrict__ colptr) {
+    const unsigned long long n = *ngaps;
+    for (unsigned long long g = blockIdx.x; g < n; g += gridDim.x) {
+        const i64 lo = gaps[g].lo, hi = gaps[g].hi, val = gaps[g].val;
+        for (i64 c = lo + threadIdx.x; c <= hi; c += 256) colptr[c - 1] = val;
+    }
+}
 template <bool WRITE>
 __global__ __launch_bounds__(256) void sp_heads_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ idx, const double *__restrict__ V,
                                                        i64 len, uint32_t *__restrict__ tilesums, const i64 *__restrict__ tileoffs,
-                                                       i64 n, i64 *__restrict__ colptr, i64 *__restrict__ rowval, double *__restrict__ nzval) {
+                                                       i64 n, i64 *__restrict__ colptr, i64 *__restrict__ rowval, double *__restrict__ nzval,
+                                                       unsigned long long *__restrict__ ngaps, SpGap *__restrict__ gaps) {
     __shared__ unsigned wave_tot[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const i64 e = (i64)blockIdx.x * 256 + tid;
@@ -170,12 +195,12 @@ __global__ __launch_bounds__(256) void sp_heads_kernel(const u64 *__restrict__ k
         // colptr: every column from the previous head's column + 1 up to this one starts at q + 1
         const i64 col = (i64)(key >> 32);
         const i64 pcol = (e == 0) ? 0 : (i64)(keys[e - 1] >> 32);
-        for (i64 c = pcol + 1; c <= col; ++c) colptr[c - 1] = q + 1;
+        if (col > pcol) sp_colptr_run(pcol + 1, col, q + 1, colptr, ngaps, gaps);
     }
     if (e == len - 1 || (len == 0 && e == 0)) {
         const i64 lastcol = (len == 0) ? 0 : (i64)(keys[len - 1] >> 32);
         const i64 nnz = (len == 0) ? 0 : tileoffs[blockIdx.x] + before + inwave + (head ? 1 : 0);
-        for (i64 c = lastcol + 1; c <= n + 1; ++c) colptr[c - 1] = nnz + 1;
+        sp_colptr_run(lastcol + 1, n + 1, nnz + 1, colptr, ngaps, gaps);
     }
 }
 
@@ -293,7 +318,8 @@ int32_t otmb_sparse_plan_dev(otmb_ctx *ctx, const int64_t *I, const int64_t *J, 
         if ((rc = otmb_reserve(ctx, ctx->sort[4], tmp + 16))) return rc;
         if (rocprim::radix_sort_pairs(ctx->sort[4].p, tmp, k0, k1, v0, v1, (size_t)len, 0, 64, ctx->stream) != hipSuccess) return otmb_fail(ctx, OTMB_ERR_HIP, "radix_sort_pairs");
         hipLaunchKernelGGL(sp_heads_kernel<false>, dim3((unsigned)nt), dim3(256), 0, ctx->stream, (const u64 *)k1, (const u64 *)v1, V, (i64)len,
-                           (uint32_t *)ctx->blocksums.p, (const i64 *)nullptr, (i64)n, (i64 *)nullptr, (i64 *)nullptr, (double *)nullptr);
+                           (uint32_t *)ctx->blocksums.p, (const i64 *)nullptr, (i64)n, (i64 *)nullptr, (i64 *)nullptr, (double *)nullptr,
+                           (unsigned long long *)nullptr, (SpGap *)nullptr);
         otmb_launch_tilescan(ctx->stream, (const uint32_t *)ctx->blocksums.p, (i64 *)ctx->blockoffs.p, dtot, nt, 1, (i64 *)ctx->blockoffs.p + nt + 1);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -310,9 +336,19 @@ int32_t otmb_sparse_fill_dev(otmb_ctx *ctx, int64_t *colptr, int64_t *rowval, do
     if (!colptr || (ctx->sp.nnz > 0 && (!rowval || !nzval))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 len = ctx->sp.len, nt = (len + 255) / 256;
+    // the list of long runs of empty columns: at most one per head (+ the tail) and at most (n + 1) / SP_GAP_SELF, each cut into pieces
+    const i64 ncol = ctx->sp.n + 1;
+    const i64 runs = ((len + 1 < ncol / SP_GAP_SELF + 1) ? len + 1 : ncol / SP_GAP_SELF + 1);
+    const size_t gap_bytes = 16 + (size_t)(runs + ncol / SP_GAP_PIECE + 2) * sizeof(SpGap);
+    int32_t rc;
+    if ((rc = otmb_reserve(ctx, ctx->sort[0], gap_bytes))) return rc;  // (the unsorted keys are no longer needed)
+    unsigned long long *ngaps = (unsigned long long *)ctx->sort[0].p;
+    SpGap *gaps = (SpGap *)((char *)ctx->sort[0].p + 16);
+    HIP_TRY(ctx, hipMemsetAsync(ngaps, 0, 16, ctx->stream));
     hipLaunchKernelGGL(sp_heads_kernel<true>, dim3((unsigned)(nt > 0 ? nt : 1)), dim3(256), 0, ctx->stream, (const u64 *)ctx->sort[1].p,
                        (const u64 *)ctx->sort[3].p, ctx->sp.V, len, (uint32_t *)nullptr, (const i64 *)ctx->blockoffs.p, ctx->sp.n, (i64 *)colptr,
-                       (i64 *)rowval, nzval);
+                       (i64 *)rowval, nzval, ngaps, gaps);
+    hipLaunchKernelGGL(sp_fill_gaps_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const unsigned long long *)ngaps, (const SpGap *)gaps, (i64 *)colptr);
     HIP_TRY(ctx, hipGetLastError());
     return OTMB_OK;
 }

@@ -82,6 +82,40 @@ def test_device_sparse_on_arbitrary_triplets(oracle):
     assert_csc_equal((cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy()), oracle.sparse(I, J, V, m, n), "after the failures")
 
 
+def test_device_sparse_with_long_runs_of_empty_columns(oracle):
+    """sparse(I, J, V, m, n) whose entries sit in a few columns of a wide matrix (TκVML: the mixed layer only): colptr over a run of empty columns
+    is filled by the entry after it -- short runs by its thread, long ones (> 16 columns, in pieces of 65 536) through a list and whole workgroups
+    (one thread used to walk them all: 26 ms of a 27 ms call at 1 degree).  Leading, inner and trailing runs of every kind, against scipy's CSC."""
+    import scipy.sparse as sp
+    import torch
+
+    g, gm, ref, rphi, asm = _setup(oracle, "tiny_tripolar")
+    rng = np.random.default_rng(9)
+    m, n = 1000, 400000
+    cols = np.concatenate([[40, 41, 42, 58, 59, 75, 76], np.arange(100, 140), [70000, 70001, 135537, 135538, 201074, 399000]])  # runs of 39, 15, 16, 17, ~70 k, 65 536, 65 535, ...
+    J = np.repeat(cols, 3).astype(np.int64)
+    I = rng.integers(1, m + 1, J.size).astype(np.int64)
+    V = rng.standard_normal(J.size)
+    perm = rng.permutation(J.size)
+    I, J, V = I[perm], J[perm], V[perm]
+    cp, rv, nz = asm.sparse(torch.from_numpy(I).cuda(), torch.from_numpy(J).cuda(), torch.from_numpy(V).cuda(), m, n)
+    want = sp.coo_matrix((V, (I - 1, J - 1)), shape=(m, n)).tocsc()
+    want.sum_duplicates()
+    want.sort_indices()
+    assert np.array_equal(cp.cpu().numpy(), want.indptr.astype(np.int64) + 1)
+    assert np.array_equal(rv.cpu().numpy(), want.indices.astype(np.int64) + 1)
+    assert np.allclose(nz.cpu().numpy(), want.data, rtol=1e-15, atol=0)
+    assert_csc_equal((cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy()), oracle.sparse(I, J, V, m, n), "wide matrix, few columns")
+    # one entry in the last column; one entry in the first column; nothing at all
+    for jj in (n, 1):
+        cp, rv, nz = asm.sparse(torch.tensor([7], device="cuda"), torch.tensor([jj], device="cuda"), torch.tensor([2.5], dtype=torch.float64, device="cuda"), m, n)
+        c = cp.cpu().numpy()
+        assert (c[:jj] == 1).all() and (c[jj:] == 2).all() and rv.cpu().tolist() == [7]
+    e = torch.empty(0, dtype=torch.int64, device="cuda")
+    cp, rv, nz = asm.sparse(e, e, torch.empty(0, dtype=torch.float64, device="cuda"), m, n)
+    assert (cp.cpu().numpy() == 1).all() and cp.numel() == n + 1
+
+
 @pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold"])
 def test_build_single_operators_like_the_reference(oracle, name):
     """buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120) one at a time equal the operators

@@ -214,6 +214,31 @@ def test_spadd_matches_oracle(api, oracle):
     assert_csc_equal(tuple(api.spadd(A, E)), oracle.spadd(tuple(A), tuple(E), n), "spadd with empty")
 
 
+def test_spadd_staged_and_unstaged_blocks(api, oracle):
+    """Round 4's sparse add stages the entries of a workgroup's 256 columns in LDS when they fit (2040 per operand) and walks global memory
+    otherwise: a matrix whose first columns are dense (unstaged blocks) and whose other columns hold a handful of entries (staged blocks), both
+    ways round, with exact cancellations, against the oracle; and n not a multiple of 256."""
+    from otmb_amd.api import SparseMatrixCSC
+
+    rng = np.random.default_rng(12)
+    n = 1100
+
+    def rand(dense_cols, per_dense, ln_sparse):
+        J = np.concatenate([rng.integers(1, dense_cols + 1, per_dense * dense_cols), rng.integers(dense_cols + 1, n + 1, ln_sparse)])
+        I = rng.integers(1, n + 1, J.size)
+        V = rng.integers(-2, 3, J.size).astype(float)
+        cp, rv, nz = oracle.sparse(I, J, V, n, n)
+        return SparseMatrixCSC(n, n, cp, rv, nz)
+
+    A, B = rand(300, 40, 4000), rand(200, 3, 5000)
+    assert int(A.colptr[256]) - 1 > 2040 and int(B.colptr[256]) - 1 <= 2040  # block 0: A does not fit, B does
+    for X, Y, what in ((A, B, "A + B"), (B, A, "B + A"), (A, A, "A + A"), (B, B, "B + B")):
+        assert_csc_equal(tuple(api.spadd(X, Y)), oracle.spadd(tuple(X), tuple(Y), n), what)
+    neg = SparseMatrixCSC(n, n, A.colptr, A.rowval, -A.nzval)
+    Z = api.spadd(A, neg)  # everything cancels exactly: an empty matrix
+    assert Z.nzval.size == 0 and (Z.colptr == 1).all()
+
+
 def test_transportmatrix_with_precomputed_operators(api, oracle):
     g, gm = make_case("tiny_rho3d")
     ref = oracle.makeindices(gm.v3D)
