@@ -24,7 +24,7 @@ struct OtmbXfer;  // otmb_xfer.h: pinned staging ring + host copy threads of the
 
 // pending plan of the general path (otmb_coo.hip): COO generator and sparse()
 struct CooPlan { int which = -1; otmb_tm_args args; int64_t ntiles = 0, len = 0; };
-struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = nullptr; int64_t len = -1, m = 0, n = 0, nnz = 0; };
+struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = nullptr; int64_t len = -1, m = 0, n = 0, nnz = 0; int rowbits = 32; };  // rowbits: the sort keys are (column << rowbits) | row
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
