@@ -406,6 +406,20 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
     int32_t rc;
     if ((rc = set_partition(mg, counts, nx, ny))) return rc;
     for (Slab *sl : mg->slabs) { sl->plane_ready = false; sl->plane_failed = false; }
+    // The plane buffer of slab s is written by the thread of slab s + 1 (send_plane): every slab's buffer is (re)allocated HERE, before any
+    // slab thread runs -- reserved inside its owner's thread it could still be missing, or be freed for a larger one (an otmb_mgpu reused
+    // on a larger grid), while the slab below was already copying into it (an intermittent "plane hand-off" error in
+    // tests/test_mgpu.py::test_mgpu_reports_the_reference_error_of_the_failing_slab, round 4 call 42).
+    {
+        int dev0 = 0;
+        (void)hipGetDevice(&dev0);
+        for (Slab *sl : mg->slabs) {
+            void *q;
+            if (hipSetDevice(sl->device) != hipSuccess) { (void)hipSetDevice(dev0); return mg_fail(mg, OTMB_ERR_HIP, "hipSetDevice"); }
+            if ((rc = reserve(*sl, B_PLANE, (size_t)P * 8, &q))) { (void)hipSetDevice(dev0); return mg_fail(mg, rc, "plane buffer"); }
+        }
+        (void)hipSetDevice(dev0);
+    }
     run_slabs(mg, [&](int s) {
         Slab &sl = *mg->slabs[s];
         auto fail = [&](int32_t st) {

@@ -171,6 +171,29 @@ def test_mgpu_reports_the_reference_error_of_the_failing_slab(oracle):
 
 
 @pytest.mark.gpu
+def test_mgpu_facefluxes_on_grids_of_alternating_size(oracle):
+    """One otmb_mgpu (the host layer keeps one per device list) used on a small and a larger grid in turn: the plane buffer of slab s is written
+    by the thread of slab s + 1, so it has to exist at its final size before any slab thread runs (round 4: it was reserved inside its owner's
+    thread, and on a grid larger than the previous one the slab below could copy into a buffer that was missing or being replaced -- an
+    intermittent "plane hand-off" error).  Ten alternations, four slabs, every ϕ against the oracle."""
+    import otmb_amd.api as api
+
+    rng = np.random.default_rng(21)
+    devices = [0, 0, 0, 0]
+    topo = dict(gridtopology=dict(kind=1))
+    for rep in range(10):
+        nx, ny, nz = ((5, 4, 8), (40 + rep, 30, 9))[rep % 2]
+        wet = rng.random((nx, ny, nz)) > 0.2
+        wet[:, :, 0] |= True
+        u = np.asfortranarray(np.where(wet, rng.standard_normal((nx, ny, nz)), 1e20))
+        v = np.asfortranarray(np.where(wet, rng.standard_normal((nx, ny, nz)), 1e20))
+        got = api.facefluxes(u, v, topo, dict(wet3D=wet), FillValue=1e20, devices=devices)
+        want = oracle.facefluxes(u, v, wet, 1e20, 1)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (rep, k)
+
+
+@pytest.mark.gpu
 def test_mgpu_at_the_headline_grid_matches_the_single_device_path():
     """BASELINE.json configs[0/1]'s grid (360x300x50) cut into 4 slabs on GPU 0 against the single-context host path of the same
     library: identical bytes (the single-context path is compared with the oracle on this grid by tests/test_baseline_configs.py)."""

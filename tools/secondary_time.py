@@ -72,6 +72,25 @@ e_east, e_north = asm.edge[capi.HDIRS.index("east")], asm.edge[capi.HDIRS.index(
 for fn in ("otmb_velocity2fluxes_dev", "otmb_fluxes2velocity_dev"):
     timed(fn, 8 * G * 6 + 16 * P, lambda fn=fn: ctx.check(getattr(lib, fn)(ctx.handle, u.data_ptr(), v.data_ptr(), 0, asm.rho.data_ptr(), 0.0, asm.thk.data_ptr(), e_east.data_ptr(),
                                                                         e_north.data_ptr(), nx, ny, nz, asm.topology, fi.data_ptr(), fj.data_ptr())))
+# f4 B-grid -> C-grid interpolation: two arrays in, two out
+u2, v2 = torch.empty_like(u), torch.empty_like(u)
+timed("otmb_bgrid_to_cgrid_dev", 8 * G * 4, lambda: ctx.check(lib.otmb_bgrid_to_cgrid_dev(ctx.handle, u.data_ptr(), v.data_ptr(), 0, 1e20, nx, ny, nz, u2.data_ptr(), v2.data_ptr())))
+# f2 makegridmetrics on the device: the library's own HIP events around its kernels (the call also uploads the raw CMIP arrays from the host)
+asm2 = DeviceAssembler(0)
+asm2.ctx.timing_enable(True)
+for _ in range(3):
+    asm2.set_grid_from_raw(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev, lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices,
+                           mlotst=g.mlotst, rho=g.rho)
+asm2.ctx.synchronize()
+tg = asm2.ctx.timing_collect()
+asm2.ctx.timing_enable(False)
+for kname, (ms_sum, cnt) in tg.items():
+    if "gridmetrics" in kname:
+        nb = 8 * G * 4 + 8 * P * 30  # volcello in, v3D / thkcello / Z3D out; the 2-D fields (vertices, edges, distances): nominal
+        rows.append({"call": f"otmb_makegridmetrics_dev: {kname}", "ms": round(ms_sum / cnt, 4), "algorithmic_MB": round(nb / 1e6, 1), "TBps": round(nb / (ms_sum / cnt * 1e-3) / 1e12, 3),
+                     "frac_of_8TBps": round(nb / (ms_sum / cnt * 1e-3) / 8e12, 3), "note": "kernels only (HIP events of the library); 12 haversines per (i, j) + the 3-D arrays"})
+        print(json.dumps(rows[-1]), flush=True)
+del asm2
 # a15 bolus_GM_velocity: rho, Z3D, wet byte in (+ two 2-D distances); u, v out
 dn = gm.distance_to_neighbour_2D
 flat = lambda a: torch.from_numpy(np.asfortranarray(a, dtype=np.float64).ravel(order="F")).to(dev)
