@@ -323,6 +323,7 @@ class DeviceAssembler:
         return self.fill()
 
     PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold
+    FILL_KERNELS = ("tm_kernel<fill>", "tm_kernel<onepass>", "dm_fill_kernel")  # the pass that writes the matrices, by formulation (otmb_kernel_name)
 
     def new_output_set(self):
         """A set of five CSC output buffers at their upper bound (for transportmatrix_onepass(out=...): a pipeline whose
@@ -358,7 +359,8 @@ class DeviceAssembler:
             rec["skipped"] = "candidates do not fit"
             return rec
 
-        def timed(kernel, launch):
+        def timed(kernels, launch):
+            """mean duration of the pass: whichever of `kernels` ran (the fill pass has another name under the look-back / dense-march formulations)"""
             for _ in range(2):
                 launch()
             self.ctx.synchronize()
@@ -368,12 +370,15 @@ class DeviceAssembler:
             self.ctx.synchronize()
             t = self.ctx.timing_collect()
             self.ctx.timing_enable(False)
-            return t[kernel][0] / t[kernel][1]
+            ran = [t[k] for k in kernels if k in t]
+            if not ran:
+                raise RuntimeError(f"choose_placement: none of {kernels} was launched ({sorted(t)})")
+            return max(ms / cnt for ms, cnt in ran)
 
         phis = [([self._empty(self.G, torch.float64) for _ in range(6)], self._empty(self.G, torch.int16)) for _ in range(candidates)]
         for p, m in phis:
             self.phi, self.push_mask = p, m
-            rec["facefluxes_ms"].append(timed("facefluxes_kernel", lambda: self.facefluxes_async(umo, vmo, fill)))
+            rec["facefluxes_ms"].append(timed(("facefluxes_kernel",), lambda: self.facefluxes_async(umo, vmo, fill)))
         self.finish_facefluxes()
         kp = int(np.argmin(rec["facefluxes_ms"]))
         self.phi, self.push_mask = phis[kp]
@@ -381,7 +386,7 @@ class DeviceAssembler:
         phi = self.facefluxes(umo, vmo, fill)
         outs = [self.new_output_set() for _ in range(candidates)]
         for o in outs:
-            rec["fill_ms"].append(timed("tm_kernel<fill>", lambda: self.transportmatrix_onepass(phi, sync=False, out=o)))
+            rec["fill_ms"].append(timed(self.FILL_KERNELS, lambda: self.transportmatrix_onepass(phi, sync=False, out=o)))
             self.result()
         ko = int(np.argmin(rec["fill_ms"]))
         self.out, self._out_cap = outs[ko], [self.N * k + 1 for k in self.PER_COLUMN_MAX]

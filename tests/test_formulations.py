@@ -2,6 +2,8 @@
 (otmb_ctx_set_formulation) and every tile order of the gather kernels (otmb_ctx_set_tile_order) against the oracle, bit for bit,
 on the cases that stress them -- tripolar seam row, odd nx (a cell that is its own fold neighbour), nx just above the dense kernels'
 minimum, rows longer than one 62-cell segment, depth parts that do not divide the levels, scalar and 3-D ρ, upwind and centred."""
+import os
+
 import numpy as np
 import pytest
 
@@ -105,6 +107,8 @@ def test_choose_placement_never_changes_a_result(oracle):
     assert asm.choose_placement(umo, vmo, 1e20, candidates=1, min_output_bytes=0)["chosen"] is None
     assert "skipped" in asm.choose_placement(umo, vmo, 1e20, candidates=10 ** 9, min_output_bytes=0)
 
+@pytest.mark.skipif(any(os.environ.get(k) for k in ("OTMB_LOOKBACK", "OTMB_DENSE", "OTMB_MARCH_ROWS")),
+                    reason="counts the default formulation's kernels (the suite is also run under the library's experiment switches: tools/r04_call44.sh)")
 def test_tile_order_is_computed_once_per_grid(oracle):
     """The march order is a function of the grid: its three kernels run on the first step and again only when the band height changes
     (otmb_ctx_set_tile_order); the default (-1) is the march order, i.e. they do run."""
