@@ -158,6 +158,10 @@ def test_large_grid_properties_and_subslab_oracle(oracle, workload, slab, protoc
     asm = synthetic_device.assembler_for(dg)
     assert asm.G == dg.nx * dg.ny * dg.nz
     if protocol == "async":
+        # the flux arrays and the output set are chosen by timing among freshly allocated candidates first (what bench.py does on this
+        # grid): set-up only -- everything below is checked on the arrays that were kept
+        rec = asm.choose_placement(dg.umo, dg.vmo, dg.fill, candidates=3, reps=2)
+        assert rec.get("skipped") == "candidates do not fit" or (rec["chosen"] is not None and len(rec["fill_ms"]) == 3), rec
         asm.step_async(dg.umo, dg.vmo, dg.fill)
         asm.finish()
     else:  # outputs sized exactly by plan -> fill (the upper-bound buffers of the async protocol would not fit at 0.1 degree)
