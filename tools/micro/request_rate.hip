@@ -129,6 +129,43 @@ int main(int argc, char **argv) {
         SWEEP(true, 2, 8, ncu * 3) SWEEP(false, 2, 8, ncu * 3)
         return 0;
     }
+    if (only == 200) {  // scaling with the number of busy CUs: NW persistent workgroups (one per CU while NW <= CUs), the same streams
+        char *wb;
+        const size_t tot = (size_t)4 << 30;
+        CK(hipMalloc(&wb, tot));
+        CK(hipMemset(wb, 0, tot));
+        for (int nw : {16, 32, 64, 128, 256, 512, 1024, 2048}) {
+            // where do NW workgroups of 256 threads land?
+            CK(hipMemset(pr, 0xff, NPROBE * sizeof(unsigned)));
+            hipLaunchKernelGGL(probe, dim3(nw), dim3(256), 0, 0, pr);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned> h(nw);
+            CK(hipMemcpy(h.data(), pr, nw * sizeof(unsigned), hipMemcpyDeviceToHost));
+            std::set<unsigned> xcds, cus;
+            for (unsigned v : h) { xcds.insert(v >> 16); cus.insert(v); }
+            const int active = (int)cus.size();
+            auto run = [&](const char *name, double bytes, double req_bytes, auto launch) {
+                launch();
+                (void)hipDeviceSynchronize();
+                (void)hipEventRecord(e0, 0);
+                const int REP = 3;
+                for (int r = 0; r < REP; ++r) launch();
+                (void)hipEventRecord(e1, 0);
+                (void)hipDeviceSynchronize();
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                const double sec = ms * 1e-3 / REP;
+                printf("  %4d workgroups on %3d CUs of %zu XCDs: %-34s %7.2f TB/s  %7.1f G requests/s  %6.3f per busy CU and cycle\n", nw, active, xcds.size(), name, bytes / sec / 1e12,
+                       bytes / req_bytes / sec / 1e9, bytes / req_bytes / sec / ((double)active * prop.clockRate * 1e3));
+            };
+            const int PH = 2048, PB = (int)(((size_t)1 << 30) / ((size_t)nw * 256 * 8 * 16)) > 4096 ? 4096 : (int)(((size_t)1 << 30) / ((size_t)nw * 256 * 8 * 16));
+            auto bytes = [&](int passes) { return (double)passes * nw * 256 * 8 * 16; };
+            run("reads 16 B/lane, L2 hits (2 MB)", bytes(PH), 128, [&] { hipLaunchKernelGGL((reads<d2, 8>), dim3(nw), dim3(256), 0, 0, (const d2 *)wb, small / 16, PH, sink); });
+            run("reads 16 B/lane, HBM (4 GiB)", bytes(PB), 128, [&] { hipLaunchKernelGGL((reads<d2, 8>), dim3(nw), dim3(256), 0, 0, (const d2 *)wb, tot / 16, PB, sink); });
+            run("writes 16 B/lane nt, HBM (4 GiB)", bytes(PB), 64, [&] { hipLaunchKernelGGL((writes<8>), dim3(nw), dim3(256), 0, 0, (d2 *)wb, tot / 16, PB); });
+        }
+        return 0;
+    }
     for (size_t mi = 0; mi < masks.size(); ++mi) {
         auto &mk = masks[mi];
         if (only >= 0 && (int)mi != only) continue;
