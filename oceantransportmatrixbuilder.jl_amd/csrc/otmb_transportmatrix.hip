@@ -252,10 +252,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     __shared__ int s_tile;
     __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // rows, then value bits
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#ifdef OTMB_LDS_PAD  // experiment (profiles/r04 section 11): fewer resident workgroups per CU through LDS that nothing uses (31000: two per CU, 61000: one)
-    __shared__ char s_pad[OTMB_LDS_PAD];
-    if (p.n_own < 0) s_pad[tid] = (char)tid;  // (never true: keeps the array)
-#endif
     Stamps st;
 #ifdef OTMB_DBG_STAMPS
     for (int q = 0; q < OTMB_NSTAMP; ++q) st.t[q] = 0;
