@@ -2,7 +2,7 @@
 # Round-4 final check: what the driver runs at round end -- pytest -m gpu, smoke(), python bench.py.
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/r04_final2
+OUT=$REPO/gpurun_out/r04_final3
 mkdir -p $OUT
 cd $REPO
 timeout -k 10 800 python3 -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; rc=$?
