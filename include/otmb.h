@@ -168,6 +168,37 @@ int32_t otmb_wetflags_dev(otmb_ctx *ctx, const uint8_t *wet3d, int64_t nx, int64
 int32_t otmb_facefluxes_flags_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                   const uint8_t *wetflags, double fill, int64_t nx, int64_t ny, int64_t nz,
                                   int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask);
+/* Speed only: facefluxes that ALSO counts.  Which rows the four operators of transportmatrix hold in column c
+ * (src/matrixbuilding.jl:244-296, :348-415, :450-477) follows from the wet mask, the mixed-layer mask zt[k] < mlotst[i,j] (:85) and the
+ * signs of the fluxes c's six neighbours push with -- which, for fluxes facefluxes itself writes, are c's OWN six fluxes
+ * (ϕwest[E] = ϕeast[c], ..., ϕbottom[A] = ϕtop[c]: src/velocities.jl:206-224, :238-240).  otmb_facefluxes_counts_dev is
+ * otmb_facefluxes_flags_dev whose kernel also accumulates, per tile of 256 matrix columns, the row counts of Tadv and TκVML that
+ * transportmatrix's counting pass would derive (the counts of TκH, TκVdeep and T's reserved union depend on the wet mask alone and come
+ * from the grid's tables); an otmb_transportmatrix_dev / _plan_dev that is then handed EXACTLY these ϕ arrays, this push_mask pointer,
+ * mlotst, zt, lwet3d, n_wet, topology, upwind and only_t -- with no other facefluxes call on the context in between -- skips its
+ * counting pass (6-7 % of a device-resident step).  Any other transportmatrix call counts for itself as before, and the fill pass
+ * compares every tile's counts with the columns it builds (OTMB_ERR_PUSH_MASK), so stale counts cannot produce a wrong matrix.
+ * In this mode push_mask is NOT written: the pointer only names the fluxes (the library knows and never reads it as a mask).  Whole
+ * grids only (no top_below, wet ranks from 1).  Falls back to otmb_facefluxes_flags_dev's behaviour (mask written, no counts) when
+ * nx < 3 or OTMB_COUNT_IN_FF=0.
+ * tables: once per grid by otmb_count_tables_dev from the indices and otmb_wetflags_dev's bytes (otmb_count_tables_bytes bytes: the wet
+ * rank of the first wet cell of every 64-cell segment a wave of the kernel covers, and the static counts of every tile).  Both
+ * asynchronous.                                                                                                                   */
+typedef struct {
+    const void *tables;      /* otmb_count_tables_dev */
+    const int64_t *lwet3d;   /* indices.Lwet3D */
+    const double *mlotst;    /* (nx,ny) */
+    const double *zt;        /* (nz) */
+    int64_t n_wet;
+    int32_t upwind;          /* as otmb_tm_args.upwind */
+    int32_t only_t;          /* as otmb_tm_args.only_t */
+} otmb_ff_counts;
+int64_t otmb_count_tables_bytes(const otmb_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t n_wet);
+int32_t otmb_count_tables_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet,
+                              int64_t nx, int64_t ny, int64_t nz, int32_t topology, void *tables);
+int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                   const uint8_t *wetflags, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                   int32_t topology, double *const phi[6], uint16_t *push_mask, const otmb_ff_counts *counts);
 /* The same two flags for EVERY facefluxes call on this context since the previous call of this function, oldest
  * first (a pipeline of asynchronous steps: the reference asserts per call, src/velocities.jl:199-200, so a field
  * without a single valid value in step 3 of 12 must not be hidden by steps 4-12).  Synchronises.  At most the 64

@@ -14,8 +14,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libotmb_hip.so")
 # (LLVM's alternative machine-scheduler strategies -- max-memory-clause, max-ilp, iterative-* -- were compared with
 # tools/ab_variants.py over several array placements each: none beats the default on the fill pass.)
+# -amdgpu-atomic-optimizer-strategy=None: every atomic of this library with a wave-uniform address is issued by ONE elected lane already (the
+# counts in facefluxes: two per wave and level); LLVM's optimizer wraps each in its own lane election + popcount multiply (~12 instructions).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-Wno-bitwise-instead-of-logical"]
+         "-Wno-bitwise-instead-of-logical", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))

@@ -46,6 +46,11 @@ class TmArgs(C.Structure):
     ]
 
 
+class FfCounts(C.Structure):
+    _fields_ = [("tables", C.c_void_p), ("lwet3d", C.c_void_p), ("mlotst", C.c_void_p), ("zt", C.c_void_p),
+                ("n_wet", C.c_int64), ("upwind", C.c_int32), ("only_t", C.c_int32)]
+
+
 # every symbol include/otmb.h declares: (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -93,6 +98,9 @@ SYMBOLS = {
     "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
     "otmb_wetflags_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp]),
     "otmb_facefluxes_flags_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
+    "otmb_count_tables_bytes": (C.c_int64, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "otmb_count_tables_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp]),
+    "otmb_facefluxes_counts_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, C.POINTER(FfCounts)]),
     "otmb_push_mask_dev": (C.c_int32, [_vp, C.POINTER(_vp * 6), _vp, C.c_int64, C.c_int64, _vp]),
     "otmb_lump_and_spray_plan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp,
                                                   C.c_int64, C.c_int64, C.c_int64, _ip]),
@@ -269,7 +277,7 @@ class Context:
     def timing_enable(self, on=True):
         self.check(self._lib.otmb_ctx_timing_enable(self._h, int(on)))
 
-    def timing_collect(self, n=16):
+    def timing_collect(self, n=32):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()

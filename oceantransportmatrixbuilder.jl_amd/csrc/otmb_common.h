@@ -28,7 +28,7 @@ struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = null
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_TM_ORDER, K_DM_COUNT, K_DM_FILL, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_TM_ORDER, K_DM_COUNT, K_DM_FILL, K_FF_BASES, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 
@@ -55,6 +55,23 @@ struct otmb_ctx {
     int ff_lds_south = 1;     // four-row facefluxes workgroups take a wave's south row from the neighbouring wave through LDS (experiments: OTMB_FF_LDS_SOUTH)
     int ff_rows = 0;          // facefluxes: rows per workgroup, 1 or 4; 0 = by grid size (experiments: OTMB_FF_ROWS)
     int count_order = 2;      // counting pass: 0 = blockIdx (wet-rank) order, 1 = XCD-contiguous eighths of wet-rank order, 2 = of the fill pass's tile order (default: HBM fetch 1.06-1.11 x its inputs instead of 2.1-2.7 x, +2-4 % of this pass's time; OTMB_COUNT_ORDER)
+    // ---- counts in facefluxes (otmb_facefluxes_counts_dev): the five per-tile row counts of the transportmatrix that will be built from the
+    // fluxes a facefluxes call is writing are accumulated by that call (packed 64-bit atomics, one word per tile of 256 columns), so the
+    // device-resident step has no counting pass.  Two buffers: the call after next may run beside the fill pass that consumes this one.
+    int count_in_ff = 1;      // 0: otmb_facefluxes_counts_dev behaves as otmb_facefluxes_flags_dev (experiments / A-B: OTMB_COUNT_IN_FF)
+    DevBuf ffc_sums[2];
+    bool ffc_dirty[2] = {true, true};  // the buffer is not known to be all zero
+    int ffc_next = 0;
+    struct FfCountsKey {      // what the pending counts describe; consumed (valid = false) by the transportmatrix that uses them
+        bool valid = false;
+        int buf = 0, gen = 0;
+        const void *phi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const void *mask = nullptr, *mlotst = nullptr, *zt = nullptr, *lwet3d = nullptr;
+        const void *stat = nullptr;  // the grid's static per-tile counts (otmb_count_tables_dev), added by the scan
+        int64_t nx = 0, ny = 0, nz = 0, n_wet = 0;
+        int topo = -1, upwind = -1, only_t = -1;
+    } ffc;
+    const void *ffc_partial_mask = nullptr;  // the push_mask argument of the last counting facefluxes call: NOT written by it, never a counting pass's input
     int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)
     int dense_kparts = 1;     // dense march: depth pieces per (row, segment)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)
@@ -138,6 +155,12 @@ static inline int *otmb_ring_ff(int *ring, int gen) { return (int *)((char *)rin
 
 int32_t otmb_fail(otmb_ctx *ctx, int32_t status, const char *detail = nullptr);
 int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);
+// counts in facefluxes: bit layout of a tile's packed word (the block scan's: T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10) + two flag bits
+#define FFC_TILE_SHIFT 8                  // tiles of 256 columns (TM_THREADS)
+#define FFC_BAD_FLUX (1ull << 63)         // some cell of the tile pushes a non-zero flux into land / out of the grid
+#define FFC_BAD_TABLE (1ull << 62)        // the bases table was built for another wave geometry
+void otmb_launch_tilescan_packed(hipStream_t s, unsigned long long *packed, const unsigned long long *stat, uint32_t *sums, i64 *offs, i64 *tot, i64 *gsum, i64 ntiles,
+                                 int *flags, int only_t, bool all_levels);  // otmb_scan.hip
 int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
                               uint16_t *push_mask);  // otmb_facefluxes.hip
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip

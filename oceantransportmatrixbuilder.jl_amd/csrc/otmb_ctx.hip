@@ -76,6 +76,7 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     if (const char *e = getenv("OTMB_COUNT_ORDER")) c->count_order = atoi(e);
     if (const char *e = getenv("OTMB_DEAL_HEAVY")) c->deal_heavy = atoi(e);
     if (const char *e = getenv("OTMB_DENSE_KPARTS")) c->dense_kparts = atoi(e);
+    if (const char *e = getenv("OTMB_COUNT_IN_FF")) c->count_in_ff = atoi(e);  // A/B in one library
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return OTMB_ERR_HIP;
@@ -112,7 +113,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     otmb_tm_plan_free(ctx);
     otmb_xfer_free(ctx);
-    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->lookback, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4]})
+    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->lookback, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4], &ctx->ffc_sums[0], &ctx->ffc_sums[1]})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
@@ -202,7 +203,7 @@ const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
                                             "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
-                                            "push_mask_kernel", "tm_order_kernels", "dm_count_kernel", "dm_fill_kernel"};
+                                            "push_mask_kernel", "tm_order_kernels", "dm_count_kernel", "dm_fill_kernel", "ff_count_bases_kernel"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

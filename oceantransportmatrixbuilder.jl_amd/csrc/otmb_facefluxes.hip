@@ -21,6 +21,8 @@ template <typename T>
 struct FfChunk {
     T u[FF_KB], v[FF_KB], uw[FF_KB], vs[FF_KB];
     unsigned char wc[FF_KB], wE[FF_KB], wW[FF_KB], wS[FF_KB], wN[FF_KB];  // (FLAGS: wc holds the cell's five flags, the others are unused)
+    unsigned char wup;  // (COUNTS) the flags of the level above the chunk's last level
+    T vn[FF_KB];        // (COUNTS, waves with lanes on the tripolar seam row) vmo of the fold cell
 };
 // wet flags of a cell and its four horizontal neighbours (otmb_wetflags_dev): the boundary rule of nofluxboundaries!
 // (:161-175) needs five wet bytes per cell and level -- grid constants -- which this byte replaces by one load
@@ -43,10 +45,139 @@ struct FfCol {
     bool hS, hN;
 };
 
+// ---- counts in facefluxes (otmb_facefluxes_counts_dev) ----------------------------------------------------------------------------
+// Which rows the four operators hold in column c (src/matrixbuilding.jl:244-296, :348-415, :450-477) is a function of the wet mask,
+// the mixed-layer mask and the sign of the six fluxes the NEIGHBOURS push towards c -- and for fluxes that this kernel writes those are
+// c's OWN six fluxes: ϕwest[E] = ϕeast[c], ϕeast[W] = ϕwest[c], ϕnorth[S] = ϕsouth[c], ϕsouth[N] = ϕnorth[c] (src/velocities.jl:206-224),
+// ϕbottom[A] = ϕtop[c], ϕtop[B] = ϕbottom[c] (:238-240).  Of the five per-tile row counts that transportmatrix's counting pass derives
+// from the push mask (tm_count_kernel), three -- TκH, TκVdeep and T's reserved union -- depend on the WET MASK alone (a flux is non-zero
+// only towards a wet cell, :167-173, so the union is "every wet neighbour + the diagonal"): they are summed once per grid
+// (ff_static_counts_kernel).  The other two -- Tadv (flux signs) and TκVML (zt[k] < mlotst, :85) -- are accumulated HERE, from registers:
+// a wave's 64 cells of one level are consecutive in linear order, hence consecutive in wet rank -- rank = bases[level][wave segment] +
+// (wet lanes before) -- and fall into at most two tiles of 256 columns: one wave sum (DPP adds) of a packed word and at most two packed
+// 64-bit atomic adds per wave and level (integers: the sums do not depend on the order).  The fill pass still compares every tile's
+// counts with what it builds (FLAG_COUNT_MISMATCH): counts that do not describe the fluxes cannot corrupt anything.
+// (A first version took 19 ballots and 38 scalar popcounts per level and all five counts: the CU's one scalar unit then bounded the
+// kernel, 1.38 -> 1.91 ms at 0.25 degree; profiles/r05.)
+// The tripolar seam row (j = ny - 1): the north neighbour is the fold cell (nx - 1 - i, ny - 1), which pushes with ITS north flux
+// (:271-278 seen from the other side) -- the one flux a cell does not own: waves with lanes on that row prefetch vmo of the fold cell
+// with the chunk -- and lies in the cell's own matrix row block, where it can coincide with the east / west row-mate or the cell itself
+// (the slot logic of build_column / general_presence, reduced to "the N bit lands on the E or W bit, or nowhere").
+// Bits of a neighbour set: E 2, W 4, S 8, N 16 (as in the five-flag byte); A 32, B 64.
+struct FfCountArgs {
+    const uint32_t *bases;     // [0] header, then [nseg][nz]: 0-based wet rank of the first wet cell of the segment at each level (otmb_count_tables_dev)
+    const double *mlotst, *zt;
+    unsigned long long *sums;  // packed per-tile counts (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10): this kernel adds Tadv and TκVML
+    int upwind, only_t;
+    int nseg;                  // wave segments per level
+};
+#define FFC_MAX_NZ 128  // a wave keeps its per-level table entries and zt in registers, lane l = level l and level 64 + l
+struct FfCountState {
+    double mld;
+    unsigned seg;
+    unsigned base_lo, base_hi;  // lane l: 0-based wet rank of the first wet cell of this wave's segment at level l / 64 + l
+    double zt_lo, zt_hi;        // lane l: zt[l] / zt[64 + l]
+    bool om_cur, om_below;      // zt[k] < mlotst for the level being counted / the level below it (a window that moves up with the march)
+    unsigned amask;            // seam row: flag bit (E / W) of the row-mate the fold neighbour coincides with, else 0
+    bool aclear;               // seam row: the fold neighbour is the east / west row-mate or the cell itself: it has no slot of its own
+    bool fold;                 // the lane's cell is on the tripolar seam row
+    bool has_fold;             // (wave-uniform) so is some lane of this wave
+    bool act, wet_below;
+};
+#define FFC_HEADER(rows, nseg) (((unsigned)(rows) << 28) ^ (unsigned)(nseg))
+__device__ __forceinline__ unsigned ff_mbcnt(u64 m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ bool ff_nonzero(double x) { return (x > 0.0) | (x < 0.0); }
+// the seam row's slot rule on a neighbour set: the fold neighbour's bit (N) moves onto the row-mate it coincides with, or vanishes
+// into the diagonal
+__device__ __forceinline__ unsigned ff_fold_alias(unsigned bits, unsigned amask) { return (bits & 16u) ? ((bits | amask) & ~16u) : bits; }
+// Sum of one 32-bit value per lane over the wave (every lane active): four row_shr adds put each row's total in its last lane,
+// row_bcast:15 / :31 carry them to lane 63.
+__device__ __forceinline__ unsigned ff_wave_sum(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// a per-level value kept one level per lane (k is wave-uniform: a v_readlane, no memory access in the march)
+__device__ __forceinline__ unsigned ff_level_u32(unsigned lo, unsigned hi, int k) {
+    return (unsigned)((k < 64) ? __builtin_amdgcn_readlane((int)lo, k) : __builtin_amdgcn_readlane((int)hi, k - 64));
+}
+__device__ __forceinline__ double ff_level_f64(double lo, double hi, int k) {
+    const double v = (k < 64) ? lo : hi;
+    const int l = k & 63;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// One level of one wave (all 64 lanes execute).  wc / f: the cell's wet flag and five-flag byte, fa: the flag byte of the cell above,
+// vn: vmo of the fold cell (seam-row lanes of waves with has_fold).
+__device__ __forceinline__ void ff_count_level(const FfCountArgs &cnt, FfCountState &cs, int k, int nz, bool wc, unsigned f, unsigned fa,
+                                               double e, double w, double so, double n, double b, double t, double vn, double fill) {
+    const bool wet = cs.act & wc;
+    const u64 wetb = __builtin_amdgcn_ballot_w64(wet);
+    if (wetb != 0) {  // (uniform)
+        const bool hA = k > 0, hB = k + 1 < nz;
+        const unsigned vw = ((hA && (fa & WF_C)) ? 32u : 0u) | ((hB && cs.wet_below) ? 64u : 0u);  // wet cells above / below
+        // the flux the north neighbour pushes with, signed so that "towards c" is positive: ϕsouth[N] = ϕnorth[c]; through the seam -ϕnorth[fold]
+        double nn = n;
+        if (cs.has_fold) {  // (uniform)
+            const double nf = (f & WF_N) ? ff_replace(vn, fill) : 0.0;  // the fold cell's ϕnorth after ITS boundary rule (its north neighbour is c)
+            nn = cs.fold ? -nf : n;
+        }
+        unsigned ab;   // which neighbours push mass into c: max(ϕ,0) / min(ϕ,0) / ϕ/2 non-zero (:244-289), exactly otmb_push_bits
+        unsigned own;  // c's own vertical pushes (bottom 64, top 32): they must land in a wet cell (the reference indexes Lwet3D[C𝑗]
+                       // unconditionally); the horizontal fluxes are zero towards land by construction (:167-173)
+        if (cnt.upwind) {
+            ab = (e > 0.0 ? 2u : 0u) | (w < 0.0 ? 4u : 0u) | (so < 0.0 ? 8u : 0u) | (nn > 0.0 ? 16u : 0u) | (t > 0.0 ? 32u : 0u) | (b < 0.0 ? 64u : 0u);
+            own = (b > 0.0 ? 64u : 0u) | ((hA && t < 0.0) ? 32u : 0u);
+        } else {
+            const double he = e / 2, hw = w / 2, hs = so / 2, hn = nn / 2, hb = b / 2, ht = t / 2;
+            const unsigned vb = ff_nonzero(hb) ? 64u : 0u, vt = ff_nonzero(ht) ? 32u : 0u;
+            ab = (ff_nonzero(he) ? 2u : 0u) | (ff_nonzero(hw) ? 4u : 0u) | (ff_nonzero(hs) ? 8u : 0u) | (ff_nonzero(hn) ? 16u : 0u) | vt | vb;
+            own = vb | (hA ? vt : 0u);
+        }
+        const bool bad = (own & ~vw) != 0;
+        ab &= vw | 0x1eu;  // the cells above / below push only if they are wet
+        const unsigned anyA = ab != 0;  // the diagonal's bit
+        if (cs.has_fold && cs.aclear) ab = ff_fold_alias(ab, cs.amask);
+        unsigned x = wet ? __popc(ab) + anyA : 0u;  // Tadv rows of this column
+        const unsigned base = ff_level_u32(cs.base_lo, cs.base_hi, k);
+        const bool in0 = ff_mbcnt(wetb) < 256u - (base & 255u);  // this lane's column still belongs to the wave's first tile
+        const unsigned sx = ff_wave_sum(in0 ? x : (x << 16));    // both tiles' sums in one word (<= 7 * 64 each)
+        u64 c0 = (u64)(sx & 0xffffu) << 11, c1 = (u64)(sx >> 16) << 11;
+        // TκVML: only within the mixed layer -- Ω[c] = zt[k] < mlotst (:85; NaN compares false), and the same for the cells above / below
+        const bool omC = wet & cs.om_cur;
+        if (__builtin_amdgcn_ballot_w64(omC) != 0) {  // (uniform)
+            const bool om_above = ff_level_f64(cs.zt_lo, cs.zt_hi, hA ? k - 1 : k) < cs.mld;
+            const unsigned ml = ((om_above ? 32u : 0u) | (cs.om_below ? 64u : 0u)) & vw;
+            const unsigned y = omC ? __popc(ml) + (ml != 0) : 0u;
+            const unsigned sy = ff_wave_sum(in0 ? y : (y << 16));
+            c0 |= (u64)(sy & 0xffffu) << 33;
+            c1 |= (u64)(sy >> 16) << 33;
+        }
+        if (cnt.only_t) c0 = c1 = 0;
+        const bool anybad = __builtin_amdgcn_ballot_w64(wet & bad) != 0;
+        if ((threadIdx.x & 63) == 0) {  // one lane: the sums are wave-uniform
+            const unsigned t0 = base >> FFC_TILE_SHIFT;
+            if (c0) __hip_atomic_fetch_add(cnt.sums + t0, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c1) __hip_atomic_fetch_add(cnt.sums + t0 + 1, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (anybad) __hip_atomic_fetch_or(cnt.sums + t0, FFC_BAD_FLUX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    cs.wet_below = wc;
+    // the mixed-layer window moves up one level
+    cs.om_below = cs.om_cur;
+    cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, k > 0 ? k - 1 : 0) < cs.mld;
+}
+
 // load_vs (wave-uniform): false when the wave's south row comes from the neighbouring wave through LDS (ff_south_from_lds)
-template <typename T, bool FLAGS>
+template <typename T, bool FLAGS, bool COUNTS = false>
 __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo, const T *__restrict__ vmo,
-                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0, bool load_vs = true) {
+                                        const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0, bool load_vs = true,
+                                        bool load_vn = false) {
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = (k0 - q >= 0) ? k0 - q : 0;  // clamped: loads are unconditional, the level is skipped later
@@ -56,48 +187,64 @@ __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo
         c.uw[q] = ff_ld(ul, col.sW);
         if (load_vs) c.vs[q] = ff_ld(vl, col.cS);
         c.wc[q] = ff_ld(wl, col.s);
+        if (COUNTS && load_vn) c.vn[q] = ff_ld(vl, col.cN);
         if (!FLAGS) {
             c.wE[q] = ff_ld(wl, col.sE); c.wW[q] = ff_ld(wl, col.sW); c.wS[q] = ff_ld(wl, col.cS);
             c.wN[q] = ff_ld(wl, col.cN);
         }
     }
+    if (COUNTS) {  // the wet flag above the chunk's last level (the next chunk's first level: not waited for here)
+        const int ku = (k0 - FF_KB >= 0) ? k0 - FF_KB : 0;
+        c.wup = ff_ld(wet + (i64)ku * P, col.s);
+    }
 }
 
-template <typename T, bool FLAGS, bool NT>
+template <typename T, bool FLAGS, bool NT, bool COUNTS = false>
 __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
                                           bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
                                           double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
-                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask, bool active = true) {
+                                          double *__restrict__ bottom, uint16_t *__restrict__ push_mask, bool active,
+                                          const FfCountArgs &cnt, FfCountState &cs, int nz) {
+    static_assert(!COUNTS || FLAGS, "the counts read the five-flag byte");
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = k0 - q;
-        if (k >= 0 && active) {  // (active: lanes beyond the row / rows beyond the grid of a four-row workgroup march along for the barriers only)
-            const i64 o = (i64)k * P;
+        if (k >= 0) {
+            double e = 0.0, w = 0.0, so = 0.0, n = 0.0, b = 0.0, t = 0.0;
+            bool wc = false;
             const unsigned f = c.wc[q];
-            const bool wc = FLAGS ? (f & WF_C) != 0 : c.wc[q] != 0, wE = FLAGS ? (f & WF_E) != 0 : c.wE[q] != 0,
-                       wW = FLAGS ? (f & WF_W) != 0 : c.wW[q] != 0;
-            const bool wS = FLAGS ? (f & WF_S) != 0 : (col.hS && c.wS[q] != 0), wN = FLAGS ? (f & WF_N) != 0 : (col.hN && c.wN[q] != 0);
-            double u = (double)c.u[q], v = (double)c.v[q];  // Array{Float64}(umo), :125-126
-            // nofluxboundaries!, :167-173
-            if (!wc || !wE) u = 0.0;
-            if (!wc || !wN) v = 0.0;
-            uvalid |= !(isnan(u) || u == fill);  // :199
-            vvalid |= !(isnan(v) || v == fill);  // :200
-            const double e = ff_replace(u, fill), n = ff_replace(v, fill);
-            // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
-            double uw = (double)c.uw[q];
-            if (!wW || !wc) uw = 0.0;
-            const double w = ff_replace(uw, fill);
-            // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
-            double vs = (double)c.vs[q];
-            if (!wS || !wc) vs = 0.0;
-            const double so = col.hS ? ff_replace(vs, fill) : 0.0;
-            const double b = topbelow;                  // :238-240
-            const double t = (((b + w) + so) - e) - n;  // :242
-            ff_st<NT>(east + o, col.s, e); ff_st<NT>(west + o, col.s, w); ff_st<NT>(north + o, col.s, n); ff_st<NT>(south + o, col.s, so);
-            ff_st<NT>(top + o, col.s, t); ff_st<NT>(bottom + o, col.s, b);
-            if (push_mask) ff_st<false>(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
-            topbelow = t;
+            if (active) {  // (lanes beyond the row / rows beyond the grid of a four-row workgroup march along for the barriers only)
+                const i64 o = (i64)k * P;
+                wc = FLAGS ? (f & WF_C) != 0 : c.wc[q] != 0;
+                const bool wE = FLAGS ? (f & WF_E) != 0 : c.wE[q] != 0, wW = FLAGS ? (f & WF_W) != 0 : c.wW[q] != 0;
+                const bool wS = FLAGS ? (f & WF_S) != 0 : (col.hS && c.wS[q] != 0), wN = FLAGS ? (f & WF_N) != 0 : (col.hN && c.wN[q] != 0);
+                double u = (double)c.u[q], v = (double)c.v[q];  // Array{Float64}(umo), :125-126
+                // nofluxboundaries!, :167-173
+                if (!wc || !wE) u = 0.0;
+                if (!wc || !wN) v = 0.0;
+                uvalid |= !(isnan(u) || u == fill);  // :199
+                vvalid |= !(isnan(v) || v == fill);  // :200
+                e = ff_replace(u, fill);
+                n = ff_replace(v, fill);
+                // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
+                double uw = (double)c.uw[q];
+                if (!wW || !wc) uw = 0.0;
+                w = ff_replace(uw, fill);
+                // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
+                double vs = (double)c.vs[q];
+                if (!wS || !wc) vs = 0.0;
+                so = col.hS ? ff_replace(vs, fill) : 0.0;
+                b = topbelow;                      // :238-240
+                t = (((b + w) + so) - e) - n;      // :242
+                ff_st<NT>(east + o, col.s, e); ff_st<NT>(west + o, col.s, w); ff_st<NT>(north + o, col.s, n); ff_st<NT>(south + o, col.s, so);
+                ff_st<NT>(top + o, col.s, t); ff_st<NT>(bottom + o, col.s, b);
+                if (push_mask && !COUNTS) ff_st<false>(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
+                topbelow = t;
+            }
+            if (COUNTS) {
+                const unsigned fa = (q + 1 < FF_KB) ? c.wc[q + 1] : c.wup;  // the cell above (level k - 1; unused at k == 0)
+                ff_count_level(cnt, cs, k, nz, wc, f, fa, e, w, so, n, b, t, cs.has_fold ? (double)c.vn[q] : 0.0, fill);
+            }
         }
     }
 }
@@ -110,12 +257,22 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
 // in the same workgroup, marching through the same levels at the same time -- an L1 hit (or a ride on the fill already in flight)
 // instead of one more request to the L2 (4 of the ~14 read requests per level and wave).  Large grids only: the last chunk of a row
 // is partly idle (nx = 1440: 2 % more waves), and a grid with fewer waves than the chip has slots wants them spread singly.
-template <typename T, bool FLAGS, bool NT, int ROWS>
-__global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
+#ifndef FF_COUNTS_WAVES
+#define FF_COUNTS_WAVES 1
+#endif
+template <typename T, bool FLAGS, bool NT, int ROWS, bool COUNTS>
+__global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_eu(COUNTS ? FF_COUNTS_WAVES : 1))) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
-    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen, int xcd_chunks, int lds_south) {
+    const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen, int xcd_chunks, int lds_south,
+    // (COUNTS) FfCountArgs, member by member: only a `const __restrict__` kernel argument lets the compiler read the wave-uniform table
+    // entries and zt through the scalar cache -- as a vector load the table entry made every level wait for ALL outstanding vector memory
+    // operations (s_waitcnt vmcnt(0)), i.e. for the next chunk's prefetch
+    const uint32_t *__restrict__ c_bases, const double *__restrict__ c_mlotst, const double *__restrict__ c_zt, unsigned long long *c_sums,
+    int c_upwind, int c_only_t, int c_nseg) {
+    FfCountArgs cnt;
+    cnt.bases = c_bases; cnt.mlotst = c_mlotst; cnt.zt = c_zt; cnt.sums = c_sums; cnt.upwind = c_upwind; cnt.only_t = c_only_t; cnt.nseg = c_nseg;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  In blockIdx order a wave's south row
     // (vmo[s - nx], nx / 64 blocks back) and the west cell of its first lane (the previous block) belong to workgroups of OTHER XCDs:
     // every XCD's L2 then fetches vmo twice and a quarter of umo again (profiles/r03: 3.27 GB fetched for 1.98 GB of inputs at
@@ -126,21 +283,45 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
         const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
         cb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
-    unsigned s, i, j;
+    unsigned s, i, j, seg;
     bool inside;
     if (ROWS == 1) {
+        seg = cb;
         s = cb * FF_THREADS + threadIdx.x;
+        inside = s < (unsigned)P;
+        if (COUNTS && !inside) s = (unsigned)P - 1;
         j = s / (unsigned)nx;
         i = s - j * (unsigned)nx;
-        inside = s < (unsigned)P;
     } else {
         const unsigned nchunk = ((unsigned)nx + FF_THREADS - 1) / FF_THREADS, grp = cb / nchunk, chunk = cb - grp * nchunk;
         i = chunk * FF_THREADS + (threadIdx.x & (FF_THREADS - 1));
         j = grp * ROWS + threadIdx.x / FF_THREADS;
         inside = i < (unsigned)nx && j < (unsigned)ny;
         s = j * (unsigned)nx + i;
+        seg = ((grp * ROWS + threadIdx.x / FF_THREADS < (unsigned)ny) ? grp * ROWS + threadIdx.x / FF_THREADS : (unsigned)ny - 1) * nchunk + chunk;
     }
     bool uvalid = false, vvalid = false;
+    FfCountState cs;
+    cs.mld = 0.0; cs.seg = 0; cs.base_lo = cs.base_hi = 0; cs.zt_lo = cs.zt_hi = 0.0; cs.om_cur = cs.om_below = false; cs.amask = 0; cs.aclear = false; cs.fold = false; cs.has_fold = false; cs.act = false; cs.wet_below = false;
+    if (COUNTS) {
+        cs.seg = (unsigned)__builtin_amdgcn_readfirstlane((int)seg);
+        cs.act = inside;
+        cs.fold = inside && topo == OTMB_TRIPOLAR && j + 1 == (unsigned)ny;
+        cs.has_fold = __builtin_amdgcn_ballot_w64(cs.fold) != 0;
+        const unsigned ifd = (unsigned)nx - 1 - i, ie = (i + 1 < (unsigned)nx) ? i + 1 : 0, iw = (i > 0) ? i - 1 : (unsigned)nx - 1;
+        cs.amask = cs.fold ? ((ifd == ie) ? (unsigned)WF_E : ((ifd == iw) ? (unsigned)WF_W : 0u)) : 0u;
+        cs.aclear = cs.fold && (ifd == ie || ifd == iw || ifd == i);
+        {   // this wave's table entries and zt, one level per lane (nz <= FFC_MAX_NZ, checked on the host)
+            const unsigned lane = threadIdx.x & 63, l0 = (lane < (unsigned)nz) ? lane : (unsigned)nz - 1, l1 = (64 + lane < (unsigned)nz) ? 64 + lane : (unsigned)nz - 1;
+            const uint32_t *mine = cnt.bases + 1 + (size_t)cs.seg * (size_t)nz;
+            cs.base_lo = mine[l0]; cs.base_hi = mine[l1];
+            cs.zt_lo = cnt.zt[l0]; cs.zt_hi = cnt.zt[l1];
+        }
+        if (cnt.bases[0] != FFC_HEADER(ROWS, cnt.nseg)) {  // a table for another wave geometry: count nothing, and say so
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(cnt.sums, FFC_BAD_TABLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cs.act = false;
+        }
+    }
     if (ROWS > 1 && lds_south) {
         // Four-row workgroups, south row through LDS: wave r's south row IS wave r-1's own row, so every wave posts the vmo values of
         // its chunk in LDS and takes its south values from the wave below it -- no load at all for three waves out of four (the L1 kept
@@ -160,6 +341,7 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
         col.cS = col.hS ? sc - nx : sc;
         col.cN = (jc + 1 < (unsigned)ny) ? sc + nx : (fold ? row + (nx - 1 - ic) : sc);
         double topbelow = top_below ? top_below[sc] : 0.0;
+        if (COUNTS) { cs.mld = cnt.mlotst[sc]; cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, nz - 1) < cs.mld; }
         const bool own_vs = r == 0;  // (wave-uniform) the first row of the workgroup has its south row in another workgroup
         FfChunk<T> A, B;
         int k0 = nz - 1, buf = 0;
@@ -173,19 +355,19 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
             }
             buf ^= 1;  // (the next chunk writes the other half: one barrier per chunk is enough, see the ordering argument in DESIGN.md 3.2)
         };
-        ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0, own_vs);
+        ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, own_vs, cs.has_fold);
         while (k0 >= 0) {
-            ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs);
+            ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold);
             south_from_lds(A);
-            ff_levels<T, FLAGS, NT>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside);
+            ff_levels<T, FLAGS, NT, COUNTS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
             if (k0 < 0) break;
-            ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs);
+            ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold);
             south_from_lds(B);
-            ff_levels<T, FLAGS, NT>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside);
+            ff_levels<T, FLAGS, NT, COUNTS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
         }
-    } else if (inside) {
+    } else if (inside || COUNTS) {  // (COUNTS: every lane takes part in the wave sums; lanes beyond the plane march along on the last column and store nothing)
         const unsigned row = j * (unsigned)nx;
         FfCol col;
         col.s = s;
@@ -199,16 +381,17 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) void facefluxes_kernel(
         // seafloor ϕbottom is zero (:238); for a depth slab that is not the deepest, the plane handed up
         // by the slab below (its ϕtop at its first level) continues the chain without re-association
         double topbelow = top_below ? top_below[s] : 0.0;
+        if (COUNTS) { cs.mld = cnt.mlotst[s]; cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, nz - 1) < cs.mld; }
         FfChunk<T> A, B;
         int k0 = nz - 1;
-        ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0);
+        ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, true, cs.has_fold);
         while (k0 >= 0) {
-            ff_load<T, FLAGS>(B, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels<T, FLAGS, NT>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold);
+            ff_levels<T, FLAGS, NT, COUNTS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
             if (k0 < 0) break;
-            ff_load<T, FLAGS>(A, umo, vmo, wet, col, P, k0 - FF_KB);
-            ff_levels<T, FLAGS, NT>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask);
+            ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold);
+            ff_levels<T, FLAGS, NT, COUNTS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
         }
     }
@@ -236,10 +419,80 @@ __global__ __launch_bounds__(256) void wetflags_kernel(const uint8_t *__restrict
     flags[L] = (uint8_t)f;
 }
 
+// four-row workgroups on grids with many more waves than the chip has slots (otmb_ctx: ff_rows = 0 lets the size decide)
+static int ff_rows_for(const otmb_ctx *ctx, i64 nx, i64 ny) {
+    const i64 P = nx * ny;
+    return ctx->ff_rows > 0 ? (ctx->ff_rows >= 4 ? 4 : 1) : ((P >= (1ll << 19) && nx >= 2 * FF_THREADS) ? 4 : 1);
+}
+// wave segments per level: what one wave of facefluxes_kernel covers at one level (64 consecutive cells of the plane, or of one row)
+static i64 ff_nseg(int rows, i64 nx, i64 ny) {
+    return rows == 1 ? (nx * ny + FF_THREADS - 1) / FF_THREADS : ((nx + FF_THREADS - 1) / FF_THREADS) * ny;
+}
+
+// one wave per (level, segment): the 0-based wet rank of the segment's first wet cell (Lwet3D is the wet rank, src/matrixbuilding.jl:19-20)
+__global__ __launch_bounds__(256) void ff_count_bases_kernel(const i64 *__restrict__ lw, int nx, int ny, int nz, i64 P, int rows, int nseg,
+                                                             uint32_t *__restrict__ bases) {
+    const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    if (gw == 0 && lane == 0) bases[0] = FFC_HEADER(rows, nseg);
+    if (gw >= (i64)nz * nseg) return;
+    const i64 k = gw / nseg, seg = gw - k * nseg;
+    i64 s;
+    bool valid;
+    if (rows == 1) {
+        s = seg * FF_THREADS + lane;
+        valid = s < P;
+    } else {
+        const i64 nchunk = (nx + FF_THREADS - 1) / FF_THREADS, j = seg / nchunk, chunk = seg - j * nchunk, i = chunk * FF_THREADS + lane;
+        valid = i < nx;
+        s = j * nx + i;
+    }
+    const i64 v = valid ? lw[k * P + s] : 0;
+    const u64 b = __builtin_amdgcn_ballot_w64(v != 0);
+    const int first = b ? __builtin_ctzll(b) : 0;
+    const i64 r = __shfl(v, first);
+    if (lane == 0) bases[1 + seg * nz + k] = b ? (uint32_t)(r - 1) : 0u;  // [segment][level]: a wave of facefluxes reads its nz entries in one go
+}
+
+// The counts that depend on the wet mask alone, per tile of 256 consecutive wet cells (one workgroup per tile, one thread per column):
+// TκH holds the wet horizontal neighbours + the diagonal (:348-415), TκVdeep the wet cells above / below + the diagonal (:450-477), and
+// T's reserved union every wet neighbour + the diagonal (Tadv and TκVML rows are among them: a flux is non-zero only towards a wet cell).
+// Packed as the block scan packs them; the Tadv and TκVML fields stay zero (facefluxes_kernel<COUNTS> adds those per time slice).
+__global__ __launch_bounds__(256) void ff_static_counts_kernel(const i64 *__restrict__ lwet, const uint8_t *__restrict__ flags, i64 n_wet,
+                                                               int nx, int ny, int nz, i64 P, int topo, unsigned long long *__restrict__ stat) {
+    __shared__ unsigned long long part[4];
+    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (w < n_wet) {
+        const i64 L = lwet[w] - 1;
+        const i64 k = L / P, s = L - k * P;
+        const int j = (int)(s / nx), i = (int)(s - (i64)j * nx);
+        unsigned hb = flags[L] & 0x1eu;
+        const unsigned vw = ((k > 0 && (flags[L - P] & WF_C)) ? 32u : 0u) | ((k + 1 < nz && (flags[L + P] & WF_C)) ? 64u : 0u);
+        const unsigned anyH = hb != 0, anyU = (hb | vw) != 0;
+        if (topo == OTMB_TRIPOLAR && j == ny - 1) {  // the fold neighbour's slot (see ff_fold_alias)
+            const int ifd = nx - 1 - i, ie = (i + 1 < nx) ? i + 1 : 0, iw = (i > 0) ? i - 1 : nx - 1;
+            if (ifd == ie || ifd == iw || ifd == i) hb = ff_fold_alias(hb, (ifd == ie) ? (unsigned)WF_E : ((ifd == iw) ? (unsigned)WF_W : 0u));
+        }
+        const unsigned h = __popc(hb), d = __popc(vw);
+        mine = (unsigned long long)(h + d + anyU) | ((unsigned long long)(h + anyH) << 22) | ((unsigned long long)(d + (vw != 0)) << 43);
+    }
+#pragma unroll
+    for (int q = 32; q >= 1; q >>= 1) mine += __shfl_xor(mine, q);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// layout of the caller's table: [header | nz * nseg bases] uint32, padded to 8 bytes, then one packed uint64 per tile
+static size_t ff_tables_static_offset(int rows, i64 nx, i64 ny, i64 nz) {
+    return ((size_t)(1 + nz * ff_nseg(rows, nx, ny)) * sizeof(uint32_t) + 7) / 8 * 8;
+}
+
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
-                               bool check_missing, bool flags = false) {
+                               bool check_missing, bool flags = false, const otmb_ff_counts *counts = nullptr) {
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -251,24 +504,59 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     if (ctx->ff_gen == 0x7fffffff) { ctx->ff_gen = 0; ctx->ff_first = 1; }
     ctx->ff_gen += 1;
     int *dflags = otmb_ring_ff((int *)ctx->ring.p, ctx->ff_gen);
-    // four-row workgroups on grids with many more waves than the chip has slots (otmb_ctx: ff_rows = 0 lets the size decide)
-    const int rows = ctx->ff_rows > 0 ? (ctx->ff_rows >= 4 ? 4 : 1) : ((P >= (1ll << 19) && nx >= 2 * FF_THREADS) ? 4 : 1);
+    const int rows = ff_rows_for(ctx, nx, ny);
     const unsigned nb = rows == 1 ? (unsigned)((P + FF_THREADS - 1) / FF_THREADS)
                                   : (unsigned)(((nx + FF_THREADS - 1) / FF_THREADS) * ((ny + rows - 1) / rows));
+    // any facefluxes call on this context ends the validity of counts an earlier call left behind (they are keyed to ff_gen), and a full
+    // mask written over a partial one makes that array an ordinary push mask again
+    ctx->ffc.valid = false;
+    if (push_mask && push_mask == ctx->ffc_partial_mask && !counts) ctx->ffc_partial_mask = nullptr;
+    FfCountArgs ca;
+    memset(&ca, 0, sizeof ca);
+    const bool with_counts = counts != nullptr;
+    if (with_counts) {
+        // (the caller -- otmb_facefluxes_counts_dev -- has checked that this grid can be counted here)
+        const i64 ntiles = (counts->n_wet + (1ll << FFC_TILE_SHIFT) - 1) >> FFC_TILE_SHIFT;
+        const int buf = ctx->ffc_next;
+        ctx->ffc_next ^= 1;
+        const size_t need = (size_t)(ntiles + 2) * sizeof(unsigned long long);
+        if (!ctx->ffc_sums[buf].p || ctx->ffc_sums[buf].cap < need) {
+            int32_t rc;
+            if ((rc = otmb_reserve(ctx, ctx->ffc_sums[buf], need))) return rc;
+            ctx->ffc_dirty[buf] = true;
+        }
+        if (ctx->ffc_dirty[buf]) HIP_TRY(ctx, hipMemsetAsync(ctx->ffc_sums[buf].p, 0, need, ctx->stream));
+        ctx->ffc_dirty[buf] = true;  // until a scan has consumed (and zeroed) it
+        ca.bases = (const uint32_t *)counts->tables; ca.mlotst = counts->mlotst; ca.zt = counts->zt;
+        ca.sums = (unsigned long long *)ctx->ffc_sums[buf].p;
+        ca.upwind = counts->upwind; ca.only_t = counts->only_t;
+        ca.nseg = (int)ff_nseg(rows, nx, ny);
+        otmb_ctx::FfCountsKey &key = ctx->ffc;
+        key.buf = buf; key.gen = ctx->ff_gen;
+        for (int f = 0; f < 6; ++f) key.phi[f] = phi[f];
+        key.stat = (const char *)counts->tables + ff_tables_static_offset(rows, nx, ny, nz);
+        key.mask = push_mask; key.mlotst = counts->mlotst; key.zt = counts->zt; key.lwet3d = counts->lwet3d;
+        key.nx = nx; key.ny = ny; key.nz = nz; key.n_wet = counts->n_wet;
+        key.topo = topology; key.upwind = counts->upwind != 0; key.only_t = counts->only_t != 0;
+        ctx->ffc_partial_mask = push_mask;
+    }
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
     const bool nt = (i64)48 * P * nz > (1ll << 30);  // six Float64 arrays beyond a gigabyte: streaming stores
-#define FF_LAUNCH(T, FL, NTS, R)                                                                                                       \
-    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
+#define FF_LAUNCH(T, FL, NTS, R, CN)                                                                                                   \
+    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R, CN>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
-                       phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks, ctx->ff_lds_south)
-#define FF_LAUNCH2(T, FL) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4); else FF_LAUNCH(T, FL, false, 4); } \
-                               else { if (nt) FF_LAUNCH(T, FL, true, 1); else FF_LAUNCH(T, FL, false, 1); } } while (0)
-    if (src_is_f32) { if (flags) FF_LAUNCH2(float, true); else FF_LAUNCH2(float, false); }
-    else { if (flags) FF_LAUNCH2(double, true); else FF_LAUNCH2(double, false); }
+                       phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks, ctx->ff_lds_south, \
+                       ca.bases, ca.mlotst, ca.zt, ca.sums, ca.upwind, ca.only_t, ca.nseg)
+#define FF_LAUNCH2(T, FL, CN) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4, CN); else FF_LAUNCH(T, FL, false, 4, CN); } \
+                                   else { if (nt) FF_LAUNCH(T, FL, true, 1, CN); else FF_LAUNCH(T, FL, false, 1, CN); } } while (0)
+    if (with_counts) { if (src_is_f32) FF_LAUNCH2(float, true, true); else FF_LAUNCH2(double, true, true); }
+    else if (src_is_f32) { if (flags) FF_LAUNCH2(float, true, false); else FF_LAUNCH2(float, false, false); }
+    else { if (flags) FF_LAUNCH2(double, true, false); else FF_LAUNCH2(double, false, false); }
 #undef FF_LAUNCH2
 #undef FF_LAUNCH
     }
+    if (with_counts) ctx->ffc.valid = true;
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
     if (!check_missing) return OTMB_OK;  // slab / asynchronous: otmb_facefluxes_slab_flags fetches the flags when asked
@@ -314,6 +602,45 @@ extern "C" int32_t otmb_facefluxes_flags_dev(otmb_ctx *ctx, const void *umo, con
                                              int32_t topology, double *const phi[6], const double *top_below,
                                              uint16_t *push_mask) {
     return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, top_below, push_mask, false, true);
+}
+
+extern "C" int64_t otmb_count_tables_bytes(const otmb_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t n_wet) {
+    if (!ctx || nx < 1 || ny < 1 || nz < 1 || n_wet < 0) return 0;
+    const i64 ntiles = (n_wet + (1ll << FFC_TILE_SHIFT) - 1) >> FFC_TILE_SHIFT;
+    return (int64_t)(ff_tables_static_offset(ff_rows_for(ctx, nx, ny), nx, ny, nz) + (size_t)(ntiles + 1) * sizeof(unsigned long long));
+}
+
+extern "C" int32_t otmb_count_tables_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet,
+                                         int64_t nx, int64_t ny, int64_t nz, int32_t topology, void *tables) {
+    if (!ctx || !lwet3d || !wetflags || !tables || (n_wet > 0 && !lwet)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1 || n_wet < 0 || nx * ny >= (1ll << 28) || nx * ny * nz >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = ff_rows_for(ctx, nx, ny);
+    const i64 nseg = ff_nseg(rows, nx, ny), nw = nz * nseg, ntiles = (n_wet + (1ll << FFC_TILE_SHIFT) - 1) >> FFC_TILE_SHIFT;
+    KernelTimer kt(ctx, K_FF_BASES);
+    hipLaunchKernelGGL(ff_count_bases_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx->stream, (const i64 *)lwet3d, (int)nx, (int)ny,
+                       (int)nz, nx * ny, rows, (int)nseg, (uint32_t *)tables);
+    if (ntiles > 0)
+        hipLaunchKernelGGL(ff_static_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const i64 *)lwet, wetflags, (i64)n_wet,
+                           (int)nx, (int)ny, (int)nz, nx * ny, (int)topology,
+                           (unsigned long long *)((char *)tables + ff_tables_static_offset(rows, nx, ny, nz)));
+    HIP_TRY(ctx, hipGetLastError());
+    return OTMB_OK;
+}
+
+// facefluxes + the tile counts of the transportmatrix that will be built from its fluxes (see FfCountArgs).  Grids whose row-mates can
+// coincide (nx < 3) and contexts with OTMB_COUNT_IN_FF=0 take the plain kernel and write the whole push mask, as
+// otmb_facefluxes_flags_dev does: the caller need not know which happened.
+extern "C" int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                              const uint8_t *wetflags, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                              int32_t topology, double *const phi[6], uint16_t *push_mask,
+                                              const otmb_ff_counts *counts) {
+    if (!ctx || !counts) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    const bool can = ctx->count_in_ff != 0 && nx >= 3 && push_mask && counts->tables && counts->lwet3d && counts->mlotst && counts->zt &&
+                     counts->n_wet > 0 && nx * ny * nz < (1ll << 32) && nz <= FFC_MAX_NZ;
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, nullptr, push_mask, false, true,
+                           can ? counts : nullptr);
 }
 
 // Push mask of existing ϕ arrays (include/otmb.h): one thread per cell of [first, first + count).

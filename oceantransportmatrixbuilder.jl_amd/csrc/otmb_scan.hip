@@ -81,6 +81,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups5(const uint32_t 
     }
 }
 
+// The same level-1 scan for tile counts that facefluxes accumulated as ONE packed 64-bit word per tile (otmb_facefluxes_counts_dev:
+// T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 bits, bit 63 = a flux into land was seen, bit 62 = wrong bases table; the fields that
+// depend on the wet mask alone come from the grid's static table): every thread
+// takes its tile's word, writes ZERO back (the buffer is clean again for the facefluxes call after next: same thread, same address, so
+// the store is ordered behind the load), hands the five counts to the fill pass in the layout the counting pass writes (sums[t][5]) and
+// scans them as above.
+__global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups5_packed(unsigned long long *__restrict__ packed,
+                                                                         const unsigned long long *__restrict__ stat, uint32_t *__restrict__ sums,
+                                                                         i64 *__restrict__ offs, i64 *__restrict__ gsum, i64 ntiles,
+                                                                         int *__restrict__ flags, int only_t) {
+    __shared__ uint32_t wave_tot[5][SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const i64 t = (i64)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    unsigned long long w = 0;
+    if (t < ntiles) {
+        w = packed[t] + stat[t];  // per time slice (Tadv, TκVML, flag bits) + per grid (T's union, TκH, TκVdeep): disjoint fields
+        packed[t] = 0ull;
+    }
+    if (w & FFC_BAD_FLUX) { if (flags[FLAG_FLUX_INTO_LAND] == 0) atomicExch(&flags[FLAG_FLUX_INTO_LAND], 1); }
+    if (w & FFC_BAD_TABLE) { if (flags[FLAG_COUNT_MISMATCH] == 0) atomicExch(&flags[FLAG_COUNT_MISMATCH], 1); }
+    uint32_t mine[5], x[5];
+    mine[0] = (uint32_t)(w & 0x7ff);
+    mine[1] = only_t ? 0u : (uint32_t)((w >> 11) & 0x7ff);
+    mine[2] = only_t ? 0u : (uint32_t)((w >> 22) & 0x7ff);
+    mine[3] = only_t ? 0u : (uint32_t)((w >> 33) & 0x3ff);
+    mine[4] = only_t ? 0u : (uint32_t)((w >> 43) & 0x3ff);
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        if (t < ntiles) sums[t * 5 + f] = mine[f];
+        x[f] = mine[f];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x[f], d);
+            if (lane >= d) x[f] += y;
+        }
+        if (lane == 63) wave_tot[f][wid] = x[f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < SCAN_THREADS / 64; ++q) {
+            const uint32_t v = wave_tot[f][q];
+            if (q < wid) before += v;
+            all += v;
+        }
+        if (t < ntiles) offs[t * 5 + f] = (i64)(before + x[f] - mine[f]);
+        if (threadIdx.x == 0) gsum[(i64)blockIdx.x * 5 + f] = (i64)all;
+    }
+}
+
 // level 2: exclusive scan of the group totals (ngroups <= 1024 per pass, looped), totals to tot[f]
 __global__ __launch_bounds__(SCAN_THREADS) void tilescan_top(i64 *__restrict__ gsum, i64 *__restrict__ tot, i64 ngroups, int nf) {
     __shared__ i64 wave_tot[SCAN_MAXF][SCAN_THREADS / 64];
@@ -199,4 +251,18 @@ void otmb_launch_tilescan_groups(hipStream_t s, const uint32_t *sums, i64 *offs,
         hipLaunchKernelGGL(tilescan_groups5, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, sums, offs, gsum, ntiles);
     else
         hipLaunchKernelGGL(tilescan_groups, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, sums, offs, gsum, ntiles, nf);
+}
+
+// Tile counts from facefluxes (one packed word per tile): level 1 always; all_levels adds the group bases to offs and leaves the
+// totals in tot, as otmb_launch_tilescan does (the two-phase plan, and grids of more groups than the fill pass adds up itself).
+void otmb_launch_tilescan_packed(hipStream_t s, unsigned long long *packed, const unsigned long long *stat, uint32_t *sums, i64 *offs, i64 *tot, i64 *gsum, i64 ntiles,
+                                 int *flags, int only_t, bool all_levels) {
+    const i64 ngroups = (ntiles + SCAN_THREADS - 1) / SCAN_THREADS;
+    hipLaunchKernelGGL(tilescan_groups5_packed, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, packed, stat, sums, offs, gsum, ntiles, flags, only_t);
+    if (!all_levels) return;
+    hipLaunchKernelGGL(tilescan_top, dim3(1), dim3(SCAN_THREADS), 0, s, gsum, tot, ngroups, 5);
+    if (ngroups > 1) {
+        const i64 n = ntiles * 5;
+        hipLaunchKernelGGL(tilescan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, offs, (const i64 *)gsum, ntiles, 5);
+    }
 }

@@ -51,6 +51,7 @@ struct TmPlan {
     i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
     bool dense = false;  // the plan's counting pass was the dense-march one: its fill must be too (same offsets table)
+    bool rho_in_fill = false;  // the plan took its counts from facefluxes: no pass has looked at ρ yet, the fill pass does (:233)
     DmGeomHost dm;
 };
 
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
         }
     }
 }
+
+static_assert(TM_THREADS == (1 << FFC_TILE_SHIFT), "the counts in facefluxes are per tile of TM_THREADS columns");
 
 // ---- decoupled look-back (one-pass mode) ---------------------------------------------------------------------
 // One status word per tile: flag | the tile's five aggregates packed as in the block scan (55 bits).  A predecessor
@@ -909,7 +912,8 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
 // The counting pass reads the push mask: the caller's (written by facefluxes for exactly these ϕ), or one derived
 // here from ϕ and Lwet3D.
 static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &p) {
-    if (a.push_mask) {
+    // (the mask argument of a counting facefluxes call was not written by it: never a counting pass's input)
+    if (a.push_mask && a.push_mask != ctx->ffc_partial_mask) {
         p.mask = a.push_mask;
         return OTMB_OK;
     }
@@ -917,6 +921,33 @@ static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &
     if ((rc = otmb_reserve(ctx, ctx->mask, (size_t)p.G * sizeof(uint16_t) + 16))) return rc;
     p.mask = (const uint16_t *)ctx->mask.p;
     return otmb_launch_push_mask(ctx, a.phi, a.lwet3d, 0, p.G, (uint16_t *)ctx->mask.p);
+}
+
+// Counts in facefluxes: do the tile counts that the last facefluxes call on this context accumulated describe exactly this
+// transportmatrix?  (Same ϕ arrays, the mask pointer that call was given, mixed-layer inputs, indices, weighting; whole grid.)
+// Returns the buffer that holds them, or -1.
+static int ffc_match(const otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl) {
+    const otmb_ctx::FfCountsKey &k = ctx->ffc;
+    if (!k.valid || k.gen != ctx->ff_gen || !a.push_mask || a.push_mask != k.mask || pl.wet_base != 0) return -1;
+    for (int f = 0; f < 6; ++f)
+        if (a.phi[f] != k.phi[f]) return -1;
+    if (a.mlotst != k.mlotst || a.zt != k.zt || a.lwet3d != k.lwet3d || a.nx != k.nx || a.ny != k.ny || a.nz != k.nz ||
+        a.n_wet != k.n_wet || a.topology != k.topo || (a.upwind != 0) != (k.upwind != 0) || (a.only_t != 0) != (k.only_t != 0))
+        return -1;
+    return k.buf;
+}
+// ... then the scan takes them (and leaves the buffer zeroed for the facefluxes call after next)
+static void ffc_consume(otmb_ctx *ctx, int buf, const TmParams &p, i64 *offs, i64 *dtot, i64 *gsum, i64 ntiles, bool all_levels) {
+    KernelTimer kt(ctx, K_TILESCAN);
+    otmb_launch_tilescan_packed(ctx->stream, (unsigned long long *)ctx->ffc_sums[buf].p, (const unsigned long long *)ctx->ffc.stat, p.tilesums, offs, dtot, gsum, ntiles, p.flags,
+                                p.only_t, all_levels);
+    ctx->ffc.valid = false;
+    ctx->ffc_dirty[buf] = false;
+}
+// ρ on the wet cells (:233), for the one case where no pass has read ρ before an error must be ranked (see otmb_transportmatrix_plan_dev)
+__global__ __launch_bounds__(256) void rho_nan_kernel(const double *__restrict__ rho, const i64 *__restrict__ lwet, i64 n, int *flags) {
+    const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (w < n && isnan(rho[lwet[w] - 1])) raise_flag(flags, FLAG_RHO_NAN);
 }
 
 // ignore: otmb_tm_args.ignore_ops -- errors that only an operator the caller already has would have raised
@@ -1074,11 +1105,17 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
     pl.dense = ntiles > 0 && use_dense(ctx, *a);
+    pl.rho_in_fill = false;
+    int fbuf = -1;
     if (pl.dense) {
         DmGeom g;
         if ((rc = dense_prepare(ctx, *a, pl.dm, p, g))) return rc;
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
+    } else if (ntiles > 0 && (fbuf = ffc_match(ctx, *a, pl)) >= 0) {
+        // the counts came with the fluxes (otmb_facefluxes_counts_dev): no counting pass
+        pl.rho_in_fill = true;
+        ffc_consume(ctx, fbuf, p, (i64 *)ctx->tm_offs.p, dtot, (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF, ntiles, true);
     } else if (ntiles > 0) {
         if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
@@ -1096,6 +1133,13 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (fbuf >= 0 && ctx->h_flags[FLAG_FLUX_INTO_LAND] && a->rho && a->n_wet > 0) {
+        // the reference tests ρ (:233) before its loop can run into land: rank the two errors as it does (nothing has read ρ yet)
+        hipLaunchKernelGGL(rho_nan_kernel, dim3((unsigned)((a->n_wet + 255) / 256)), dim3(256), 0, ctx->stream, a->rho, (const i64 *)a->lwet,
+                           (i64)a->n_wet, dflags);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if ((rc = check_flags(ctx, nullptr, a->ignore_ops))) return rc;
     for (int m = 0; m < 5; ++m) nnz[m] = pl.nnz[m] = ctx->h_tot[m];
     pl.valid = true;
@@ -1126,6 +1170,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     TmParams p;
     fill_params(p, pl.args, ctx, &pl);
+    p.rho_in_fill = pl.rho_in_fill ? 1 : 0;
     for (int m = 0; m < 5; ++m) {
         const bool wanted = (m == 0) || !pl.args.only_t;
         if (wanted && (!colptr[m] || (pl.nnz[m] > 0 && (!rowval[m] || !nzval[m])))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -1275,18 +1320,24 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
         KernelTimer kt(ctx, K_TM_ONEPASS);
         hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     } else {
-        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
         p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
-        if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
-        {
-            KernelTimer kt(ctx, K_TM_COUNT);
-            hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
-                               dim3(TM_THREADS), 0, ctx->stream, p, (i64)ntiles);
-        }
-        {
+        i64 *gsum = (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF;
+        const bool infill = ntiles <= TM_INFILL_GROUPS * OTMB_SCAN_GROUP;  // first scan level only; the fill pass adds the group bases
+        const int fbuf = ffc_match(ctx, *a, pl);
+        if (fbuf >= 0) {
+            // the counts came with the fluxes (otmb_facefluxes_counts_dev): no counting pass, the scan unpacks them
+            ffc_consume(ctx, fbuf, p, (i64 *)ctx->tm_offs.p, dtot, gsum, ntiles, !infill);
+            if (infill) p.gsum = gsum;
+        } else {
+            if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
+            if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
+            {
+                KernelTimer kt(ctx, K_TM_COUNT);
+                hipLaunchKernelGGL(tm_count_kernel<TM_COUNT_TPB>, dim3((unsigned)((ntiles + TM_COUNT_TPB - 1) / TM_COUNT_TPB)),
+                                   dim3(TM_THREADS), 0, ctx->stream, p, (i64)ntiles);
+            }
             KernelTimer kt(ctx, K_TILESCAN);
-            i64 *gsum = (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF;
-            if (ntiles <= TM_INFILL_GROUPS * OTMB_SCAN_GROUP) {  // first level only; the fill pass adds the group bases
+            if (infill) {
                 otmb_launch_tilescan_groups(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, gsum, ntiles, TM_NF);
                 p.gsum = gsum;
             } else {

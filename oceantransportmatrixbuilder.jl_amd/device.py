@@ -31,6 +31,9 @@ class DeviceAssembler:
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.lib = capi.lib()
         self.out = None
+        # facefluxes also accumulates the tile counts of the transportmatrix that follows (otmb_facefluxes_counts_dev); False: the plain
+        # kernel + the whole push mask + a counting pass, as before round 5 (A/B, and tests that look at the mask itself)
+        self.count_in_ff = os.environ.get("OTMB_COUNT_IN_FF", "1") != "0"
         arena_gb = float(os.environ.get("OTMB_ARENA_GB", "0"))
         if arena_gb > 0 and os.environ.get("OTMB_ARENA_WHEN", "start") == "start":  # (see _empty)
             _arena = torch.empty(int(arena_gb * 2 ** 30), dtype=torch.uint8, device=self.device)
@@ -155,6 +158,7 @@ class DeviceAssembler:
 
     def makeindices(self):
         """otmb_makeindices_dev on the resident v3D (src/matrixbuilding.jl:10-24)."""
+        self._mask_key = None  # (fluxes of an earlier facefluxes call no longer come with counts / a mask for THESE indices)
         self.lwet3d = self._empty(self.G, torch.int64)
         self.lwet = self._empty(self.G, torch.int64)
         self.wet3d = torch.empty(self.G, dtype=torch.uint8, device=self.device)
@@ -168,7 +172,16 @@ class DeviceAssembler:
         self.ctx.check(self.lib.otmb_wetflags_dev(self.ctx.handle, self.wet3d.data_ptr(), self.nx, self.ny, self.nz, self.topology,
                                                   self.wetflags.data_ptr()))
         self._wetflags_version = self.wet3d._version
+        self._count_tables()
         return self.N
+
+    def _count_tables(self):
+        """Counts in facefluxes (otmb_facefluxes_counts_dev), once per grid: the wet rank at which every 64-cell wave segment starts and the
+        per-tile row counts that depend on the wet mask alone."""
+        nb = int(self.lib.otmb_count_tables_bytes(self.ctx.handle, self.nx, self.ny, self.nz, self.N))
+        self.count_tables = torch.empty(max((nb + 7) // 8, 1), dtype=torch.int64, device=self.device)
+        self.ctx.check(self.lib.otmb_count_tables_dev(self.ctx.handle, self.lwet3d.data_ptr(), self.lwet.data_ptr(), self.wetflags.data_ptr(),
+                                                      self.N, self.nx, self.ny, self.nz, self.topology, self.count_tables.data_ptr()))
 
     # ---- per time slice -----------------------------------------------------------------------
     def facefluxes(self, umo, vmo, fill):
@@ -192,10 +205,23 @@ class DeviceAssembler:
             self.ctx.check(self.lib.otmb_wetflags_dev(self.ctx.handle, self.wet3d.data_ptr(), self.nx, self.ny, self.nz, self.topology,
                                                       self.wetflags.data_ptr()))
             self._wetflags_version = self.wet3d._version
-        self.ctx.check(self.lib.otmb_facefluxes_flags_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
-                                                          int(umo.dtype == torch.float32), self.wetflags.data_ptr(), float(fill),
-                                                          self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
-                                                          self.push_mask.data_ptr()))
+        # The kernel also accumulates the tile counts of the transportmatrix these fluxes will be handed to (same mlotst, weighting, indices):
+        # that call then has no counting pass.  (The library falls back to the plain kernel where it cannot count: nx < 3, OTMB_COUNT_IN_FF=0.)
+        if not self.count_in_ff:
+            self.ctx.check(self.lib.otmb_facefluxes_flags_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
+                                                              int(umo.dtype == torch.float32), self.wetflags.data_ptr(), float(fill),
+                                                              self.nx, self.ny, self.nz, self.topology, C.byref(ptrs), None,
+                                                              self.push_mask.data_ptr()))
+            self._mask_key = self._phi_key(self.phi)
+            return self.phi
+        cnt = capi.FfCounts()
+        cnt.tables, cnt.lwet3d = self.count_tables.data_ptr(), self.lwet3d.data_ptr()
+        cnt.mlotst, cnt.zt, cnt.n_wet = self.mlotst.data_ptr(), self.zt.data_ptr(), self.N
+        cnt.upwind, cnt.only_t = int(self.upwind), 1 if getattr(self, "only_T", False) else 0
+        self.ctx.check(self.lib.otmb_facefluxes_counts_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(),
+                                                           int(umo.dtype == torch.float32), self.wetflags.data_ptr(), float(fill),
+                                                           self.nx, self.ny, self.nz, self.topology, C.byref(ptrs),
+                                                           self.push_mask.data_ptr(), C.byref(cnt)))
         self._mask_key = self._phi_key(self.phi)
         return self.phi
 
@@ -208,10 +234,10 @@ class DeviceAssembler:
             setattr(self, which, [])
         getattr(self, which).append(self._seq)
 
-    @staticmethod
-    def _phi_key(phi):
-        # the mask describes exactly the values facefluxes wrote: any later in-place torch op bumps _version
-        return tuple((p.data_ptr(), p._version) for p in phi)
+    def _phi_key(self, phi):
+        # the mask (and the tile counts that came with it) describes exactly the values facefluxes wrote, and the mixed-layer inputs and
+        # weighting it was told: any later in-place torch op bumps _version
+        return tuple((p.data_ptr(), p._version) for p in (*phi, self.mlotst, self.zt)) + (bool(self.upwind), bool(getattr(self, "only_T", False)))
 
     PIPELINE_DEPTH = 60  # the library remembers the verdicts of its 64 most recent asynchronous calls: drain before that
 

@@ -90,7 +90,7 @@ def test_tmargs_struct_matches_header_and_ctypes_mirror():
     for (name, jt), (_, ct) in zip(fields, mirror):
         assert julia_kind(jt) == ctypes_kind(ct), name
     # and the header's own struct, field by field
-    hbody = re.search(r"typedef struct \{(.*?)\} otmb_tm_args;", HEADER, re.S).group(1)
+    hbody = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} otmb_tm_args;", HEADER, re.S).group(1)
     hbody = re.sub(r"/\*.*?\*/", "", hbody, flags=re.S)
     hfields = []
     for decl in hbody.split(";"):
