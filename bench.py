@@ -355,24 +355,25 @@ def box_probe(dev):
     e1.record()
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / reps
-    smi = None
-    try:  # clocks / power / temperature right after the run (boxes of the pool differ by 15 % on the same kernels: something to correlate with)
-        if under_profiler():
-            # rocm-smi is an `env python3` script: under a profiler preload every hop of that chain is a process whose GPU the preload has
-            # already initialised replacing itself with another program -- the GPU boxes refuse exactly that (profiles/r04, call 21)
-            raise RuntimeError("skipped under a profiler preload")
-        r = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--showpower", "--showtemp", "--showmemuse", "--json"],
+    return {"copy_2GiB_ms": ms, "copy_gbs_read_plus_write": 2 * n * 8 / (ms * 1e-3) / 1e9,
+            "note": "torch device-to-device copy of 2 GiB after the timed region: this box's plain streaming rate.  (Round 3: the pool's boxes differ by up to 15 % on the "
+                    "fill pass and this rate does not follow it -- 4.63 TB/s on a box with a 0.316 ms fill, 4.98 TB/s on one with 0.360 ms -- the pass is bound by "
+                    "request latency, not by streaming bandwidth: profiles/r03/README.md 5b, 6.)"}
+
+
+def rocm_smi_probe(index=0):
+    """Clocks / power / temperature of the card, from a process that has NOT initialised the GPU (rocm-smi is an `env python3` script: started
+    from a process whose GPU a HIP call or a profiler preload has initialised, every hop of that chain is an exec the GPU boxes refuse --
+    profiles/r04 call 21, gpurun_out/.graft_exec_refused): only the launcher parent of bench.py calls this, right after the headline child."""
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showpower", "--showtemp", "--showmemuse", "--json"],
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
         j = json.loads(r.stdout.decode() or "{}")
         card = next(iter(j.values())) if j else {}
         keep = ("sclk", "mclk", "fclk", "socclk", "Power", "Temperature", "junction", "memory", "GPU Memory Allocated")
-        smi = {k: v for k, v in card.items() if any(t.lower() in k.lower() for t in keep)}
+        return {k: v for k, v in card.items() if any(t.lower() in k.lower() for t in keep)}
     except Exception as e:
-        smi = {"error": f"{type(e).__name__}: {e}"[:120]}
-    return {"copy_2GiB_ms": ms, "copy_gbs_read_plus_write": 2 * n * 8 / (ms * 1e-3) / 1e9, "rocm_smi": smi,
-            "note": "torch device-to-device copy of 2 GiB after the timed region: this box's plain streaming rate.  (Round 3: the pool's boxes differ by up to 15 % on the "
-                    "fill pass and this rate does not follow it -- 4.63 TB/s on a box with a 0.316 ms fill, 4.98 TB/s on one with 0.360 ms -- the pass is bound by "
-                    "request latency, not by streaming bandwidth: profiles/r03/README.md 5b, 6.)"}
+        return {"error": f"{type(e).__name__}: {e}"[:120]}
 
 
 def traffic_for(workload, kernel, args, world=1):
@@ -416,6 +417,8 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         except (subprocess.TimeoutExpired, OSError, ValueError):
             head = None
         if head is not None:
+            if isinstance(head.get("box_probe"), dict):
+                head["box_probe"]["rocm_smi"] = rocm_smi_probe()  # this process never touches the GPU
             head.update(extra_configs_in_children(args))
             head["measured_by"] = "fresh processes, one per configuration, headline first: " + " ".join(cmd[1:])
             print(json.dumps(head), flush=True)
@@ -580,6 +583,9 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             def facefluxes_bytes(self):
                 return asm.facefluxes_bytes()
 
+            def bytes_split(self, fill_pass):  # (read, written) of the dominant kernel
+                return asm.algorithmic_bytes_split() if fill_pass else (asm.G * 17, asm.G * 48)
+
         runner = _Single()
 
     def barrier():
@@ -642,6 +648,18 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg,
                     "avg_kernel_ms": kavg[dom]}
+        if roof is not None and world == 1 and not force_slab and not rehearsal and hasattr(runner, "bytes_split"):
+            # The same kernel time as a fraction of what THIS box sustains: one plain read stream and one plain non-temporal write stream
+            # (otmb_ctx_box_ceilings, measured here, in this process, right after the timed region), combined for the kernel's own read : write
+            # mix -- bytes / (reads / read rate + writes / write rate).  The pool's boxes differ by up to 15 % on the same binary.
+            try:
+                rd, wr = runner.ctx.box_ceilings()
+                br, bw = runner.bytes_split(dom.startswith(("tm_kernel", "dm_fill")))
+                mix = (br + bw) / (br / rd + bw / wr)
+                roof["box"] = {"read_gbs": rd, "write_gbs": wr, "mix_ceiling": mix, "frac_of_box": achieved / mix,
+                               "bytes_read": br, "bytes_written": bw}
+            except Exception as e:  # a diagnostic must never cost the line
+                roof["box"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         k0, k1, nzg = runner.slab
         if world > 1:
             shape = (f"{nx}x{ny}x{nzg} cut into {world} depth slabs (rank 0: levels [{k0},{k1}))"

@@ -125,6 +125,10 @@ const char *otmb_version(void);
 int32_t otmb_ctx_timing_enable(otmb_ctx *ctx, int32_t on);
 int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, int32_t n);
 const char *otmb_kernel_name(int32_t kernel_id);
+/* Diagnostic (not part of any result): what the box this context runs on sustains for one plain HBM read stream and one plain
+ * non-temporal HBM write stream (2 GiB each, all CUs, 16 bytes per lane, eight accesses in flight), in GB/s.  bench.py reports a
+ * kernel's time as a fraction of the rate these two give for the kernel's own read : write mix.  Allocates 2 GiB for the call.   */
+int32_t otmb_ctx_box_ceilings(otmb_ctx *ctx, double *read_gbs, double *write_gbs);
 
 /* ---- makeindices(v3D)  -- src/matrixbuilding.jl:10-24 ------------------------------------- *
  * wet = !isnan(v3D).  Outputs (any may be NULL): lwet3d (nx*ny*nz) wet rank or 0;

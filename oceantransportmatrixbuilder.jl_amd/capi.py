@@ -85,6 +85,7 @@ SYMBOLS = {
     "otmb_ctx_timing_enable": (C.c_int32, [_vp, C.c_int32]),
     "otmb_ctx_timing_collect": (C.c_int32, [_vp, _dp, _ip, C.c_int32]),
     "otmb_kernel_name": (C.c_char_p, [C.c_int32]),
+    "otmb_ctx_box_ceilings": (C.c_int32, [_vp, _dp, _dp]),
     "otmb_makeindices_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
     "otmb_makeindices": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
     "otmb_facefluxes_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
@@ -276,6 +277,12 @@ class Context:
 
     def timing_enable(self, on=True):
         self.check(self._lib.otmb_ctx_timing_enable(self._h, int(on)))
+
+    def box_ceilings(self):
+        """(read GB/s, write GB/s) of one plain HBM read / non-temporal write stream on this box (otmb_ctx_box_ceilings; diagnostic)."""
+        r, w = C.c_double(0), C.c_double(0)
+        self.check(self._lib.otmb_ctx_box_ceilings(self._h, C.byref(r), C.byref(w)))
+        return float(r.value), float(w.value)
 
     def timing_collect(self, n=32):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""

@@ -13,8 +13,9 @@
 
 __device__ __forceinline__ double gm_haversine(double lon1, double lat1, double lon2, double lat2) {
     const double d2r = 3.14159265358979323846 / 180.0;
-    const double dl = (lon2 - lon1) * d2r, dp = (lat2 - lat1) * d2r;
-    const double p1 = lat1 * d2r, p2 = lat2 * d2r;
+    const double dl = (lon2 - lon1) * d2r;          // Δλ = deg2rad(y[1] - x[1])
+    const double p1 = lat1 * d2r, p2 = lat2 * d2r;  // φ₁ = deg2rad(x[2]), φ₂ = deg2rad(y[2])
+    const double dp = p2 - p1;                      // Δφ = φ₂ - φ₁: converted first, subtracted after (Distances.jl 0.10, haversine.jl)
     const double s1 = sin(dp / 2), s2 = sin(dl / 2);
     const double a = s1 * s1 + cos(p1) * cos(p2) * (s2 * s2);
     const double r = sqrt(a);

@@ -577,6 +577,16 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             if (wide) {
                 char *rvb = (char *)(rv - par);
                 char *nzb = (char *)(nz - par);
+#ifdef OTMB_STORE_SPLIT  // experiment (profiles/r05): all rowval pieces of the run, then all nzval pieces -- one output stream per burst
+                for (unsigned base = 0; base < end; base += 128) {
+                    const unsigned u = base + 2 * lane;
+                    if ((u >= par) & (u + 1 < end)) TM_STORE(*(const i64x2 *)(my_row + u), (i64x2g *)(rvb + u * 8u));
+                }
+                for (unsigned base = 0; base < end; base += 128) {
+                    const unsigned u = base + 2 * lane;
+                    if ((u >= par) & (u + 1 < end)) TM_STORE(*(const i64x2 *)(my_val + u), (i64x2g *)(nzb + u * 8u));
+                }
+#else
                 for (unsigned base = 0; base < end; base += 128) {  // full pairs
                     const unsigned u = base + 2 * lane;
                     if ((u >= par) & (u + 1 < end)) {
@@ -584,6 +594,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                         TM_STORE(*(const i64x2 *)(my_val + u), (i64x2g *)(nzb + u * 8u));
                     }
                 }
+#endif
                 // the (at most two) entries without a partner: index 1 of an odd-parity run, and the last one if
                 // it sits at an even index
 #ifdef OTMB_ALIGNED16

@@ -558,6 +558,11 @@ class DeviceAssembler:
         b += sum(16 * z + 8 * (self.N + 1) for z in self.nnz)
         return b
 
+    def algorithmic_bytes_split(self):
+        """(bytes read, bytes written) of algorithmic_bytes()."""
+        n3d = 9 + (1 if self.rho is not None else 0)
+        return 8 * self.G * n3d + 80 * self.nx * self.ny + 8 * self.nz, sum(16 * z + 8 * (self.N + 1) for z in self.nnz)
+
     def facefluxes_bytes(self, itemsize=8):
         """umo, vmo, wet3D read once; six ϕ arrays written once."""
         return self.G * (2 * itemsize + 1 + 6 * 8)

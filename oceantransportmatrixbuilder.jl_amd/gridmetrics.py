@@ -23,10 +23,10 @@ _VERTEXINDICES = {"south": (0, 1), "east": (1, 2), "north": (2, 3), "west": (0, 
 def haversine(lon1, lat1, lon2, lat2):
     """Distances.Haversine(6371000)((lon1,lat1),(lon2,lat2)), degrees in, metres out."""
     d2r = np.pi / 180.0
-    dl = (lon2 - lon1) * d2r
-    dp = (lat2 - lat1) * d2r
-    p1 = lat1 * d2r
-    p2 = lat2 * d2r
+    dl = (lon2 - lon1) * d2r  # Δλ = deg2rad(y[1] - x[1])
+    p1 = lat1 * d2r           # φ₁ = deg2rad(x[2])
+    p2 = lat2 * d2r           # φ₂ = deg2rad(y[2])
+    dp = p2 - p1              # Δφ = φ₂ - φ₁: converted first, subtracted after (Distances.jl 0.10, haversine.jl)
     s1 = np.sin(dp / 2)
     s2 = np.sin(dl / 2)
     a = s1 * s1 + np.cos(p1) * np.cos(p2) * (s2 * s2)

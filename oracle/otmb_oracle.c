@@ -894,9 +894,10 @@ int32_t orc_bolus_gm_velocity(const double *rho, const double *Z3D, const uint8_
 /* ---- Distances.haversine 0.10 (radius 6371000), points are (lon°, lat°) --- */
 double orc_haversine(double lon1, double lat1, double lon2, double lat2) {
     const double d2r = M_PI / 180.0; /* deg2rad(z) = z * (pi/180) */
-    double dl = (lon2 - lon1) * d2r;
-    double dp = (lat2 - lat1) * d2r;
-    double p1 = lat1 * d2r, p2 = lat2 * d2r;
+    double dl = (lon2 - lon1) * d2r;          /* Δλ = deg2rad(y[1] - x[1]) */
+    double p1 = lat1 * d2r, p2 = lat2 * d2r;  /* φ₁ = deg2rad(x[2]), φ₂ = deg2rad(y[2]) */
+    double dp = p2 - p1;                      /* Δφ = φ₂ - φ₁: the latitudes are converted FIRST and subtracted after (Distances.jl 0.10
+                                               * haversine.jl); (lat2 - lat1) * d2r, as rounds 1-4 had it, differs in the last ulp */
     double s1 = sin(dp / 2), s2 = sin(dl / 2);
     double a = s1 * s1 + cos(p1) * cos(p2) * (s2 * s2);
     double r = sqrt(a);

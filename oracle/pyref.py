@@ -310,9 +310,9 @@ def transportmatrix(phi, gm, idx, topo, rho, mlotst, kappaH=500.0, kappaVML=0.1,
 # ---- Distances.haversine / makegridmetrics pieces: src/gridcellgeometry.jl ------------------
 def haversine(A, B, radius=6371000.0):
     d2r = math.pi / 180
-    dl = (B[0] - A[0]) * d2r
-    dp = (B[1] - A[1]) * d2r
-    p1, p2 = A[1] * d2r, B[1] * d2r
+    dl = (B[0] - A[0]) * d2r            # Δλ = deg2rad(y[1] - x[1])
+    p1, p2 = A[1] * d2r, B[1] * d2r      # φ₁ = deg2rad(x[2]), φ₂ = deg2rad(y[2])
+    dp = p2 - p1                         # Δφ = φ₂ - φ₁ (Distances.jl 0.10 haversine.jl: converted first, subtracted after)
     a = math.sin(dp / 2) ** 2 + math.cos(p1) * math.cos(p2) * math.sin(dl / 2) ** 2
     return 2 * (radius * math.asin(min(math.sqrt(a), 1.0)))
 

@@ -118,6 +118,61 @@ def test_unknown_topology_detected():
                                  lon_vertices=lonv, lat_vertices=g.lat_vertices)
 
 
+def _haversine_answers():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "known_answer", "haversine.json")))["pairs"]
+
+
+def test_haversine_converts_the_latitudes_before_subtracting(oracle):
+    """Distances.jl 0.10: φ₁ = deg2rad(x[2]); φ₂ = deg2rad(y[2]); Δφ = φ₂ - φ₁ (rounds 1-4 had deg2rad(lat₂ - lat₁)).  Known answers made by
+    tests/golden/known_answer/make_haversine_answer.py without oracle or product.  The C oracle and the Python transliteration share the
+    generator's libm: bit for bit, including the pairs where the two forms differ in the last place only; numpy's sin / cos may differ
+    from libm's by an ulp, so the host product is held to 1e-12 -- on the pairs whose forms differ by 1e-7."""
+    from otmb_amd import gridmetrics as hostgm
+
+    pairs = _haversine_answers()
+    assert sum(p["relative_difference_of_the_two_forms"] > 1e-9 for p in pairs) >= 2
+    for p in pairs:
+        want, other = p["convert_then_subtract"]["distance"], p["subtract_then_convert"]["distance"]
+        args = (p["lon1"], p["lat1"], p["lon2"], p["lat2"])
+        assert oracle.haversine(*args) == want != other
+        assert pyref.haversine(args[:2], args[2:]) == want
+        got = float(hostgm.haversine(*(np.float64(a) for a in args)))
+        assert abs(got / want - 1) <= 1e-12
+        if p["relative_difference_of_the_two_forms"] > 1e-9:
+            assert abs(got / other - 1) > 1e-9
+
+
+@pytest.mark.gpu
+def test_device_haversine_converts_the_latitudes_before_subtracting():
+    """The device kernel's copy of the formula, through otmb_makegridmetrics_dev: a 3 x 3 grid whose cell centres in column i = 1 sit at the
+    latitudes of a known-answer pair with NEARLY EQUAL latitudes -- distance_to_neighbour_2D[north] of the lower cell is that pair's
+    distance, and the two forms of Δφ differ by 1e-7 there."""
+    from otmb_amd.device import DeviceAssembler
+    from otmb_amd._nt import Cube
+
+    for p in [q for q in _haversine_answers() if q["relative_difference_of_the_two_forms"] > 1e-9]:
+        nx, ny, nz = 3, 3, 1
+        lon = np.asfortranarray(np.tile(np.array([p["lon1"] - 1.0, p["lon1"], p["lon1"] + 1.0])[:, None], (1, ny)))
+        lat = np.asfortranarray(np.tile(np.array([p["lat1"] - 1.0, p["lat1"], p["lat2"]])[None, :], (nx, 1)))
+        lonv = np.zeros((4, nx, ny), order="F")
+        latv = np.zeros((4, nx, ny), order="F")
+        for v, (dx, dy) in enumerate(((-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5))):
+            lonv[v], latv[v] = lon + dx, lat + dy * 1e-3
+        latv[2:, :, ny - 1] = 90.0  # bipolar: the top row's north vertices at the pole (gridtopology.jl:41)
+        area = Cube(np.ones((nx, ny), order="F"))
+        vol = Cube(np.ones((nx, ny, nz), order="F"))
+        asm = DeviceAssembler(0)
+        asm.set_grid_from_raw(areacello=area, volcello=vol, lon=lon, lat=lat, lev=np.array([5.0]), lon_vertices=lonv, lat_vertices=latv,
+                              mlotst=np.ones((nx, ny), order="F"), rho=1035.0)
+        got = float(asm.dist[3].cpu().numpy().reshape((nx, ny), order="F")[1, 1])  # north neighbour of cell (2, 2)
+        want, other = p["convert_then_subtract"]["distance"], p["subtract_then_convert"]["distance"]
+        assert abs(got / want - 1) <= 1e-12, (got, want)
+        assert abs(got / other - 1) > 1e-9
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(), dict(topology="bipolar"), dict(vertex_order=(2, 3, 0, 1))])
 def test_device_makegridmetrics_matches_oracle(oracle, kw):
