@@ -146,11 +146,7 @@ __device__ __forceinline__ void raise_flag(int *flags, int f) {
 
 // ---- THE value expressions of the three generators: one copy, used by the generic column builder (build_column) and by the
 // regular-cell arithmetic (column_compute) that both the gather kernel (fast_column) and the dense-march kernel call. -------------
-#ifdef OTMB_DBG_MULDIV  // timing experiment only: what the 28 divisions of a column cost (wrong values)
-#define FDIV(a, b) ((a) * (b))
-#else
 #define FDIV(a, b) ((a) / (b))
-#endif
 // pushTadvectionvalues! (src/matrixbuilding.jl:193-204): ρ̄ = (ρx + ρc) / 2; row x: -ϕ / (ρ̄ vx); diagonal: ϕ / (ρ̄ vc)
 __device__ __forceinline__ void adv_pair(double phi, double rx, double rc, double vx, double vc, double &off, double &dg) {
     const double rb = (rx + rc) / 2;
@@ -536,11 +532,7 @@ struct TileBase {  // array pointers advanced to the tile's lowest neighbour (un
     const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb, *mk;
 };
 __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
-#ifdef OTMB_DBG_NOVALLOAD  // timing experiment only (wrong values): value-only inputs are not loaded, the pattern inputs are
-__device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return 1.0 + (double)byteoff * 1e-9 + (double)((size_t)b & 0xfff) * 1e-7; }
-#else
 __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return ldd(b, byteoff); }
-#endif
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
 // CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
 // The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
@@ -576,40 +568,24 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
         qW0 = ldd(tb.pw, oC); qE0 = ldd(tb.pe, oC); qS0 = ldd(tb.ps, oC); qN0 = ldd(tb.pn, oC); qB0 = ldd(tb.pb, oC);
         qT0 = ldd(tb.pt, oC);
     }
-#ifdef OTMB_DBG_NOEW  // timing experiment only (wrong values): no second load instruction into lines that are in flight
-    const double vC = ldv(tb.v, oC), vE = vC, vW = vC, vS = ldv(tb.v, oS), vN = ldv(tb.v, oN), vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
-#else
     const double vC = ldv(tb.v, oC), vE = ldv(tb.v, oE), vW = ldv(tb.v, oW), vS = ldv(tb.v, oS), vN = ldv(tb.v, oN),
                  vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
-#endif
     // (a scalar ρ is filled in AFTER the last load is issued: assigning it here makes the compiler drain the loads above first)
     double rC = 0, rE = 0, rW = 0, rS = 0, rN = 0, rA = 0, rB = 0;
     if (tb.rho) {
         rC = ldv(tb.rho, oC); rS = ldv(tb.rho, oS); rN = ldv(tb.rho, oN); rA = ldv(tb.rho, oA); rB = ldv(tb.rho, oB);
-#ifdef OTMB_DBG_NOEW
-        rE = rC; rW = rC;
-#else
         rE = ldv(tb.rho, oE); rW = ldv(tb.rho, oW);
-#endif
     }
-#ifdef OTMB_DBG_NOEW
-    const double tC = ldv(tb.thk, oC), tE = tC, tW = tC, tS = ldv(tb.thk, oS), tN = ldv(tb.thk, oN);
-#else
     const double tC = ldv(tb.thk, oC), tE = ldv(tb.thk, oE), tW = ldv(tb.thk, oW), tS = ldv(tb.thk, oS),
                  tN = ldv(tb.thk, oN);
-#endif
     const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
                *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
     const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
                *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
     const double eW_c = ldv(eWp, s2), eE_c = ldv(eEp, s2), eS_c = ldv(eSp, s2), eN_c = ldv(eNp, s2);
     const double dW_c = ldv(dWp, s2), dE_c = ldv(dEp, s2), dS_c = ldv(dSp, s2), dN_c = ldv(dNp, s2);
-#ifdef OTMB_DBG_NOEW
-    const double eE_w = eE_c, dE_w = dE_c, eW_e = eW_c, dW_e = dW_c;
-#else
     const double eE_w = ldv(eEp, sW), dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
     const double eW_e = ldv(eWp, sE), dW_e = ldv(dWp, sE);
-#endif
     const double eN_s = ldv(eNp, sS), dN_s = ldv(dNp, sS);
     const double eS_n = ldv(eSp, sN), dS_n = ldv(dSp, sN);  // oppdir = south away from the seam row (:407)
     const double ar = ldv((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);

@@ -265,14 +265,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
 #endif
     if (p.next_state && blockIdx.x == 0 && tid < (int)(OTMB_TM_STATE_BYTES / sizeof(int))) p.next_state[tid] = 0;
-#ifdef OTMB_STAGGER_UNITS
-    // Experiment: the workgroups of the first dispatch round start together and march through their phases (loads,
-    // arithmetic, stores) in lockstep; delay the k-th workgroup of a CU by k * OTMB_STAGGER_UNITS * 64 * 127 cycles
-    if (MODE == MODE_FILL && blockIdx.x < 1024) {
-        const int slot = blockIdx.x / 256;
-        for (int q = 0; q < slot * OTMB_STAGGER_UNITS; ++q) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Give XCD x the x-th
     // contiguous eighth of the tiles, so that a tile's south/north rows and the levels above/below, which
@@ -291,11 +283,9 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     if (MODE == MODE_ONEPASS) {
         // dynamic tile id: tiles start in ticket order, so every predecessor a tile waits for is already
         // running or finished whatever order the hardware dispatches workgroups in
-#ifndef OTMB_DBG_NOTICKET
         if (tid == 0) s_tile = atomicAdd(p.ticket, 1);
         __syncthreads();
         tile = s_tile;
-#endif
     }
     // One-pass mode: the tile's five counts follow from the push mask alone (count_cell), so they are published
     // FIRST and the look-back runs now, while the predecessors are still busy with their columns: nobody ever waits
@@ -389,14 +379,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #else
                 if (regular) canonical = fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
 #endif
-#ifdef OTMB_DBG_NOGENERIC  // timing experiment only (wrong on the seam row)
-                else { canonical = true; col.padv = col.phh = col.pml = col.pdp = 0; }
-#else
                 else {
                     canonical = ldi(tb.lw, oC) == c;
                     if (canonical) build_column(p, cell, c, col);
                 }
-#endif
             }
             if (!canonical) {
                 raise_flag(p.flags, FLAG_NONCANONICAL);
@@ -539,11 +525,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         const unsigned par = 0;
         const bool wide = true;
 #endif
-#ifdef OTMB_DBG_NOLDS
-        if (false) {
-#else
         if (live) {
-#endif
             const unsigned q0 = par + ex[m] - wb[m];
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
@@ -569,24 +551,11 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             room = run0 + cnt <= p.cap[m];
             if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
         }
-#ifdef OTMB_DBG_NOSTORE
-        room = false;
-#endif
         if (room) {
             const unsigned end = par + cnt;  // staged entries occupy LDS indices [par, end)
             if (wide) {
                 char *rvb = (char *)(rv - par);
                 char *nzb = (char *)(nz - par);
-#ifdef OTMB_STORE_SPLIT  // experiment (profiles/r05): all rowval pieces of the run, then all nzval pieces -- one output stream per burst
-                for (unsigned base = 0; base < end; base += 128) {
-                    const unsigned u = base + 2 * lane;
-                    if ((u >= par) & (u + 1 < end)) TM_STORE(*(const i64x2 *)(my_row + u), (i64x2g *)(rvb + u * 8u));
-                }
-                for (unsigned base = 0; base < end; base += 128) {
-                    const unsigned u = base + 2 * lane;
-                    if ((u >= par) & (u + 1 < end)) TM_STORE(*(const i64x2 *)(my_val + u), (i64x2g *)(nzb + u * 8u));
-                }
-#else
                 for (unsigned base = 0; base < end; base += 128) {  // full pairs
                     const unsigned u = base + 2 * lane;
                     if ((u >= par) & (u + 1 < end)) {
@@ -594,7 +563,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                         TM_STORE(*(const i64x2 *)(my_val + u), (i64x2g *)(nzb + u * 8u));
                     }
                 }
-#endif
                 // the (at most two) entries without a partner: index 1 of an odd-parity run, and the last one if
                 // it sits at an even index
 #ifdef OTMB_ALIGNED16

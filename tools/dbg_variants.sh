@@ -10,6 +10,9 @@
 # NOEW 0.391 -- the three parts (arithmetic + 13 pattern loads + LDS, value loads, stores) ADD UP; fewer VALU instructions
 # or fewer loads into busy lines change nothing.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+# (round 5: the macros live in tools/experiments/timing_ablations.patch, not in the product sources -- apply it for this run, revert after)
+(cd oceantransportmatrixbuilder.jl_amd/csrc && patch -p0 < ../../tools/experiments/timing_ablations.patch) || exit 1
+trap '(cd oceantransportmatrixbuilder.jl_amd/csrc && patch -R -p0 < ../../tools/experiments/timing_ablations.patch)' EXIT
 REPS=${REPS:-2} ROUNDS=${ROUNDS:-3} python tools/ab_variants.py base="" nostore="-DOTMB_DBG_NOSTORE" \
     novalload="-DOTMB_DBG_NOVALLOAD" neither="-DOTMB_DBG_NOSTORE -DOTMB_DBG_NOVALLOAD" muldiv="-DOTMB_DBG_MULDIV" \
     noew="-DOTMB_DBG_NOEW" 2>&1 | tail -6
