@@ -222,3 +222,61 @@ def test_access1deg_bolus_gm_velocity_matches_oracle(access1deg, oracle):
         assert rel.mean() >= 0.99999, (name, 1 - rel.mean())
         typical = np.median(np.abs(r[fin][r[fin] != 0]))
         np.testing.assert_allclose(h, r, rtol=1e-12, atol=1e-12 * typical, equal_nan=True, err_msg=name)
+
+
+# ---- SURVEY section 8(f) rows at the 1 degree grid's size (they were GPU-tested on small grids only) ------------------------------
+def test_access1deg_velocity_fluxes_bgrid_and_device_gridmetrics_at_full_size(access1deg, oracle):
+    """f1 velocity2fluxes / fluxes2velocity / facefluxesfromvelocities (src/velocities.jl:10-108,132-151), f4 B-grid -> C-grid
+    interpolation (src/gridcellgeometry.jl:106-140) and f2 makegridmetrics on the device (:265-311) on 360x300x50, against the oracle:
+    bit for bit, except the haversine distances (device libm: 1e-12)."""
+    import otmb_amd.api as api
+    from otmb_amd import NT, Cube
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = access1deg
+    kind = gm.gridtopology.kind
+    rng = np.random.default_rng(11)
+    wet = ~np.isnan(gm.v3D)
+    u = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, 1e20))
+    v = np.asfortranarray(np.where(wet, rng.standard_normal(wet.shape) * 0.1, 1e20))
+    lv, tv = gm.lon_vertices, gm.lat_vertices
+    u_lon, u_lat, v_lon, v_lat = (lv[1] + lv[2]) / 2, (tv[1] + tv[2]) / 2, (lv[2] + lv[3]) / 2, (tv[2] + tv[3]) / 2
+    # f1
+    fi, fj = api.velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gm, g.rho)
+    ri, rj = oracle.velocity_flux(u, v, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], kind)
+    assert np.array_equal(fi, ri, equal_nan=True) and np.array_equal(fj, rj, equal_nan=True)
+    ui, uj = api.fluxes2velocity(fi, fj, gm, g.rho)
+    qi, qj = oracle.velocity_flux(ri, rj, g.rho, gm.thkcello, gm.edge_length_2D["east"], gm.edge_length_2D["north"], kind, True)
+    assert np.array_equal(ui, qi, equal_nan=True) and np.array_equal(uj, qj, equal_nan=True)
+    both_e = wet & np.roll(wet, -1, axis=0)
+    np.testing.assert_allclose(ui[both_e], u[both_e], rtol=1e-12)  # test/local_full.jl:300-304
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfromvelocities(uo=Cube(u, _FillValue=1e20), uo_lon=u_lon, uo_lat=u_lat, vo=Cube(v, _FillValue=1e20),
+                                       vo_lon=v_lon, vo_lat=v_lat, gridmetrics=gm, indices=idx, ρ=g.rho)
+    ref = oracle.facefluxes(ri, rj, idx.wet3D.view(np.uint8), 1e20, kind)
+    for k in ref:
+        assert np.array_equal(phi[k], ref[k]), k
+    # f4
+    ne_lon, ne_lat = lv[2], tv[2]
+    got = api.interpolateontodefaultCgrid(Cube(u, _FillValue=1e20), ne_lon, ne_lat, Cube(v, _FillValue=1e20), ne_lon, ne_lat, gm)
+    want = oracle.bgrid_to_cgrid(u, v, 1e20, gm)
+    for name, a, b in zip(("u2", "u2_lon", "u2_lat", "v2", "v2_lon", "v2_lat"), got, want):
+        assert np.array_equal(np.asarray(a), b), name
+    # f2
+    ref = oracle.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
+                                 lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
+    rgm = NT(**{k: v for k, v in ref.items() if k != "gridtopology"}, gridtopology=NT(kind=ref["gridtopology"]["kind"]))
+    asm = DeviceAssembler(0)
+    asm.set_grid_from_raw(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
+                          lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices, mlotst=g.mlotst, rho=g.rho)
+    shp = rgm.v3D.shape
+    back = lambda t, s: t.cpu().numpy().reshape(s, order="F")
+    assert asm.topology == rgm.gridtopology.kind
+    for got_t, want_a in ((asm.v3d, rgm.v3D), (asm.thk, rgm.thkcello), (asm.z3d, rgm.Z3D)):
+        assert np.array_equal(back(got_t, shp), want_a, equal_nan=True)
+    assert np.array_equal(back(asm.area, shp[:2]), rgm.area2D, equal_nan=True)
+    for k, d in enumerate(("west", "east", "south", "north")):
+        np.testing.assert_allclose(back(asm.edge[k], shp[:2]), rgm.edge_length_2D[d], rtol=1e-12)
+        np.testing.assert_allclose(back(asm.dist_edge[k], shp[:2]), rgm.distance_to_edge_2D[d], rtol=1e-12)
+        np.testing.assert_allclose(back(asm.dist[k], shp[:2]), rgm.distance_to_neighbour_2D[d], rtol=1e-12, equal_nan=True)
+    assert asm.N == int(wet.sum())
