@@ -547,7 +547,8 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             vmo = torch.from_numpy(np.asfortranarray(g.vmo.data).ravel(order="F")).to(dev)
             fill = g.umo.properties["_FillValue"]
 
-        if args.placement_candidates > 1 and args.protocol == "async" and args.workload != "tenthdeg":
+        # (not under a profiler: the candidates' launches would enter the per-kernel averages of profiles/*_kernel_stats.csv and traffic.json)
+        if args.placement_candidates > 1 and args.protocol == "async" and args.workload != "tenthdeg" and not under_profiler():
             try:  # set-up, outside the timed region; never results (tests/test_device_api.py)
                 placement = asm.choose_placement(umo, vmo, fill, candidates=args.placement_candidates)
             except Exception as e:

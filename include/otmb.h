@@ -305,7 +305,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
  * to back with no host round trip.  capacity[m] = entries rowval[m]/nzval[m] can hold; colptr[m] holds
  * n_wet+1.  otmb_transportmatrix_result synchronises, raises the reference's errors / OTMB_ERR_CAPACITY,
  * compacts T if entries cancelled and returns the five nnz.  (Environment OTMB_LOOKBACK=1 selects an
- * experimental single-kernel variant whose tile offsets come from a decoupled look-back.)             */
+ * experimental single-kernel variant whose tile offsets come from a decoupled look-back.)
+ * One exception to "no host round trip": the FIRST call for a grid (and the first after otmb_ctx_set_stream changed the stream)
+ * builds the fill pass's tile order and waits for its number of heavy tiles -- one stream synchronisation per grid, not per step. */
 int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t *const colptr[5],
                                  int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
 int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);

@@ -22,8 +22,19 @@ static int32_t stage(otmb_ctx *ctx, int slot, size_t bytes, void **dptr) {
 // Uploads are collected and handed to the transfer engine (otmb_xfer.hip) in one batch, so that its pipeline of pinned
 // chunks runs across arrays.  grid_constant: the array belongs to gridmetrics / indices; with otmb_ctx_set_reuse_grid it is
 // uploaded only when the slot does not already hold this very host array (same pointer, same size).
+// A slot's residency key says "this buffer HOLDS that host array": it is written when the upload is queued, so a batch that never
+// reaches the device (a later reserve fails, the transfer fails) must take the keys of its slots back -- otherwise a retry with
+// otmb_ctx_set_reuse_grid on would treat arrays that were never copied as resident.
 struct Uploads {
     std::vector<OtmbXferItem> items;
+    otmb_ctx *ctx = nullptr;
+    std::vector<int> slots;  // slots whose key this batch has touched
+    bool done = true;        // nothing pending
+    ~Uploads() {
+        if (!done && ctx)
+            for (int q : slots)
+                if ((size_t)q < ctx->stage_key.size()) ctx->stage_key[q] = otmb_ctx::StageKey();
+    }
 };
 // kind: 0 = uploaded every call; 1 = grid constant (otmb_ctx_set_reuse_grid); 2 = a face-flux array (otmb_ctx_set_reuse_fluxes:
 // resident when the slot still holds what otmb_facefluxes computed and copied to this very host array)
@@ -35,7 +46,11 @@ static int32_t upload(otmb_ctx *ctx, Uploads &up, int slot, const void *h, size_
     otmb_ctx::StageKey &key = ctx->stage_key[slot];
     const bool promised = (kind == 1 && ctx->reuse_grid) || (kind == 2 && ctx->reuse_fluxes);
     const bool resident = promised && key.host == h && key.bytes == bytes && bytes > 0;
-    if (bytes && !resident) { up.items.push_back({d, const_cast<void *>(h), bytes}); ctx->uploaded_bytes += (i64)bytes; }
+    if (bytes && !resident) {
+        up.items.push_back({d, const_cast<void *>(h), bytes});
+        ctx->uploaded_bytes += (i64)bytes;
+        up.ctx = ctx; up.slots.push_back(slot); up.done = false;
+    }
     key.host = (promised || resident) ? h : nullptr;
     key.bytes = bytes;
     *dptr = d;
@@ -67,9 +82,10 @@ bool otmb_host_is_pinned(const otmb_ctx *, const void *p, size_t bytes) {
     return false;
 }
 static int32_t flush(otmb_ctx *ctx, Uploads &up) {
-    if (up.items.empty()) return OTMB_OK;
+    if (up.items.empty()) { up.done = true; return OTMB_OK; }
     int32_t rc = otmb_xfer(ctx, true, up.items.data(), (int)up.items.size());
     up.items.clear();
+    if (rc == OTMB_OK) { up.done = true; up.slots.clear(); }  // (a failed batch keeps done == false: the destructor forgets its keys)
     return rc;
 }
 static int32_t download(otmb_ctx *ctx, std::vector<OtmbXferItem> &items) {

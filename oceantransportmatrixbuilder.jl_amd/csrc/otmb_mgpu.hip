@@ -46,7 +46,7 @@ struct Rccl {
         if (!h) { err = std::string("librccl.so: ") + dlerror(); return false; }
 #define OTMB_SYM(field, name)                                                         \
     field = (decltype(field))dlsym(h, name);                                          \
-    if (!field) { err = std::string("librccl.so lacks ") + name; h = nullptr; return false; }
+    if (!field) { err = std::string("librccl.so lacks ") + name; dlclose(h); h = nullptr; return false; }
         OTMB_SYM(CommInitAll, "ncclCommInitAll")
         OTMB_SYM(CommDestroy, "ncclCommDestroy")
         OTMB_SYM(GroupStart, "ncclGroupStart")
@@ -132,10 +132,13 @@ int32_t mg_fail(otmb_mgpu *mg, int32_t st, const std::string &detail = std::stri
 template <typename F>
 void run_slabs(otmb_mgpu *mg, F &&fn) {  // one host thread per slab (the calling thread takes slab 0)
     const int n = (int)mg->slabs.size();
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);  // slab 0 switches the CALLER's thread to its device: put the caller's current device back afterwards
     std::vector<std::thread> th;
     for (int s = 1; s < n; ++s) th.emplace_back([&, s] { fn(s); });
     fn(0);
     for (auto &t : th) t.join();
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
 }
 
 int32_t reserve(Slab &sl, int b, size_t bytes, void **out) {
@@ -297,7 +300,7 @@ int32_t otmb_mgpu_create(int32_t ndev, const int32_t *device_ids, otmb_mgpu **ou
             if (mg->rccl.CommInitAll(mg->comms.data(), 1, device_ids) == ncclSuccess) mg->transport = 1;
             else mg->comms.clear();
         }
-        if (mg->transport != 1) { mg->err = "RCCL: " + why; }
+        if (mg->transport != 1) { mg->err = "RCCL transport not available: " + (why.empty() ? std::string("ncclCommInitAll failed") : why); }
     } else if (same) {
         mg->transport = 0;
     } else if (!distinct) {
@@ -313,13 +316,23 @@ int32_t otmb_mgpu_create(int32_t ndev, const int32_t *device_ids, otmb_mgpu **ou
         if (!want_peer && mg->rccl.load(why)) {
             mg->comms.assign(ndev, nullptr);
             if (mg->rccl.CommInitAll(mg->comms.data(), ndev, device_ids) == ncclSuccess) mg->transport = 1;
-            else mg->comms.clear();
+            else { mg->comms.clear(); why = "ncclCommInitAll failed"; }
         }
         if (mg->transport == 2) {
-            for (int s = 0; s + 1 < ndev; ++s) {  // neighbours hand planes upwards: enable access both ways (an error = already enabled)
-                (void)hipSetDevice(device_ids[s]); (void)hipDeviceEnablePeerAccess(device_ids[s + 1], 0);
-                (void)hipSetDevice(device_ids[s + 1]); (void)hipDeviceEnablePeerAccess(device_ids[s], 0);
-                (void)hipGetLastError();
+            // which transport runs and why is the caller's to see (otmb_mgpu_last_error right after create, otmb_mgpu_transport; bench.py prints both)
+            mg->err = want_peer ? "peer copies (OTMB_MGPU_TRANSPORT=peer)" : "peer copies, RCCL not used: " + why;
+            for (int s = 0; s + 1 < ndev; ++s) {  // neighbours hand planes upwards: enable access both ways
+                for (int dir = 0; dir < 2; ++dir) {
+                    const int from = device_ids[s + dir], to = device_ids[s + 1 - dir];
+                    (void)hipSetDevice(from);
+                    const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                        char msg[128];
+                        snprintf(msg, sizeof msg, "; hipDeviceEnablePeerAccess(%d -> %d): %s", from, to, hipGetErrorString(e));
+                        mg->err += msg;
+                    }
+                    (void)hipGetLastError();
+                }
             }
         }
     }
@@ -523,7 +536,17 @@ int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *a, int
     mg->N = N;
     run_slabs(mg, [&](int s) {
         Slab &sl = *mg->slabs[s];
-        auto fail = [&](int32_t st) { sl.status = st; sl.msg = otmb_last_error(sl.ctx); };
+        // The residency keys are written when an upload is QUEUED: a slab that fails before its batch has reached the device (a later
+        // reserve, the transfer, the index shift) must forget them, or a retry with reuse on would take arrays that were never copied
+        // for resident and build matrices from uninitialised memory.
+        bool on_device = false;
+        auto fail = [&](int32_t st) {
+            sl.status = st; sl.msg = otmb_last_error(sl.ctx);
+            if (!on_device) {
+                for (int b = 0; b < B_COUNT; ++b) sl.key[b] = Slab::Key();
+                sl.phi_resident = false;
+            }
+        };
         if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
         const i64 e0 = sl.k0 - sl.ha, e1 = sl.k1 + sl.hb, nze = e1 - e0;
         const size_t Ge = (size_t)(nze * P), off = (size_t)e0 * P;
@@ -596,6 +619,7 @@ int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *a, int
             hipLaunchKernelGGL(shift_i64_kernel, dim3((unsigned)((sl.n_own + 255) / 256)), dim3(256), 0, sl.ctx->stream, dlwet, sl.n_own, (i64)off);
             if (hipGetLastError() != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "shift_i64_kernel"); return fail(OTMB_ERR_HIP); }
         }
+        on_device = true;  // (errors from here on are the reference's own: the arrays ARE where the keys say)
         if ((r = otmb_transportmatrix_set_slab(sl.ctx, sl.wet_base))) return fail(r);
         if ((r = otmb_transportmatrix_plan_dev(sl.ctx, &d, sl.nnz))) return fail(r);
     });
@@ -613,10 +637,10 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
                                         int64_t nnz_out[5]) {
     if (!mg || !colptr || !rowval || !nzval || !nnz_out) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null argument");
     if (!mg->planned) return mg_fail(mg, OTMB_ERR_NO_PLAN);
-    mg->planned = false;  // a plan is consumed by its fetch
     const int nm = mg->args.only_t ? 1 : 5, n = (int)mg->slabs.size();
     for (int m = 0; m < nm; ++m)
         if (!colptr[m] || (mg->nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
+    mg->planned = false;  // a plan is consumed by its fetch (not by a call that is refused for its arguments)
     // phase 1: every slab fills its column range on its device and copies the four operators home (their counts are exact
     // since the plan); T's final count is only known now (entries that summed to exactly zero, src/matrixbuilding.jl:147)
     run_slabs(mg, [&](int s) {

@@ -97,6 +97,10 @@ static void par_memcpy(OtmbThreadPool *pool, char *dst, const char *src, size_t 
 
 int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int n) {
     int32_t rc;
+    if (to_device) {  // fault injection for the tests of the residency keys (a batch that never reaches the device must not be remembered)
+        const char *e = getenv("OTMB_TEST_FAIL_UPLOAD");
+        if (e && e[0] == '1') return otmb_fail(ctx, OTMB_ERR_HIP, "upload failure injected (OTMB_TEST_FAIL_UPLOAD)");
+    }
     if ((rc = xfer_init(ctx))) return rc;
     OtmbXfer &x = *ctx->xfer;
     struct Piece { char *dev, *host; size_t bytes; };

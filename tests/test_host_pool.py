@@ -149,5 +149,19 @@ def test_reuse_flags_are_independent(oracle):
         assert run(reuse_grid=True, reuse_fluxes=True) == every_call
         assert run(reuse_fluxes=True) == grid_bytes + every_call            # reuse_grid off again: the grid is forgotten, ϕ is not
         assert run() == phi_bytes + grid_bytes + every_call
+        # a batch that never reached the device is not remembered: the keys are written when an upload is queued, so a
+        # failed transfer must take them back -- or the retry below would assemble from buffers nothing was ever copied into
+        import os
+
+        from otmb_amd.capi import OtmbError
+
+        os.environ["OTMB_TEST_FAIL_UPLOAD"] = "1"
+        try:
+            with pytest.raises(OtmbError) as e:
+                run(reuse_grid=True)
+            assert "injected" in str(e.value)
+        finally:
+            del os.environ["OTMB_TEST_FAIL_UPLOAD"]
+        assert run(reuse_grid=True) == phi_bytes + grid_bytes + every_call  # everything goes up again, and the matrices are right
     finally:
         api._ctx.pop(9).close()

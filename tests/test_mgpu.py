@@ -286,6 +286,43 @@ def test_mgpu_reuse_flags_keep_grid_and_fluxes_on_the_devices(oracle):
 
 
 @pytest.mark.gpu
+def test_mgpu_forgets_uploads_that_never_reached_the_devices(oracle):
+    """a slab's residency keys are written when an upload is QUEUED.  A plan whose transfer fails must take them back, or a
+    retry on the same handle with reuse_grid on would treat arrays that were never copied as resident and build matrices from
+    uninitialised device memory (and skip the local-index shift of Lwet)."""
+    import os
+
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+    from otmb_amd.capi import OtmbError
+
+    g = synthetic.make_grid(28, 20, 13, seed=46, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    devices = [0, 0, 0]
+    idx = api.makeindices(gm.v3D)
+    mg = api.mgpu(devices)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+    os.environ["OTMB_TEST_FAIL_UPLOAD"] = "1"
+    try:
+        with pytest.raises(OtmbError) as e:
+            api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices, reuse_grid=True)
+        assert "injected" in str(e.value)
+    finally:
+        del os.environ["OTMB_TEST_FAIL_UPLOAD"]
+    b0 = mg.uploaded_bytes()
+    tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices, reuse_grid=True)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    first = mg.uploaded_bytes() - b0
+    b0 = mg.uploaded_bytes()
+    tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices, reuse_grid=True)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    assert mg.uploaded_bytes() - b0 < first  # the retry uploaded the grid in full; only now is it resident
+
+
+@pytest.mark.gpu
 def test_mgpu_with_precomputed_operators(oracle):
     """transportmatrix(…; Tadv = …, devices = …) (src/matrixbuilding.jl:133-147): ignore_ops travels to every slab -- a NaN in ρ or a flux
     into land is no error when Tadv is handed in -- and T is the three sparse adds of the given and the built operators."""
