@@ -4,6 +4,8 @@ thread while a call is in flight on the context; and the two reuse flags are ind
 import ctypes as C
 import threading
 
+import os
+
 import numpy as np
 import pytest
 
@@ -134,10 +136,15 @@ def test_reuse_flags_are_independent(oracle):
         grid_bytes = 3 * G * 8 + N * 8 + 9 * P * 8 + gm.v3D.shape[2] * 8  # v3D, thkcello, Lwet3D | Lwet | 8 metrics + area | zt
         every_call = G * 8 + P * 8                                        # ρ, mlotst
 
-        def run(**kw):
+        def run(inject=False, **kw):
             phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, device=9)
             b0 = lib.otmb_ctx_uploaded_bytes(ctx.handle)
-            tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, device=9, **kw)
+            if inject:  # (the uploads of transportmatrix fail: otmb_xfer.hip's test hook)
+                os.environ["OTMB_TEST_FAIL_UPLOAD"] = "1"
+            try:
+                tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, device=9, **kw)
+            finally:
+                os.environ.pop("OTMB_TEST_FAIL_UPLOAD", None)
             for m in MATS:
                 assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/{kw}")
             return lib.otmb_ctx_uploaded_bytes(ctx.handle) - b0
@@ -151,17 +158,11 @@ def test_reuse_flags_are_independent(oracle):
         assert run() == phi_bytes + grid_bytes + every_call
         # a batch that never reached the device is not remembered: the keys are written when an upload is queued, so a
         # failed transfer must take them back -- or the retry below would assemble from buffers nothing was ever copied into
-        import os
-
         from otmb_amd.capi import OtmbError
 
-        os.environ["OTMB_TEST_FAIL_UPLOAD"] = "1"
-        try:
-            with pytest.raises(OtmbError) as e:
-                run(reuse_grid=True)
-            assert "injected" in str(e.value)
-        finally:
-            del os.environ["OTMB_TEST_FAIL_UPLOAD"]
+        with pytest.raises(OtmbError) as e:
+            run(inject=True, reuse_grid=True)
+        assert "injected" in str(e.value)
         assert run(reuse_grid=True) == phi_bytes + grid_bytes + every_call  # everything goes up again, and the matrices are right
     finally:
         api._ctx.pop(9).close()
