@@ -88,7 +88,8 @@ int64_t otmb_ctx_uploaded_bytes(const otmb_ctx *ctx);
 /* Pinned (page-locked) host memory owned by the context, for the arrays a caller hands to the host-pointer entry points:
  * a buffer inside such a block is the DMA's own source / target -- no staging copy, no page faults on freshly allocated
  * output arrays (1 GB of them per transportmatrix at 1 degree).  Julia: unsafe_wrap(Array, ptr, n) + a finalizer calling
- * otmb_host_free.  Freed blocks are kept and handed out again (up to 4 GiB idle).                                   */
+ * otmb_host_free.  Freed blocks are kept and handed out again (up to 4 GiB idle).  ctx may be NULL (a caller that only uses an
+ * otmb_mgpu has no single-device context): the pool belongs to no context.                                          */
 int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out);
 /* Lifetime and threads: the blocks belong to ONE pool of the process, behind a lock, which no context owns: otmb_ctx_destroy
  * frees none of them, and otmb_host_free IGNORES its context argument (NULL and an already destroyed context are fine) and may
@@ -393,6 +394,12 @@ int32_t otmb_makegridmetrics_dev(otmb_ctx *ctx, const double *volcello, const do
                                  const double *lat_vertices, const int32_t perm[4], int64_t nx, int64_t ny, int64_t nz,
                                  int32_t topology, double *area2d, double *v3d, double *thkcello, double *z3d,
                                  double *const edge_length[4], double *const dist_edge[4], double *const dist_nbr[4]);
+/* the same on host arrays (what a Julia / C caller has): inputs up, the seventeen derived arrays back; blocking */
+int32_t otmb_makegridmetrics(otmb_ctx *ctx, const double *volcello, const double *areacello, double fill_area, double fill_vol,
+                             const double *lon, const double *lat, const double *lon_vertices, const double *lat_vertices,
+                             const int32_t perm[4], int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *area2d, double *v3d,
+                             double *thkcello, double *z3d, double *const edge_length[4], double *const dist_edge[4],
+                             double *const dist_nbr[4]);
 
 /* ---- bolus_GM_velocity(ρ, gridmetrics, indices; κGM = 600, maxslope = 0.01) -- src/RediGM.jl:46-79 with
  *      globalverticalfacetriadderivative (src/triads.jl:84-146) and globalverticaldyadderivative

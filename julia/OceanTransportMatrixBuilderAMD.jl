@@ -5,9 +5,15 @@
 #   makeindices                 src/matrixbuilding.jl:10-24
 #   facefluxesfrommasstransport src/velocities.jl:118-130   (facefluxes :190-255, nofluxboundaries! :154-179)
 #   transportmatrix             src/matrixbuilding.jl:128-150
-# lump_and_spray (src/extratools.jl:38-119) is bound too; everything else (makegridmetrics, velocity2fluxes, ...) is re-exported from the
-# reference package unchanged, so `using OceanTransportMatrixBuilderAMD` replaces
-# `using OceanTransportMatrixBuilder` in a TMIP script.
+#   velocity2fluxes / fluxes2velocity / facefluxesfromvelocities / interpolateontodefaultCgrid
+#                               src/velocities.jl:10-74,140-151, src/gridcellgeometry.jl:103-140 (round 5: bound here too, so that a script
+#                               that starts from uo / vo runs THIS module's facefluxes and not the reference's CPU one)
+#   lump_and_spray              src/extratools.jl:38-119
+#   bolus_GM_velocity           src/RediGM.jl:46-79 (unexported and experimental there, unexported here)
+#   makegridmetrics             src/gridcellgeometry.jl:265-311: the reference's own by default (its haversines are Julia's libm);
+#                               `makegridmetrics(...; gpu = true)` opts into the library's array work (distances within 1e-12)
+# Host-side decisions stay the reference's own functions (getgridtopology, vertexpermutation, getarakawagrid), so
+# `using OceanTransportMatrixBuilderAMD` replaces `using OceanTransportMatrixBuilder` in a TMIP script.
 #
 # NOTE: no Julia toolchain exists in the build image, so this file has never been executed there; it is
 # kept thin and mechanical (argument flattening + ccall) and mirrors the Python host layer
@@ -19,14 +25,13 @@ using SparseArrays
 using Libdl
 import OceanTransportMatrixBuilder as OTMB
 
-# re-export the untouched part of the reference API
-using OceanTransportMatrixBuilder: makegridmetrics, velocity2fluxes, fluxes2velocity, facefluxesfromvelocities
+# the reference's exported names (src/OceanTransportMatrixBuilder.jl:31-36), every one of them defined in THIS module
 export makegridmetrics, velocity2fluxes, fluxes2velocity, facefluxesfromvelocities
 export makeindices, facefluxesfrommasstransport, facefluxes, transportmatrix, lump_and_spray
 
 const LIBPATH = get(ENV, "OTMB_HIP_LIB", joinpath(@__DIR__, "..", "oceantransportmatrixbuilder.jl_amd", "lib", "libotmb_hip.so"))
 const lib = Ref{Ptr{Cvoid}}(C_NULL)
-const ctx = Ref{Ptr{Cvoid}}(C_NULL)
+const ctx = Ref{Ptr{Cvoid}}(C_NULL)              # the single-GPU context: created by the first call that needs it (`context()`)
 const host_free_fn = Ref{Ptr{Cvoid}}(C_NULL)     # otmb_host_free, resolved once: finalizers must not look symbols up
 const MGPU = Dict{Vector{Int32},Ptr{Cvoid}}()    # otmb_mgpu objects by device list (`devices = 0:7`)
 # A context (and an otmb_mgpu) is "not shared between threads" (include/otmb.h): every public entry point of this module runs
@@ -42,10 +47,7 @@ function __init__()
     Libdl.dlopen(get(ENV, "OTMB_HIP_RUNTIME", "/opt/rocm/lib/libamdhip64.so"), Libdl.RTLD_GLOBAL)
     lib[] = Libdl.dlopen(LIBPATH)
     host_free_fn[] = Libdl.dlsym(lib[], :otmb_host_free)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall(Libdl.dlsym(lib[], :otmb_ctx_create), Int32, (Int32, Ptr{Ptr{Cvoid}}), parse(Int32, get(ENV, "OTMB_DEVICE", "0")), h)
-    rc == 0 || error("otmb_ctx_create failed (status $rc): is a ROCm GPU visible?")
-    ctx[] = h[]
+    # (no context yet: a caller that only ever passes `devices = 4:7` must not have one created on GPU 0 behind its back)
     # Julia runs atexit hooks BEFORE its final finalizer sweep: result arrays that are still alive are finalized AFTER this hook.
     # That is safe by construction: pinned blocks belong to a process-wide pool that no context owns (otmb_ctx_destroy frees none of
     # them) and otmb_host_free ignores its context argument -- the finalizers below pass C_NULL.
@@ -55,13 +57,24 @@ function __init__()
                 ccall(Libdl.dlsym(lib[], :otmb_mgpu_destroy), Cvoid, (Ptr{Cvoid},), h)
             end
             empty!(MGPU)
-            ccall(Libdl.dlsym(lib[], :otmb_ctx_destroy), Cvoid, (Ptr{Cvoid},), ctx[])
+            ctx[] == C_NULL || ccall(Libdl.dlsym(lib[], :otmb_ctx_destroy), Cvoid, (Ptr{Cvoid},), ctx[])
             ctx[] = C_NULL
         end
     end
 end
 
 sym(name) = Libdl.dlsym(lib[], name)
+
+# the single-GPU context (ENV["OTMB_DEVICE"], default 0), created on first use -- always called under CALL_LOCK
+function context()
+    if ctx[] == C_NULL
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall(sym(:otmb_ctx_create), Int32, (Int32, Ptr{Ptr{Cvoid}}), parse(Int32, get(ENV, "OTMB_DEVICE", "0")), h)
+        rc == 0 || error("otmb_ctx_create failed (status $rc): is a ROCm GPU visible?")
+        ctx[] = h[]
+    end
+    return ctx[]
+end
 
 # status -> the reference's own exception types and texts (include/otmb.h, otmb_status)
 function check(rc::Int32)
@@ -109,7 +122,7 @@ function makeindices(v3D)
     lock(CALL_LOCK) do
         check(ccall(sym(:otmb_makeindices), Int32,
             (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{UInt8}, Ptr{Int64}),
-            ctx[], v, nx, ny, nz, lwet3d, lwet, wet, N))
+            context(), v, nx, ny, nz, lwet3d, lwet, wet, N))
     end
     resize!(lwet, N[])
     wet3D = BitArray(wet .!= 0)
@@ -136,7 +149,7 @@ function facefluxes(umo, vmo, gridmetrics, indices; FillValue, pinned = PINNED_R
         if devices === nothing
             GC.@preserve ϕ u v wet check(ccall(sym(:otmb_facefluxes), Int32,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{UInt8}, Float64, Int64, Int64, Int64, Int32, Ptr{Ptr{Float64}}),
-                ctx[], u, v, Int32(is32), wet, Float64(FillValue), nx, ny, nz, topologykind(gridmetrics.gridtopology), ptrs))
+                context(), u, v, Int32(is32), wet, Float64(FillValue), nx, ny, nz, topologykind(gridmetrics.gridtopology), ptrs))
         else
             mg = mgpu_of(devices)
             GC.@preserve ϕ u v wet check_mgpu(mg, ccall(sym(:otmb_mgpu_facefluxes), Int32,
@@ -182,7 +195,9 @@ end
 # Julia vectors instead (the library then stages the copy through its own pinned ring; about a third slower at 1 degree).
 function pinned_array(::Type{T}, dims...) where {T}
     p = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall(sym(:otmb_host_alloc), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx[], Int64(max(prod(dims), 1) * sizeof(T)), p))
+    # (NULL context: the pool belongs to no context, and the `devices = ...` path must not create the single-GPU one)
+    rc = ccall(sym(:otmb_host_alloc), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), C_NULL, Int64(max(prod(dims), 1) * sizeof(T)), p)
+    rc == 0 || error("otmb_host_alloc failed (status $rc)")
     a = unsafe_wrap(Array, Ptr{T}(p[]), dims; own = false)
     block = p[]
     finalizer(_ -> ccall(host_free_fn[], Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, block), a)
@@ -199,7 +214,7 @@ function spadd(A::SparseMatrixCSC{Float64,Int64}, B::SparseMatrixCSC{Float64,Int
     lock(CALL_LOCK) do
         check(ccall(sym(:otmb_spadd), Int32,
             (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
-            ctx[], n, A.colptr, A.rowval, A.nzval, B.colptr, B.rowval, B.nzval, Cp, Ci, Cx, k))
+            context(), n, A.colptr, A.rowval, A.nzval, B.colptr, B.rowval, B.nzval, Cp, Ci, Cx, k))
     end
     resize!(Ci, k[]); resize!(Cx, k[])
     return SparseMatrixCSC{Float64,Int64}(size(A, 1), n, Cp, Ci, Cx)
@@ -296,7 +311,7 @@ function fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind
     devices === nothing || return fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes,
                                               ignore_ops, usepinned, devices)
     lock(CALL_LOCK) do
-        check(ccall(sym(:otmb_ctx_set_reuse_grid), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_grid)))
+        check(ccall(sym(:otmb_ctx_set_reuse_grid), Int32, (Ptr{Cvoid}, Int32), context(), Int32(reuse_grid)))
         check(ccall(sym(:otmb_ctx_set_reuse_fluxes), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_fluxes)))
         a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops)
         N = indices.N
@@ -335,6 +350,149 @@ function fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, u
     end
 end
 
+# ---- velocities <-> fluxes (src/velocities.jl:10-74) and facefluxesfromvelocities (:140-151) ------------------------------------
+cubedata(x) = x isa AbstractArray ? x : Array(x)
+
+"""
+    interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics)
+
+gridcellgeometry.jl:103-140.  The Arakawa grid is detected by the reference's own `getarakawagrid` (host, first cell only); C-grid fields
+pass through, B-grid fields on the NE corner are averaged onto the east / north faces by the library, anything else raises the
+reference's errors.
+"""
+function interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics)
+    arakawa = OTMB.getarakawagrid(u_lon, u_lat, v_lon, v_lat, gridmetrics)
+    arakawa isa OTMB.CGridCell && return u, u_lon, u_lat, v, v_lon, v_lat
+    arakawa isa OTMB.AGridCell && error("Interpolation not implemented for A-grid type")
+    (; u_pos, v_pos) = arakawa
+    u_pos == v_pos == :NE || error("Interpolation not implemented for this B-grid($u_pos,$v_pos) type")
+    FillValue = u.properties["_FillValue"]                      # :111
+    is32 = eltype(u) == Float32 && eltype(v) == Float32
+    T = is32 ? Float32 : Float64
+    a = Array{T,3}(u); b = Array{T,3}(v)
+    nx, ny, nz = size(a)
+    u2 = Array{Float64,3}(undef, nx, ny, nz); v2 = Array{Float64,3}(undef, nx, ny, nz)
+    lock(CALL_LOCK) do
+        check(ccall(sym(:otmb_bgrid_to_cgrid), Int32,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+            context(), a, b, Int32(is32), Float64(FillValue), nx, ny, nz, u2, v2))
+    end
+    (; lon_vertices, lat_vertices) = gridmetrics                # the faces' midpoints, as the reference computes them (:127-137)
+    SE = [(lo, la) for (lo, la) in zip(lon_vertices[2, :, :], lat_vertices[2, :, :])]
+    NE = [(lo, la) for (lo, la) in zip(lon_vertices[3, :, :], lat_vertices[3, :, :])]
+    NW = [(lo, la) for (lo, la) in zip(lon_vertices[4, :, :], lat_vertices[4, :, :])]
+    u2p = [OTMB.midpointonsphere(A, B) for (A, B) in zip(NE, SE)]
+    v2p = [OTMB.midpointonsphere(A, B) for (A, B) in zip(NW, NE)]
+    return u2, [P[1] for P in u2p], [P[2] for P in u2p], v2, [P[1] for P in v2p], [P[2] for P in v2p]
+end
+
+# otmb_velocity2fluxes / otmb_fluxes2velocity: the same argument list
+function velocityflux(name::Symbol, a, b, gridmetrics, ρ)
+    (; thkcello, edge_length_2D, gridtopology) = gridmetrics
+    x = cubedata(a); y = cubedata(b)
+    is32 = eltype(x) == Float32 && eltype(y) == Float32
+    T = is32 ? Float32 : Float64
+    x = Array{T,3}(x); y = Array{T,3}(y)
+    nx, ny, nz = size(x)
+    thk = f64(thkcello); ee = f64(edge_length_2D[:east]); en = f64(edge_length_2D[:north])
+    rho3 = ρ isa Number ? Float64[] : f64(ρ)
+    oi = Array{Float64,3}(undef, nx, ny, nz); oj = Array{Float64,3}(undef, nx, ny, nz)
+    lock(CALL_LOCK) do
+        GC.@preserve rho3 check(ccall(sym(name), Int32,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Int32,
+             Ptr{Float64}, Ptr{Float64}),
+            context(), x, y, Int32(is32), ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0, thk, ee, en,
+            nx, ny, nz, topologykind(gridtopology), oi, oj))
+    end
+    return oi, oj
+end
+
+"""
+    velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics, ρ)
+
+velocities.jl:10-39 -> `(ϕᵢ, ϕⱼ)`.
+"""
+function velocity2fluxes(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics, ρ)
+    u, _, _, v, _, _ = interpolateontodefaultCgrid(u, u_lon, u_lat, v, v_lon, v_lat, gridmetrics)
+    return velocityflux(:otmb_velocity2fluxes, u, v, gridmetrics, ρ)
+end
+
+"""
+    fluxes2velocity(ϕᵢ, ϕⱼ, gridmetrics, ρ)
+
+velocities.jl:50-74 -> `(u, v)` on the C-grid.
+"""
+fluxes2velocity(ϕᵢ, ϕⱼ, gridmetrics, ρ) = velocityflux(:otmb_fluxes2velocity, ϕᵢ, ϕⱼ, gridmetrics, ρ)
+
+"""
+    facefluxesfromvelocities(; uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetrics, indices, ρ)
+
+velocities.jl:140-151: THIS module's velocity2fluxes, then THIS module's facefluxes.
+"""
+function facefluxesfromvelocities(; uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetrics, indices, ρ, pinned = PINNED_RESULTS[], devices = nothing)
+    FillValue = uo.properties["_FillValue"]
+    @assert isequal(FillValue, vo.properties["_FillValue"])      # velocities.jl:143
+    umo, vmo = velocity2fluxes(uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetrics, ρ)
+    return facefluxes(umo, vmo, gridmetrics, indices; FillValue, pinned, devices)
+end
+
+"""
+    bolus_GM_velocity(ρ, gridmetrics, indices; κGM = 600, maxslope = 0.01)
+
+RediGM.jl:46-79 -> `(u, v)`.  Experimental in the reference (never enters T), unexported there and here.
+"""
+function bolus_GM_velocity(ρ, gridmetrics, indices; κGM = 600, maxslope = 0.01)
+    rho = f64(ρ)
+    nx, ny, nz = size(rho)
+    z3d = f64(gridmetrics.Z3D)
+    wet = Array{UInt8,3}(indices.wet3D)
+    de = f64(gridmetrics.distance_to_neighbour_2D[:east]); dn = f64(gridmetrics.distance_to_neighbour_2D[:north])
+    u = Array{Float64,3}(undef, nx, ny, nz); v = Array{Float64,3}(undef, nx, ny, nz)
+    lock(CALL_LOCK) do
+        check(ccall(sym(:otmb_bolus_gm_velocity), Int32,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Int32, Float64, Float64,
+             Ptr{Float64}, Ptr{Float64}),
+            context(), rho, z3d, wet, de, dn, nx, ny, nz, topologykind(gridmetrics.gridtopology), Float64(κGM), Float64(maxslope), u, v))
+    end
+    return u, v
+end
+
+"""
+    makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices, gpu = false)
+
+gridcellgeometry.jl:265-311.  `gpu = false` (default): the reference's own function, unchanged.  `gpu = true` (extension): the replace
+rules, divisions, cumulative sums and the twelve haversine arrays are computed by the library (otmb_makegridmetrics); the vertex
+permutation and the topology test stay the reference's host functions.  Same 13-field NamedTuple; the distances agree with the
+reference's to 1e-12 (another math library), everything else bit for bit.
+"""
+function makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices, gpu = false)
+    gpu || return OTMB.makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices)
+    fillof(x) = haskey(x.properties, "_FillValue") ? Float64(x.properties["_FillValue"]) : NaN
+    vol = f64(Array{Union{Missing,Float64}}(volcello)); area = f64(Array{Union{Missing,Float64}}(areacello))   # missing -> NaN (:269-280)
+    nx, ny, nz = size(vol)
+    zt = lev |> Array
+    lat = Array{Float64}(lat); lon = Array{Float64}(lon)
+    lonv = Array{Float64}(lon_vertices); latv = Array{Float64}(lat_vertices)
+    vertexidx = OTMB.vertexpermutation(lonv, latv)                                   # :296
+    perm = Int32[Int32(q - 1) for q in vertexidx]                                    # 0-based for the C side, applied while reading
+    lon_vertices = lonv[vertexidx, :, :]; lat_vertices = latv[vertexidx, :, :]       # what the NamedTuple carries (:297-298)
+    gridtopology = OTMB.getgridtopology(lon_vertices, lat_vertices, zt)              # :302
+    area2D = Array{Float64,2}(undef, nx, ny)
+    v3D = Array{Float64,3}(undef, nx, ny, nz); thkcello = similar(v3D); Z3D = similar(v3D)
+    el = [Array{Float64,2}(undef, nx, ny) for _ in 1:4]; de = [Array{Float64,2}(undef, nx, ny) for _ in 1:4]; dn = [Array{Float64,2}(undef, nx, ny) for _ in 1:4]
+    lock(CALL_LOCK) do
+        pel = [pointer(a) for a in el]; pde = [pointer(a) for a in de]; pdn = [pointer(a) for a in dn]
+        GC.@preserve el de dn check(ccall(sym(:otmb_makegridmetrics), Int32,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
+             Int64, Int64, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}),
+            context(), vol, area, fillof(areacello), fillof(volcello), lon, lat, lonv, latv, perm, nx, ny, nz, topologykind(gridtopology),
+            area2D, v3D, thkcello, Z3D, pel, pde, pdn))
+    end
+    bydir(a) = Dict(d => a[k] for (k, d) in enumerate(HDIRS))                        # OTMB_DIR_* order: west, east, south, north
+    return (; area2D, v3D, thkcello, lon_vertices, lat_vertices, lon, lat, Z3D, zt, edge_length_2D = bydir(el),
+            distance_to_edge_2D = bydir(de), distance_to_neighbour_2D = bydir(dn), gridtopology)
+end
+
 """
     LUMP, SPRAY, vol_c = lump_and_spray(wet3D, vol, T, mask = trues(size(wet3D)); di = 2, dj = 2, dk = 1)
 
@@ -352,7 +510,7 @@ function lump_and_spray(wet3D, vol, T, mask = trues(size(wet3D)); di = 2, dj = 2
         check(ccall(sym(:otmb_lump_and_spray), Int32,
             (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Int64, Int64, Int64, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Int64,
              Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
-            ctx[], wet, msk, nx, ny, nz, v, N, Tp, Ti, di, dj, dk, lrow, lval, scp, srow, vc, Nc))
+            context(), wet, msk, nx, ny, nz, v, N, Tp, Ti, di, dj, dk, lrow, lval, scp, srow, vc, Nc))
     end
     resize!(scp, Nc[] + 1); resize!(vc, Nc[])
     LUMP = SparseMatrixCSC{Float64,Int64}(Nc[], N, collect(Int64, 1:(N + 1)), lrow, lval)

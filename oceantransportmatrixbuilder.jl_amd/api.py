@@ -236,6 +236,45 @@ def facefluxesfromvelocities(*, uo, uo_lon, uo_lat, vo, vo_lon, vo_lat, gridmetr
     return facefluxes(umo, vmo, gridmetrics, indices, FillValue=fill, device=device)
 
 
+def makegridmetrics_gpu(*, areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices, device=0):
+    """makegridmetrics (src/gridcellgeometry.jl:265-311) with the array work done by the library on host arrays (otmb_makegridmetrics):
+    what `makegridmetrics(...; gpu = true)` of the Julia shim runs.  Vertex permutation and topology test are host decisions, as there.
+    Same 13-field result as gridmetrics.makegridmetrics; the haversine distances agree to 1e-12, everything else bit for bit."""
+    from . import gridtopology as gt
+    from ._nt import NT
+    from .gridmetrics import vertexpermutation
+
+    area, ap = data_and_props(areacello)
+    vol, vp = data_and_props(volcello)
+    area = _f64(area)
+    vol = _f64(vol)
+    nx, ny, nz = vol.shape
+    lonv = _f64(data_and_props(lon_vertices)[0])
+    latv = _f64(data_and_props(lat_vertices)[0])
+    lon2 = _f64(data_and_props(lon)[0])
+    lat2 = _f64(data_and_props(lat)[0])
+    zt = np.array(data_and_props(lev)[0], dtype=np.float64)
+    perm = vertexpermutation(lonv, latv)
+    lonv_p = np.asfortranarray(lonv[perm, :, :])
+    latv_p = np.asfortranarray(latv[perm, :, :])
+    topo = gt.getgridtopology(lonv_p, latv_p)
+    f2 = lambda: np.empty((nx, ny), dtype=np.float64, order="F")
+    f3 = lambda: np.empty((nx, ny, nz), dtype=np.float64, order="F")
+    area2D, v3D, thk, Z3D = f2(), f3(), f3(), f3()
+    el, de, dn = [f2() for _ in range(4)], [f2() for _ in range(4)], [f2() for _ in range(4)]
+    ctx = context(device)
+    pa = (C.c_int32 * 4)(*[int(q) for q in perm])
+    ctx.check(capi.lib().otmb_makegridmetrics(
+        ctx.handle, vol.ctypes.data, area.ctypes.data, float(ap.get("_FillValue", np.nan)), float(vp.get("_FillValue", np.nan)),
+        lon2.ctypes.data, lat2.ctypes.data, lonv.ctypes.data, latv.ctypes.data, C.byref(pa), nx, ny, nz, int(topo),
+        area2D.ctypes.data, v3D.ctypes.data, thk.ctypes.data, Z3D.ctypes.data,
+        C.byref(capi.ptr_array(4, [a.ctypes.data for a in el])), C.byref(capi.ptr_array(4, [a.ctypes.data for a in de])),
+        C.byref(capi.ptr_array(4, [a.ctypes.data for a in dn]))))
+    bydir = lambda arrs: {d: arrs[k] for k, d in enumerate(capi.HDIRS)}
+    return NT(area2D=area2D, v3D=v3D, thkcello=thk, lon_vertices=lonv_p, lat_vertices=latv_p, lon=lon2, lat=lat2, Z3D=Z3D, zt=zt,
+              edge_length_2D=bydir(el), distance_to_edge_2D=bydir(de), distance_to_neighbour_2D=bydir(dn), gridtopology=NT(kind=int(topo), name=gt.NAMES[int(topo)], nx=nx, ny=ny, nz=len(zt)))
+
+
 def bolus_GM_velocity(ρ, gridmetrics, indices, *, κGM=600, maxslope=0.01, device=0):
     """src/RediGM.jl:46-79 -> (u, v).  Experimental in the reference; parity unpinned (oracle only)."""
     ctx = context(device)

@@ -119,6 +119,9 @@ SYMBOLS = {
     "otmb_makegridmetrics_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32 * 4),
                                               C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp,
                                               C.POINTER(_vp * 4), C.POINTER(_vp * 4), C.POINTER(_vp * 4)]),
+    "otmb_makegridmetrics": (C.c_int32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32 * 4),
+                                          C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp,
+                                          C.POINTER(_vp * 4), C.POINTER(_vp * 4), C.POINTER(_vp * 4)]),
     "otmb_bolus_gm_velocity_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
     "otmb_bolus_gm_velocity": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
     "otmb_sparse_entries_plan_dev": (C.c_int32, [_vp, C.c_int32, C.POINTER(TmArgs), _ip]),

@@ -225,6 +225,62 @@ int32_t otmb_bolus_gm_velocity(otmb_ctx *ctx, const double *rho, const double *z
     return OTMB_OK;
 }
 
+// makegridmetrics' array work on host arrays (what a Julia caller has): the raw CMIP arrays go up, the derived ones come back.
+int32_t otmb_makegridmetrics(otmb_ctx *ctx, const double *volcello, const double *areacello, double fill_area, double fill_vol,
+                             const double *lon, const double *lat, const double *lon_vertices, const double *lat_vertices,
+                             const int32_t perm[4], int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *area2d, double *v3d,
+                             double *thkcello, double *z3d, double *const edge_length[4], double *const dist_edge[4],
+                             double *const dist_nbr[4]) {
+    if (!ctx || !volcello || !areacello || !lon || !lat || !lon_vertices || !lat_vertices || !perm || !area2d || !v3d || !thkcello || !z3d ||
+        !edge_length || !dist_edge || !dist_nbr)
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    for (int d = 0; d < 4; ++d)
+        if (!edge_length[d] || !dist_edge[d] || !dist_nbr[d]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)(nx * ny), G = P * (size_t)nz;
+    otmb_tm_plan_invalidate(ctx);
+    // (every staging slot used here is forgotten afterwards: none of them holds what its residency key may say)
+    const int in_slots[6] = {ST_RHO, ST_ML, ST_UMO, ST_VMO, ST_LW, ST_LWET};
+    const void *dvol, *darea, *dlon, *dlat, *dlonv, *dlatv;
+    Uploads up;
+    TRY(upload(ctx, up, ST_RHO, volcello, G * 8, &dvol));
+    TRY(upload(ctx, up, ST_ML, areacello, P * 8, &darea));
+    TRY(upload(ctx, up, ST_UMO, lon, P * 8, &dlon));
+    TRY(upload(ctx, up, ST_VMO, lat, P * 8, &dlat));
+    TRY(upload(ctx, up, ST_LW, lon_vertices, 4 * P * 8, &dlonv));
+    TRY(upload(ctx, up, ST_LWET, lat_vertices, 4 * P * 8, &dlatv));
+    void *o_area, *o_v, *o_thk, *o_z, *o_edge[4], *o_de[4], *o_dn[4];
+    TRY(stage(ctx, ST_AREA, P * 8, &o_area));
+    TRY(stage(ctx, ST_V, G * 8, &o_v));
+    TRY(stage(ctx, ST_THK, G * 8, &o_thk));
+    TRY(stage(ctx, ST_PHI0, G * 8, &o_z));
+    for (int d = 0; d < 4; ++d) {
+        TRY(stage(ctx, ST_EDGE0 + d, P * 8, &o_edge[d]));
+        TRY(stage(ctx, ST_DIST0 + d, P * 8, &o_dn[d]));
+        TRY(stage(ctx, ST_PHI0 + 1 + d, P * 8, &o_de[d]));
+    }
+    TRY(flush(ctx, up));
+    for (int q : in_slots) ctx->stage_key[q] = otmb_ctx::StageKey();
+    for (int q : {(int)ST_AREA, (int)ST_V, (int)ST_THK, (int)ST_PHI0, ST_PHI0 + 1, ST_PHI0 + 2, ST_PHI0 + 3, ST_PHI0 + 4}) ctx->stage_key[q] = otmb_ctx::StageKey();
+    for (int d = 0; d < 4; ++d) ctx->stage_key[ST_EDGE0 + d] = ctx->stage_key[ST_DIST0 + d] = otmb_ctx::StageKey();
+    double *pe[4] = {(double *)o_edge[0], (double *)o_edge[1], (double *)o_edge[2], (double *)o_edge[3]};
+    double *pde[4] = {(double *)o_de[0], (double *)o_de[1], (double *)o_de[2], (double *)o_de[3]};
+    double *pdn[4] = {(double *)o_dn[0], (double *)o_dn[1], (double *)o_dn[2], (double *)o_dn[3]};
+    TRY(otmb_makegridmetrics_dev(ctx, (const double *)dvol, (const double *)darea, fill_area, fill_vol, (const double *)dlon, (const double *)dlat,
+                                 (const double *)dlonv, (const double *)dlatv, perm, nx, ny, nz, topology, (double *)o_area, (double *)o_v,
+                                 (double *)o_thk, (double *)o_z, pe, pde, pdn));
+    std::vector<OtmbXferItem> down = {{o_area, area2d, P * 8}, {o_v, v3d, G * 8}, {o_thk, thkcello, G * 8}, {o_z, z3d, G * 8}};
+    for (int d = 0; d < 4; ++d) {
+        down.push_back({o_edge[d], edge_length[d], P * 8});
+        down.push_back({o_de[d], dist_edge[d], P * 8});
+        down.push_back({o_dn[d], dist_nbr[d], P * 8});
+    }
+    TRY(download(ctx, down));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OTMB_OK;
+}
+
 int32_t otmb_bgrid_to_cgrid(otmb_ctx *ctx, const void *u, const void *v, int32_t src_is_f32, double fill, int64_t nx, int64_t ny,
                             int64_t nz, double *u2, double *v2) {
     if (!ctx || !u || !v || !u2 || !v2) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
@@ -343,9 +399,10 @@ int32_t otmb_ctx_set_reuse_fluxes(otmb_ctx *ctx, int32_t on) {
 // Pinned host memory for the caller's arrays: freed blocks are kept (pinning a gigabyte costs a quarter of a second) and handed
 // out again to the next request they fit.  Thread-safe; the blocks outlive the context (see host_pool above).
 int32_t otmb_host_alloc(otmb_ctx *ctx, int64_t bytes, void **out) {
-    if (!ctx || !out || bytes < 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_host_alloc");
+    if (!out || bytes < 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_host_alloc");
     *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // (the pool belongs to no context and pinned memory to no device: a caller that only ever uses an otmb_mgpu passes NULL)
+    if (ctx) HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t want = ((size_t)(bytes > 0 ? bytes : 1) + 4095) & ~(size_t)4095;
     HostPool &hp = host_pool();
     std::lock_guard<std::mutex> l(hp.m);

@@ -199,3 +199,33 @@ def test_device_makegridmetrics_matches_oracle(oracle, kw):
         np.testing.assert_allclose(back(asm.dist_edge[k], shp[:2]), gm.distance_to_edge_2D[d], rtol=1e-12)
         np.testing.assert_allclose(back(asm.dist[k], shp[:2]), gm.distance_to_neighbour_2D[d], rtol=1e-12, equal_nan=True)
     assert asm.N == int((~np.isnan(gm.v3D)).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(topology="bipolar"), dict(vertex_order=(3, 2, 1, 0))])
+def test_host_pointer_makegridmetrics_entry_point_matches_oracle(oracle, kw):
+    """otmb_makegridmetrics (host arrays in, host arrays out): what `makegridmetrics(...; gpu = true)` of the Julia shim calls, through its
+    Python mirror api.makegridmetrics_gpu.  Exact arithmetic bit for bit against the oracle, haversines to 1e-12; and the result drives
+    the rest of the path: the transportmatrix built from it equals the one built from the host metrics to 1e-12."""
+    import otmb_amd.api as api
+
+    g = synthetic.make_grid(36, 30, 10, seed=6, rho="array", **kw)
+    args = dict(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev, lon_vertices=g.lon_vertices,
+                lat_vertices=g.lat_vertices)
+    ref = oracle.makegridmetrics(**args)
+    got = api.makegridmetrics_gpu(**args)
+    assert got.gridtopology.kind == ref["gridtopology"]["kind"]
+    for k in ("v3D", "thkcello", "Z3D", "area2D", "lon_vertices", "lat_vertices", "lon", "lat", "zt"):
+        assert np.array_equal(np.asarray(got[k]), np.asarray(ref[k]), equal_nan=True), k
+    for group in ("edge_length_2D", "distance_to_edge_2D", "distance_to_neighbour_2D"):
+        for d in ("west", "east", "south", "north"):
+            np.testing.assert_allclose(got[group][d], ref[group][d], rtol=1e-12, equal_nan=True, err_msg=f"{group}[{d}]")
+    idx = api.makeindices(got.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=got, indices=idx)
+    tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=got, indices=idx, ρ=g.rho)
+    hgm = otmb_amd.makegridmetrics(**args)
+    tm0 = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=hgm, indices=idx, ρ=g.rho)
+    for m in ("T", "Tadv", "TκH", "TκVML", "TκVdeep"):
+        a, b = tuple(tm[m]), tuple(tm0[m])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), m
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-12, err_msg=m)

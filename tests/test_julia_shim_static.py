@@ -131,6 +131,62 @@ def test_every_ccall_matches_its_c_prototype():
         assert must in seen, must
 
 
+def test_the_whole_reference_api_is_defined_in_the_shim_and_nothing_falls_back_to_the_reference_hot_path():
+    """VERDICT r04 "What's missing" 3: with `facefluxesfromvelocities` re-exported from the reference package, a script that starts from
+    uo / vo ran the reference's CPU facefluxes.  Every exported name must be DEFINED in the shim; the reference package is used for
+    host-side decisions only (topology / vertex order / Arakawa detection, the default makegridmetrics)."""
+    code = "\n".join(l.split("#")[0] for l in SHIM.splitlines())
+    assert "using OceanTransportMatrixBuilder:" not in code  # nothing is re-exported
+    exported = set(re.findall(r"\b(\w+)\b", " ".join(re.findall(r"^export (.*)$", code, re.M))))
+    # src/OceanTransportMatrixBuilder.jl:31-36 exports these seven (+ lump_and_spray and facefluxes, which the reference's scripts reach too)
+    for name in ("makegridmetrics", "makeindices", "velocity2fluxes", "fluxes2velocity", "facefluxesfromvelocities", "facefluxesfrommasstransport",
+                 "transportmatrix", "facefluxes", "lump_and_spray"):
+        assert name in exported, name
+        assert re.search(r"^(?:function )?" + name + r"\(", code, re.M), f"{name} is exported but not defined in the shim"
+    # what may come from the reference package: host decisions, and makegridmetrics when the caller does not opt into the GPU
+    used = set(re.findall(r"OTMB\.(\w+)", code))
+    assert used <= {"BipolarGridTopology", "TripolarGridTopology", "getarakawagrid", "CGridCell", "AGridCell", "midpointonsphere",
+                    "vertexpermutation", "getgridtopology", "makegridmetrics"}, used
+    # facefluxesfromvelocities = this module's velocity2fluxes + this module's facefluxes (src/velocities.jl:140-151), in that order
+    ffv = _julia_function("facefluxesfromvelocities")
+    assert "OTMB." not in ffv and ffv.index("velocity2fluxes(") < ffv.index("facefluxes(umo, vmo")
+    api_src = open(os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "api.py"), encoding="utf-8").read()
+    pffv = _python_function(api_src, "facefluxesfromvelocities")
+    assert pffv.index("velocity2fluxes(") < pffv.index("facefluxes(umo, vmo")
+    # velocity2fluxes: interpolation first, then ONE C call; the same one in both layers
+    v2f = _julia_function("velocity2fluxes")
+    assert v2f.index("interpolateontodefaultCgrid(") < v2f.index(":otmb_velocity2fluxes")
+    assert ":otmb_fluxes2velocity" in code and "otmb_fluxes2velocity" in _python_function(api_src, "fluxes2velocity")
+    assert "otmb_bgrid_to_cgrid" in _julia_function("interpolateontodefaultCgrid") and "otmb_bgrid_to_cgrid" in _python_function(api_src, "interpolateontodefaultCgrid")
+    assert "otmb_bolus_gm_velocity" in _julia_function("bolus_GM_velocity") and "otmb_bolus_gm_velocity" in _python_function(api_src, "bolus_GM_velocity")
+    assert "otmb_makegridmetrics" in _julia_function("makegridmetrics") and "otmb_makegridmetrics" in _python_function(api_src, "makegridmetrics_gpu")
+    # the two velocity <-> flux entry points share one argument list: the shim passes the symbol as a value, so check it here
+    protos = header_prototypes()
+    assert protos["otmb_velocity2fluxes"] == protos["otmb_fluxes2velocity"]
+    m = re.search(r"ccall\(sym\(name\), (\w+),\s*\((.*?)\),\s*\n\s*context\(\)", _julia_function("velocityflux"), re.S)
+    assert m, "velocityflux's ccall"
+    jargs = [k for a in split_top(m.group(2).replace("\n", " ")) for k in julia_kind(a)]
+    assert (julia_kind(m.group(1))[0], jargs) == protos["otmb_velocity2fluxes"]
+
+
+def test_the_single_gpu_context_is_created_lazily():
+    """VERDICT r04 "What's weak" 9: a caller that only ever passes `devices = 4:7` must not get a context on GPU 0 from `__init__`.  The
+    context is made by `context()` under the module's lock; pinned result arrays come from the pool with a NULL context."""
+    init = SHIM[SHIM.index("function __init__()"):SHIM.index("sym(name) =")]
+    assert "otmb_ctx_create" not in init
+    assert "ctx[] == C_NULL ||" in init  # the exit hook copes with a context that was never made
+    ctxfn = _julia_function("context")
+    assert "otmb_ctx_create" in ctxfn and "ctx[] == C_NULL" in ctxfn
+    pa = _julia_function("pinned_array")
+    assert "C_NULL, Int64(max(prod(dims), 1) * sizeof(T))" in pa and "context()" not in pa
+    assert "ctx may be NULL" in HEADER
+    # the multi-GPU paths never ask for the single-GPU context
+    for fn in ("fused_mgpu",):
+        assert "context()" not in _julia_function(fn) and "ctx[]" not in _julia_function(fn)
+    ff = _julia_function("facefluxes")
+    assert ff.index("if devices === nothing") < ff.index("context()") < ff.index("else")
+
+
 def test_status_codes_the_shim_maps_exist_in_the_header():
     codes = dict(re.findall(r"(OTMB_ERR_\w+)\s*=\s*(\d+)", HEADER))
     assert codes["OTMB_ERR_ALL_MISSING"] == "8" and "rc == 8 && throw(AssertionError" in SHIM
@@ -217,7 +273,8 @@ def test_lifetimes_and_threads_are_safe_by_construction():
     ctx_src = open(os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "csrc", "otmb_ctx.hip"), encoding="utf-8").read()
     assert "hipHostFree(b.p)" not in ctx_src and "host_pool" not in ctx_src.split("void otmb_ctx_destroy")[1].split("\n}\n")[0].replace("process-wide pool", "")
     # (2) the lock
-    for fn in ("makeindices", "facefluxes", "spadd", "fused", "fused_mgpu", "lump_and_spray"):
+    for fn in ("makeindices", "facefluxes", "spadd", "fused", "fused_mgpu", "lump_and_spray", "interpolateontodefaultCgrid", "velocityflux",
+               "bolus_GM_velocity", "makegridmetrics"):
         src = _julia_function(fn)
         assert "lock(CALL_LOCK) do" in src, fn
         first_c = min(src.find("ccall("), src.find("outarray(") if "outarray(" in src else 1 << 30)
