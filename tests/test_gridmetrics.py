@@ -157,11 +157,16 @@ def test_device_haversine_converts_the_latitudes_before_subtracting():
         nx, ny, nz = 3, 3, 1
         lon = np.asfortranarray(np.tile(np.array([p["lon1"] - 1.0, p["lon1"], p["lon1"] + 1.0])[:, None], (1, ny)))
         lat = np.asfortranarray(np.tile(np.array([p["lat1"] - 1.0, p["lat1"], p["lat2"]])[None, :], (nx, 1)))
+        # a consistent vertex lattice (neighbouring cells share their corners: vertexpermutation needs that); bipolar: the top row's north
+        # vertices at the pole (gridtopology.jl:41).  The cell CENTRES -- all that distance_to_neighbour_2D reads -- are the known-answer points.
+        le = np.array([p["lon1"] - 1.5, p["lon1"] - 0.5, p["lon1"] + 0.5, p["lon1"] + 1.5])
+        te = np.array([p["lat1"] - 2.0, p["lat1"] - 0.5, min(p["lat1"], p["lat2"]) + abs(p["lat2"] - p["lat1"]) / 2, 90.0])
         lonv = np.zeros((4, nx, ny), order="F")
         latv = np.zeros((4, nx, ny), order="F")
-        for v, (dx, dy) in enumerate(((-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5))):
-            lonv[v], latv[v] = lon + dx, lat + dy * 1e-3
-        latv[2:, :, ny - 1] = 90.0  # bipolar: the top row's north vertices at the pole (gridtopology.jl:41)
+        for i in range(nx):
+            for j in range(ny):
+                lonv[:, i, j] = (le[i], le[i + 1], le[i + 1], le[i])
+                latv[:, i, j] = (te[j], te[j], te[j + 1], te[j + 1])
         area = Cube(np.ones((nx, ny), order="F"))
         vol = Cube(np.ones((nx, ny, nz), order="F"))
         asm = DeviceAssembler(0)
