@@ -162,6 +162,15 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
 int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                  const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                  int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask);
+/* The same for ONE ROW BAND of the plane: rows [j0, j1) (0-based) of every level.  A cell's fluxes depend on its own column's
+ * top_below and on INPUTS of its west / south neighbours only, so the chain over depth slabs can run piece by piece -- slab s piece c
+ * waits for slab s + 1 piece c, not for its whole plane (src/velocities.jl:236-243) -- with bit-identical arrays for any
+ * partition of the rows.  top_below / the phi arrays are whole-plane arrays as above; first = 1 on the first piece of a field
+ * (all pieces of a field share one pair of validity flags).                                                               */
+int32_t otmb_facefluxes_rows_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
+                                 const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
+                                 int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
+                                 int64_t j0, int64_t j1, int32_t first);
 int32_t otmb_facefluxes_slab_flags(otmb_ctx *ctx, int32_t *u_valid, int32_t *v_valid);
 /* Speed only.  nofluxboundaries! (src/velocities.jl:161-175) looks at the wet byte of every cell AND of its east, west,
  * south and north (or fold) neighbours, for every level of every time slice -- all grid constants.  otmb_wetflags_dev folds
@@ -375,6 +384,10 @@ int32_t otmb_balanced_partition(const int64_t *level_counts, int64_t nz, int32_t
  * wants, with the one flux each halo level pushes into an owned cell filled in (ϕbottom above = the slab's first ϕtop,
  * src/velocities.jl:240; ϕtop below = the plane received from the slab below).  otmb_mgpu_uploaded_bytes: host -> device bytes so far. */
 int32_t otmb_mgpu_set_reuse(otmb_mgpu *mg, int32_t reuse_grid, int32_t reuse_fluxes);
+/* Speed only: the facefluxes chain hands its plane from slab to slab in `pieces` row bands (whole rows), so that slab s starts piece c
+ * as soon as piece c of slab s + 1 has arrived: critical path of one field t_ff / W x (1 + (W - 1) / pieces) instead of t_ff
+ * (src/velocities.jl:236-243).  0 (default): 4 on grids of 2^19 columns and more, else 1.  Same arrays for any number. */
+int32_t otmb_mgpu_set_chain_pieces(otmb_mgpu *mg, int32_t pieces);
 int64_t otmb_mgpu_uploaded_bytes(const otmb_mgpu *mg);
 int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d,
                              double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6]);

@@ -73,6 +73,7 @@ SYMBOLS = {
     "otmb_mgpu_partition": (C.c_int32, [_vp, _ip]),
     "otmb_mgpu_set_reuse": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "otmb_mgpu_uploaded_bytes": (C.c_int64, [_vp]),
+    "otmb_mgpu_set_chain_pieces": (C.c_int32, [_vp, C.c_int32]),
     "otmb_balanced_partition": (C.c_int32, [_ip, C.c_int64, C.c_int32, _ip]),
     "otmb_mgpu_facefluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
     "otmb_mgpu_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
@@ -97,6 +98,8 @@ SYMBOLS = {
     "otmb_velocity2fluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_fluxes2velocity": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "otmb_facefluxes_slab_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
+    "otmb_facefluxes_rows_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp,
+                                              C.c_int64, C.c_int64, C.c_int32]),
     "otmb_wetflags_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp]),
     "otmb_facefluxes_flags_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, _vp]),
     "otmb_count_tables_bytes": (C.c_int64, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
@@ -336,6 +339,10 @@ class Mgpu:
 
     def uploaded_bytes(self):
         return int(self._lib.otmb_mgpu_uploaded_bytes(self._h))
+
+    def set_chain_pieces(self, pieces):
+        """Speed only: row bands the facefluxes chain is handed over in (0 = the library's rule)."""
+        self.check(self._lib.otmb_mgpu_set_chain_pieces(self._h, int(pieces)))
 
     def partition(self):
         n = self._lib.otmb_mgpu_ndev(self._h)

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
     double *__restrict__ north, double *__restrict__ south, double *__restrict__ top, double *__restrict__ bottom,
     const double *__restrict__ top_below, uint16_t *__restrict__ push_mask, int *uv, int gen, int xcd_chunks, int lds_south,
+    int j_begin, int j_end,  // rows [j_begin, j_end) of the plane are computed (the whole plane: 0, ny; a piece: the chain over depth slabs, piece by piece)
     // (COUNTS) FfCountArgs, member by member: only a `const __restrict__` kernel argument lets the compiler read the wave-uniform table
     // entries and zt through the scalar cache -- as a vector load the table entry made every level wait for ALL outstanding vector memory
     // operations (s_waitcnt vmcnt(0)), i.e. for the next chunk's prefetch
@@ -286,19 +287,19 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
     unsigned s, i, j, seg;
     bool inside;
     if (ROWS == 1) {
-        seg = cb;
-        s = cb * FF_THREADS + threadIdx.x;
-        inside = s < (unsigned)P;
-        if (COUNTS && !inside) s = (unsigned)P - 1;
+        seg = cb;  // (COUNTS: whole planes only, j_begin == 0)
+        s = (unsigned)j_begin * (unsigned)nx + cb * FF_THREADS + threadIdx.x;
+        inside = s < (unsigned)j_end * (unsigned)nx;
+        if (COUNTS && !inside) s = (unsigned)j_end * (unsigned)nx - 1;
         j = s / (unsigned)nx;
         i = s - j * (unsigned)nx;
     } else {
         const unsigned nchunk = ((unsigned)nx + FF_THREADS - 1) / FF_THREADS, grp = cb / nchunk, chunk = cb - grp * nchunk;
         i = chunk * FF_THREADS + (threadIdx.x & (FF_THREADS - 1));
-        j = grp * ROWS + threadIdx.x / FF_THREADS;
-        inside = i < (unsigned)nx && j < (unsigned)ny;
+        j = (unsigned)j_begin + grp * ROWS + threadIdx.x / FF_THREADS;
+        inside = i < (unsigned)nx && j < (unsigned)j_end;
         s = j * (unsigned)nx + i;
-        seg = ((grp * ROWS + threadIdx.x / FF_THREADS < (unsigned)ny) ? grp * ROWS + threadIdx.x / FF_THREADS : (unsigned)ny - 1) * nchunk + chunk;
+        seg = ((j < (unsigned)ny) ? j : (unsigned)ny - 1) * nchunk + chunk;
     }
     bool uvalid = false, vvalid = false;
     FfCountState cs;
@@ -492,7 +493,10 @@ static size_t ff_tables_static_offset(int rows, i64 nx, i64 ny, i64 nz) {
 static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
-                               bool check_missing, bool flags = false, const otmb_ff_counts *counts = nullptr) {
+                               bool check_missing, bool flags = false, const otmb_ff_counts *counts = nullptr, int64_t j0 = 0, int64_t j1 = -1,
+                               bool same_call = false) {
+    // j0, j1: rows [j0, j1) of the plane only (j1 < 0: all of them); same_call: a further piece of the facefluxes call that the
+    // previous piece began -- the validity flags of the pieces accumulate in ONE pair of words
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -501,12 +505,16 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 P = nx * ny;
-    if (ctx->ff_gen == 0x7fffffff) { ctx->ff_gen = 0; ctx->ff_first = 1; }
-    ctx->ff_gen += 1;
+    if (j1 < 0) j1 = ny;
+    if (j0 < 0 || j0 >= j1 || j1 > ny) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "row range");
+    if (!same_call || ctx->ff_gen == 0) {
+        if (ctx->ff_gen == 0x7fffffff) { ctx->ff_gen = 0; ctx->ff_first = 1; }
+        ctx->ff_gen += 1;
+    }
     int *dflags = otmb_ring_ff((int *)ctx->ring.p, ctx->ff_gen);
     const int rows = ff_rows_for(ctx, nx, ny);
-    const unsigned nb = rows == 1 ? (unsigned)((P + FF_THREADS - 1) / FF_THREADS)
-                                  : (unsigned)(((nx + FF_THREADS - 1) / FF_THREADS) * ((ny + rows - 1) / rows));
+    const unsigned nb = rows == 1 ? (unsigned)(((j1 - j0) * nx + FF_THREADS - 1) / FF_THREADS)
+                                  : (unsigned)(((nx + FF_THREADS - 1) / FF_THREADS) * ((j1 - j0 + rows - 1) / rows));
     // any facefluxes call on this context ends the validity of counts an earlier call left behind (they are keyed to ff_gen), and a full
     // mask written over a partial one makes that array an ordinary push mask again
     ctx->ffc.valid = false;
@@ -547,7 +555,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R, CN>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
                        phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks, ctx->ff_lds_south, \
-                       ca.bases, ca.mlotst, ca.zt, ca.sums, ca.upwind, ca.only_t, ca.nseg)
+                       (int)j0, (int)j1, ca.bases, ca.mlotst, ca.zt, ca.sums, ca.upwind, ca.only_t, ca.nseg)
 #define FF_LAUNCH2(T, FL, CN) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4, CN); else FF_LAUNCH(T, FL, false, 4, CN); } \
                                    else { if (nt) FF_LAUNCH(T, FL, true, 1, CN); else FF_LAUNCH(T, FL, false, 1, CN); } } while (0)
     if (with_counts) { if (src_is_f32) FF_LAUNCH2(float, true, true); else FF_LAUNCH2(double, true, true); }
@@ -581,6 +589,18 @@ extern "C" int32_t otmb_facefluxes_slab_dev(otmb_ctx *ctx, const void *umo, cons
                                             int32_t topology, double *const phi[6], const double *top_below,
                                             uint16_t *push_mask) {
     return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, push_mask, false);
+}
+
+// One row band of the plane: rows [j0, j1) of every level (0-based).  The chain over depth slabs runs piece by piece (slab s
+// piece c waits for slab s + 1 piece c only): a cell's fluxes depend on its own column's top_below and on INPUTS of its west / south
+// neighbours, never on another cell's outputs, so any partition of the rows gives the same arrays.  first = 1 for the first piece of a
+// field (the pieces of one field share one pair of validity flags).
+extern "C" int32_t otmb_facefluxes_rows_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wet3d,
+                                            double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6],
+                                            const double *top_below, uint16_t *push_mask, int64_t j0, int64_t j1, int32_t first) {
+    if (j0 < 0 || j1 > ny || j0 >= j1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "row range");
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wet3d, fill, nx, ny, nz, topology, phi, top_below, push_mask, false, false, nullptr, j0, j1,
+                           first == 0);
 }
 
 extern "C" int32_t otmb_wetflags_dev(otmb_ctx *ctx, const uint8_t *wet3d, int64_t nx, int64_t ny, int64_t nz, int32_t topology,

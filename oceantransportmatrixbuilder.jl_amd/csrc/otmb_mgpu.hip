@@ -79,10 +79,13 @@ struct Slab {
     bool phi_resident = false;       // B_PHI0.. hold what otmb_mgpu_facefluxes computed for levels [k0 - ha, k1 + hb) ...
     const void *phi_host[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and copied to these host arrays
     i64 uploaded = 0;                // bytes copied to this slab's device so far
-    // hand-off of the chain's plane to this slab (from the slab below it)
+    // hand-off of the chain's plane to this slab (from the slab below it), piece by piece: pieces_ready of the C row bands have been
+    // enqueued (RCCL: the receive sits on THIS slab's stream) or copied behind piece_ev[c] (copies: recorded on the producer's stream)
     std::mutex m;
     std::condition_variable cv;
-    bool plane_ready = false, plane_failed = false;
+    int pieces_ready = 0;
+    bool plane_failed = false;
+    std::vector<hipEvent_t> piece_ev;  // events of THIS slab as a producer: its c-th piece has left for the slab above
 };
 
 __global__ void shift_i64_kernel(i64 *p, i64 n, i64 delta) {
@@ -112,6 +115,7 @@ struct otmb_mgpu {
     i64 nx = 0, ny = 0, nz = 0;
     std::vector<i64> bounds;
     bool reuse_grid = false, reuse_fluxes = false;  // otmb_mgpu_set_reuse
+    int chain_pieces = 0;  // row bands the facefluxes chain is handed over in (otmb_mgpu_set_chain_pieces); 0 = by grid size
     // pending plan
     bool planned = false;
     otmb_tm_args args;  // host pointers of the plan
@@ -190,37 +194,40 @@ int32_t set_partition(otmb_mgpu *mg, const std::vector<i64> &counts, i64 nx, i64
     return OTMB_OK;
 }
 
-// Hand the plane src (device memory of slab `from`, P doubles, produced on its stream) to slab `to`'s receive buffer and wake
-// the thread of `to`.  Called by the thread of `from`.
-int32_t send_plane(otmb_mgpu *mg, int from, int to, const double *src, i64 P) {
+// Hand piece c of the plane -- elements [off, off + len) of src (device memory of slab `from`, produced on its stream) -- to slab
+// `to`'s receive buffer and wake the thread of `to`.  Called by the thread of `from`.  No host wait anywhere: RCCL puts the receive on
+// the consumer's stream (in front of the kernel its thread enqueues after being woken); the copy transports record an event behind the
+// copy on the producer's stream, which the consumer's stream waits for (hipStreamWaitEvent) before its kernel of that piece.
+int32_t send_piece(otmb_mgpu *mg, int from, int to, const double *src, i64 off, i64 len, int c) {
     Slab &a = *mg->slabs[from], &b = *mg->slabs[to];
-    double *dst = (double *)b.buf[B_PLANE].p;
+    double *dst = (double *)b.buf[B_PLANE].p + off;
+    src += off;
     int32_t rc = OTMB_OK;
-    if (a.device == b.device) {
-        // same device (tests): the copy is ordered behind the producing kernel on the producer's stream; the consumer's stream
-        // must not start before it has landed -- the producer waits for it here and then wakes the consumer
-        if (hipMemcpyAsync(dst, src, (size_t)P * 8, hipMemcpyDeviceToDevice, a.ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(a.ctx->stream) != hipSuccess)
-            rc = OTMB_ERR_HIP;
-    } else if (mg->transport == 1) {
-        // one grouped send / receive pair on the single-process communicator: the send is ordered behind the producing kernel on
-        // the producer's stream, the receive goes onto the CONSUMER's stream, in front of the kernel its thread enqueues after
-        // being woken -- the plane crosses xGMI without a host round trip
+    if (const char *e = getenv("OTMB_TEST_FAIL_PIECE")) {  // fault injection (tests): "<slab>:<piece>" fails that hand-off
+        int fs = -1, fc = -1;
+        if (sscanf(e, "%d:%d", &fs, &fc) == 2 && fs == from && fc == c) { a.msg = "plane hand-off failure injected (OTMB_TEST_FAIL_PIECE)"; rc = OTMB_ERR_HIP; }
+    }
+    if (rc != OTMB_OK) {
+        // (nothing is sent: the consumer is released below with the failure)
+    } else if (mg->transport == 1 && a.device != b.device) {
+        // one grouped send / receive pair on the single-process communicator per piece: the send is ordered behind the producing
+        // kernel on the producer's stream, the receive goes onto the CONSUMER's stream -- the piece crosses xGMI without a host round trip
         ncclResult_t r = mg->rccl.GroupStart();
-        if (r == ncclSuccess) r = mg->rccl.Send(src, (size_t)P, ncclDouble, to, mg->comms[from], a.ctx->stream);
-        if (r == ncclSuccess) r = mg->rccl.Recv(dst, (size_t)P, ncclDouble, from, mg->comms[to], b.ctx->stream);
+        if (r == ncclSuccess) r = mg->rccl.Send(src, (size_t)len, ncclDouble, to, mg->comms[from], a.ctx->stream);
+        if (r == ncclSuccess) r = mg->rccl.Recv(dst, (size_t)len, ncclDouble, from, mg->comms[to], b.ctx->stream);
         const ncclResult_t r2 = mg->rccl.GroupEnd();
         if (r == ncclSuccess) r = r2;
         if (r != ncclSuccess) { a.msg = std::string("RCCL: ") + mg->rccl.GetErrorString(r); rc = OTMB_ERR_HIP; }
     } else {
-        if (hipMemcpyPeerAsync(dst, b.device, src, a.device, (size_t)P * 8, a.ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(a.ctx->stream) != hipSuccess)
-            rc = OTMB_ERR_HIP;
+        // same device (tests on a one-GPU box) or peer copy: behind the producing kernel on the producer's stream, then the event
+        const hipError_t e = (a.device == b.device) ? hipMemcpyAsync(dst, src, (size_t)len * 8, hipMemcpyDeviceToDevice, a.ctx->stream)
+                                                    : hipMemcpyPeerAsync(dst, b.device, src, a.device, (size_t)len * 8, a.ctx->stream);
+        if (e != hipSuccess || hipEventRecord(a.piece_ev[c], a.ctx->stream) != hipSuccess) rc = OTMB_ERR_HIP;
     }
     {
         std::lock_guard<std::mutex> l(b.m);
-        b.plane_ready = true;
-        b.plane_failed = rc != OTMB_OK;
+        b.pieces_ready = c + 1;
+        b.plane_failed |= rc != OTMB_OK;
     }
     b.cv.notify_all();
     return rc;
@@ -230,7 +237,7 @@ void fail_plane(otmb_mgpu *mg, int to) {  // a slab that cannot produce its plan
     Slab &b = *mg->slabs[to];
     {
         std::lock_guard<std::mutex> l(b.m);
-        b.plane_ready = true;
+        b.pieces_ready = 1 << 30;
         b.plane_failed = true;
     }
     b.cv.notify_all();
@@ -355,6 +362,7 @@ void otmb_mgpu_destroy(otmb_mgpu *mg) {
             (void)hipSetDevice(sl->device);
             for (DevBuf &b : sl->buf)
                 if (b.p) (void)hipFree(b.p);
+            for (hipEvent_t e : sl->piece_ev) (void)hipEventDestroy(e);
             otmb_ctx_destroy(sl->ctx);
         }
         delete sl;
@@ -377,6 +385,13 @@ int32_t otmb_mgpu_set_reuse(otmb_mgpu *mg, int32_t grid, int32_t fluxes) {
         if (!mg->reuse_grid)
             for (int b = B_V; b < B_UMO; ++b) sl->key[b] = Slab::Key();
     }
+    return OTMB_OK;
+}
+// Speed only: in how many row bands the facefluxes chain hands its plane from slab to slab (0 = by grid size: 4 on grids of half a
+// million columns and more, else 1).  Any number gives the same six arrays.
+int32_t otmb_mgpu_set_chain_pieces(otmb_mgpu *mg, int32_t pieces) {
+    if (!mg || pieces < 0) return OTMB_ERR_INVALID_ARG;
+    mg->chain_pieces = pieces;
     return OTMB_OK;
 }
 // bytes copied host -> device over all slabs since the object was created (diagnostics / tests)
@@ -418,7 +433,14 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
     }
     int32_t rc;
     if ((rc = set_partition(mg, counts, nx, ny))) return rc;
-    for (Slab *sl : mg->slabs) { sl->plane_ready = false; sl->plane_failed = false; }
+    for (Slab *sl : mg->slabs) { sl->pieces_ready = 0; sl->plane_failed = false; }
+    // The chain in C row bands: slab s piece c needs only piece c of the plane of slab s + 1, so the slabs of ONE field
+    // overlap: critical path t_ff / W x (1 + (W - 1) / C) instead of t_ff.  Whole rows per piece: the south-row dependence of a cell is on
+    // INPUTS of its own slab (src/velocities.jl:219-224), never on another piece's results.
+    int C = mg->chain_pieces > 0 ? mg->chain_pieces : ((P >= (1ll << 19) && n > 1) ? 4 : 1);
+    if (C > ny) C = (int)ny;
+    std::vector<i64> jb(C + 1);
+    for (int c = 0; c <= C; ++c) jb[c] = ny * c / C;
     // The plane buffer of slab s is written by the thread of slab s + 1 (send_plane): every slab's buffer is (re)allocated HERE, before any
     // slab thread runs -- reserved inside its owner's thread it could still be missing, or be freed for a larger one (an otmb_mgpu reused
     // on a larger grid), while the slab below was already copying into it (an intermittent "plane hand-off" error in
@@ -430,6 +452,11 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
             void *q;
             if (hipSetDevice(sl->device) != hipSuccess) { (void)hipSetDevice(dev0); return mg_fail(mg, OTMB_ERR_HIP, "hipSetDevice"); }
             if ((rc = reserve(*sl, B_PLANE, (size_t)P * 8, &q))) { (void)hipSetDevice(dev0); return mg_fail(mg, rc, "plane buffer"); }
+            while ((int)sl->piece_ev.size() < C) {  // (created on the producer's device, before any slab thread runs)
+                hipEvent_t e;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipSetDevice(dev0); return mg_fail(mg, OTMB_ERR_HIP, "hipEventCreate"); }
+                sl->piece_ev.push_back(e);
+            }
         }
         (void)hipSetDevice(dev0);
     }
@@ -463,26 +490,35 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
                               {dw, (char *)wet3d + (size_t)sl.k0 * P, Gl}};
         if ((r = otmb_xfer(sl.ctx, true, up, 3))) return fail(r);
         sl.uploaded += (i64)(2 * Gl * es + Gl);
-        const double *top_below = nullptr;
-        if (sl.hb) {  // the chain: ϕtop of the level below this slab
-            std::unique_lock<std::mutex> l(sl.m);
-            sl.cv.wait(l, [&] { return sl.plane_ready; });
-            if (sl.plane_failed) {  // the slab below failed: its status is the one reported; release the slab above
-                l.unlock();
-                if (s > 0) fail_plane(mg, s - 1);
-                return;
-            }
-            top_below = (const double *)dplane;
-        }
         double *dp[6];
         for (int f = 0; f < 6; ++f) dp[f] = (double *)dphi[f];
-        if ((r = otmb_facefluxes_slab_dev(sl.ctx, du, dv, src_is_f32, (const uint8_t *)dw, fill, nx, ny, nl, topology, dp, top_below, nullptr)))
-            return fail(r);
-        if (s > 0 && (r = send_plane(mg, s, s - 1, dp[OTMB_TOP], P))) {  // ϕtop of this slab's first level goes up
-            otmb_fail(sl.ctx, r, sl.msg.empty() ? "plane hand-off" : sl.msg.c_str());
-            sl.status = r;
-            sl.msg = otmb_last_error(sl.ctx);
-            return;
+        const bool by_event = !(mg->transport == 1 && s + 1 < n && mg->slabs[s + 1]->device != sl.device);
+        for (int c = 0; c < C; ++c) {
+            if (sl.hb) {  // the chain: piece c of ϕtop of the level below this slab
+                std::unique_lock<std::mutex> l(sl.m);
+                sl.cv.wait(l, [&] { return sl.pieces_ready > c; });
+                if (sl.plane_failed) {  // the slab below failed: its status is the one reported; release the slab above
+                    l.unlock();
+                    if (s > 0) fail_plane(mg, s - 1);
+                    return;
+                }
+                l.unlock();
+                // (copy transports: this slab's stream waits for the copy of piece c -- an event, no host wait)
+                if (by_event && hipStreamWaitEvent(sl.ctx->stream, mg->slabs[s + 1]->piece_ev[c], 0) != hipSuccess) {
+                    otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipStreamWaitEvent");
+                    return fail(OTMB_ERR_HIP);
+                }
+            }
+            if ((r = otmb_facefluxes_rows_dev(sl.ctx, du, dv, src_is_f32, (const uint8_t *)dw, fill, nx, ny, nl, topology, dp,
+                                              sl.hb ? (const double *)dplane : nullptr, nullptr, jb[c], jb[c + 1], c == 0)))
+                return fail(r);
+            if (s > 0 && (r = send_piece(mg, s, s - 1, dp[OTMB_TOP], jb[c] * nx, (jb[c + 1] - jb[c]) * nx, c))) {  // ϕtop of this slab's first level goes up
+                otmb_fail(sl.ctx, r, sl.msg.empty() ? "plane hand-off" : sl.msg.c_str());
+                sl.status = r;
+                sl.msg = otmb_last_error(sl.ctx);
+                fail_plane(mg, s - 1);
+                return;
+            }
         }
         // the halo levels act as neighbours only; the one flux each of them pushes into an owned cell: the halo above pushes its ϕbottom =
         // this slab's first ϕtop (src/velocities.jl:240), the halo below its ϕtop = the plane received from the slab below

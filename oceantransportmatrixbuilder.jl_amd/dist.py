@@ -22,6 +22,8 @@ ABI); the CPU tests plug in a checker backend to exercise the orchestration with
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -133,10 +135,22 @@ class SlabRunner:
     """Orchestrates one rank's slab.  `grid` holds this rank's OWN levels [k0,k1) of the global grid (host
     numpy, Julia shapes) plus the replicated 2-D/1-D data; see make_local_grid()."""
 
-    def __init__(self, backend, comm, grid):
+    def __init__(self, backend, comm, grid, chain_pieces=None):
         self.be, self.comm, self.g = backend, comm, grid
         self.rank, self.world = comm.rank, comm.world
         self.device = backend.device
+        # The facefluxes chain (src/velocities.jl:236-243) is handed from slab to slab in C row bands (whole rows): slab s starts piece c as
+        # soon as piece c of slab s + 1 has arrived -- SURVEY 8e -- so that the slabs of ONE field overlap: critical path
+        # t_ff / W x (1 + (W - 1) / C) instead of t_ff.  A cell's fluxes depend on its own column's plane value and on INPUTS of its west /
+        # south neighbours only, so any C gives the same arrays.  Default (the rule of otmb_mgpu_set_chain_pieces): 4 on grids of 2^19
+        # columns and more, else 1; OTMB_CHAIN_PIECES overrides.  The same number on every rank.
+        P = int(grid["nx"]) * int(grid["ny"])
+        if chain_pieces is None:
+            chain_pieces = int(os.environ.get("OTMB_CHAIN_PIECES", "0")) or (4 if (P >= (1 << 19) and comm.world > 1) else 1)
+        self.chain_pieces = max(1, min(int(chain_pieces), int(grid["ny"])))
+        ny, nx = int(grid["ny"]), int(grid["nx"])
+        self._rows = [ny * c // self.chain_pieces for c in range(self.chain_pieces + 1)]   # row bounds of the pieces
+        self._cuts = [(self._rows[c] * nx, self._rows[c + 1] * nx) for c in range(self.chain_pieces)]  # the same as plane offsets
         self.setup()
 
     def setup(self):
@@ -218,11 +232,14 @@ class SlabRunner:
     def step(self, umo, vmo, fill):
         """One (umo, vmo) field of this rank's own levels -> this rank's columns of the five matrices."""
         cm = self.comm
-        if self.has_below:  # chain: wait for ϕtop of the level below my slab
-            cm.recv(self.top_below, self.rank + 1)
-        top_first = self.be.facefluxes(umo, vmo, fill, self.top_below)
-        if self.has_above:
-            cm.send(top_first, self.rank - 1)
+        top_first = None
+        for c, (a, b) in enumerate(self._cuts):
+            if self.has_below:  # chain: wait for piece c of ϕtop of the level below my slab
+                cm.recv(self.top_below[a:b], self.rank + 1)
+            top_first = self.be.facefluxes_piece(umo, vmo, fill, self.top_below, self._rows[c], self._rows[c + 1], c == 0)
+            if self.has_above:
+                cm.send(top_first[a:b], self.rank - 1)
+        self.be.facefluxes_finish(self.top_below)
         nnz, uv = self.be.plan()
         allv = cm.allgather_i64(list(nnz) + [int(uv[0]), int(uv[1])], self.device)
         if not (allv[:, 5].any() and allv[:, 6].any()):
@@ -253,30 +270,36 @@ class SlabRunner:
         if getattr(self, "_n_async", 0) >= self.PIPELINE_DEPTH:  # same count on every rank: the drain is collective
             self.finish()
         self._n_async = getattr(self, "_n_async", 0) + 1
-        cm.wait_send(getattr(self, "_pending_send", None))  # the plane handed up by the previous field has left
+        for h in getattr(self, "_pending_send", None) or ():  # the plane handed up by the previous field has left
+            cm.wait_send(h)
         self._pending_send = None
         if self.has_below:
-            # The plane from below was posted as a non-blocking receive BEFORE the previous field's count/fill kernels
-            # were enqueued (see below), so the transfer ran beside them; here the compute stream only waits for it.
+            # The plane from below was posted as non-blocking receives (one per piece) BEFORE the previous field's count/fill kernels
+            # were enqueued (see below), so the transfer ran beside them; here the compute stream only waits for piece after piece.
             if getattr(self, "_recv", None) is None:  # first field since setup / finish
                 self._recv_bufs = getattr(self, "_recv_bufs", None) or [self.top_below, torch.empty_like(self.top_below)]
                 self._recv_cur = 0
-                self._recv = cm.irecv(self._recv_bufs[0], self.rank + 1)
-            cm.wait_recv(self._recv)
+                self._recv = [cm.irecv(self._recv_bufs[0][a:b], self.rank + 1) for a, b in self._cuts]
             plane = self._recv_bufs[self._recv_cur]
         else:
             plane = None
-        top_first = self.be.facefluxes(umo, vmo, fill, plane)
-        if self.has_above:
-            # the plane goes up from its own buffer without holding back this rank's count/fill kernels: nothing waits
-            # for the send until the next field is about to reuse the buffer
-            if getattr(self, "_send_buf", None) is None:
-                self._send_buf = torch.empty_like(top_first)
-            self._send_buf.copy_(top_first)
-            self._pending_send = cm.isend(self._send_buf, self.rank - 1)
+        if self.has_above and getattr(self, "_send_buf", None) is None:
+            self._send_buf = torch.empty(self.be.P, dtype=torch.float64, device=self.device)
+        sends = []
+        for c, (a, b) in enumerate(self._cuts):
+            if self.has_below:
+                cm.wait_recv(self._recv[c])
+            top_first = self.be.facefluxes_piece(umo, vmo, fill, plane, self._rows[c], self._rows[c + 1], c == 0)
+            if self.has_above:
+                # the piece goes up from its own buffer without holding back this rank's later kernels: nothing waits for the send
+                # until the next field is about to reuse the buffer
+                self._send_buf[a:b].copy_(top_first[a:b])
+                sends.append(cm.isend(self._send_buf[a:b], self.rank - 1))
+        self.be.facefluxes_finish(plane)
+        self._pending_send = sends or None
         if self.has_below:  # the NEXT field's plane (or finish()'s closing message) lands in the other buffer meanwhile
             self._recv_cur ^= 1
-            self._recv = cm.irecv(self._recv_bufs[self._recv_cur], self.rank + 1)
+            self._recv = [cm.irecv(self._recv_bufs[self._recv_cur][a:b], self.rank + 1) for a, b in self._cuts]
         self.be.assemble_async()
 
     PIPELINE_DEPTH = 60  # the library keeps the verdicts of its 64 most recent asynchronous calls
@@ -290,13 +313,16 @@ class SlabRunner:
         the same error -- that of the earliest failing step (facefluxes' assertion first within a step, as in the
         reference), so no rank is left waiting in a collective for one that has raised."""
         cm = self.comm
-        cm.wait_send(getattr(self, "_pending_send", None))
+        for h in getattr(self, "_pending_send", None) or ():
+            cm.wait_send(h)
         self._pending_send = None
-        # every rank with a slab below keeps one receive posted ahead: close it with one last (unused) plane
+        # every rank with a slab below keeps one plane of receives posted ahead: close them with one last (unused) plane
         if self.has_above and getattr(self, "_send_buf", None) is not None and getattr(self, "_n_async", 0) > 0:
-            cm.wait_send(cm.isend(self._send_buf, self.rank - 1))
+            for h in [cm.isend(self._send_buf[a:b], self.rank - 1) for a, b in self._cuts]:
+                cm.wait_send(h)
         if self.has_below and getattr(self, "_recv", None) is not None:
-            cm.wait_recv(self._recv)
+            for h in self._recv:
+                cm.wait_recv(h)
             self._recv = None
         r = self.be.result()  # never raises for the reference's own errors: dict(nnz, u, v, status, step, message)
         D = self.PIPELINE_DEPTH + 4
@@ -374,17 +400,29 @@ class HipSlabBackend:
         self.lwet = own.to(torch.int64).contiguous()
 
     def facefluxes(self, umo, vmo, fill, top_below):
+        """The whole plane at once (one piece)."""
+        self.facefluxes_piece(umo, vmo, fill, top_below, 0, self.ny, True)
+        return self.facefluxes_finish(top_below)
+
+    def facefluxes_piece(self, umo, vmo, fill, top_below, j0, j1, first):
+        """Rows [j0, j1) of the plane (otmb_facefluxes_rows_dev): one piece of the chain.  top_below: the whole-plane buffer, of which
+        rows [j0, j1) have arrived.  Returns the (whole-plane) view of this slab's first-level ϕtop, of which rows [j0, j1) are now valid."""
         o, n = self.own0, self.nown_lev * self.P
         views = [p[o:o + n] for p in self.phi]
         ptrs = self.capi.ptr_array(6, [v.data_ptr() for v in views])
-        self.ctx.check(self.lib.otmb_facefluxes_slab_dev(
+        self.ctx.check(self.lib.otmb_facefluxes_rows_dev(
             self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), self.wet_own.data_ptr(),
             float(fill), self.nx, self.ny, self.nown_lev, self.s["topology"], C.byref(ptrs),
-            top_below.data_ptr() if top_below is not None else None, self.push_mask[o:o + n].data_ptr()))
+            top_below.data_ptr() if top_below is not None else None, self.push_mask[o:o + n].data_ptr(), int(j0), int(j1), int(bool(first))))
+        return self.phi[4][o:o + self.P]  # OTMB_TOP, first owned level
+
+    def facefluxes_finish(self, top_below):
+        """After the last piece: the halo levels act as neighbours only -- the one flux each of them pushes into an owned cell, and its
+        push mask."""
+        o = self.own0
         top, bottom = self.phi[4], self.phi[5]  # OTMB_TOP, OTMB_BOTTOM
         top_first = top[o:o + self.P]
         allphi = self.capi.ptr_array(6, [p.data_ptr() for p in self.phi])
-        # halo levels act as neighbours only: the one flux each of them pushes into an owned cell, and its push mask
         if self.s["k_own0"] > 0:  # halo above: its ϕbottom is my first level's ϕtop (velocities.jl:240)
             bottom[0:self.P].copy_(top_first)
             self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), 0, self.P,

@@ -34,21 +34,35 @@ class OracleSlabBackend:
         self.phi = {k: np.zeros((self.nx, self.ny, self.nz), order="F") for k in orc.PHI_ORDER}
 
     def facefluxes(self, umo, vmo, fill, top_below):
+        self.facefluxes_piece(umo, vmo, fill, top_below, 0, self.ny, True)
+        return self.facefluxes_finish(top_below)
+
+    def facefluxes_piece(self, umo, vmo, fill, top_below, j0, j1, first):
+        """Rows [j0, j1) only, as the HIP backend's otmb_facefluxes_rows_dev: the oracle runs on the whole slab with whatever the plane
+        buffer holds -- rows of the plane that have not arrived yet are garbage and only rows [j0, j1) of the result are kept (a cell's
+        fluxes depend on its own column's plane value and on inputs of its neighbours) -- so a piece that is used before it has arrived
+        shows up as a wrong matrix."""
         nown = self.k1 - self.k0
         u = umo.numpy().reshape(self.nx, self.ny, nown, order="F")
         v = vmo.numpy().reshape(self.nx, self.ny, nown, order="F")
-        tb = None if top_below is None else top_below.numpy()
-        phi, self.uv = orc.facefluxes(u, v, self.s["wet_own"].astype(np.uint8), fill, self.s["topology"], top_below=tb,
-                                      return_flags=True)
+        tb = None if top_below is None else top_below.numpy().copy()
+        phi, uv = orc.facefluxes(u, v, self.s["wet_own"].astype(np.uint8), fill, self.s["topology"], top_below=tb, return_flags=True)
+        if first:
+            for k in orc.PHI_ORDER:
+                self.phi[k][:] = 0.0
+            self._top_first = np.full((self.nx, self.ny), np.nan, order="F")
+        self.uv = uv  # (the validity flags concern umo / vmo of the whole slab: the same in every piece's call)
         for k in orc.PHI_ORDER:
-            self.phi[k][:] = 0.0
-            self.phi[k][:, :, self.k0:self.k1] = phi[k]
-        top_first = np.ascontiguousarray(phi["top"][:, :, 0].ravel(order="F"))
+            self.phi[k][:, j0:j1, self.k0:self.k1] = phi[k][:, j0:j1, :]
+        self._top_first[:, j0:j1] = phi["top"][:, j0:j1, 0]
+        return torch.from_numpy(np.ascontiguousarray(self._top_first.ravel(order="F")))
+
+    def facefluxes_finish(self, top_below):
         if self.k0 > 0:
-            self.phi["bottom"][:, :, 0] = phi["top"][:, :, 0]
-        if tb is not None:
-            self.phi["top"][:, :, -1] = tb.reshape(self.nx, self.ny, order="F")
-        return torch.from_numpy(top_first)
+            self.phi["bottom"][:, :, 0] = self.phi["top"][:, :, self.k0]
+        if top_below is not None:
+            self.phi["top"][:, :, -1] = top_below.numpy().reshape(self.nx, self.ny, order="F")
+        return torch.from_numpy(np.ascontiguousarray(self.phi["top"][:, :, self.k0].ravel(order="F")))
 
     def plan(self):
         s = self.s

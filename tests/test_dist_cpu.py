@@ -34,9 +34,11 @@ def whole_grid_reference(oracle, nx, ny, nz, seed, rho, topo):
     return idx, oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
 
 
-def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None, rccl=False):
+def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None, rccl=False, pieces=None):
     port = free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTMB_TEST_ASYNC="1" if async_mode else "0", OTMB_TEST_RCCL="1" if rccl else "0")
+    if pieces is not None:
+        env["OTMB_CHAIN_PIECES"] = str(pieces)  # SlabRunner: the facefluxes chain in this many row bands
     if fault:
         env["OTMB_TEST_FAULT"] = fault
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), kind,
@@ -76,6 +78,15 @@ def test_slab_async_pipeline_gloo(oracle, tmp_path):
     """step_async x3 + finish: no collective per field, local colptrs shifted to global ones at the end."""
     case = (12, 10, 9, 22, "array", "tripolar")
     z = run_ranks(3, "oracle", case, tmp_path, async_mode=True)
+    check_against_whole_grid(oracle, z, case)
+
+
+@pytest.mark.parametrize("pieces,world,async_mode", [(2, 2, False), (5, 3, False), (10, 3, True), (3, 4, True)])
+def test_facefluxes_chain_in_row_bands_gloo(oracle, tmp_path, pieces, world, async_mode):
+    """slab s piece c waits for slab s + 1 piece c only (whole rows per piece; 10 = one row per piece here).  The checker
+    backend computes a piece with whatever the plane buffer holds, so a piece used before it arrived would give a wrong matrix."""
+    case = (12, 10, 9, 23, "array", "tripolar")
+    z = run_ranks(world, "oracle", case, tmp_path, async_mode=async_mode, pieces=pieces)
     check_against_whole_grid(oracle, z, case)
 
 

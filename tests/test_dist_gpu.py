@@ -21,6 +21,14 @@ def test_hip_slabs_async_pipeline(oracle, tmp_path):
     check_against_whole_grid(oracle, z, case)
 
 
+@pytest.mark.parametrize("pieces,world,async_mode", [(2, 2, False), (5, 3, True), (18, 3, False)])
+def test_hip_slabs_chain_in_row_bands(oracle, tmp_path, pieces, world, async_mode):
+    """The facefluxes chain handed over in row bands (otmb_facefluxes_rows_dev per piece): bit-identical to the whole-grid oracle."""
+    case = (24, 18, 11, 35, "array", "tripolar")
+    z = run_ranks(world, "hip", case, tmp_path, async_mode=async_mode, pieces=pieces)
+    check_against_whole_grid(oracle, z, case)
+
+
 def _gpus():
     import torch
 

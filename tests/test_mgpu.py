@@ -286,6 +286,89 @@ def test_mgpu_reuse_flags_keep_grid_and_fluxes_on_the_devices(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+def test_mgpu_facefluxes_chain_in_row_bands(oracle, ndev):
+    """the chain over depth slabs is handed over piece by piece (row bands), slab s piece c waiting for slab s + 1 piece c
+    only.  Any number of pieces -- 1, 2, 5 (bands of unequal height), one row per piece -- gives the oracle's six arrays bit for bit,
+    float32 inputs included; a hand-off that fails in the middle of the chain releases every slab (no deadlock), is reported, and
+    leaves the object usable."""
+    import os
+
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+    from otmb_amd.capi import OtmbError
+
+    g = synthetic.make_grid(28, 20, 13, seed=47, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, _ = _reference(oracle, g, gm)
+    devices = [0] * ndev
+    idx = api.makeindices(gm.v3D)
+    mg = api.mgpu(devices)
+    try:
+        for pieces in (1, 2, 5, 20):
+            mg.set_chain_pieces(pieces)
+            phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+            for k in rphi:
+                assert np.array_equal(phi[k], rphi[k]) and np.array_equal(np.signbit(phi[k]), np.signbit(rphi[k])), (k, pieces)
+        mg.set_chain_pieces(5)
+        os.environ["OTMB_TEST_FAIL_PIECE"] = f"{ndev - 1}:2"  # the deepest slab's third piece never leaves
+        try:
+            with pytest.raises(OtmbError) as e:
+                api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+            assert "injected" in str(e.value)
+        finally:
+            del os.environ["OTMB_TEST_FAIL_PIECE"]
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+        for k in rphi:
+            assert np.array_equal(phi[k], rphi[k]), k
+    finally:
+        mg.set_chain_pieces(0)
+
+
+@pytest.mark.gpu
+def test_facefluxes_row_bands_on_one_device_equal_the_whole_plane(oracle):
+    """otmb_facefluxes_rows_dev: the plane in row bands (any cut, one-row and four-row workgroups) -- the same six arrays and the same
+    validity flags as one call over the whole plane."""
+    import ctypes as C
+
+    import torch
+
+    from otmb_amd import capi, synthetic
+
+    for rows_env, shape in (("1", (40, 23, 7)), ("4", (150, 23, 7))):
+        os_env = {"OTMB_FF_ROWS": rows_env}
+        import os
+
+        os.environ.update(os_env)
+        try:
+            ctx = capi.Context(0)
+        finally:
+            del os.environ["OTMB_FF_ROWS"]
+        lib = capi.lib()
+        g = synthetic.make_grid(*shape, seed=48, rho="array")
+        gm = gridmetrics_of(g)
+        idx = oracle.makeindices(gm.v3D)
+        rphi = oracle.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], 1e20, gm.gridtopology.kind)
+        nx, ny, nz = shape
+        G = nx * ny * nz
+        flat = lambda a, dt=np.float64: torch.from_numpy(np.asfortranarray(a, dtype=dt).ravel(order="F")).cuda()
+        umo, vmo, wet = flat(g.umo.data), flat(g.vmo.data), flat(idx["wet3D"], np.uint8)
+        for cuts in ([0, ny], [0, 1, 2, ny], [0, 7, 8, 19, ny], list(range(ny + 1))):
+            phi = [torch.full((G,), np.nan, dtype=torch.float64, device="cuda") for _ in range(6)]
+            ptrs = capi.ptr_array(6, [p.data_ptr() for p in phi])
+            for c in range(len(cuts) - 1):
+                ctx.check(lib.otmb_facefluxes_rows_dev(ctx.handle, umo.data_ptr(), vmo.data_ptr(), 0, wet.data_ptr(), 1e20, nx, ny, nz,
+                                                       gm.gridtopology.kind, C.byref(ptrs), None, None, cuts[c], cuts[c + 1], int(c == 0)))
+            u, v = C.c_int32(0), C.c_int32(0)
+            ctx.check(lib.otmb_facefluxes_slab_flags(ctx.handle, C.byref(u), C.byref(v)))
+            assert u.value == 1 and v.value == 1
+            for k, name in enumerate(capi.PHI_ORDER):
+                got = phi[k].cpu().numpy().reshape(shape, order="F")
+                assert np.array_equal(got, rphi[name]), (name, cuts, rows_env)
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_mgpu_forgets_uploads_that_never_reached_the_devices(oracle):
     """a slab's residency keys are written when an upload is QUEUED.  A plan whose transfer fails must take them back, or a
     retry on the same handle with reuse_grid on would treat arrays that were never copied as resident and build matrices from
