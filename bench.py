@@ -587,6 +587,9 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             def bytes_split(self, fill_pass):  # (read, written) of the dominant kernel
                 return asm.algorithmic_bytes_split() if fill_pass else (asm.G * 17, asm.G * 48)
 
+            def stream_mix(self):
+                return asm.fill_pass_stream_mix()
+
         runner = _Single()
 
     def barrier():
@@ -659,6 +662,12 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
                 mix = (br + bw) / (br / rd + bw / wr)
                 roof["box"] = {"read_gbs": rd, "write_gbs": wr, "mix_ceiling": mix, "frac_of_box": achieved / mix,
                                "bytes_read": br, "bytes_written": bw}
+                if dom.startswith("tm_kernel") and hasattr(runner, "stream_mix"):
+                    # ... and of what an ideal streaming kernel reaches over the fill pass's OWN arrays, where they lie (destroys the matrices:
+                    # everything that reads them has run).  The two plain streams above are the same on fast and slow boxes (profiles/r05).
+                    sm = runner.stream_mix()  # {columns per slice: GB/s}; 256 = the fill pass's own tile
+                    roof["box"]["stream_mix_gbs"] = {str(k): v for k, v in sm.items()}
+                    roof["box"]["frac_of_mix"] = achieved / max(sm.values())  # against the BEST plain stream over these arrays
             except Exception as e:  # a diagnostic must never cost the line
                 roof["box"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         k0, k1, nzg = runner.slab

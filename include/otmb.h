@@ -130,6 +130,13 @@ const char *otmb_kernel_name(int32_t kernel_id);
  * non-temporal HBM write stream (2 GiB each, all CUs, 16 bytes per lane, eight accesses in flight), in GB/s.  bench.py reports a
  * kernel's time as a fraction of the rate these two give for the kernel's own read : write mix.  Allocates 2 GiB for the call.   */
 int32_t otmb_ctx_box_ceilings(otmb_ctx *ctx, double *read_gbs, double *write_gbs);
+/* Diagnostic, DESTRUCTIVE for the outputs: the plainest kernel there is over the very arrays a kernel reads and writes -- every byte of the
+ * n_in input arrays read once, every byte of the n_out output arrays written once (device pointers, 16-byte aligned; at most 24 each), cut
+ * into `tiles` proportional slices taken by one workgroup each in the fill pass's XCD-contiguous order.  *gbs = bytes / time: what an ideal
+ * streaming kernel with this byte mix reaches ON THESE ALLOCATIONS -- the fill pass's time depends reproducibly on where its ~30 arrays lie
+ * in the HBM (profiles/r04 section 12), which the two plain streams of otmb_ctx_box_ceilings do not see.                              */
+int32_t otmb_ctx_stream_mix(otmb_ctx *ctx, int32_t n_in, const void *const *in, const int64_t *in_bytes, int32_t n_out,
+                            void *const *out, const int64_t *out_bytes, int64_t tiles, double *gbs);
 
 /* ---- makeindices(v3D)  -- src/matrixbuilding.jl:10-24 ------------------------------------- *
  * wet = !isnan(v3D).  Outputs (any may be NULL): lwet3d (nx*ny*nz) wet rank or 0;

@@ -87,6 +87,7 @@ SYMBOLS = {
     "otmb_ctx_timing_collect": (C.c_int32, [_vp, _dp, _ip, C.c_int32]),
     "otmb_kernel_name": (C.c_char_p, [C.c_int32]),
     "otmb_ctx_box_ceilings": (C.c_int32, [_vp, _dp, _dp]),
+    "otmb_ctx_stream_mix": (C.c_int32, [_vp, C.c_int32, _vp, _ip, C.c_int32, _vp, _ip, C.c_int64, _dp]),
     "otmb_makeindices_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
     "otmb_makeindices": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _ip]),
     "otmb_facefluxes_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
@@ -289,6 +290,16 @@ class Context:
         r, w = C.c_double(0), C.c_double(0)
         self.check(self._lib.otmb_ctx_box_ceilings(self._h, C.byref(r), C.byref(w)))
         return float(r.value), float(w.value)
+
+    def stream_mix(self, inputs, outputs, tiles):
+        """GB/s of an ideal streaming kernel over these arrays (otmb_ctx_stream_mix): inputs / outputs = [(device pointer, bytes)].
+        DESTROYS the outputs' contents."""
+        ni, no = len(inputs), len(outputs)
+        ip, ib = (_vp * max(ni, 1))(*[p for p, _ in inputs]), (C.c_int64 * max(ni, 1))(*[int(b) for _, b in inputs])
+        op, ob = (_vp * max(no, 1))(*[p for p, _ in outputs]), (C.c_int64 * max(no, 1))(*[int(b) for _, b in outputs])
+        g = C.c_double(0)
+        self.check(self._lib.otmb_ctx_stream_mix(self._h, ni, ip, ib, no, op, ob, int(tiles), C.byref(g)))
+        return float(g.value)
 
     def timing_collect(self, n=32):
         """{kernel name: (sum_ms, launches)} since the previous collect (HIP events on the launch stream)."""

@@ -61,3 +61,103 @@ extern "C" int32_t otmb_ctx_box_ceilings(otmb_ctx *ctx, double *read_gbs, double
     (void)hipFree(buf);
     return rc;
 }
+
+// ---- the same question for a kernel's OWN arrays -----------------------------------------------------------------------------------------
+// The two plain streams above do not see what makes one box, one process or one set of allocations slow (profiles/r05: 7.0 / 5.2 TB/s on a
+// box where the fill pass takes 5.9 ms and on one where it takes 7.3 ms): the fill pass streams through ~30 arrays at once, and it is how
+// THOSE lie in the HBM that differs (profiles/r04 section 12).  otmb_ctx_stream_mix runs the plainest kernel there is over the very arrays a
+// kernel reads and writes -- every input read once, every output written once (CONTENTS DESTROYED), with the kernel's own granularity: the
+// arrays are cut into `tiles` proportional slices, a workgroup takes slice t of every array (contiguous 16-byte-per-lane accesses, all loads
+// before the stores), XCD x takes the x-th contiguous eighth of the tiles.  bytes / time is what an ideal streaming kernel with this byte mix
+// reaches on these arrays; bench.py reports the fill pass's rate as a fraction of it (roofline.box.frac_of_mix).
+#define DIAG_MAXARR 24
+struct DiagMixArgs {
+    const char *in[DIAG_MAXARR];
+    char *out[DIAG_MAXARR];
+    unsigned long long in_el[DIAG_MAXARR], out_el[DIAG_MAXARR];  // 16-byte elements
+    int n_in, n_out;
+    unsigned tiles;
+};
+__global__ __launch_bounds__(256) void diag_mix_kernel(const DiagMixArgs a, double *sink) {
+    // XCD-contiguous eighths of the tile sequence, as the fill pass takes its tiles
+    const unsigned nb = a.tiles, q = nb / 8, r = nb % 8, x = blockIdx.x % 8, y = blockIdx.x / 8;
+    if (y >= q + (x < r ? 1u : 0u)) return;
+    const unsigned long long t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    // slice t of array k: elements [t L_k, (t + 1) L_k) with L_k = ceil(elements / tiles), cut at the array's end.  Every load of a round
+    // (one 16-byte element per lane and array) is issued before anything waits for one: up to DIAG_MAXARR requests in flight per lane.
+    double acc = 0;
+    unsigned long long lmax = 0;
+#pragma unroll
+    for (int k = 0; k < DIAG_MAXARR; ++k)
+        if (k < a.n_in) { const unsigned long long L = (a.in_el[k] + nb - 1) / nb; lmax = L > lmax ? L : lmax; }
+    for (unsigned long long it = 0; it < lmax; it += 256) {
+        d2 v[DIAG_MAXARR];
+#pragma unroll
+        for (int k = 0; k < DIAG_MAXARR; ++k) {
+            v[k] = d2{0.0, 0.0};
+            if (k < a.n_in) {
+                const unsigned long long L = (a.in_el[k] + nb - 1) / nb, off = it + threadIdx.x, e = t * L + off;
+                if (off < L && e < a.in_el[k]) v[k] = __builtin_nontemporal_load((const d2 *)a.in[k] + e);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DIAG_MAXARR; ++k) acc += v[k].x;
+    }
+    const d2 w = {acc, (double)t};
+    lmax = 0;
+#pragma unroll
+    for (int k = 0; k < DIAG_MAXARR; ++k)
+        if (k < a.n_out) { const unsigned long long L = (a.out_el[k] + nb - 1) / nb; lmax = L > lmax ? L : lmax; }
+    for (unsigned long long it = 0; it < lmax; it += 256) {
+#pragma unroll
+        for (int k = 0; k < DIAG_MAXARR; ++k) {
+            if (k < a.n_out) {
+                const unsigned long long L = (a.out_el[k] + nb - 1) / nb, off = it + threadIdx.x, e = t * L + off;
+                if (off < L && e < a.out_el[k]) __builtin_nontemporal_store(w, (d2 *)a.out[k] + e);
+            }
+        }
+    }
+    if (acc == 1.2345e-300) sink[0] = acc;
+}
+
+extern "C" int32_t otmb_ctx_stream_mix(otmb_ctx *ctx, int32_t n_in, const void *const *in, const int64_t *in_bytes, int32_t n_out,
+                                       void *const *out, const int64_t *out_bytes, int64_t tiles, double *gbs) {
+    if (!ctx || !gbs || n_in < 0 || n_out < 0 || n_in > DIAG_MAXARR || n_out > DIAG_MAXARR || tiles < 8 || tiles >= (1ll << 31) ||
+        (n_in && (!in || !in_bytes)) || (n_out && (!out || !out_bytes)))
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_ctx_stream_mix");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DiagMixArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_in = n_in; a.n_out = n_out; a.tiles = (unsigned)tiles;
+    double total = 0;
+    for (int k = 0; k < n_in; ++k) {
+        if (!in[k] || in_bytes[k] < 0 || ((size_t)in[k] & 15)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_ctx_stream_mix: input (16-byte aligned, non-null)");
+        a.in[k] = (const char *)in[k]; a.in_el[k] = (unsigned long long)in_bytes[k] / 16; total += 16.0 * (double)a.in_el[k];
+    }
+    for (int k = 0; k < n_out; ++k) {
+        if (!out[k] || out_bytes[k] < 0 || ((size_t)out[k] & 15)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_ctx_stream_mix: output (16-byte aligned, non-null)");
+        a.out[k] = (char *)out[k]; a.out_el[k] = (unsigned long long)out_bytes[k] / 16; total += 16.0 * (double)a.out_el[k];
+    }
+    double *sink = nullptr;
+    if (hipMalloc((void **)&sink, 64) != hipSuccess) return otmb_fail(ctx, OTMB_ERR_ALLOC, "hipMalloc (stream mix)");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int32_t rc = OTMB_OK;
+    const unsigned grid = (unsigned)((tiles + 7) / 8 * 8);
+    const int reps = 3;
+    float ms = 0.f;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = otmb_fail(ctx, OTMB_ERR_HIP, "stream mix set-up");
+    if (rc == OTMB_OK) {
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(diag_mix_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, sink);
+        (void)hipEventRecord(e0, ctx->stream);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(diag_mix_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, sink);
+        if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
+            hipGetLastError() != hipSuccess)
+            rc = otmb_fail(ctx, OTMB_ERR_HIP, "stream mix run");
+    }
+    if (rc == OTMB_OK) *gbs = total * reps / (ms * 1e-3) / 1e9;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(sink);
+    return rc;
+}

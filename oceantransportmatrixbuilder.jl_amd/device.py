@@ -563,6 +563,21 @@ class DeviceAssembler:
         n3d = 9 + (1 if self.rho is not None else 0)
         return 8 * self.G * n3d + 80 * self.nx * self.ny + 8 * self.nz, sum(16 * z + 8 * (self.N + 1) for z in self.nnz)
 
+    def fill_pass_stream_mix(self):
+        """What an ideal streaming kernel reaches over the fill pass's OWN arrays (otmb_ctx_stream_mix): its ten 3-D inputs (+ the 2-D
+        metrics) read once, its fifteen output arrays written once at their actual lengths, in as many slices as the pass has tiles.
+        DESTROYS the matrices of self.out: call it after the results have been used.  {columns per slice: GB/s}."""
+        b8 = lambda t, n=None: (t.data_ptr(), 8 * (t.numel() if n is None else n))
+        ins = [b8(p) for p in self.phi] + [b8(self.v3d), b8(self.thk), b8(self.lwet3d)] + ([b8(self.rho)] if self.rho is not None else [])
+        ins += [b8(t) for t in (*self.edge, *self.dist, self.area, self.mlotst)]
+        outs = []
+        for k, m in enumerate(MATS):
+            cp, rv, nz = self.out[m]
+            outs += [b8(cp, self.N + 1), b8(rv, self.nnz[k]), b8(nz, self.nnz[k])]
+        # the fill pass's own granularity (256 columns per slice) and longer slices: a plain stream likes them longer where the grid is large
+        # enough to still fill the chip (profiles/r05: 4.3 / 4.3 / 3.9 / 3.7 TB/s at 1 degree, 4.9 / 5.4 / 5.6 / 5.5 TB/s at 0.25 degree)
+        return {cols: self.ctx.stream_mix(ins, outs, max(8, self.N // cols)) for cols in (256, 512, 1024, 2048)}
+
     def facefluxes_bytes(self, itemsize=8):
         """umo, vmo, wet3D read once; six ϕ arrays written once."""
         return self.G * (2 * itemsize + 1 + 6 * 8)
