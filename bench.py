@@ -227,7 +227,7 @@ def extra_configs_in_children(args):
                 rec.update({"grid": d["config"]["workload"].split("grid ")[1].split(",")[0], "wet_cells": d["config"]["wet_cells"], "nnz": d["config"]["nnz"],
                             "protocol": d["config"]["protocol"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
                             "value": d["value"], "unit": d["unit"], "repeats": d["repeats"], "roofline": d["roofline"], "kernels_ms": d["kernels_ms"],
-                            "step_gbs": d["step_gbs"], "placement": d.get("placement"), "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
+                            "step_gbs": d["step_gbs"], "placement": d.get("placement"), "fused_step": d.get("fused_step"), "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
         except subprocess.TimeoutExpired:
             rec["error"] = "child timed out"
         except Exception as e:  # an extra record must never cost the headline
@@ -590,6 +590,11 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             def stream_mix(self):
                 return asm.fill_pass_stream_mix()
 
+            def fused_step(self):  # the extension otmb_step_dev: only ϕtop stored (never `value`: the two-call path is the drop-in)
+                asm.step_fused_async(umo, vmo, fill)
+
+            fused_available = args.protocol == "async" and args.workload != "tenthdeg" and nx >= 3
+
         runner = _Single()
 
     def barrier():
@@ -628,6 +633,41 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         runner.sync()
         ktimes = runner.ctx.timing_collect()
         runner.ctx.timing_enable(False)
+
+    # The fused device-resident step (otmb_step_dev: facefluxes stores ϕtop only, the fill pass re-derives the other five fluxes from umo /
+    # vmo; the same five matrices bit for bit, tests/test_fused_step.py), measured the same way right after the headline and reported as an
+    # EXTRA record: `value` stays the two-call path, which is what the reference's API is (facefluxesfrommasstransport returns six arrays).
+    fused = None
+    if getattr(runner, "fused_available", False) and not rehearsal:
+        try:
+            for _ in range(args.warmup):
+                runner.fused_step()
+            runner.pending = True
+            runner.sync()
+            reps = []
+            for _ in range(min(args.repeats, 3)):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    runner.fused_step()
+                runner.pending = True
+                runner.sync()
+                barrier()
+                reps.append(time.perf_counter() - t0)
+            runner.ctx.timing_enable(True)
+            for _ in range(args.steps):
+                runner.fused_step()
+            runner.pending = True
+            runner.sync()
+            fk = runner.ctx.timing_collect()
+            runner.ctx.timing_enable(False)
+            fms = 1e3 * float(np.median(reps)) / args.steps
+            fused = {"what": "otmb_step_dev (extension, NOT the headline): one call from (umo, vmo) to the five matrices, only ϕtop stored -- "
+                             "64 bytes per cell less HBM traffic; the same matrices bit for bit",
+                     "ms_per_step": fms, "wet_cells_per_s": runner.n_wet_total / (fms * 1e-3),
+                     "kernels_ms": {k: round(v[0] / v[1], 5) for k, v in fk.items()}}
+        except Exception as e:  # an extra record must never cost the headline
+            fused = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # N > 1: BASELINE.json configs[3] (the fixed 0.25 degree grid cut into N depth slabs) beside the headline, unless it IS the headline
     config4 = None
@@ -694,6 +734,8 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             "kernels_ms": {k: round(v, 5) for k, v in kavg.items()},
             "step_gbs": None if rehearsal else (runner.algorithmic_bytes() + runner.facefluxes_bytes()) / (ms_step * 1e-3) / 1e9,
         }
+        if fused is not None:
+            out["fused_step"] = fused
         if world == 1 and not force_slab and not rehearsal:
             out["placement"] = placement
         if world > 1 or force_slab:

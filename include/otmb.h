@@ -327,6 +327,18 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
  * builds the fill pass's tile order and waits for its number of heavy tiles -- one stream synchronisation per grid, not per step. */
 int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t *const colptr[5],
                                  int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
+/* Extension for device-resident pipelines that go from (umo, vmo) straight to the matrices and do not need the six ϕ arrays themselves:
+ * ONE call = otmb_facefluxes_counts_dev + otmb_transportmatrix_dev with the SAME five matrices bit for bit, but only ϕtop is ever stored
+ * (phi_top: nx*ny*nz doubles of the caller's; it holds facefluxes' ϕtop afterwards).  The other five fluxes are what facefluxes would have
+ * stored -- ϕeast / ϕwest / ϕnorth / ϕsouth are masked copies of umo / vmo (nofluxboundaries! + replace + shift, src/velocities.jl:161-175,
+ * :203-224), ϕbottom is ϕtop of the level below (:238-240) -- and the fill pass re-derives them where it uses them: 64 bytes per cell less
+ * HBM traffic than writing six arrays and reading them back (~14 % of a step).  args->phi and args->push_mask are ignored; wetflags /
+ * count_tables as for otmb_facefluxes_counts_dev; asynchronous like otmb_transportmatrix_dev (otmb_transportmatrix_result,
+ * otmb_facefluxes_pending_flags collect the verdicts).  Whole grids, nx >= 3, nz <= 128.  NOT a replacement for the two-call API:
+ * facefluxesfrommasstransport returns the six arrays (src/velocities.jl:245-254).                                                       */
+int32_t otmb_step_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, double fill, const uint8_t *wetflags,
+                      const void *count_tables, double *phi_top, const otmb_tm_args *args, int64_t *const colptr[5],
+                      int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]);
 int32_t otmb_transportmatrix_result(otmb_ctx *ctx, int64_t nnz[5]);
 /* Several otmb_transportmatrix_dev calls may be enqueued before one otmb_transportmatrix_result (a pipeline over time
  * slices).  Every call keeps its own error flags, its own nnz and its own output arrays: like every transportmatrix call of

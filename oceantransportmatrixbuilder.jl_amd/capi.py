@@ -119,6 +119,8 @@ SYMBOLS = {
     "otmb_transportmatrix_set_slab": (C.c_int32, [_vp, C.c_int64]),
     "otmb_transportmatrix_dev": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_result": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
+    "otmb_step_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_double, _vp, _vp, _vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5),
+                                   C.POINTER(C.c_int64 * 5)]),
     "otmb_transportmatrix_set_nnz_base": (C.c_int32, [_vp, C.POINTER(C.c_int64 * 5)]),
     "otmb_makegridmetrics_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32 * 4),
                                               C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp,

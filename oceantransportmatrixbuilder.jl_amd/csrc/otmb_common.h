@@ -163,6 +163,9 @@ void otmb_launch_tilescan_packed(hipStream_t s, unsigned long long *packed, cons
                                  int *flags, int only_t, bool all_levels);  // otmb_scan.hip
 int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
                               uint16_t *push_mask);  // otmb_facefluxes.hip
+int32_t otmb_facefluxes_top_counts(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wetflags, double fill,
+                                   int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6], uint16_t *token,
+                                   const otmb_ff_counts *counts);  // otmb_facefluxes.hip (the fused step)
 void otmb_tm_plan_free(otmb_ctx *ctx);                               // otmb_transportmatrix.hip
 void otmb_tm_plan_invalidate(otmb_ctx *ctx);                         // otmb_transportmatrix.hip
 void otmb_xfer_free(otmb_ctx *ctx);                                  // otmb_host.hip

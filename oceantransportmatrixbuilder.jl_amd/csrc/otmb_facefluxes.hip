@@ -199,7 +199,7 @@ __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo
     }
 }
 
-template <typename T, bool FLAGS, bool NT, bool COUNTS = false>
+template <typename T, bool FLAGS, bool NT, bool COUNTS = false, bool TOPONLY = false>
 __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col, i64 P, int k0, double fill, double &topbelow,
                                           bool &uvalid, bool &vvalid, double *__restrict__ east, double *__restrict__ west,
                                           double *__restrict__ north, double *__restrict__ south, double *__restrict__ top,
@@ -210,37 +210,40 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
     for (int q = 0; q < FF_KB; ++q) {
         const int k = k0 - q;
         if (k >= 0) {
-            double e = 0.0, w = 0.0, so = 0.0, n = 0.0, b = 0.0, t = 0.0;
-            bool wc = false;
+            // (every lane computes: lanes beyond the row / rows beyond the grid of a four-row workgroup, and lanes beyond the plane of a counting
+            // kernel, march along on clamped -- valid -- addresses; only their STORES and their validity flags are switched off.  A branch around
+            // the arithmetic cost a save / restore of the execution mask and six zero-initialised doubles per level.)
             const unsigned f = c.wc[q];
-            if (active) {  // (lanes beyond the row / rows beyond the grid of a four-row workgroup march along for the barriers only)
-                const i64 o = (i64)k * P;
-                wc = FLAGS ? (f & WF_C) != 0 : c.wc[q] != 0;
-                const bool wE = FLAGS ? (f & WF_E) != 0 : c.wE[q] != 0, wW = FLAGS ? (f & WF_W) != 0 : c.wW[q] != 0;
-                const bool wS = FLAGS ? (f & WF_S) != 0 : (col.hS && c.wS[q] != 0), wN = FLAGS ? (f & WF_N) != 0 : (col.hN && c.wN[q] != 0);
-                double u = (double)c.u[q], v = (double)c.v[q];  // Array{Float64}(umo), :125-126
-                // nofluxboundaries!, :167-173
-                if (!wc || !wE) u = 0.0;
-                if (!wc || !wN) v = 0.0;
-                uvalid |= !(isnan(u) || u == fill);  // :199
-                vvalid |= !(isnan(v) || v == fill);  // :200
-                e = ff_replace(u, fill);
-                n = ff_replace(v, fill);
-                // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
-                double uw = (double)c.uw[q];
-                if (!wW || !wc) uw = 0.0;
-                w = ff_replace(uw, fill);
-                // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
-                double vs = (double)c.vs[q];
-                if (!wS || !wc) vs = 0.0;
-                so = col.hS ? ff_replace(vs, fill) : 0.0;
-                b = topbelow;                      // :238-240
-                t = (((b + w) + so) - e) - n;      // :242
-                ff_st<NT>(east + o, col.s, e); ff_st<NT>(west + o, col.s, w); ff_st<NT>(north + o, col.s, n); ff_st<NT>(south + o, col.s, so);
-                ff_st<NT>(top + o, col.s, t); ff_st<NT>(bottom + o, col.s, b);
+            const i64 o = (i64)k * P;
+            const bool wc = FLAGS ? (f & WF_C) != 0 : c.wc[q] != 0;
+            const bool wE = FLAGS ? (f & WF_E) != 0 : c.wE[q] != 0, wW = FLAGS ? (f & WF_W) != 0 : c.wW[q] != 0;
+            const bool wS = FLAGS ? (f & WF_S) != 0 : (col.hS && c.wS[q] != 0), wN = FLAGS ? (f & WF_N) != 0 : (col.hN && c.wN[q] != 0);
+            double u = (double)c.u[q], v = (double)c.v[q];  // Array{Float64}(umo), :125-126
+            // nofluxboundaries!, :167-173
+            if (!wc || !wE) u = 0.0;
+            if (!wc || !wN) v = 0.0;
+            uvalid |= active & !(isnan(u) || u == fill);  // :199
+            vvalid |= active & !(isnan(v) || v == fill);  // :200
+            const double e = ff_replace(u, fill), n = ff_replace(v, fill);
+            // ϕwest[c] = ϕeast[i₋₁(c)] (:206-211): the west cell's east flux after ITS boundary rule
+            double uw = (double)c.uw[q];
+            if (!wW || !wc) uw = 0.0;
+            const double w = ff_replace(uw, fill);
+            // ϕsouth[c] = ϕnorth[j₋₁(c)], 0 at j == 1 (:219-224); j₊₁ of the south cell is c
+            double vs = (double)c.vs[q];
+            if (!wS || !wc) vs = 0.0;
+            const double so = col.hS ? ff_replace(vs, fill) : 0.0;
+            const double b = topbelow;                  // :238-240
+            const double t = (((b + w) + so) - e) - n;  // :242
+            if (active) {
+                if (!TOPONLY) {
+                    ff_st<NT>(east + o, col.s, e); ff_st<NT>(west + o, col.s, w); ff_st<NT>(north + o, col.s, n); ff_st<NT>(south + o, col.s, so);
+                    ff_st<NT>(bottom + o, col.s, b);
+                }
+                ff_st<NT>(top + o, col.s, t);  // (TOPONLY -- the fused step, otmb_step_dev: the other five are re-derived by the fill pass from umo / vmo / ϕtop)
                 if (push_mask && !COUNTS) ff_st<false>(push_mask + o, col.s, (uint16_t)otmb_push_bits(w, e, so, n, b, t, wc));
-                topbelow = t;
             }
+            topbelow = t;
             if (COUNTS) {
                 const unsigned fa = (q + 1 < FF_KB) ? c.wc[q + 1] : c.wup;  // the cell above (level k - 1; unused at k == 0)
                 ff_count_level(cnt, cs, k, nz, wc, f, fa, e, w, so, n, b, t, cs.has_fold ? (double)c.vn[q] : 0.0, fill);
@@ -260,7 +263,7 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
 #ifndef FF_COUNTS_WAVES
 #define FF_COUNTS_WAVES 1
 #endif
-template <typename T, bool FLAGS, bool NT, int ROWS, bool COUNTS>
+template <typename T, bool FLAGS, bool NT, int ROWS, bool COUNTS, bool TOPONLY = false>
 __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_eu(COUNTS ? FF_COUNTS_WAVES : 1))) void facefluxes_kernel(
     const T *__restrict__ umo, const T *__restrict__ vmo, const uint8_t *__restrict__ wet, double fill, int nx,
     int ny, int nz, int topo, i64 P, double *__restrict__ east, double *__restrict__ west,
@@ -360,12 +363,12 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
         while (k0 >= 0) {
             ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold);
             south_from_lds(A);
-            ff_levels<T, FLAGS, NT, COUNTS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
+            ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
             if (k0 < 0) break;
             ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold);
             south_from_lds(B);
-            ff_levels<T, FLAGS, NT, COUNTS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
+            ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
         }
     } else if (inside || COUNTS) {  // (COUNTS: every lane takes part in the wave sums; lanes beyond the plane march along on the last column and store nothing)
@@ -388,11 +391,11 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
         ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, true, cs.has_fold);
         while (k0 >= 0) {
             ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold);
-            ff_levels<T, FLAGS, NT, COUNTS>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
+            ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
             if (k0 < 0) break;
             ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold);
-            ff_levels<T, FLAGS, NT, COUNTS>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
+            ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
         }
     }
@@ -494,12 +497,12 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
                                bool check_missing, bool flags = false, const otmb_ff_counts *counts = nullptr, int64_t j0 = 0, int64_t j1 = -1,
-                               bool same_call = false) {
+                               bool same_call = false, bool top_only = false) {
     // j0, j1: rows [j0, j1) of the plane only (j1 < 0: all of them); same_call: a further piece of the facefluxes call that the
     // previous piece began -- the validity flags of the pieces accumulate in ONE pair of words
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     for (int f = 0; f < 6; ++f)
-        if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
+        if (!phi[f] && !(top_only && f != OTMB_TOP)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
     if (nx < 1 || ny < 1 || nz < 1 || nx * ny >= (1ll << 28)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
     if (topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);  // :163 -> gridtopology.jl:111
     if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
@@ -552,16 +555,23 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     KernelTimer kt(ctx, K_FACEFLUXES);
     const bool nt = (i64)48 * P * nz > (1ll << 30);  // six Float64 arrays beyond a gigabyte: streaming stores
 #define FF_LAUNCH(T, FL, NTS, R, CN)                                                                                                   \
-    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R, CN>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
+    FF_LAUNCH_T(T, FL, NTS, R, CN, false)
+#define FF_LAUNCH_T(T, FL, NTS, R, CN, TO)                                                                                             \
+    hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R, CN, TO>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
                        phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks, ctx->ff_lds_south, \
                        (int)j0, (int)j1, ca.bases, ca.mlotst, ca.zt, ca.sums, ca.upwind, ca.only_t, ca.nseg)
 #define FF_LAUNCH2(T, FL, CN) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4, CN); else FF_LAUNCH(T, FL, false, 4, CN); } \
                                    else { if (nt) FF_LAUNCH(T, FL, true, 1, CN); else FF_LAUNCH(T, FL, false, 1, CN); } } while (0)
-    if (with_counts) { if (src_is_f32) FF_LAUNCH2(float, true, true); else FF_LAUNCH2(double, true, true); }
+#define FF_LAUNCH2T(T) do { if (rows == 4) { if (nt) FF_LAUNCH_T(T, true, true, 4, true, true); else FF_LAUNCH_T(T, true, false, 4, true, true); } \
+                            else { if (nt) FF_LAUNCH_T(T, true, true, 1, true, true); else FF_LAUNCH_T(T, true, false, 1, true, true); } } while (0)
+    if (with_counts && top_only) { if (src_is_f32) FF_LAUNCH2T(float); else FF_LAUNCH2T(double); }
+    else if (with_counts) { if (src_is_f32) FF_LAUNCH2(float, true, true); else FF_LAUNCH2(double, true, true); }
     else if (src_is_f32) { if (flags) FF_LAUNCH2(float, true, false); else FF_LAUNCH2(float, false, false); }
     else { if (flags) FF_LAUNCH2(double, true, false); else FF_LAUNCH2(double, false, false); }
+#undef FF_LAUNCH2T
 #undef FF_LAUNCH2
+#undef FF_LAUNCH_T
 #undef FF_LAUNCH
     }
     if (with_counts) ctx->ffc.valid = true;
@@ -661,6 +671,14 @@ extern "C" int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, co
                      counts->n_wet > 0 && nx * ny * nz < (1ll << 32) && nz <= FFC_MAX_NZ;
     return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, nullptr, push_mask, false, true,
                            can ? counts : nullptr);
+}
+
+// facefluxes of the fused step (otmb_step_dev, otmb_transportmatrix.hip): counts + ϕtop only.  `token`: the pointer the counts are keyed to in
+// place of a push mask (never read or written).
+int32_t otmb_facefluxes_top_counts(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wetflags, double fill,
+                                   int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6], uint16_t *token,
+                                   const otmb_ff_counts *counts) {
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, nullptr, token, false, true, counts, 0, -1, false, true);
 }
 
 // Push mask of existing ϕ arrays (include/otmb.h): one thread per cell of [first, first + count).

@@ -17,6 +17,12 @@
 
 struct TmParams {
     const double *phi[6];
+    // The fused step (otmb_step_dev): only ϕtop exists in memory (phi[OTMB_TOP]); the other five fluxes are what facefluxes WOULD have stored,
+    // re-derived where they are used: ϕeast / ϕwest / ϕnorth / ϕsouth are masked copies of umo / vmo (nofluxboundaries! + replace + shift,
+    // src/velocities.jl:161-175,203-224) and ϕbottom is ϕtop of the level below (:238-240).  fused: 0 = six arrays, 1 = umo / vmo are Float64, 2 = Float32.
+    const void *umo, *vmo;
+    double fillv;
+    int fused;
     const double *v, *thk, *rho;
     double rho_s;
     const i64 *lw;    // Lwet3D (global wet ranks in a slab run), 0 = missing
@@ -144,6 +150,10 @@ __device__ __forceinline__ void raise_flag(int *flags, int f) {
     if (flags[f] == 0) atomicExch(&flags[f], 1);
 }
 
+// replace(x, NaN => 0.0, FillValue => 0.0) with isequal semantics (src/velocities.jl:203,215): facefluxes' ff_replace
+__device__ __forceinline__ double tm_replace(double x, double fill) {
+    return (isnan(x) || __double_as_longlong(x) == __double_as_longlong(fill)) ? 0.0 : x;
+}
 // ---- THE value expressions of the three generators: one copy, used by the generic column builder (build_column) and by the
 // regular-cell arithmetic (column_compute) that both the gather kernel (fast_column) and the dense-march kernel call. -------------
 #define FDIV(a, b) ((a) / (b))
@@ -187,11 +197,36 @@ __device__ __forceinline__ void build_column(const TmParams &p, const Cell &cell
     const i64 s2W = (i64)j * nx + iw, s2E = (i64)j * nx + ie, s2S = (LS >= 0) ? s2 - nx : s2;
     const i64 s2N = (LNq >= 0) ? (fold ? (i64)j * nx + ifd : s2 + nx) : s2;
     const i64 lEc = p.lw[LEc], lWc = p.lw[LWc], lS_ = p.lw[cS], lN_ = p.lw[cN], lA_ = p.lw[cA], lB_ = p.lw[cB];
-    const double *phiN_in = fold ? p.phi[OTMB_NORTH] : p.phi[OTMB_SOUTH];  // through the seam the north neighbour pushes with its NORTH flux
-    const double gEc = p.phi[OTMB_WEST][LEc], gWc = p.phi[OTMB_EAST][LWc], gNq = phiN_in[cN], gS = p.phi[OTMB_NORTH][cS],
-                 gA = p.phi[OTMB_BOTTOM][cA], gB = p.phi[OTMB_TOP][cB];
-    const double qW = p.phi[OTMB_WEST][L], qE = p.phi[OTMB_EAST][L], qS = p.phi[OTMB_SOUTH][L], qN = p.phi[OTMB_NORTH][L],
-                 qB = p.phi[OTMB_BOTTOM][L], qT = p.phi[OTMB_TOP][L];
+    double gEc, gWc, gNq, gS, gA, gB, qW, qE, qS, qN, qB, qT;
+    if (!p.fused) {
+        const double *phiN_in = fold ? p.phi[OTMB_NORTH] : p.phi[OTMB_SOUTH];  // through the seam the north neighbour pushes with its NORTH flux
+        gEc = p.phi[OTMB_WEST][LEc]; gWc = p.phi[OTMB_EAST][LWc]; gNq = phiN_in[cN]; gS = p.phi[OTMB_NORTH][cS];
+        gA = p.phi[OTMB_BOTTOM][cA]; gB = p.phi[OTMB_TOP][cB];
+        qW = p.phi[OTMB_WEST][L]; qE = p.phi[OTMB_EAST][L]; qS = p.phi[OTMB_SOUTH][L]; qN = p.phi[OTMB_NORTH][L];
+        qB = p.phi[OTMB_BOTTOM][L]; qT = p.phi[OTMB_TOP][L];
+    } else {
+        // (fused step, nx >= 3) the same twelve values as facefluxes would have stored them: ϕeast[x] = x's transport if x and its east
+        // neighbour are wet, ϕnorth[x] likewise with its north (or fold) neighbour, NaN / fill -> 0; ϕwest / ϕsouth are those of the west /
+        // south cell; ϕbottom[x] = ϕtop of the cell below (0 at the sea floor level), ϕtop from memory.  c is wet.
+        auto U = [&](i64 x) { return p.fused == 2 ? (double)((const float *)p.umo)[x] : ((const double *)p.umo)[x]; };
+        auto V = [&](i64 x) { return p.fused == 2 ? (double)((const float *)p.vmo)[x] : ((const double *)p.vmo)[x]; };
+        const bool wEc = lEc != 0, wWc = lWc != 0, wS_ = (LS >= 0) && lS_ != 0, wN_ = (LNq >= 0) && lN_ != 0;
+        const double eC = wEc ? tm_replace(U(L), p.fillv) : 0.0;           // ϕeast[c]
+        const double eW = wWc ? tm_replace(U(LWc), p.fillv) : 0.0;         // ϕeast[W] (W's east neighbour is c)
+        const double nC = wN_ ? tm_replace(V(L), p.fillv) : 0.0;           // ϕnorth[c] (north or fold neighbour wet)
+        const double nS = wS_ ? tm_replace(V(cS), p.fillv) : 0.0;          // ϕnorth[S] (S's north neighbour is c: S is never on the seam row)
+        const double nF = (fold && wN_) ? tm_replace(V(cN), p.fillv) : 0.0;  // ϕnorth[fold cell] (its fold neighbour is c)
+        gEc = eC;                     // ϕwest[E] = ϕeast[i₋₁(E)] = ϕeast[c]
+        gWc = eW;
+        gNq = fold ? nF : nC;         // ϕnorth[fold cell] through the seam, else ϕsouth[N] = ϕnorth[c]
+        gS = nS;
+        const double topC = p.phi[OTMB_TOP][L];
+        gA = topC;                    // ϕbottom[A] = ϕtop[c]
+        gB = p.phi[OTMB_TOP][cB];     // ϕtop[B]
+        qW = eW; qE = eC; qS = (LS >= 0) ? nS : 0.0; qN = nC;
+        qB = (LB >= 0) ? p.phi[OTMB_TOP][LB] : 0.0;  // ϕbottom[c]
+        qT = topC;
+    }
     const double vc = p.v[L], vEc = p.v[LEc], vWc = p.v[LWc], vS_ = p.v[cS], vN_ = p.v[cN], vA_ = p.v[cA], vB_ = p.v[cB];
     const double rc = p.rho ? p.rho[L] : p.rho_s;
     const double rEc = p.rho ? p.rho[LEc] : p.rho_s, rWc = p.rho ? p.rho[LWc] : p.rho_s, rS_ = p.rho ? p.rho[cS] : p.rho_s,
@@ -530,14 +565,19 @@ __device__ __forceinline__ void column_compute(const TmParams &p, const Stencil 
 //    sparse()'s "first touch copies, later ones add" without tracking the first touch.
 struct TileBase {  // array pointers advanced to the tile's lowest neighbour (uniform per workgroup)
     const char *lw, *v, *thk, *rho, *pe, *pw, *pn, *ps, *pt, *pb, *mk;
+    const char *pu, *pv;  // (fused step) umo / vmo, advanced likewise -- in THEIR element size
 };
+// (fused step) one mass transport value as Float64 (Array{Float64}(umo), :125-126), by byte offset in units of 8-byte elements
+template <int FUSED> __device__ __forceinline__ double ld_uv(const char *b, unsigned off8) {
+    return FUSED == 2 ? (double)__builtin_nontemporal_load((const float *)(b + (off8 >> 1))) : __builtin_nontemporal_load((const double *)(b + off8));
+}
 __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
 __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return ldd(b, byteoff); }
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
 // CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
 // The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
 // Returns whether Lwet3D holds c at the cell itself (the canonical-indices check, loaded with the stencil).
-template <bool CHECKS>
+template <bool CHECKS, int FUSED = 0>
 __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
                                             i64 c, Column &col, Stamps &st) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
@@ -561,8 +601,19 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
 #else
 #define LDPHI(b, o) ldd(b, o)
 #endif
-    const double gE0 = LDPHI(tb.pw, oE), gW0 = LDPHI(tb.pe, oW), gS0 = LDPHI(tb.pn, oS), gN0 = LDPHI(tb.ps, oN),
-                 gA0 = LDPHI(tb.pb, oA), gB0 = LDPHI(tb.pt, oB);
+    double gE0, gW0, gS0, gN0, gA0, gB0;
+    if (FUSED == 0) {
+        gE0 = LDPHI(tb.pw, oE); gW0 = LDPHI(tb.pe, oW); gS0 = LDPHI(tb.pn, oS); gN0 = LDPHI(tb.ps, oN);
+        gA0 = LDPHI(tb.pb, oA); gB0 = LDPHI(tb.pt, oB);
+    } else {
+        // the raw transports; masked and replaced below, once the wet ranks that travel with them are back
+        gE0 = ld_uv<FUSED>(tb.pu, oC);  // ϕwest[E] = ϕeast[c]   (:206-211)
+        gW0 = ld_uv<FUSED>(tb.pu, oW);  // ϕeast[W]
+        gS0 = ld_uv<FUSED>(tb.pv, oS);  // ϕnorth[S]
+        gN0 = ld_uv<FUSED>(tb.pv, oC);  // ϕsouth[N] = ϕnorth[c] (:219-224)
+        gA0 = LDPHI(tb.pt, oC);         // ϕbottom[A] = ϕtop[c]  (:238-240)
+        gB0 = LDPHI(tb.pt, oB);         // ϕtop[B]
+    }
     double qW0 = 0, qE0 = 0, qS0 = 0, qN0 = 0, qB0 = 0, qT0 = 0;
     if (CHECKS) {  // own fluxes, for the outgoing check
         qW0 = ldd(tb.pw, oC); qE0 = ldd(tb.pe, oC); qS0 = ldd(tb.ps, oC); qN0 = ldd(tb.pn, oC); qB0 = ldd(tb.pb, oC);
@@ -614,6 +665,14 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
                          (nonzero(ob) & !wB) | (nonzero(ot) & !wA);
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
         if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
+    }
+    if (FUSED != 0) {
+        // what facefluxes stores: a flux between two wet cells is the transport with NaN / fill replaced by zero, any other is zero
+        // (nofluxboundaries! on the emitting cell, :161-175; c itself is wet)
+        gE0 = (lE != 0) ? tm_replace(gE0, p.fillv) : 0.0;
+        gW0 = (lW != 0) ? tm_replace(gW0, p.fillv) : 0.0;
+        gS0 = (hS && lS != 0) ? tm_replace(gS0, p.fillv) : 0.0;
+        gN0 = (hN && lN != 0) ? tm_replace(gN0, p.fillv) : 0.0;
     }
     // the stencil as values, then THE arithmetic (column_compute: shared with the dense-march kernel)
     Stencil s;

@@ -104,7 +104,7 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
     tb.lw = (const char *)(p.lw + base_elem);
     tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
     tb.mk = (const char *)(p.mask + base_elem);
-    tb.v = tb.thk = tb.pe = tb.pw = tb.pn = tb.ps = tb.pt = tb.pb = nullptr;  // not read by the presence pass
+    tb.v = tb.thk = tb.pe = tb.pw = tb.pn = tb.ps = tb.pt = tb.pb = tb.pu = tb.pv = nullptr;  // not read by the presence pass
     const Cell cell = cell_of(L, p.nx, p.ny, p.P);
     const unsigned oC = (unsigned)(L - base_elem) * 8u;
     // (Lwet3D[Lwet[w]] == w + 1 is verified by the fill pass, which loads Lwet3D anyway)
@@ -247,7 +247,7 @@ __device__ __forceinline__ void tm_lookback(const TmParams &p, i64 tile, int lan
     }
 }
 
-template <int MODE>
+template <int MODE, int FUSED = 0>  // FUSED: the fused step's fill pass (otmb_step_dev): five of the six fluxes re-derived from umo / vmo / ϕtop (1 Float64, 2 Float32)
 __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
@@ -342,12 +342,19 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     tb.v = (const char *)(p.v + base_elem);
     tb.thk = (const char *)(p.thk + base_elem);
     tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
-    tb.pe = (const char *)(p.phi[OTMB_EAST] + base_elem);
-    tb.pw = (const char *)(p.phi[OTMB_WEST] + base_elem);
-    tb.pn = (const char *)(p.phi[OTMB_NORTH] + base_elem);
-    tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
     tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
-    tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
+    if (FUSED == 0) {
+        tb.pe = (const char *)(p.phi[OTMB_EAST] + base_elem);
+        tb.pw = (const char *)(p.phi[OTMB_WEST] + base_elem);
+        tb.pn = (const char *)(p.phi[OTMB_NORTH] + base_elem);
+        tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
+        tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
+        tb.pu = tb.pv = nullptr;
+    } else {
+        tb.pe = tb.pw = tb.pn = tb.ps = tb.pb = nullptr;
+        tb.pu = (const char *)p.umo + base_elem * (FUSED == 2 ? 4 : 8);
+        tb.pv = (const char *)p.vmo + base_elem * (FUSED == 2 ? 4 : 8);
+    }
     tb.mk = nullptr;  // the push mask is read by the counting pass only
 
     // ---- 1. the column ----
@@ -375,9 +382,9 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
             {
 #ifdef OTMB_CHECKS_IN_FILL
-                if (regular) canonical = fast_column<true>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
+                if (regular) canonical = fast_column<true, FUSED>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
 #else
-                if (regular) canonical = fast_column<false>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
+                if (regular) canonical = fast_column<false, FUSED>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
 #endif
                 else {
                     canonical = ldi(tb.lw, oC) == c;
@@ -946,14 +953,14 @@ static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr, int ignore = 0
     return OTMB_OK;
 }
 
-static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a) {
+static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a, bool top_only = false) {
     if (a->nx < 1 || a->ny < 1 || a->nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
     const i64 G = a->nx * a->ny * a->nz;
     if (a->nx * a->ny >= (1ll << 27) || G >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid too large");
     if (a->topology == OTMB_UNKNOWN_TOPOLOGY) return otmb_fail(ctx, OTMB_ERR_UNKNOWN_TOPOLOGY);
     if (a->topology != OTMB_BIPOLAR && a->topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     for (int f = 0; f < 6; ++f)
-        if (!a->phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
+        if (!a->phi[f] && !(top_only && f != OTMB_TOP)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
     for (int d = 0; d < 4; ++d)
         if (!a->edge_length[d] || !a->dist_nbr[d]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "metrics");
     if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst)
@@ -1215,11 +1222,46 @@ int32_t otmb_transportmatrix_nnz(otmb_ctx *ctx, int64_t nnz[5]) {
 // One pass, asynchronous: the caller provides output buffers of known capacity (nnz per column is at
 // most 7, 7, 5, 3, 3 for T, Tadv, TκH, TκVML, TκVdeep).  Errors and the nnz are collected afterwards by
 // otmb_transportmatrix_result (which synchronises).
+struct TmFused { const void *umo = nullptr, *vmo = nullptr; double fill = 0.0; int kind = 0; };  // kind: 0 none, 1 Float64, 2 Float32
+static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *const colptr[5], int64_t *const rowval[5],
+                                        double *const nzval[5], const int64_t capacity[5], const TmFused &fu);
+
 int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *const colptr[5],
                                  int64_t *const rowval[5], double *const nzval[5], const int64_t capacity[5]) {
+    return transportmatrix_dev_impl(ctx, a, colptr, rowval, nzval, capacity, TmFused());
+}
+
+// The fused device-resident step (include/otmb.h): facefluxes that stores ϕtop only (+ the tile counts), then scan + fill with the other
+// five fluxes re-derived from umo / vmo where they are used.  Same five matrices bit for bit as otmb_facefluxes_counts_dev +
+// otmb_transportmatrix_dev; 64 bytes per cell less HBM traffic.
+int32_t otmb_step_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, double fill, const uint8_t *wetflags,
+                      const void *count_tables, double *phi_top, const otmb_tm_args *a, int64_t *const colptr[5], int64_t *const rowval[5],
+                      double *const nzval[5], const int64_t capacity[5]) {
+    if (!ctx || !umo || !vmo || !wetflags || !count_tables || !phi_top || !a) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (a->nx < 3 || a->nz > 128 || ctx->count_in_ff == 0 || a->n_wet <= 0)
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_step_dev needs nx >= 3, nz <= 128, wet cells and the counts in facefluxes (OTMB_COUNT_IN_FF)");
+    otmb_tm_args b = *a;
+    for (int f = 0; f < 6; ++f) b.phi[f] = nullptr;
+    b.phi[OTMB_TOP] = phi_top;
+    b.push_mask = (const uint16_t *)phi_top;  // the token the counts are keyed to (never read as a mask)
+    int32_t rc;
+    if ((rc = validate_args(ctx, &b, true))) return rc;
+    otmb_ff_counts cnt;
+    cnt.tables = count_tables; cnt.lwet3d = b.lwet3d; cnt.mlotst = b.mlotst; cnt.zt = b.zt; cnt.n_wet = b.n_wet;
+    cnt.upwind = b.upwind; cnt.only_t = b.only_t;
+    double *phi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    phi[OTMB_TOP] = phi_top;
+    if ((rc = otmb_facefluxes_top_counts(ctx, umo, vmo, src_is_f32, wetflags, fill, b.nx, b.ny, b.nz, b.topology, phi, (uint16_t *)phi_top, &cnt))) return rc;
+    TmFused fu;
+    fu.umo = umo; fu.vmo = vmo; fu.fill = fill; fu.kind = src_is_f32 ? 2 : 1;
+    return transportmatrix_dev_impl(ctx, &b, colptr, rowval, nzval, capacity, fu);
+}
+
+static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *const colptr[5], int64_t *const rowval[5],
+                                        double *const nzval[5], const int64_t capacity[5], const TmFused &fu) {
     if (!ctx || !a || !colptr || !rowval || !nzval || !capacity) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
     int32_t rc;
-    if ((rc = validate_args(ctx, a))) return rc;
+    if ((rc = validate_args(ctx, a, fu.kind != 0))) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
     // Default: COUNT -> tile scan -> FILL enqueued back to back with no host round trip (the totals stay on the
@@ -1228,8 +1270,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
 #define OTMB_DEFAULT_LOOKBACK 0
 #endif
     static const bool env_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e ? e[0] == '1' : (OTMB_DEFAULT_LOOKBACK != 0); }();
-    const bool dense = ntiles > 0 && use_dense(ctx, *a);
-    const bool use_lookback = env_lookback && !dense;
+    const bool dense = ntiles > 0 && use_dense(ctx, *a) && fu.kind == 0;   // (the fused step exists for the gather kernels only)
+    const bool use_lookback = env_lookback && !dense && fu.kind == 0;
     const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);  // look-back words + prefixes (+ ticket)
     if (use_lookback) {
         if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
@@ -1244,6 +1286,7 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
     pl.ntiles = ntiles;
     TmParams p;
     fill_params(p, *a, ctx, &pl);
+    p.umo = fu.umo; p.vmo = fu.vmo; p.fillv = fu.fill; p.fused = fu.kind;
     for (int m = 0; m < 5; ++m) {
         const bool wanted = (m == 0) || !a->only_t;
         if (wanted && (!colptr[m] || !rowval[m] || !nzval[m])) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
@@ -1307,6 +1350,8 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
             // the counts came with the fluxes (otmb_facefluxes_counts_dev): no counting pass, the scan unpacks them
             ffc_consume(ctx, fbuf, p, (i64 *)ctx->tm_offs.p, dtot, gsum, ntiles, !infill);
             if (infill) p.gsum = gsum;
+        } else if (fu.kind != 0) {
+            return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "otmb_step_dev: the counts of its own facefluxes are not there (depth slab?)");
         } else {
             if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
             if (p.count_order == 2 && (rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
@@ -1330,7 +1375,9 @@ int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *a, int64_t *
 #endif
             if ((rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
             KernelTimer kt(ctx, K_TM_FILL);
-            hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            if (fu.kind == 1) hipLaunchKernelGGL((tm_kernel<MODE_FILL, 1>), dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            else if (fu.kind == 2) hipLaunchKernelGGL((tm_kernel<MODE_FILL, 2>), dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            else hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

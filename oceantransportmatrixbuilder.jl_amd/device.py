@@ -276,6 +276,38 @@ class DeviceAssembler:
         self._ff_pending = getattr(self, "_ff_pending", 0) + 1
         return out
 
+    def step_fused_async(self, umo, vmo, fill, out=None):
+        """Extension (otmb_step_dev): one pass from (umo, vmo) to the five matrices WITHOUT the six ϕ arrays in memory -- only ϕtop is stored,
+        the fill pass re-derives the other five fluxes from umo / vmo where it uses them.  The same matrices bit for bit as step_async, 64
+        bytes per cell less HBM traffic.  Not the drop-in path: facefluxesfrommasstransport returns the six arrays."""
+        if getattr(self, "_ff_pending", 0) >= self.PIPELINE_DEPTH:
+            self.finish()
+        if getattr(self, "phi_top", None) is None:
+            self.phi_top = self._empty(self.G, torch.float64)
+        if out is None and (self.out is None or getattr(self, "_out_cap", None) is None):
+            self.out = self.new_output_set()
+            self._out_cap = [self.N * k + 1 for k in self.PER_COLUMN_MAX]
+        if out is None:
+            out = self.out
+        if self.wet3d._version != self._wetflags_version:
+            self.ctx.check(self.lib.otmb_wetflags_dev(self.ctx.handle, self.wet3d.data_ptr(), self.nx, self.ny, self.nz, self.topology,
+                                                      self.wetflags.data_ptr()))
+            self._wetflags_version = self.wet3d._version
+            self._count_tables()
+        self._mask_key = None
+        a = self._args([self.phi_top] * 6)
+        cp = capi.ptr_array(5, [out[m][0].data_ptr() for m in MATS])
+        rv = capi.ptr_array(5, [out[m][1].data_ptr() for m in MATS])
+        nz = capi.ptr_array(5, [out[m][2].data_ptr() for m in MATS])
+        caps = (C.c_int64 * 5)(*[self.N * k + 1 for k in self.PER_COLUMN_MAX])
+        self._note("_ff_seq")
+        self.ctx.check(self.lib.otmb_step_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), float(fill),
+                                              self.wetflags.data_ptr(), self.count_tables.data_ptr(), self.phi_top.data_ptr(), C.byref(a),
+                                              C.byref(cp), C.byref(rv), C.byref(nz), C.byref(caps)))
+        self._note("_tm_seq")
+        self._ff_pending = getattr(self, "_ff_pending", 0) + 1
+        return out
+
     def finish(self):
         """Drain the pipeline: the earliest failing step wins; within a step facefluxes' assertion comes first, as in
         the reference (facefluxes runs before transportmatrix)."""

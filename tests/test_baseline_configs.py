@@ -177,6 +177,18 @@ def test_large_grid_properties_and_subslab_oracle(oracle, workload, slab, protoc
     if workload == "quarterdeg":
         _subslab_oracle_check(oracle, dg, asm, 0, 1)
         _subslab_oracle_check(oracle, dg, asm, dg.nz - 1, dg.nz)
+        # the fused step (otmb_step_dev: only ϕtop stored) into a second output set: the same matrices bit for bit, at full size
+        nnz_two_call, first = list(asm.nnz), asm.out
+        second = asm.new_output_set()
+        asm.step_fused_async(dg.umo, dg.vmo, dg.fill, out=second)
+        asm.finish()
+        assert asm.nnz == nnz_two_call
+        assert torch.equal(asm.phi_top, asm.phi[4])
+        for kk, m in enumerate(MATS):
+            assert torch.equal(second[m][0], first[m][0]), m
+            assert torch.equal(second[m][1][: asm.nnz[kk]], first[m][1][: asm.nnz[kk]]), m
+            assert torch.equal(second[m][2][: asm.nnz[kk]].view(torch.int64), first[m][2][: asm.nnz[kk]].view(torch.int64)), m
+        del second, first
     del asm, dg
     torch.cuda.empty_cache()
 
@@ -222,6 +234,23 @@ def test_access1deg_bolus_gm_velocity_matches_oracle(access1deg, oracle):
         assert rel.mean() >= 0.99999, (name, 1 - rel.mean())
         typical = np.median(np.abs(r[fin][r[fin] != 0]))
         np.testing.assert_allclose(h, r, rtol=1e-12, atol=1e-12 * typical, equal_nan=True, err_msg=name)
+
+
+def test_access1deg_fused_step_matches_oracle_bit_for_bit(access1deg, access1deg_ref, oracle):
+    """The fused device-resident step (otmb_step_dev: only ϕtop stored) on the whole 1 degree grid: the five matrices of the oracle."""
+    from otmb_amd.device import DeviceAssembler
+
+    g, gm = access1deg
+    idx, rphi = access1deg_ref
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep, upwind=True)
+    asm.step_fused_async(_flat(g.umo.data), _flat(g.vmo.data), 1e20)
+    asm.finish()
+    got = asm.result_to_host()
+    ref = oracle.transportmatrix(rphi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    for m in MATS:
+        assert_csc_equal(got[m], ref[m], m)
+    assert np.array_equal(asm.phi_top.cpu().numpy(), rphi["top"].ravel(order="F"))
 
 
 # ---- SURVEY section 8(f) rows at the 1 degree grid's size (they were GPU-tested on small grids only) ------------------------------

@@ -25,7 +25,7 @@ for r in $(seq 1 "$ROUNDS"); do
         --repeats 3 --placement-candidates 1 $BENCH_FLAGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.load(sys.stdin)
-print(json.dumps({'tag':'$name','round':$r,'workload':'$WL','ms_per_step':round(d['ms_per_step'],4),'kernels_ms':{k:round(x,4) for k,x in d['kernels_ms'].items()},'frac':round(d['roofline']['frac'],4),'box':{k:(round(x,4) if isinstance(x,float) else x) for k,x in (d['roofline'].get('box') or {}).items() if isinstance(x,(float,dict))}}))" | tee -a "$OUT/$TAG.jsonl"
+print(json.dumps({'tag':'$name','round':$r,'workload':'$WL','ms_per_step':round(d['ms_per_step'],4),'kernels_ms':{k:round(x,4) for k,x in d['kernels_ms'].items()},'frac':round(d['roofline']['frac'],4),'fused':({'ms_per_step':round(d['fused_step']['ms_per_step'],4),'kernels_ms':{k:round(x,4) for k,x in d['fused_step']['kernels_ms'].items()}} if isinstance(d.get('fused_step'),dict) and 'ms_per_step' in d['fused_step'] else d.get('fused_step')),'box':{k:(round(x,4) if isinstance(x,float) else x) for k,x in (d['roofline'].get('box') or {}).items() if isinstance(x,(float,dict))}}))" | tee -a "$OUT/$TAG.jsonl"
     rc=$?; if [ $rc -ne 0 ]; then echo "($WL $name rc=$rc)" | tee -a "$OUT/$TAG.jsonl"; fi
   done
 done
