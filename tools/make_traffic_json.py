@@ -18,7 +18,16 @@ import bench
 
 dst = sys.argv[1]
 os.makedirs(dst, exist_ok=True)
-names = {"tm_kernel<1>": "tm_kernel<fill>", "tm_count_kernel": "tm_count_kernel", "facefluxes_kernel": "facefluxes_kernel"}
+# kernel name patterns of the PMC summary -> the names bench.py uses (round 5: the fill pass is tm_kernel<1, 0>, the fused step's variants
+# -- tm_kernel<1, 1 | 2> and the ϕtop-only facefluxes, whose last template argument is true -- get their own entries)
+names = {"tm_kernel<1>": "tm_kernel<fill>", "tm_kernel<1, 0>": "tm_kernel<fill>", "tm_kernel<1, 1>": "tm_kernel<fill, fused>",
+         "tm_kernel<1, 2>": "tm_kernel<fill, fused>", "tm_count_kernel": "tm_count_kernel"}
+
+
+def ff_name(k):
+    if "facefluxes_kernel" not in k:
+        return None
+    return "facefluxes_kernel<top only>" if re.search(r",\s*true\s*>\s*$", k.strip()) and k.count(",") >= 5 else "facefluxes_kernel"
 out = {
     "_comment": "HBM-side bytes per launch from rocprofv3 PMC passes (tools/profile.sh = `bench.py --steps 10 --warmup 2`, separate passes for "
                 "FETCH_SIZE and WRITE_SIZE).  gfx950 correction: fetch_bytes = 2 x FETCH_SIZE (every TCC_EA0_RDREQ is a 128-byte request "
@@ -43,8 +52,11 @@ for arg in sys.argv[2:]:
                 kern.setdefault(cur, {})[m.group(1)] = float(m.group(2))
     rec = {}
     for k, d in kern.items():
-        for pat, name in names.items():
-            if pat in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        cands = [name for pat, name in names.items() if pat in k]
+        if ff_name(k):
+            cands.append(ff_name(k))
+        for name in cands:
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 fb, wb = 2 * 1024 * d["FETCH_SIZE"], 1024 * d["WRITE_SIZE"]
                 rec[name] = dict(fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb + wb, rdreq_128B=d.get("TCC_EA0_RDREQ_sum"),
                                  wrreq=d.get("TCC_EA0_WRREQ_sum"), wrreq_64B=d.get("TCC_EA0_WRREQ_64B_sum"))
