@@ -220,6 +220,31 @@ int32_t otmb_count_tables_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_
 int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32,
                                    const uint8_t *wetflags, double fill, int64_t nx, int64_t ny, int64_t nz,
                                    int32_t topology, double *const phi[6], uint16_t *push_mask, const otmb_ff_counts *counts);
+/* The same for a depth slab (otmb_facefluxes_slab_dev / _rows_dev: SURVEY 8e, the chain over depth slabs).  The slab's nz levels are
+ * levels [k_own0, k_own0 + nz) of its EXTENDED local grid of nz_ext levels -- the owned levels plus one halo level above (k_own0 = 1)
+ * and / or below (k_own0 + nz < nz_ext), whose cells are neighbours of owned cells and rows of the slab's matrices but not columns.
+ * wetflags (otmb_wetflags_dev of the extended grid's mask), counts->zt and counts->lwet3d are arrays of the EXTENDED grid, exactly the
+ * ones the slab's otmb_tm_args will name; umo, vmo, phi[6], push_mask and top_below hold the owned levels only, as for
+ * otmb_facefluxes_rows_dev.  counts->n_wet: the slab's owned wet cells; wet_base: the global 0-based wet rank of the first of them
+ * (otmb_transportmatrix_set_slab).  The transportmatrix call that may skip its counting pass is the one whose arguments are the extended
+ * arrays these owned-level pointers lie in (phi[d] - k_own0 * nx * ny, ...), after the halo planes' fluxes have been put in place.
+ * j0, j1, first: a row band, as for otmb_facefluxes_rows_dev (bands other than the whole plane count only under the four-row wave
+ * geometry of large planes; otherwise -- and wherever otmb_facefluxes_counts_dev falls back -- the mask is written and nothing is
+ * counted).                                                                                                                       */
+typedef struct {
+    int64_t k_own0;   /* first owned level inside the extended local grid (0-based): 0 or 1 */
+    int64_t nz_ext;   /* levels of the extended local grid (<= nz + 2) */
+    int64_t wet_base; /* global 0-based wet rank of the slab's first owned wet cell */
+} otmb_ff_slab;
+int32_t otmb_count_tables_slab_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet,
+                                   int64_t nx, int64_t ny, int64_t nz, int32_t topology, const otmb_ff_slab *slab, void *tables);
+int32_t otmb_facefluxes_slab_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wetflags,
+                                        double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6],
+                                        const double *top_below, uint16_t *push_mask, const otmb_ff_counts *counts,
+                                        const otmb_ff_slab *slab, int64_t j0, int64_t j1, int32_t first);
+/* 1 when the last facefluxes call on this context counted (its push_mask argument was therefore not written, and need not be completed
+ * for halo planes by otmb_push_mask_dev), 0 when it took the plain kernel or the counts have been consumed.  No device work.   */
+int32_t otmb_facefluxes_counts_pending(const otmb_ctx *ctx);
 /* The same two flags for EVERY facefluxes call on this context since the previous call of this function, oldest
  * first (a pipeline of asynchronous steps: the reference asserts per call, src/velocities.jl:199-200, so a field
  * without a single valid value in step 3 of 12 must not be hidden by steps 4-12).  Synchronises.  At most the 64

@@ -51,6 +51,10 @@ class FfCounts(C.Structure):
                 ("n_wet", C.c_int64), ("upwind", C.c_int32), ("only_t", C.c_int32)]
 
 
+class FfSlab(C.Structure):
+    _fields_ = [("k_own0", C.c_int64), ("nz_ext", C.c_int64), ("wet_base", C.c_int64)]
+
+
 # every symbol include/otmb.h declares: (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -106,6 +110,10 @@ SYMBOLS = {
     "otmb_count_tables_bytes": (C.c_int64, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "otmb_count_tables_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _vp]),
     "otmb_facefluxes_counts_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp, C.POINTER(FfCounts)]),
+    "otmb_count_tables_slab_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(FfSlab), _vp]),
+    "otmb_facefluxes_slab_counts_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6), _vp,
+                                                    _vp, C.POINTER(FfCounts), C.POINTER(FfSlab), C.c_int64, C.c_int64, C.c_int32]),
+    "otmb_facefluxes_counts_pending": (C.c_int32, [_vp]),
     "otmb_push_mask_dev": (C.c_int32, [_vp, C.POINTER(_vp * 6), _vp, C.c_int64, C.c_int64, _vp]),
     "otmb_lump_and_spray_plan_dev": (C.c_int32, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp,
                                                   C.c_int64, C.c_int64, C.c_int64, _ip]),

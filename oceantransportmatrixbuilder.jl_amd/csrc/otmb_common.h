@@ -68,8 +68,10 @@ struct otmb_ctx {
         const void *phi[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         const void *mask = nullptr, *mlotst = nullptr, *zt = nullptr, *lwet3d = nullptr;
         const void *stat = nullptr;  // the grid's static per-tile counts (otmb_count_tables_dev), added by the scan
-        int64_t nx = 0, ny = 0, nz = 0, n_wet = 0;
+        int64_t nx = 0, ny = 0, nz = 0, n_wet = 0;  // (nz: of the grid the transportmatrix sees -- a depth slab's extended local grid)
+        int64_t k_own0 = 0, wet_base = 0;           // depth slab: phi / mask name its owned levels, k_own0 levels into the extended arrays
         int topo = -1, upwind = -1, only_t = -1;
+        bool pieces_open = false;  // the last facefluxes call counted: a further row band of it (otmb_facefluxes_slab_counts_dev, first = 0) adds to the same buffer
     } ffc;
     const void *ffc_partial_mask = nullptr;  // the push_mask argument of the last counting facefluxes call: NOT written by it, never a counting pass's input
     int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)

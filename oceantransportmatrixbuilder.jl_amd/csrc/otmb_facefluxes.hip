@@ -70,13 +70,15 @@ struct FfCountArgs {
     unsigned long long *sums;  // packed per-tile counts (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10): this kernel adds Tadv and TκVML
     int upwind, only_t;
     int nseg;                  // wave segments per level
+    int halo;                  // depth slab: bit 0 -- a level above the first one exists (wet flags at level -1, zt[-1]), bit 1 -- one below the last
 };
 #define FFC_MAX_NZ 128  // a wave keeps its per-level table entries and zt in registers, lane l = level l and level 64 + l
 struct FfCountState {
     double mld;
     unsigned seg;
     unsigned base_lo, base_hi;  // lane l: 0-based wet rank of the first wet cell of this wave's segment at level l / 64 + l
-    double zt_lo, zt_hi;        // lane l: zt[l] / zt[64 + l]
+    double zt_lo, zt_hi;        // lane l: zt[l - ha] / zt[64 + l - ha] (ha = 1 when a halo level lies above: its depth is needed too)
+    bool ha, hb;                // (uniform) a halo level above the first / below the last level: depth slab of a deeper grid
     bool om_cur, om_below;      // zt[k] < mlotst for the level being counted / the level below it (a window that moves up with the march)
     unsigned amask;            // seam row: flag bit (E / W) of the row-mate the fold neighbour coincides with, else 0
     bool aclear;               // seam row: the fold neighbour is the east / west row-mate or the cell itself: it has no slot of its own
@@ -119,7 +121,7 @@ __device__ __forceinline__ void ff_count_level(const FfCountArgs &cnt, FfCountSt
     const bool wet = cs.act & wc;
     const u64 wetb = __builtin_amdgcn_ballot_w64(wet);
     if (wetb != 0) {  // (uniform)
-        const bool hA = k > 0, hB = k + 1 < nz;
+        const bool hA = k > 0 || cs.ha, hB = k + 1 < nz || cs.hb;
         const unsigned vw = ((hA && (fa & WF_C)) ? 32u : 0u) | ((hB && cs.wet_below) ? 64u : 0u);  // wet cells above / below
         // the flux the north neighbour pushes with, signed so that "towards c" is positive: ϕsouth[N] = ϕnorth[c]; through the seam -ϕnorth[fold]
         double nn = n;
@@ -151,7 +153,7 @@ __device__ __forceinline__ void ff_count_level(const FfCountArgs &cnt, FfCountSt
         // TκVML: only within the mixed layer -- Ω[c] = zt[k] < mlotst (:85; NaN compares false), and the same for the cells above / below
         const bool omC = wet & cs.om_cur;
         if (__builtin_amdgcn_ballot_w64(omC) != 0) {  // (uniform)
-            const bool om_above = ff_level_f64(cs.zt_lo, cs.zt_hi, hA ? k - 1 : k) < cs.mld;
+            const bool om_above = ff_level_f64(cs.zt_lo, cs.zt_hi, (hA ? k - 1 : k) + (int)cs.ha) < cs.mld;
             const unsigned ml = ((om_above ? 32u : 0u) | (cs.om_below ? 64u : 0u)) & vw;
             const unsigned y = omC ? __popc(ml) + (ml != 0) : 0u;
             const unsigned sy = ff_wave_sum(in0 ? y : (y << 16));
@@ -170,14 +172,25 @@ __device__ __forceinline__ void ff_count_level(const FfCountArgs &cnt, FfCountSt
     cs.wet_below = wc;
     // the mixed-layer window moves up one level
     cs.om_below = cs.om_cur;
-    cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, k > 0 ? k - 1 : 0) < cs.mld;
+    cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, k > 0 ? k - 1 + (int)cs.ha : 0) < cs.mld;
+}
+
+// Before the march: the column's mixed-layer depth, the window at the deepest level and -- depth slab with a halo level below -- that
+// level's wet flag and its place in the mixed layer.
+__device__ __forceinline__ void ff_count_begin(const FfCountArgs &cnt, FfCountState &cs, const uint8_t *__restrict__ wet, unsigned s, i64 P, int nz) {
+    cs.mld = cnt.mlotst[s];
+    cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, nz - 1 + (int)cs.ha) < cs.mld;
+    if (cs.hb) {  // (uniform)
+        cs.wet_below = (wet[(i64)nz * P + s] & WF_C) != 0;
+        cs.om_below = ff_level_f64(cs.zt_lo, cs.zt_hi, nz + (int)cs.ha) < cs.mld;
+    }
 }
 
 // load_vs (wave-uniform): false when the wave's south row comes from the neighbouring wave through LDS (ff_south_from_lds)
 template <typename T, bool FLAGS, bool COUNTS = false>
 __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo, const T *__restrict__ vmo,
                                         const uint8_t *__restrict__ wet, const FfCol &col, i64 P, int k0, bool load_vs = true,
-                                        bool load_vn = false) {
+                                        bool load_vn = false, int kup_min = 0) {
 #pragma unroll
     for (int q = 0; q < FF_KB; ++q) {
         const int k = (k0 - q >= 0) ? k0 - q : 0;  // clamped: loads are unconditional, the level is skipped later
@@ -194,7 +207,7 @@ __device__ __forceinline__ void ff_load(FfChunk<T> &c, const T *__restrict__ umo
         }
     }
     if (COUNTS) {  // the wet flag above the chunk's last level (the next chunk's first level: not waited for here)
-        const int ku = (k0 - FF_KB >= 0) ? k0 - FF_KB : 0;
+        const int ku = (k0 - FF_KB >= 0) ? k0 - FF_KB : kup_min;  // (kup_min = -1: the halo level above a depth slab)
         c.wup = ff_ld(wet + (i64)ku * P, col.s);
     }
 }
@@ -245,7 +258,8 @@ __device__ __forceinline__ void ff_levels(const FfChunk<T> &c, const FfCol &col,
             }
             topbelow = t;
             if (COUNTS) {
-                const unsigned fa = (q + 1 < FF_KB) ? c.wc[q + 1] : c.wup;  // the cell above (level k - 1; unused at k == 0)
+                // the cell above (level k - 1; at k == 0 it is the halo level above a depth slab -- c.wup -- or unused)
+                const unsigned fa = (q + 1 < FF_KB && k > 0) ? c.wc[q + 1] : c.wup;
                 ff_count_level(cnt, cs, k, nz, wc, f, fa, e, w, so, n, b, t, cs.has_fold ? (double)c.vn[q] : 0.0, fill);
             }
         }
@@ -274,9 +288,10 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
     // entries and zt through the scalar cache -- as a vector load the table entry made every level wait for ALL outstanding vector memory
     // operations (s_waitcnt vmcnt(0)), i.e. for the next chunk's prefetch
     const uint32_t *__restrict__ c_bases, const double *__restrict__ c_mlotst, const double *__restrict__ c_zt, unsigned long long *c_sums,
-    int c_upwind, int c_only_t, int c_nseg) {
+    int c_upwind, int c_only_t, int c_nseg, int c_halo) {
     FfCountArgs cnt;
     cnt.bases = c_bases; cnt.mlotst = c_mlotst; cnt.zt = c_zt; cnt.sums = c_sums; cnt.upwind = c_upwind; cnt.only_t = c_only_t; cnt.nseg = c_nseg;
+    cnt.halo = c_halo;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  In blockIdx order a wave's south row
     // (vmo[s - nx], nx / 64 blocks back) and the west cell of its first lane (the previous block) belong to workgroups of OTHER XCDs:
     // every XCD's L2 then fetches vmo twice and a quarter of umo again (profiles/r03: 3.27 GB fetched for 1.98 GB of inputs at
@@ -305,8 +320,10 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
         seg = ((j < (unsigned)ny) ? j : (unsigned)ny - 1) * nchunk + chunk;
     }
     bool uvalid = false, vvalid = false;
+    const int kup_min = (COUNTS && (c_halo & 1)) ? -1 : 0;
     FfCountState cs;
     cs.mld = 0.0; cs.seg = 0; cs.base_lo = cs.base_hi = 0; cs.zt_lo = cs.zt_hi = 0.0; cs.om_cur = cs.om_below = false; cs.amask = 0; cs.aclear = false; cs.fold = false; cs.has_fold = false; cs.act = false; cs.wet_below = false;
+    cs.ha = cs.hb = false;
     if (COUNTS) {
         cs.seg = (unsigned)__builtin_amdgcn_readfirstlane((int)seg);
         cs.act = inside;
@@ -319,7 +336,10 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
             const unsigned lane = threadIdx.x & 63, l0 = (lane < (unsigned)nz) ? lane : (unsigned)nz - 1, l1 = (64 + lane < (unsigned)nz) ? 64 + lane : (unsigned)nz - 1;
             const uint32_t *mine = cnt.bases + 1 + (size_t)cs.seg * (size_t)nz;
             cs.base_lo = mine[l0]; cs.base_hi = mine[l1];
-            cs.zt_lo = cnt.zt[l0]; cs.zt_hi = cnt.zt[l1];
+            // zt of levels -ha ... nz - 1 + hb (a depth slab's halo levels take part in the mixed-layer test of their neighbours, :85)
+            cs.ha = (cnt.halo & 1) != 0; cs.hb = (cnt.halo & 2) != 0;
+            const int zmax = nz - 1 + (int)cs.hb, z0 = (int)lane - (int)cs.ha, z1 = 64 + (int)lane - (int)cs.ha;
+            cs.zt_lo = cnt.zt[z0 < zmax ? z0 : zmax]; cs.zt_hi = cnt.zt[z1 < zmax ? z1 : zmax];
         }
         if (cnt.bases[0] != FFC_HEADER(ROWS, cnt.nseg)) {  // a table for another wave geometry: count nothing, and say so
             if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(cnt.sums, FFC_BAD_TABLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
         col.cS = col.hS ? sc - nx : sc;
         col.cN = (jc + 1 < (unsigned)ny) ? sc + nx : (fold ? row + (nx - 1 - ic) : sc);
         double topbelow = top_below ? top_below[sc] : 0.0;
-        if (COUNTS) { cs.mld = cnt.mlotst[sc]; cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, nz - 1) < cs.mld; }
+        if (COUNTS) ff_count_begin(cnt, cs, wet, sc, P, nz);
         const bool own_vs = r == 0;  // (wave-uniform) the first row of the workgroup has its south row in another workgroup
         FfChunk<T> A, B;
         int k0 = nz - 1, buf = 0;
@@ -359,19 +379,24 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
             }
             buf ^= 1;  // (the next chunk writes the other half: one barrier per chunk is enough, see the ordering argument in DESIGN.md 3.2)
         };
-        ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, own_vs, cs.has_fold);
+        ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, own_vs, cs.has_fold, kup_min);
         while (k0 >= 0) {
-            ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold);
+            ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold, kup_min);
             south_from_lds(A);
             ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
             if (k0 < 0) break;
-            ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold);
+            ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, own_vs, cs.has_fold, kup_min);
             south_from_lds(B);
             ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
         }
     } else if (inside || COUNTS) {  // (COUNTS: every lane takes part in the wave sums; lanes beyond the plane march along on the last column and store nothing)
+        if (COUNTS && ROWS > 1 && !inside) {  // (ROWS == 1 clamped s above) lanes beyond the row or the plane: clamped addresses, as in the LDS branch
+            i = (i < (unsigned)nx) ? i : (unsigned)nx - 1;
+            j = (j < (unsigned)ny) ? j : (unsigned)ny - 1;
+            s = j * (unsigned)nx + i;
+        }
         const unsigned row = j * (unsigned)nx;
         FfCol col;
         col.s = s;
@@ -385,16 +410,16 @@ __global__ __launch_bounds__(FF_THREADS * ROWS) __attribute__((amdgpu_waves_per_
         // seafloor ϕbottom is zero (:238); for a depth slab that is not the deepest, the plane handed up
         // by the slab below (its ϕtop at its first level) continues the chain without re-association
         double topbelow = top_below ? top_below[s] : 0.0;
-        if (COUNTS) { cs.mld = cnt.mlotst[s]; cs.om_cur = ff_level_f64(cs.zt_lo, cs.zt_hi, nz - 1) < cs.mld; }
+        if (COUNTS) ff_count_begin(cnt, cs, wet, s, P, nz);
         FfChunk<T> A, B;
         int k0 = nz - 1;
-        ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, true, cs.has_fold);
+        ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0, true, cs.has_fold, kup_min);
         while (k0 >= 0) {
-            ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold);
+            ff_load<T, FLAGS, COUNTS>(B, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold, kup_min);
             ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(A, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
             if (k0 < 0) break;
-            ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold);
+            ff_load<T, FLAGS, COUNTS>(A, umo, vmo, wet, col, P, k0 - FF_KB, true, cs.has_fold, kup_min);
             ff_levels<T, FLAGS, NT, COUNTS, TOPONLY>(B, col, P, k0, fill, topbelow, uvalid, vvalid, east, west, north, south, top, bottom, push_mask, inside, cnt, cs, nz);
             k0 -= FF_KB;
         }
@@ -434,8 +459,9 @@ static i64 ff_nseg(int rows, i64 nx, i64 ny) {
 }
 
 // one wave per (level, segment): the 0-based wet rank of the segment's first wet cell (Lwet3D is the wet rank, src/matrixbuilding.jl:19-20)
+// (depth slab: lw points at the slab's first owned level, rank_base is the global rank of its first owned wet cell)
 __global__ __launch_bounds__(256) void ff_count_bases_kernel(const i64 *__restrict__ lw, int nx, int ny, int nz, i64 P, int rows, int nseg,
-                                                             uint32_t *__restrict__ bases) {
+                                                             i64 rank_base, uint32_t *__restrict__ bases) {
     const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
     if (gw == 0 && lane == 0) bases[0] = FFC_HEADER(rows, nseg);
@@ -455,7 +481,7 @@ __global__ __launch_bounds__(256) void ff_count_bases_kernel(const i64 *__restri
     const u64 b = __builtin_amdgcn_ballot_w64(v != 0);
     const int first = b ? __builtin_ctzll(b) : 0;
     const i64 r = __shfl(v, first);
-    if (lane == 0) bases[1 + seg * nz + k] = b ? (uint32_t)(r - 1) : 0u;  // [segment][level]: a wave of facefluxes reads its nz entries in one go
+    if (lane == 0) bases[1 + seg * nz + k] = b ? (uint32_t)(r - 1 - rank_base) : 0u;  // [segment][level]: a wave of facefluxes reads its nz entries in one go
 }
 
 // The counts that depend on the wet mask alone, per tile of 256 consecutive wet cells (one workgroup per tile, one thread per column):
@@ -497,7 +523,9 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
                                const uint8_t *wet3d, double fill, int64_t nx, int64_t ny, int64_t nz,
                                int32_t topology, double *const phi[6], const double *top_below, uint16_t *push_mask,
                                bool check_missing, bool flags = false, const otmb_ff_counts *counts = nullptr, int64_t j0 = 0, int64_t j1 = -1,
-                               bool same_call = false, bool top_only = false) {
+                               bool same_call = false, bool top_only = false, const otmb_ff_slab *slab = nullptr) {
+    // slab (with counts): the nz levels are levels [k_own0, k_own0 + nz) of an extended local grid of nz_ext levels; wet3d (the flag bytes),
+    // counts->zt and counts->lwet3d are arrays of THAT grid, everything else holds the owned levels only
     // j0, j1: rows [j0, j1) of the plane only (j1 < 0: all of them); same_call: a further piece of the facefluxes call that the
     // previous piece began -- the validity flags of the pieces accumulate in ONE pair of words
     if (!ctx || !umo || !vmo || !wet3d || !phi) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
@@ -520,36 +548,47 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
                                   : (unsigned)(((nx + FF_THREADS - 1) / FF_THREADS) * ((j1 - j0 + rows - 1) / rows));
     // any facefluxes call on this context ends the validity of counts an earlier call left behind (they are keyed to ff_gen), and a full
     // mask written over a partial one makes that array an ordinary push mask again
-    ctx->ffc.valid = false;
+    const bool later_piece = same_call && counts && ctx->ffc.pieces_open;  // a further row band of a counting call: same buffer, same key
+    if (!later_piece) ctx->ffc.valid = false;
+    ctx->ffc.pieces_open = false;
     if (push_mask && push_mask == ctx->ffc_partial_mask && !counts) ctx->ffc_partial_mask = nullptr;
     FfCountArgs ca;
     memset(&ca, 0, sizeof ca);
     const bool with_counts = counts != nullptr;
+    const i64 k_own0 = slab ? slab->k_own0 : 0, nz_ext = slab ? slab->nz_ext : nz;
     if (with_counts) {
-        // (the caller -- otmb_facefluxes_counts_dev -- has checked that this grid can be counted here)
+        // (the caller -- otmb_facefluxes_counts_dev / _slab_counts_dev -- has checked that this grid can be counted here)
         const i64 ntiles = (counts->n_wet + (1ll << FFC_TILE_SHIFT) - 1) >> FFC_TILE_SHIFT;
-        const int buf = ctx->ffc_next;
-        ctx->ffc_next ^= 1;
         const size_t need = (size_t)(ntiles + 2) * sizeof(unsigned long long);
-        if (!ctx->ffc_sums[buf].p || ctx->ffc_sums[buf].cap < need) {
-            int32_t rc;
-            if ((rc = otmb_reserve(ctx, ctx->ffc_sums[buf], need))) return rc;
-            ctx->ffc_dirty[buf] = true;
+        int buf;
+        if (later_piece) {
+            buf = ctx->ffc.buf;
+        } else {
+            buf = ctx->ffc_next;
+            ctx->ffc_next ^= 1;
+            if (!ctx->ffc_sums[buf].p || ctx->ffc_sums[buf].cap < need) {
+                int32_t rc;
+                if ((rc = otmb_reserve(ctx, ctx->ffc_sums[buf], need))) return rc;
+                ctx->ffc_dirty[buf] = true;
+            }
+            if (ctx->ffc_dirty[buf]) HIP_TRY(ctx, hipMemsetAsync(ctx->ffc_sums[buf].p, 0, need, ctx->stream));
+            ctx->ffc_dirty[buf] = true;  // until a scan has consumed (and zeroed) it
         }
-        if (ctx->ffc_dirty[buf]) HIP_TRY(ctx, hipMemsetAsync(ctx->ffc_sums[buf].p, 0, need, ctx->stream));
-        ctx->ffc_dirty[buf] = true;  // until a scan has consumed (and zeroed) it
-        ca.bases = (const uint32_t *)counts->tables; ca.mlotst = counts->mlotst; ca.zt = counts->zt;
+        ca.bases = (const uint32_t *)counts->tables; ca.mlotst = counts->mlotst; ca.zt = counts->zt + k_own0;
         ca.sums = (unsigned long long *)ctx->ffc_sums[buf].p;
         ca.upwind = counts->upwind; ca.only_t = counts->only_t;
         ca.nseg = (int)ff_nseg(rows, nx, ny);
+        ca.halo = (k_own0 > 0 ? 1 : 0) | (k_own0 + nz < nz_ext ? 2 : 0);
         otmb_ctx::FfCountsKey &key = ctx->ffc;
         key.buf = buf; key.gen = ctx->ff_gen;
         for (int f = 0; f < 6; ++f) key.phi[f] = phi[f];
         key.stat = (const char *)counts->tables + ff_tables_static_offset(rows, nx, ny, nz);
         key.mask = push_mask; key.mlotst = counts->mlotst; key.zt = counts->zt; key.lwet3d = counts->lwet3d;
-        key.nx = nx; key.ny = ny; key.nz = nz; key.n_wet = counts->n_wet;
+        key.nx = nx; key.ny = ny; key.nz = nz_ext; key.n_wet = counts->n_wet;
+        key.k_own0 = k_own0; key.wet_base = slab ? slab->wet_base : 0;
         key.topo = topology; key.upwind = counts->upwind != 0; key.only_t = counts->only_t != 0;
-        ctx->ffc_partial_mask = push_mask;
+        ctx->ffc_partial_mask = push_mask ? push_mask - k_own0 * P : nullptr;  // (as the transportmatrix will name it: the extended grid's array)
+        wet3d += k_own0 * P;  // the kernel marches over the owned levels; a halo level is level -1 / nz to it
     }
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
@@ -560,7 +599,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     hipLaunchKernelGGL((facefluxes_kernel<T, FL, NTS, R, CN, TO>), dim3(nb), dim3(FF_THREADS * R), 0, ctx->stream, (const T *)umo, (const T *)vmo, wet3d, \
                        fill, (int)nx, (int)ny, (int)nz, (int)topology, P, phi[OTMB_EAST], phi[OTMB_WEST], phi[OTMB_NORTH],           \
                        phi[OTMB_SOUTH], phi[OTMB_TOP], phi[OTMB_BOTTOM], top_below, push_mask, dflags, ctx->ff_gen, ctx->ff_xcd_chunks, ctx->ff_lds_south, \
-                       (int)j0, (int)j1, ca.bases, ca.mlotst, ca.zt, ca.sums, ca.upwind, ca.only_t, ca.nseg)
+                       (int)j0, (int)j1, ca.bases, ca.mlotst, ca.zt, ca.sums, ca.upwind, ca.only_t, ca.nseg, ca.halo)
 #define FF_LAUNCH2(T, FL, CN) do { if (rows == 4) { if (nt) FF_LAUNCH(T, FL, true, 4, CN); else FF_LAUNCH(T, FL, false, 4, CN); } \
                                    else { if (nt) FF_LAUNCH(T, FL, true, 1, CN); else FF_LAUNCH(T, FL, false, 1, CN); } } while (0)
 #define FF_LAUNCH2T(T) do { if (rows == 4) { if (nt) FF_LAUNCH_T(T, true, true, 4, true, true); else FF_LAUNCH_T(T, true, false, 4, true, true); } \
@@ -574,7 +613,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
 #undef FF_LAUNCH_T
 #undef FF_LAUNCH
     }
-    if (with_counts) ctx->ffc.valid = true;
+    if (with_counts) { ctx->ffc.valid = true; ctx->ffc.pieces_open = true; }  // (valid for the caller once the last row band is enqueued)
     HIP_TRY(ctx, hipGetLastError());
     // @assert !all(missing) (:199-200): needs the whole pass, so it is reported after the kernel
     if (!check_missing) return OTMB_OK;  // slab / asynchronous: otmb_facefluxes_slab_flags fetches the flags when asked
@@ -640,23 +679,36 @@ extern "C" int64_t otmb_count_tables_bytes(const otmb_ctx *ctx, int64_t nx, int6
     return (int64_t)(ff_tables_static_offset(ff_rows_for(ctx, nx, ny), nx, ny, nz) + (size_t)(ntiles + 1) * sizeof(unsigned long long));
 }
 
-extern "C" int32_t otmb_count_tables_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet,
-                                         int64_t nx, int64_t ny, int64_t nz, int32_t topology, void *tables) {
+// nz levels from level k_own0 of a local grid of nz_ext levels (the whole grid: 0, nz); wet_base: the global 0-based wet rank of the first
+// owned wet cell.  lwet3d / wetflags: the local grid's arrays; lwet: the owned cells' local linear indices.
+static int32_t count_tables_impl(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet, int64_t nx,
+                                 int64_t ny, int64_t nz, int32_t topology, int64_t k_own0, int64_t nz_ext, int64_t wet_base, void *tables) {
     if (!ctx || !lwet3d || !wetflags || !tables || (n_wet > 0 && !lwet)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
-    if (nx < 1 || ny < 1 || nz < 1 || n_wet < 0 || nx * ny >= (1ll << 28) || nx * ny * nz >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (nx < 1 || ny < 1 || nz < 1 || n_wet < 0 || nx * ny >= (1ll << 28) || nx * ny * nz_ext >= (1ll << 32)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (k_own0 < 0 || k_own0 + nz > nz_ext || nz_ext > nz + 2 || wet_base < 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "depth slab");
     if (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "topology");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rows = ff_rows_for(ctx, nx, ny);
     const i64 nseg = ff_nseg(rows, nx, ny), nw = nz * nseg, ntiles = (n_wet + (1ll << FFC_TILE_SHIFT) - 1) >> FFC_TILE_SHIFT;
     KernelTimer kt(ctx, K_FF_BASES);
-    hipLaunchKernelGGL(ff_count_bases_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx->stream, (const i64 *)lwet3d, (int)nx, (int)ny,
-                       (int)nz, nx * ny, rows, (int)nseg, (uint32_t *)tables);
+    hipLaunchKernelGGL(ff_count_bases_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, ctx->stream, (const i64 *)lwet3d + k_own0 * nx * ny,
+                       (int)nx, (int)ny, (int)nz, nx * ny, rows, (int)nseg, (i64)wet_base, (uint32_t *)tables);
     if (ntiles > 0)
         hipLaunchKernelGGL(ff_static_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const i64 *)lwet, wetflags, (i64)n_wet,
-                           (int)nx, (int)ny, (int)nz, nx * ny, (int)topology,
+                           (int)nx, (int)ny, (int)nz_ext, nx * ny, (int)topology,
                            (unsigned long long *)((char *)tables + ff_tables_static_offset(rows, nx, ny, nz)));
     HIP_TRY(ctx, hipGetLastError());
     return OTMB_OK;
+}
+
+extern "C" int32_t otmb_count_tables_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet,
+                                         int64_t nx, int64_t ny, int64_t nz, int32_t topology, void *tables) {
+    return count_tables_impl(ctx, lwet3d, lwet, wetflags, n_wet, nx, ny, nz, topology, 0, nz, 0, tables);
+}
+extern "C" int32_t otmb_count_tables_slab_dev(otmb_ctx *ctx, const int64_t *lwet3d, const int64_t *lwet, const uint8_t *wetflags, int64_t n_wet,
+                                              int64_t nx, int64_t ny, int64_t nz, int32_t topology, const otmb_ff_slab *slab, void *tables) {
+    if (!slab) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    return count_tables_impl(ctx, lwet3d, lwet, wetflags, n_wet, nx, ny, nz, topology, slab->k_own0, slab->nz_ext, slab->wet_base, tables);
 }
 
 // facefluxes + the tile counts of the transportmatrix that will be built from its fluxes (see FfCountArgs).  Grids whose row-mates can
@@ -672,6 +724,33 @@ extern "C" int32_t otmb_facefluxes_counts_dev(otmb_ctx *ctx, const void *umo, co
     return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, nullptr, push_mask, false, true,
                            can ? counts : nullptr);
 }
+
+// The same for a depth slab, optionally one row band at a time (the chain over depth slabs, otmb_facefluxes_rows_dev).  A row band other
+// than the whole plane needs the four-row wave geometry (its segments are whole rows); otherwise, and wherever
+// otmb_facefluxes_counts_dev would fall back, the call is otmb_facefluxes_flags_dev's / _rows_dev's: mask written, no counts.
+extern "C" int32_t otmb_facefluxes_slab_counts_dev(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wetflags,
+                                                   double fill, int64_t nx, int64_t ny, int64_t nz, int32_t topology, double *const phi[6],
+                                                   const double *top_below, uint16_t *push_mask, const otmb_ff_counts *counts,
+                                                   const otmb_ff_slab *slab, int64_t j0, int64_t j1, int32_t first) {
+    if (!ctx || !counts || !slab || !wetflags) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null argument");
+    if (nx < 1 || ny < 1 || nz < 1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "grid size");
+    if (slab->k_own0 < 0 || slab->k_own0 + nz > slab->nz_ext || slab->nz_ext > nz + 2 || slab->wet_base < 0)
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "depth slab");
+    if (j0 < 0 || j1 > ny || j0 >= j1) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "row range");
+    const bool whole = j0 == 0 && j1 == ny;
+    bool can = ctx->count_in_ff != 0 && nx >= 3 && push_mask && counts->tables && counts->lwet3d && counts->mlotst && counts->zt &&
+               counts->n_wet > 0 && nx * ny * slab->nz_ext < (1ll << 32) && slab->nz_ext <= FFC_MAX_NZ &&
+               (whole || ff_rows_for(ctx, nx, ny) == 4);
+    // (a piece of a call whose first piece could not count must not start counting: the key of the call is the first piece's)
+    if (!first && !ctx->ffc.pieces_open) can = false;
+    if (!can)
+        return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags + slab->k_own0 * nx * ny, fill, nx, ny, nz, topology, phi, top_below, push_mask,
+                               false, true, nullptr, j0, j1, first == 0);
+    return facefluxes_impl(ctx, umo, vmo, src_is_f32, wetflags, fill, nx, ny, nz, topology, phi, top_below, push_mask, false, true, counts, j0, j1,
+                           first == 0, false, slab);
+}
+
+extern "C" int32_t otmb_facefluxes_counts_pending(const otmb_ctx *ctx) { return (ctx && ctx->ffc.valid) ? 1 : 0; }
 
 // facefluxes of the fused step (otmb_step_dev, otmb_transportmatrix.hip): counts + ϕtop only.  `token`: the pointer the counts are keyed to in
 // place of a push mask (never read or written).

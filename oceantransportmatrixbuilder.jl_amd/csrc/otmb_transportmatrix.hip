@@ -914,9 +914,11 @@ static int32_t ensure_push_mask(otmb_ctx *ctx, const otmb_tm_args &a, TmParams &
 // Returns the buffer that holds them, or -1.
 static int ffc_match(const otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl) {
     const otmb_ctx::FfCountsKey &k = ctx->ffc;
-    if (!k.valid || k.gen != ctx->ff_gen || !a.push_mask || a.push_mask != k.mask || pl.wet_base != 0) return -1;
+    // (depth slab: the transportmatrix names the extended local grid's arrays, facefluxes wrote their owned levels, k_own0 levels in)
+    const i64 off = k.k_own0 * a.nx * a.ny;
+    if (!k.valid || k.gen != ctx->ff_gen || !a.push_mask || a.push_mask + off != k.mask || pl.wet_base != k.wet_base) return -1;
     for (int f = 0; f < 6; ++f)
-        if (a.phi[f] != k.phi[f]) return -1;
+        if (a.phi[f] + off != k.phi[f]) return -1;
     if (a.mlotst != k.mlotst || a.zt != k.zt || a.lwet3d != k.lwet3d || a.nx != k.nx || a.ny != k.ny || a.nz != k.nz ||
         a.n_wet != k.n_wet || a.topology != k.topo || (a.upwind != 0) != (k.upwind != 0) || (a.only_t != 0) != (k.only_t != 0))
         return -1;

@@ -398,6 +398,30 @@ class HipSlabBackend:
         own = torch.nonzero(self.lw[self.own0:self.own0 + self.nown_lev * self.P]).flatten() + (self.own0 + 1)
         assert own.numel() == self.n_own
         self.lwet = own.to(torch.int64).contiguous()
+        self._setup_counts()
+
+    def _setup_counts(self):
+        """Counts in facefluxes for this slab (otmb_facefluxes_slab_counts_dev; OTMB_COUNT_IN_FF=0 switches it off): the five-flag bytes
+        of the EXTENDED local grid (the halo levels are neighbours) and the grid's tables.  Once per grid."""
+        self.counts = None
+        if os.environ.get("OTMB_COUNT_IN_FF", "1") == "0" or self.n_own == 0:
+            return
+        capi = self.capi
+        wet_ext = (self.lw != 0).to(torch.uint8)
+        self.wetflags = torch.empty(self.G, dtype=torch.uint8, device=self.device)
+        self.ctx.check(self.lib.otmb_wetflags_dev(self.ctx.handle, wet_ext.data_ptr(), self.nx, self.ny, self.nz, self.s["topology"],
+                                                  self.wetflags.data_ptr()))
+        self.ff_slab = capi.FfSlab(self.s["k_own0"], self.nz, self.s["wet_base"])
+        nbytes = int(self.lib.otmb_count_tables_bytes(self.ctx.handle, self.nx, self.ny, self.nown_lev, self.n_own))
+        self.count_tables = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
+        self.ctx.check(self.lib.otmb_count_tables_slab_dev(self.ctx.handle, self.lw.data_ptr(), self.lwet.data_ptr(), self.wetflags.data_ptr(),
+                                                           self.n_own, self.nx, self.ny, self.nown_lev, self.s["topology"],
+                                                           C.byref(self.ff_slab), self.count_tables.data_ptr()))
+        self.ctx.synchronize()  # (wet_ext is released when this returns)
+        c = capi.FfCounts()
+        c.tables, c.lwet3d, c.mlotst, c.zt = self.count_tables.data_ptr(), self.lw.data_ptr(), self.ml.data_ptr(), self.zt.data_ptr()
+        c.n_wet, c.upwind, c.only_t = self.n_own, int(self.s["upwind"]), 0
+        self.counts = c
 
     def facefluxes(self, umo, vmo, fill, top_below):
         """The whole plane at once (one piece)."""
@@ -410,6 +434,15 @@ class HipSlabBackend:
         o, n = self.own0, self.nown_lev * self.P
         views = [p[o:o + n] for p in self.phi]
         ptrs = self.capi.ptr_array(6, [v.data_ptr() for v in views])
+        if self.counts is not None:
+            # the kernel also accumulates the tile counts of this slab's transportmatrix: assemble_async / plan skip their counting pass
+            # (the library falls back to the plain call, mask written, where it cannot count: the caller need not know)
+            self.ctx.check(self.lib.otmb_facefluxes_slab_counts_dev(
+                self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), self.wetflags.data_ptr(),
+                float(fill), self.nx, self.ny, self.nown_lev, self.s["topology"], C.byref(ptrs),
+                top_below.data_ptr() if top_below is not None else None, self.push_mask[o:o + n].data_ptr(), C.byref(self.counts),
+                C.byref(self.ff_slab), int(j0), int(j1), int(bool(first))))
+            return self.phi[4][o:o + self.P]
         self.ctx.check(self.lib.otmb_facefluxes_rows_dev(
             self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), self.wet_own.data_ptr(),
             float(fill), self.nx, self.ny, self.nown_lev, self.s["topology"], C.byref(ptrs),
@@ -423,14 +456,18 @@ class HipSlabBackend:
         top, bottom = self.phi[4], self.phi[5]  # OTMB_TOP, OTMB_BOTTOM
         top_first = top[o:o + self.P]
         allphi = self.capi.ptr_array(6, [p.data_ptr() for p in self.phi])
+        # (the counting facefluxes kernel has already looked at the halo cells as neighbours: no push mask at all in that case)
+        masks = not (self.counts is not None and self.lib.otmb_facefluxes_counts_pending(self.ctx.handle))
         if self.s["k_own0"] > 0:  # halo above: its ϕbottom is my first level's ϕtop (velocities.jl:240)
             bottom[0:self.P].copy_(top_first)
-            self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), 0, self.P,
-                                                       self.push_mask.data_ptr()))
+            if masks:
+                self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), 0, self.P,
+                                                           self.push_mask.data_ptr()))
         if top_below is not None:  # halo below: its ϕtop is the plane received from the slab below
             top[self.G - self.P:self.G].copy_(top_below)
-            self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), self.G - self.P,
-                                                       self.P, self.push_mask.data_ptr()))
+            if masks:
+                self.ctx.check(self.lib.otmb_push_mask_dev(self.ctx.handle, C.byref(allphi), self.lw.data_ptr(), self.G - self.P,
+                                                           self.P, self.push_mask.data_ptr()))
         return top_first
 
     def _tm_args(self):

@@ -30,13 +30,16 @@ def run(rank, world, port, backend_kind, case, outdir):
     g = synthetic.make_slab(nx, ny, nz, k0, k1, seed=seed, rho=rho, topology=topo)
     gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev[k0:k1],
                                   lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
-    local = od.make_local_grid(gm, g.mlotst, g.rho, k0, k1, nz, g.lev)
+    local = od.make_local_grid(gm, g.mlotst, g.rho, k0, k1, nz, g.lev, upwind=os.environ.get("OTMB_TEST_CENTRED") != "1")
     if backend_kind == "hip":
         be = od.HipSlabBackend(rank if rccl else 0)
     else:
         from slab_checker_backend import OracleSlabBackend
 
         be = OracleSlabBackend()
+    record_kernels = backend_kind == "hip" and os.environ.get("OTMB_TEST_KERNELS") == "1"
+    if record_kernels:  # which kernels this rank launched (tests of the counts-in-facefluxes slab path)
+        be.ctx.timing_enable(True)
     comm = od.Comm()
     runner = od.SlabRunner(be, comm, local)
     dev = be.device
@@ -89,6 +92,11 @@ def run(rank, world, port, backend_kind, case, outdir):
         for _ in range(2):  # twice: buffers are reused between fields
             out = runner.step(umo, vmo, 1e20)
     runner.sync()
+    if record_kernels:
+        import json
+
+        with open(os.path.join(outdir, f"kernels_{rank}.json"), "w") as f:
+            json.dump({k: v[1] for k, v in be.ctx.timing_collect().items()}, f)
     host = be.result_to_host() if backend_kind == "hip" else out
     glob = od.gather_global_csc(comm, host, runner.n_own, be.nnz, dev)
     if rank == 0:

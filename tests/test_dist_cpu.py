@@ -25,18 +25,19 @@ def free_port():
     return p
 
 
-def whole_grid_reference(oracle, nx, ny, nz, seed, rho, topo):
+def whole_grid_reference(oracle, nx, ny, nz, seed, rho, topo, upwind=True):
     g = synthetic.make_slab(nx, ny, nz, 0, nz, seed=seed, rho=rho, topology=topo)
     gm = otmb_amd.makegridmetrics(areacello=g.areacello, volcello=g.volcello, lon=g.lon, lat=g.lat, lev=g.lev,
                                   lon_vertices=g.lon_vertices, lat_vertices=g.lat_vertices)
     idx = oracle.makeindices(gm.v3D)
     phi = oracle.facefluxes(g.umo.data, g.vmo.data, idx["wet3D"], 1e20, gm.gridtopology.kind)
-    return idx, oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, True)
+    return idx, oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind)
 
 
-def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None, rccl=False, pieces=None):
+def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=None, rccl=False, pieces=None, extra_env=None):
     port = free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OTMB_TEST_ASYNC="1" if async_mode else "0", OTMB_TEST_RCCL="1" if rccl else "0")
+    env.update(extra_env or {})
     if pieces is not None:
         env["OTMB_CHAIN_PIECES"] = str(pieces)  # SlabRunner: the facefluxes chain in this many row bands
     if fault:
@@ -48,8 +49,8 @@ def run_ranks(world, kind, case, outdir, timeout=300, async_mode=False, fault=No
     return np.load(os.path.join(outdir, "global.npz"))
 
 
-def check_against_whole_grid(oracle, z, case):
-    idx, ref = whole_grid_reference(oracle, *case)
+def check_against_whole_grid(oracle, z, case, upwind=True):
+    idx, ref = whole_grid_reference(oracle, *case, upwind=upwind)
     assert int(z["n"]) == idx["N"]
     for q, m in enumerate(MATS):
         got = (z[f"0_{q}"], z[f"1_{q}"], z[f"2_{q}"])
