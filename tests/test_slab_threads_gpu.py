@@ -209,3 +209,67 @@ def test_access1deg_in_three_slabs_equals_the_single_gpu_path():
     for m in MATS:
         for a, b, what in zip(glob[m], ref[m], ("colptr", "rowval", "nzval")):
             assert np.array_equal(np.asarray(a), np.asarray(b)), (m, what)
+
+
+def test_quarterdeg_in_two_slabs_equals_the_single_gpu_path():
+    """BASELINE.json configs[3]'s grid (1440x1080x75) as `bench.py --gpus 2 --scaling strong` runs it: the four-row wave geometry and the
+    chain in four row bands as the library chooses them, both slabs counting in facefluxes -- against the single-GPU path's matrices,
+    compared on the device."""
+    import torch
+
+    from otmb_amd import synthetic_device
+
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 150 * 2 ** 30:
+        pytest.skip("needs ~130 GB of device memory for the whole grid and its two slabs side by side")
+    dev = torch.device("cuda", 0)
+    nx, ny, nz, lf = synthetic.PRESETS["quarterdeg"]
+    counts = synthetic.level_wet_counts(nx, ny, nz, seed=20260501, land_fraction=lf)
+    parts = od.balanced_partition(counts, 2)
+    tw = ThreadWorld(2)
+    res, errors = [None, None], []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            k0, k1 = parts[rank]
+            dg = synthetic_device.make_device_grid("quarterdeg", dev, k0=k0, k1=k1)
+            be = od.HipSlabBackend(0)
+            be.ctx.timing_enable(True)
+            runner = od.SlabRunner(be, ThreadComm(tw, rank), od.make_local_grid_from_device(dg))
+            assert runner.chain_pieces == 4
+            for _ in range(2):
+                runner.step_async(dg.umo, dg.vmo, dg.fill)
+            runner.finish()
+            runner.sync()
+            res[rank] = (be, runner, {k: v[1] for k, v in be.ctx.timing_collect().items()})
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, e))
+            tw.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    for _, _, k in res:
+        assert "tm_count_kernel" not in k and "push_mask_kernel" not in k and k.get("facefluxes_kernel", 0) == 8, k  # 2 fields x 4 row bands
+    dg = synthetic_device.make_device_grid("quarterdeg", dev)
+    asm = synthetic_device.assembler_for(dg, 0)
+    asm.step_async(dg.umo, dg.vmo, dg.fill)
+    asm.finish()
+    asm.ctx.synchronize()
+    assert asm.N == res[0][1].n_global == res[0][1].n_own + res[1][1].n_own
+    col0 = 0
+    for be, runner, _ in res:
+        n = runner.n_own
+        for q, m in enumerate(MATS):
+            cp, rv, nzv = be.out[m]
+            rcp, rrv, rnz = asm.out[m]
+            lo, hi = int(rcp[col0]) - 1, int(rcp[col0 + n]) - 1
+            assert hi - lo == be.nnz[q], (m, hi - lo, be.nnz[q])
+            assert torch.equal(cp[: n + 1], rcp[col0:col0 + n + 1]), (m, "colptr")
+            assert torch.equal(rv[: be.nnz[q]], rrv[lo:hi]), (m, "rowval")
+            assert torch.equal(nzv[: be.nnz[q]], rnz[lo:hi]), (m, "nzval")
+        col0 += n
