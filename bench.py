@@ -170,9 +170,11 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def end_to_end(g, gm, asm_N, reps=3):
+def end_to_end(g, gm, asm_N, reps=5, warm=2):
     """What a Julia caller of the host-pointer C ABI sees (PCIe included; never `value`): facefluxesfrommasstransport +
-    transportmatrix through otmb_amd.api on host arrays, median of `reps` after one warm-up."""
+    transportmatrix through otmb_amd.api on host arrays, median of `reps` time slices after `warm` warm-up slices (the first two slices of
+    a loop allocate: device buffers, the pinned rings of the slab contexts, the pinned result blocks -- 123 and 31 ms against 23.4 ms from the
+    third on, tools/onepass_loop.py)."""
     import numpy as np
 
     import otmb_amd
@@ -180,27 +182,34 @@ def end_to_end(g, gm, asm_N, reps=3):
 
     idx = api.makeindices(gm.v3D)
     res = {}
-    for reuse in (False, True):
+    # default: what `transportmatrix(; ϕ, ...)` does with no extension keyword -- on a grid of this size the pipelined one-phase build on 4
+    # depth slabs of the GPU (api.default_slabs; otmb_mgpu_transportmatrix_onepass); two_phase: slabs=0, the plan -> allocate -> fetch call of
+    # rounds 1-4; reuse: both reuse promises (then always two-phase: nothing is left to upload beside the download)
+    for name, kw in (("default", {}), ("two_phase", {"slabs": 0}), ("reuse", {"reuse_grid": True, "reuse_fluxes": True})):
         ts = []
-        for rep in range(reps + 1):
+        for rep in range(reps + warm):
             t0 = time.perf_counter()
             phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
             t1 = time.perf_counter()
             tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML,
-                                     κVdeep=g.kappaVdeep, reuse_grid=reuse, reuse_fluxes=reuse)
+                                     κVdeep=g.kappaVdeep, **kw)
             t2 = time.perf_counter()
-            if rep:
+            if rep >= warm:
                 ts.append((t1 - t0, t2 - t1, api.last_call_seconds["plan"] + api.last_call_seconds["fetch"]))
             del tm, phi  # (a time-slice loop drops the previous matrices: their pinned blocks return to the context's pool)
-        res[reuse] = tuple(float(np.median([x[q] for x in ts])) for q in range(3))
-    ff, tm, cabi = res[False]
+        res[name] = tuple(float(np.median([x[q] for x in ts])) for q in range(3))
+    ff, tm, cabi = res["default"]
     return {"value": asm_N / (ff + tm), "unit": "wet-cells/s", "facefluxes_ms": 1e3 * ff, "transportmatrix_ms": 1e3 * tm,
-            "transportmatrix_c_abi_ms": 1e3 * cabi, "facefluxes_ms_reuse": 1e3 * res[True][0], "transportmatrix_ms_reuse": 1e3 * res[True][1],
-            "transportmatrix_c_abi_ms_reuse": 1e3 * res[True][2], "value_reuse": asm_N / (res[True][0] + res[True][1]),
+            "transportmatrix_c_abi_ms": 1e3 * cabi, "slabs": api.default_slabs(asm_N, int(g.umo.data.shape[2]), False, None),
+            "transportmatrix_ms_two_phase": 1e3 * res["two_phase"][1], "value_two_phase": asm_N / (res["two_phase"][0] + res["two_phase"][1]),
+            "facefluxes_ms_reuse": 1e3 * res["reuse"][0], "transportmatrix_ms_reuse": 1e3 * res["reuse"][1],
+            "transportmatrix_c_abi_ms_reuse": 1e3 * res["reuse"][2], "value_reuse": asm_N / (res["reuse"][0] + res["reuse"][1]),
             "note": "host-pointer C ABI (what a Julia ccall passes): pageable host input arrays, five host CSC matrices out in pinned memory "
-                    "of the library (otmb_host_alloc: the DMA writes them in place), PCIe both ways; c_abi_ms: inside "
-                    "otmb_transportmatrix_plan + _fetch; *_reuse: gridmetrics / indices uploaded once (reuse_grid) and the face fluxes "
-                    "that facefluxes just computed not uploaded again (reuse_fluxes)"}
+                    "of the library (otmb_host_alloc: the DMA writes them in place), PCIe both ways.  transportmatrix_ms: the default call -- "
+                    "pipelined over `slabs` depth slabs of the GPU, a slab uploading while the one above it copies its columns home "
+                    "(otmb_mgpu_transportmatrix_onepass); *_two_phase: slabs=0, otmb_transportmatrix_plan + _fetch (every upload before the "
+                    "count, every download after it: rounds 1-4); c_abi_ms: inside the C calls; *_reuse: gridmetrics / indices uploaded once "
+                    "(reuse_grid) and the face fluxes that facefluxes just computed not uploaded again (reuse_fluxes; two-phase)"}
 
 
 def extra_configs_in_children(args):

@@ -438,6 +438,17 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
 int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *args, int64_t nnz[5]);
 int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5], int64_t *const rowval[5],
                                         double *const nzval[5], int64_t nnz_out[5]);
+/* The same build in ONE call, pipelined over the slabs (speed only; the same five matrices bit for bit): the caller hands output arrays
+ * of `capacity[m]` entries -- 7N, 7N, 5N, 3N, 3N always suffice (src/matrixbuilding.jl:244-296, :348-415, :450-477: a column of Tadv / T
+ * holds at most the cell and its six neighbours, of TκH five, of TκVML / TκVdeep three) -- and gets the counts back in nnz_out; a host
+ * binding wraps the first nnz_out[m] entries (Julia: unsafe_wrap with that length).  Slab s uploads its levels while slab s - 1 counts,
+ * fills and copies its columns home, so the PCIe link carries both directions at once, which the two-phase protocol cannot do (every
+ * upload precedes the count there, every download follows it): slabs that share a device take the link in turn for their uploads,
+ * and a slab's column offsets are the running sums of the FINAL counts above it.  Meant for device_ids = {d, d, d, d}: four to eight
+ * slabs on ONE device hide most of a time slice's upload behind its download; with one slab per device it saves the
+ * nnz round trip.  OTMB_ERR_CAPACITY when an array is too small.                                                          */
+int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *args, int64_t *const colptr[5], int64_t *const rowval[5],
+                                          double *const nzval[5], const int64_t capacity[5], int64_t nnz_out[5]);
 
 /* ---- makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices) -- the array work of
  *      src/gridcellgeometry.jl:265-311 (device pointers; vertex permutation :158-178 and topology detection

@@ -193,16 +193,21 @@ end
 # What a wrapped vector cannot do is change its length: dropzeros!(T), resize!, and T[i,j] = x at a position that is not stored
 # throw where the reference's ordinary vectors work -- `pinned = false` (or ENV["OTMB_PINNED_RESULTS"] = "0") returns ordinary
 # Julia vectors instead (the library then stages the copy through its own pinned ring; about a third slower at 1 degree).
-function pinned_array(::Type{T}, dims...) where {T}
+# a pinned block of `n` elements that is not a Julia array yet (the one-phase build learns its lengths from the call) ...
+function pinned_block(::Type{T}, n) where {T}
     p = Ref{Ptr{Cvoid}}(C_NULL)
     # (NULL context: the pool belongs to no context, and the `devices = ...` path must not create the single-GPU one)
-    rc = ccall(sym(:otmb_host_alloc), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), C_NULL, Int64(max(prod(dims), 1) * sizeof(T)), p)
+    rc = ccall(sym(:otmb_host_alloc), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), C_NULL, Int64(max(n, 1) * sizeof(T)), p)
     rc == 0 || error("otmb_host_alloc failed (status $rc)")
-    a = unsafe_wrap(Array, Ptr{T}(p[]), dims; own = false)
-    block = p[]
+    return p[]
+end
+# ... and the array over its first elements that owns the block from here on: ONE Julia array per block, whose finalizer returns it
+function adopt(::Type{T}, block::Ptr{Cvoid}, dims...) where {T}
+    a = unsafe_wrap(Array, Ptr{T}(block), dims; own = false)
     finalizer(_ -> ccall(host_free_fn[], Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, block), a)
     return a
 end
+pinned_array(::Type{T}, dims...) where {T} = adopt(T, pinned_block(T, prod(dims)), dims...)
 outarray(::Type{T}, usepinned::Bool, dims...) where {T} = usepinned ? pinned_array(T, dims...) : Array{T}(undef, dims...)
 
 # A + B with the library's `+` (otmb_spadd: SparseArrays' map(+): union pattern, exact-zero sums dropped, :147)
@@ -246,10 +251,13 @@ the library writes colptr/rowval/nzval straight into the Julia-owned vectors.
 function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
         κH = 500.0, κVML = 0.1, κVdeep = 1.0e-5,
         Tadv = nothing, TκH = nothing, TκVML = nothing, TκVdeep = nothing, upwind = true, operators = true, reuse_grid = false,
-        reuse_fluxes = false, pinned = PINNED_RESULTS[], devices = nothing)
+        reuse_fluxes = false, pinned = PINNED_RESULTS[], devices = nothing, slabs = nothing)
     # pinned = true (default; ENV["OTMB_PINNED_RESULTS"] = "0" flips it): the five matrices' vectors are pinned memory of the library
     #   (fast; fixed length); pinned = false: ordinary Julia vectors, every in-place operation of the reference's results works
     # devices = 0:7 (extension): the grid is cut into depth slabs, one per listed GPU of this process (otmb_mgpu_*)
+    # slabs = S (extension, speed only): the pipelined one-phase build on S depth slabs of the single GPU (or one per entry of `devices`): a slab
+    #   uploads while the one above it copies its columns home -- the PCIe link carries both directions at once (otmb_mgpu_transportmatrix_onepass);
+    #   slabs = nothing (default): default_slabs() -- 4 on large grids, 0 (the two-phase call) otherwise
     # operators = false (extension, not in the reference): only T is materialised, the four operators return `nothing`
     # reuse_grid = true (extension): the caller promises that gridmetrics / indices are the arrays of the previous call,
     #   unmodified (a loop over time slices); they are then not copied to the GPU again (otmb_ctx_set_reuse_grid)
@@ -270,6 +278,12 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
                   false, false, Int32(ignore), pinned, devices)
         A = something(Tadv, r.Tadv); H = something(TκH, r.TκH); M = something(TκVML, r.TκVML); D = something(TκVdeep, r.TκVdeep)
         return (; T = spadd(spadd(spadd(A, H), M), D), Tadv = A, TκH = H, TκVML = M, TκVdeep = D)
+    end
+    slabs = something(slabs, default_slabs(indices.N, size(gridmetrics.v3D, 3), reuse_fluxes, devices))
+    if slabs > 0
+        dev = parse(Int32, get(ENV, "OTMB_DEVICE", "0"))
+        devs = devices === nothing ? fill(dev, clamp(Int(slabs), 1, size(gridmetrics.v3D, 3))) : devices
+        return fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devs)
     end
     return fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devices)
 end
@@ -346,6 +360,53 @@ function fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, u
         cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
         GC.@preserve colptr rowval nzval check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_fetch), Int32,
             (Ptr{Cvoid}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}), mg, cp, rv, nz, final))
+        return wrap(N, colptr, rowval, nzval, final, operators)
+    end
+end
+
+# otmb_mgpu_set_reuse -> otmb_mgpu_transportmatrix_onepass: the pipelined one-phase build (`slabs = S`): result vectors at their upper bounds
+# (a column holds at most 7 / 7 / 5 / 3 / 3 rows, src/matrixbuilding.jl:244-296, :348-415, :450-477), no nnz round trip, every slab's upload beside
+# the download of the slab above it.  The pinned blocks become Julia vectors of the FINAL lengths only after the call (no copy, one owner each).
+const PER_COLUMN_MAX = (7, 7, 5, 3, 3)
+# slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 wet cells and more, 8 levels and more) -- unless the fluxes
+# are promised to be resident on the single-GPU context (reuse_fluxes) or a device list was given.  ENV["OTMB_HOST_SLABS"] overrides the 4.
+function default_slabs(N, nz, reuse_fluxes, devices)
+    (devices === nothing && !reuse_fluxes) || return 0
+    s = parse(Int, get(ENV, "OTMB_HOST_SLABS", "4"))
+    return (s > 0 && N >= (1 << 18) && nz >= 2 * s) ? s : 0
+end
+function fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
+                       usepinned::Bool, devices)
+    lock(CALL_LOCK) do
+        mg = mgpu_of(devices)
+        check_mgpu(mg, ccall(sym(:otmb_mgpu_set_reuse), Int32, (Ptr{Cvoid}, Int32, Int32), mg, Int32(reuse_grid), Int32(reuse_fluxes)))
+        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops)
+        N = indices.N
+        cap = Int64[(operators || m == 1) ? N * PER_COLUMN_MAX[m] + 1 : 0 for m in 1:5]
+        colptr = [outarray(Int64, usepinned, N + 1) for _ in 1:5]
+        final = zeros(Int64, 5)
+        if usepinned
+            rvb = Ptr{Cvoid}[]; nzb = Ptr{Cvoid}[]
+            try
+                for m in 1:5
+                    push!(rvb, pinned_block(Int64, cap[m])); push!(nzb, pinned_block(Float64, cap[m]))
+                end
+                cp = [pointer(x) for x in colptr]; rv = [Ptr{Int64}(b) for b in rvb]; nz = [Ptr{Float64}(b) for b in nzb]
+                GC.@preserve keep colptr check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_onepass), Int32,
+                    (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
+            catch
+                foreach(b -> ccall(host_free_fn[], Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, b), vcat(rvb, nzb))  # nothing owns these blocks yet
+                rethrow()
+            end
+            rowval = [adopt(Int64, rvb[m], Int(final[m])) for m in 1:5]
+            nzval = [adopt(Float64, nzb[m], Int(final[m])) for m in 1:5]
+        else
+            rowval = [Vector{Int64}(undef, cap[m]) for m in 1:5]; nzval = [Vector{Float64}(undef, cap[m]) for m in 1:5]
+            cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
+            GC.@preserve keep colptr rowval nzval check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_onepass), Int32,
+                (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
+            foreach(m -> (resize!(rowval[m], final[m]); resize!(nzval[m], final[m])), 1:5)  # (ordinary vectors shrink in place)
+        end
         return wrap(N, colptr, rowval, nzval, final, operators)
     end
 end

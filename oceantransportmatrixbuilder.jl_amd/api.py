@@ -10,6 +10,7 @@ with ccall).  Arrays are numpy, Fortran-ordered, Julia shapes; indices stay 1-ba
                                                             src/matrixbuilding.jl:128-150
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -341,7 +342,7 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
 
 def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None, rho=None, κH=500.0, κVML=0.1,
                     κVdeep=1.0e-5, kappaH=None, kappaVML=None, kappaVdeep=None, Tadv=None, TκH=None, TκVML=None,
-                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, reuse_fluxes=False, device=0, devices=None):
+                    TκVdeep=None, upwind=True, operators=True, reuse_grid=False, reuse_fluxes=False, device=0, devices=None, slabs=None):
     """matrixbuilding.jl:128-150 -> NT(T, Tadv, TκH, TκVML, TκVdeep), each a SparseMatrixCSC.
     ASCII aliases (phi, rho, kappaH, ...) are accepted beside the reference's Unicode keywords.
     operators=False (extension; the reference always returns all five): only T is materialised, the other four come
@@ -351,7 +352,11 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     reuse_fluxes=True (extension): ϕ is what facefluxes* returned last on this device, unmodified: its device copy is used
     (otmb_ctx_set_reuse_fluxes).
     devices=[0, 1, ...] (extension): the grid is cut into depth slabs, one per listed GPU of this process, each moved over its own
-    PCIe link (otmb_mgpu_transportmatrix_plan / _fetch); the same five matrices bit for bit."""
+    PCIe link (otmb_mgpu_transportmatrix_plan / _fetch); the same five matrices bit for bit.
+    slabs=S (extension, speed only): the pipelined one-phase build (otmb_mgpu_transportmatrix_onepass) on S depth slabs -- of `device`, or one per
+    entry of `devices` when that is given (S is then ignored): a slab uploads while the one above it copies its columns home, so the
+    link carries both directions at once.  The matrices' arrays are views of upper-bound allocations (7N, 7N, 5N, 3N, 3N entries).
+    slabs=None (default): default_slabs() -- 4 on large grids, the two-phase call (slabs=0) otherwise."""
     phi = ϕ if ϕ is not None else phi
     rho = ρ if ρ is not None else rho
     kH = κH if kappaH is None else kappaH
@@ -361,6 +366,12 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     if any(x is not None for x in given.values()):
         # matrixbuilding.jl:140-143: operators passed in are used as they are; T = ((Tadv + TκH) + TκVML) + TκVdeep (:147)
         return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device, devices)
+    if slabs is None:
+        slabs = default_slabs(int(indices["N"]), int(np.asarray(gridmetrics["v3D"]).shape[2]), reuse_fluxes, devices)
+    if slabs:
+        nz_levels = int(np.asarray(gridmetrics["v3D"]).shape[2])
+        devs = list(devices) if devices is not None else [int(device)] * max(1, min(int(slabs), nz_levels))
+        return _transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devs, 0, reuse_grid, reuse_fluxes)
     return _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes,
                                   device, 0, devices)
 
@@ -403,6 +414,20 @@ def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVd
                  for m, name in enumerate(MATS)})
 
 
+def default_slabs(N, nz, reuse_fluxes, devices):
+    """slabs=None: the pipelined one-phase build on 4 slabs of the device for grids where the transfers dominate (2^18 wet cells and more, 8
+    levels and more) -- unless the fluxes are promised to be resident on the single-GPU context (reuse_fluxes: nothing to upload beside
+    the download then, the two-phase call is as fast) or a device list was given (`devices` keeps the two-phase protocol unless slabs is
+    set).  ENV OTMB_HOST_SLABS overrides the 4 (0: always two-phase)."""
+    if devices is not None or reuse_fluxes:
+        return 0
+    s = int(os.environ.get("OTMB_HOST_SLABS", "4"))
+    return s if (s > 0 and N >= (1 << 18) and nz >= 2 * s) else 0
+
+
+PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold (matrixbuilding.jl:244-296, :348-415, :450-477)
+
+
 def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
                           reuse_grid=False, reuse_fluxes=False):
     """otmb_mgpu_set_reuse -> otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs,
@@ -431,6 +456,35 @@ def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVde
     t0 = _time.perf_counter()
     mg.check(capi.lib().otmb_mgpu_transportmatrix_fetch(mg.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
     last_call_seconds["fetch"] = _time.perf_counter() - t0
+    return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
+                 for m, name in enumerate(MATS)})
+
+
+def _transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
+                             reuse_grid=False, reuse_fluxes=False):
+    """otmb_mgpu_set_reuse -> result arrays at their upper bounds -> otmb_mgpu_transportmatrix_onepass: no nnz round trip, every slab's upload
+    beside the download of the slab above it.  The matrices' rowval / nzval are the first nnz entries of those arrays."""
+    import time as _time
+
+    mg = mgpu(devices)
+    ctx = context(list(devices)[0])
+    keep, passthrough = [], []
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
+    mg.check(capi.lib().otmb_mgpu_set_reuse(mg.handle, int(bool(reuse_grid) and all(passthrough)), int(bool(reuse_fluxes))))
+    a.only_t = 0 if operators else 1
+    a.ignore_ops = int(ignore_ops)
+    N = int(indices["N"])
+    cap = [N * k + 1 if (operators or m == 0) else 0 for m, k in enumerate(PER_COLUMN_MAX)]
+    colptr = [_out_array(ctx, N + 1, np.int64) for _ in range(5)]
+    rowval = [_out_array(ctx, cap[m], np.int64) for m in range(5)]
+    nzval = [_out_array(ctx, cap[m], np.float64) for m in range(5)]
+    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
+    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
+    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    caps, final = (C.c_int64 * 5)(*cap), (C.c_int64 * 5)()
+    t0 = _time.perf_counter()
+    mg.check(capi.lib().otmb_mgpu_transportmatrix_onepass(mg.handle, C.byref(a), C.byref(cp), C.byref(rv), C.byref(nz), C.byref(caps), C.byref(final)))
+    last_call_seconds["plan"], last_call_seconds["fetch"] = _time.perf_counter() - t0, 0.0
     return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
                  for m, name in enumerate(MATS)})
 

@@ -82,6 +82,8 @@ SYMBOLS = {
     "otmb_mgpu_facefluxes": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp * 6)]),
     "otmb_mgpu_transportmatrix_plan": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(C.c_int64 * 5)]),
     "otmb_mgpu_transportmatrix_fetch": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
+    "otmb_mgpu_transportmatrix_onepass": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5),
+                                                      C.POINTER(C.c_int64 * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
     "otmb_ctx_set_formulation": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "otmb_last_error": (C.c_char_p, [_vp]),

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -241,6 +242,102 @@ void fail_plane(otmb_mgpu *mg, int to) {  // a slab that cannot produce its plan
         b.plane_failed = true;
     }
     b.cv.notify_all();
+}
+
+// One slab's share of a plan: stage its levels [k0 - ha, k1 + hb) of the host arrays on its device (what is resident under the reuse
+// promises is not uploaded again), then count.  Leaves sl.nnz / sl.status.  before_upload / after_upload bracket the upload batch.
+void plan_slab(otmb_mgpu *mg, int s, const otmb_tm_args *a, const std::function<void()> &before_upload, const std::function<void()> &after_upload) {
+    const i64 P = a->nx * a->ny;
+    Slab &sl = *mg->slabs[s];
+    // The residency keys are written when an upload is QUEUED: a slab that fails before its batch has reached the device (a later
+    // reserve, the transfer, the index shift) must forget them, or a retry with reuse on would take arrays that were never copied
+    // for resident and build matrices from uninitialised memory.
+    bool on_device = false;
+    auto fail = [&](int32_t st) {
+        sl.status = st; sl.msg = otmb_last_error(sl.ctx);
+        if (!on_device) {
+            for (int b = 0; b < B_COUNT; ++b) sl.key[b] = Slab::Key();
+            sl.phi_resident = false;
+        }
+    };
+    if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
+    const i64 e0 = sl.k0 - sl.ha, e1 = sl.k1 + sl.hb, nze = e1 - e0;
+    const size_t Ge = (size_t)(nze * P), off = (size_t)e0 * P;
+    otmb_tm_args d = *a;
+    d.nz = nze;
+    d.n_wet = sl.n_own;
+    d.push_mask = nullptr;
+    std::vector<OtmbXferItem> up;
+    int32_t r;
+    void *p;
+    // One staged array: uploaded unless the slot still holds this very host array (pointer, bytes, first level) and the caller has
+    // promised not to have modified it (otmb_mgpu_set_reuse).  KIND 1: grid constant; 2: a face-flux array; 0: every call.
+    auto put = [&](int B, const void *host, size_t bytes, int kind, void **out) -> int32_t {
+        const void *before = sl.buf[B].p;
+        int32_t rr = reserve(sl, B, bytes, out);
+        if (rr) return rr;
+        Slab::Key &k = sl.key[B];
+        if (sl.buf[B].p != before) k = Slab::Key();  // the buffer was (re)allocated: whatever it held is gone
+        const bool promised = (kind == 1 && mg->reuse_grid) || (kind == 2 && mg->reuse_fluxes);
+        const bool resident = promised && k.host == host && k.bytes == bytes && k.e0 == e0 && bytes > 0;
+        if (!resident && bytes) { up.push_back({*out, const_cast<void *>(host), bytes}); sl.uploaded += (i64)bytes; }
+        k.host = (promised || resident) ? host : nullptr;
+        k.bytes = bytes;
+        k.e0 = e0;
+        return resident ? -1 : OTMB_OK;  // (-1: nothing was queued)
+    };
+    // ϕ: what otmb_mgpu_facefluxes left on this device (already in the extended layout, halo fluxes filled in) is used when the
+    // caller hands back the host arrays facefluxes wrote (reuse_fluxes); otherwise the levels [e0, e1) of the host arrays go up
+    bool phi_here = mg->reuse_fluxes && sl.phi_resident && sl.buf[B_PHI0].cap >= Ge * 8;
+    for (int f = 0; f < 6 && phi_here; ++f) phi_here = sl.phi_host[f] == (const void *)a->phi[f] && sl.buf[B_PHI0 + f].p;
+    for (int f = 0; f < 6; ++f) {
+        if (phi_here) {
+            d.phi[f] = (const double *)sl.buf[B_PHI0 + f].p;
+        } else {
+            if ((r = put(B_PHI0 + f, (const char *)a->phi[f] + off * 8, Ge * 8, 0, &p)) > 0) return fail(r);
+            d.phi[f] = (const double *)p;
+        }
+    }
+    if (!phi_here) sl.phi_resident = false;
+    if ((r = put(B_V, (const char *)a->v3d + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
+    d.v3d = (const double *)p;
+    if ((r = put(B_THK, (const char *)a->thkcello + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
+    d.thkcello = (const double *)p;
+    if (a->rho) {
+        if ((r = put(B_RHO, (const char *)a->rho + off * 8, Ge * 8, 0, &p)) > 0) return fail(r);
+        d.rho = (const double *)p;
+    }
+    if ((r = put(B_LW, (const char *)a->lwet3d + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
+    d.lwet3d = (const int64_t *)p;
+    const int32_t lw_rc = put(B_LWET, (const char *)((const i64 *)a->lwet + sl.wet_base), (size_t)sl.n_own * 8, 1, &p);
+    if (lw_rc > 0) return fail(lw_rc);
+    d.lwet = (const int64_t *)p;
+    i64 *dlwet = (i64 *)p;
+    const bool lwet_fresh = lw_rc == OTMB_OK;  // (a resident Lwet has been shifted to local indices already)
+    for (int k = 0; k < 4; ++k) {
+        if ((r = put(B_EDGE0 + k, a->edge_length[k], (size_t)P * 8, 1, &p)) > 0) return fail(r);
+        d.edge_length[k] = (const double *)p;
+        if ((r = put(B_DIST0 + k, a->dist_nbr[k], (size_t)P * 8, 1, &p)) > 0) return fail(r);
+        d.dist_nbr[k] = (const double *)p;
+    }
+    if ((r = put(B_AREA, a->area2d, (size_t)P * 8, 1, &p)) > 0) return fail(r);
+    d.area2d = (const double *)p;
+    if ((r = put(B_ML, a->mlotst, (size_t)P * 8, 0, &p)) > 0) return fail(r);
+    d.mlotst = (const double *)p;
+    if ((r = put(B_ZT, a->zt + e0, (size_t)nze * 8, 1, &p)) > 0) return fail(r);
+    d.zt = (const double *)p;
+    if (before_upload) before_upload();  // (the pipelined build lets the slabs of one device take the link in turn)
+    r = up.empty() ? OTMB_OK : otmb_xfer(sl.ctx, true, up.data(), (int)up.size());
+    if (after_upload) after_upload();
+    if (r) return fail(r);
+    // Lwet of the owned cells as LOCAL linear indices of the extended grid (levels [e0, e1))
+    if (lwet_fresh && sl.n_own > 0 && off > 0) {
+        hipLaunchKernelGGL(shift_i64_kernel, dim3((unsigned)((sl.n_own + 255) / 256)), dim3(256), 0, sl.ctx->stream, dlwet, sl.n_own, (i64)off);
+        if (hipGetLastError() != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "shift_i64_kernel"); return fail(OTMB_ERR_HIP); }
+    }
+    on_device = true;  // (errors from here on are the reference's own: the arrays ARE where the keys say)
+    if ((r = otmb_transportmatrix_set_slab(sl.ctx, sl.wet_base))) return fail(r);
+    if ((r = otmb_transportmatrix_plan_dev(sl.ctx, &d, sl.nnz))) return fail(r);
 }
 
 }  // namespace
@@ -570,95 +667,7 @@ int32_t otmb_mgpu_transportmatrix_plan(otmb_mgpu *mg, const otmb_tm_args *a, int
     if ((rc = set_partition(mg, counts, a->nx, a->ny))) return rc;
     mg->args = *a;
     mg->N = N;
-    run_slabs(mg, [&](int s) {
-        Slab &sl = *mg->slabs[s];
-        // The residency keys are written when an upload is QUEUED: a slab that fails before its batch has reached the device (a later
-        // reserve, the transfer, the index shift) must forget them, or a retry with reuse on would take arrays that were never copied
-        // for resident and build matrices from uninitialised memory.
-        bool on_device = false;
-        auto fail = [&](int32_t st) {
-            sl.status = st; sl.msg = otmb_last_error(sl.ctx);
-            if (!on_device) {
-                for (int b = 0; b < B_COUNT; ++b) sl.key[b] = Slab::Key();
-                sl.phi_resident = false;
-            }
-        };
-        if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); return fail(OTMB_ERR_HIP); }
-        const i64 e0 = sl.k0 - sl.ha, e1 = sl.k1 + sl.hb, nze = e1 - e0;
-        const size_t Ge = (size_t)(nze * P), off = (size_t)e0 * P;
-        otmb_tm_args d = *a;
-        d.nz = nze;
-        d.n_wet = sl.n_own;
-        d.push_mask = nullptr;
-        std::vector<OtmbXferItem> up;
-        int32_t r;
-        void *p;
-        // One staged array: uploaded unless the slot still holds this very host array (pointer, bytes, first level) and the caller has
-        // promised not to have modified it (otmb_mgpu_set_reuse).  KIND 1: grid constant; 2: a face-flux array; 0: every call.
-        auto put = [&](int B, const void *host, size_t bytes, int kind, void **out) -> int32_t {
-            const void *before = sl.buf[B].p;
-            int32_t rr = reserve(sl, B, bytes, out);
-            if (rr) return rr;
-            Slab::Key &k = sl.key[B];
-            if (sl.buf[B].p != before) k = Slab::Key();  // the buffer was (re)allocated: whatever it held is gone
-            const bool promised = (kind == 1 && mg->reuse_grid) || (kind == 2 && mg->reuse_fluxes);
-            const bool resident = promised && k.host == host && k.bytes == bytes && k.e0 == e0 && bytes > 0;
-            if (!resident && bytes) { up.push_back({*out, const_cast<void *>(host), bytes}); sl.uploaded += (i64)bytes; }
-            k.host = (promised || resident) ? host : nullptr;
-            k.bytes = bytes;
-            k.e0 = e0;
-            return resident ? -1 : OTMB_OK;  // (-1: nothing was queued)
-        };
-        // ϕ: what otmb_mgpu_facefluxes left on this device (already in the extended layout, halo fluxes filled in) is used when the
-        // caller hands back the host arrays facefluxes wrote (reuse_fluxes); otherwise the levels [e0, e1) of the host arrays go up
-        bool phi_here = mg->reuse_fluxes && sl.phi_resident && sl.buf[B_PHI0].cap >= Ge * 8;
-        for (int f = 0; f < 6 && phi_here; ++f) phi_here = sl.phi_host[f] == (const void *)a->phi[f] && sl.buf[B_PHI0 + f].p;
-        for (int f = 0; f < 6; ++f) {
-            if (phi_here) {
-                d.phi[f] = (const double *)sl.buf[B_PHI0 + f].p;
-            } else {
-                if ((r = put(B_PHI0 + f, (const char *)a->phi[f] + off * 8, Ge * 8, 0, &p)) > 0) return fail(r);
-                d.phi[f] = (const double *)p;
-            }
-        }
-        if (!phi_here) sl.phi_resident = false;
-        if ((r = put(B_V, (const char *)a->v3d + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
-        d.v3d = (const double *)p;
-        if ((r = put(B_THK, (const char *)a->thkcello + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
-        d.thkcello = (const double *)p;
-        if (a->rho) {
-            if ((r = put(B_RHO, (const char *)a->rho + off * 8, Ge * 8, 0, &p)) > 0) return fail(r);
-            d.rho = (const double *)p;
-        }
-        if ((r = put(B_LW, (const char *)a->lwet3d + off * 8, Ge * 8, 1, &p)) > 0) return fail(r);
-        d.lwet3d = (const int64_t *)p;
-        const int32_t lw_rc = put(B_LWET, (const char *)((const i64 *)a->lwet + sl.wet_base), (size_t)sl.n_own * 8, 1, &p);
-        if (lw_rc > 0) return fail(lw_rc);
-        d.lwet = (const int64_t *)p;
-        i64 *dlwet = (i64 *)p;
-        const bool lwet_fresh = lw_rc == OTMB_OK;  // (a resident Lwet has been shifted to local indices already)
-        for (int k = 0; k < 4; ++k) {
-            if ((r = put(B_EDGE0 + k, a->edge_length[k], (size_t)P * 8, 1, &p)) > 0) return fail(r);
-            d.edge_length[k] = (const double *)p;
-            if ((r = put(B_DIST0 + k, a->dist_nbr[k], (size_t)P * 8, 1, &p)) > 0) return fail(r);
-            d.dist_nbr[k] = (const double *)p;
-        }
-        if ((r = put(B_AREA, a->area2d, (size_t)P * 8, 1, &p)) > 0) return fail(r);
-        d.area2d = (const double *)p;
-        if ((r = put(B_ML, a->mlotst, (size_t)P * 8, 0, &p)) > 0) return fail(r);
-        d.mlotst = (const double *)p;
-        if ((r = put(B_ZT, a->zt + e0, (size_t)nze * 8, 1, &p)) > 0) return fail(r);
-        d.zt = (const double *)p;
-        if (!up.empty() && (r = otmb_xfer(sl.ctx, true, up.data(), (int)up.size()))) return fail(r);
-        // Lwet of the owned cells as LOCAL linear indices of the extended grid (levels [e0, e1))
-        if (lwet_fresh && sl.n_own > 0 && off > 0) {
-            hipLaunchKernelGGL(shift_i64_kernel, dim3((unsigned)((sl.n_own + 255) / 256)), dim3(256), 0, sl.ctx->stream, dlwet, sl.n_own, (i64)off);
-            if (hipGetLastError() != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "shift_i64_kernel"); return fail(OTMB_ERR_HIP); }
-        }
-        on_device = true;  // (errors from here on are the reference's own: the arrays ARE where the keys say)
-        if ((r = otmb_transportmatrix_set_slab(sl.ctx, sl.wet_base))) return fail(r);
-        if ((r = otmb_transportmatrix_plan_dev(sl.ctx, &d, sl.nnz))) return fail(r);
-    });
+    run_slabs(mg, [&](int s) { plan_slab(mg, s, a, nullptr, nullptr); });
     if ((rc = collect_status(mg))) return rc;
     for (int m = 0; m < 5; ++m) {
         i64 run = 0;
@@ -740,6 +749,133 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         for (Slab *sl : mg->slabs) tot += sl->nnz[m];
         nnz_out[m] = mg->nnz[m] = (m < nm) ? tot : 0;
     }
+    return OTMB_OK;
+}
+
+// One-phase transportmatrix over the slabs, pipelined: HOST pointers of the whole grid in, the five matrices out into arrays of
+// `capacity` entries (7N, 7N, 5N, 3N, 3N always suffice: src/matrixbuilding.jl:244-296, :348-415, :450-477), no nnz round trip to the
+// caller in between.  Slab s uploads its levels while slab s - 1 counts, fills and copies its columns home: the link carries both
+// directions at once (tools/micro/pcie_duplex.py: 57 GB/s one way, 2 x 49 GB/s both ways on this pool's boxes), which the two-phase
+// protocol cannot use -- every upload there precedes the count, every download follows it.  Slabs that share a device take the link
+// in turn (slab order) for their uploads; a slab's column offsets are the running sums of the FINAL counts of the slabs above it
+// (T's entries that cancelled exactly included), so nothing is re-based afterwards.  Same matrices bit for bit.
+int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, int64_t *const colptr[5], int64_t *const rowval[5],
+                                          double *const nzval[5], const int64_t capacity[5], int64_t nnz_out[5]) {
+    if (!mg || !a || !colptr || !rowval || !nzval || !capacity || !nnz_out) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null argument");
+    if (a->nx < 1 || a->ny < 1 || a->nz < 1) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "grid size");
+    for (int f = 0; f < 6; ++f)
+        if (!a->phi[f]) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "phi");
+    for (int d = 0; d < 4; ++d)
+        if (!a->edge_length[d] || !a->dist_nbr[d]) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "metrics");
+    if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null input array");
+    const i64 P = a->nx * a->ny, G = P * a->nz, N = a->n_wet;
+    if (N < 0 || N > G || (N > 0 && !a->lwet)) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "lwet / n_wet");
+    const int nm = a->only_t ? 1 : 5, n = (int)mg->slabs.size();
+    for (int m = 0; m < nm; ++m)
+        if (!colptr[m] || capacity[m] < 0 || (capacity[m] > 0 && (!rowval[m] || !nzval[m]))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
+    mg->planned = false;
+    std::vector<i64> counts(a->nz, 0);
+    {
+        const i64 *lw = (const i64 *)a->lwet;
+        i64 prev = 0;
+        for (i64 k = 0; k < a->nz; ++k) {
+            const i64 pos = (i64)(std::upper_bound(lw, lw + N, (k + 1) * P) - lw);
+            counts[k] = pos - prev;
+            prev = pos;
+        }
+        if (prev != N) return mg_fail(mg, OTMB_ERR_NONCANONICAL_INDICES);
+    }
+    int32_t rc;
+    if ((rc = set_partition(mg, counts, a->nx, a->ny))) return rc;
+    mg->args = *a;
+    mg->N = N;
+    // the pipeline's state: which slabs have left the link (uploads), which have published their final counts
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<char> uploaded(n, 0);
+    int published = 0;
+    bool broken = false;  // a slab above failed: nobody below it stores anything
+    i64 next_base[5] = {0, 0, 0, 0, 0};
+    run_slabs(mg, [&](int s) {
+        Slab &sl = *mg->slabs[s];
+        int pred = -1;  // the nearest slab above me on MY device: I upload when it has
+        for (int q = s - 1; q >= 0 && pred < 0; --q)
+            if (mg->slabs[q]->device == sl.device) pred = q;
+        bool left_link = false;
+        auto leave_link = [&] {
+            if (left_link) return;
+            left_link = true;
+            { std::lock_guard<std::mutex> l(m); uploaded[s] = 1; }
+            cv.notify_all();
+        };
+        bool have_published = false;
+        auto publish = [&](bool ok) {  // my final counts are known (or never will be): release the slab below me
+            if (have_published) return;
+            have_published = true;
+            {
+                std::lock_guard<std::mutex> l(m);
+                if (ok) for (int q = 0; q < 5; ++q) next_base[q] += sl.nnz[q];
+                else broken = true;
+                published = s + 1;
+            }
+            cv.notify_all();
+        };
+        auto fail = [&](int32_t st) { sl.status = st; sl.msg = otmb_last_error(sl.ctx); };
+        plan_slab(mg, s, a,
+                  [&] {
+                      if (pred < 0) return;
+                      std::unique_lock<std::mutex> l(m);
+                      cv.wait(l, [&] { return uploaded[pred] != 0; });
+                  },
+                  leave_link);
+        leave_link();  // (a slab that failed before its upload must not hold the link)
+        {   // my turn to place my columns: every slab above me has published
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return published >= s; });
+            if (broken || sl.status != OTMB_OK) {
+                l.unlock();
+                return publish(false);
+            }
+            for (int q = 0; q < 5; ++q) sl.base[q] = next_base[q];
+        }
+        if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); fail(OTMB_ERR_HIP); return publish(false); }
+        for (int q = 0; q < nm; ++q)
+            if (sl.base[q] + sl.nnz[q] > capacity[q]) {
+                otmb_fail(sl.ctx, OTMB_ERR_CAPACITY);
+                fail(OTMB_ERR_CAPACITY);
+                return publish(false);
+            }
+        int32_t r;
+        int64_t *dcp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *drv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        double *dnz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        void *p;
+        for (int q = 0; q < nm; ++q) {
+            if ((r = reserve(sl, B_COLPTR0 + q, (size_t)(sl.n_own + 1) * 8, &p))) { fail(r); return publish(false); }
+            dcp[q] = (int64_t *)p;
+            if ((r = reserve(sl, B_ROWVAL0 + q, (size_t)sl.nnz[q] * 8, &p))) { fail(r); return publish(false); }
+            drv[q] = (int64_t *)p;
+            if ((r = reserve(sl, B_NZVAL0 + q, (size_t)sl.nnz[q] * 8, &p))) { fail(r); return publish(false); }
+            dnz[q] = (double *)p;
+        }
+        if ((r = otmb_transportmatrix_set_nnz_base(sl.ctx, sl.base)) || (r = otmb_transportmatrix_fill_dev(sl.ctx, dcp, drv, dnz)) ||
+            (r = otmb_transportmatrix_nnz(sl.ctx, sl.nnz))) {
+            fail(r);
+            return publish(false);
+        }
+        publish(true);  // (T's final count included: the slab below starts exactly where my entries end)
+        std::vector<OtmbXferItem> down;
+        const bool last = s + 1 == n;
+        for (int q = 0; q < nm; ++q) {
+            down.push_back({dcp[q], colptr[q] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8});
+            if (sl.nnz[q] > 0) {
+                down.push_back({drv[q], rowval[q] + sl.base[q], (size_t)sl.nnz[q] * 8});
+                down.push_back({dnz[q], nzval[q] + sl.base[q], (size_t)sl.nnz[q] * 8});
+            }
+        }
+        if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size()))) fail(r);
+    });
+    if ((rc = collect_status(mg))) return rc;
+    for (int q = 0; q < 5; ++q) nnz_out[q] = mg->nnz[q] = (q < nm) ? next_base[q] : 0;
     return OTMB_OK;
 }
 

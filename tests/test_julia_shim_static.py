@@ -177,11 +177,12 @@ def test_the_single_gpu_context_is_created_lazily():
     assert "ctx[] == C_NULL ||" in init  # the exit hook copes with a context that was never made
     ctxfn = _julia_function("context")
     assert "otmb_ctx_create" in ctxfn and "ctx[] == C_NULL" in ctxfn
-    pa = _julia_function("pinned_array")
-    assert "C_NULL, Int64(max(prod(dims), 1) * sizeof(T))" in pa and "context()" not in pa
+    pa = _julia_function("pinned_block")
+    assert "C_NULL, Int64(max(n, 1) * sizeof(T))" in pa and "context()" not in pa
+    assert "pinned_array(::Type{T}, dims...) where {T} = adopt(T, pinned_block(T, prod(dims)), dims...)" in SHIM
     assert "ctx may be NULL" in HEADER
     # the multi-GPU paths never ask for the single-GPU context
-    for fn in ("fused_mgpu",):
+    for fn in ("fused_mgpu", "fused_onepass"):
         assert "context()" not in _julia_function(fn) and "ctx[]" not in _julia_function(fn)
     ff = _julia_function("facefluxes")
     assert ff.index("if devices === nothing") < ff.index("context()") < ff.index("else")
@@ -236,6 +237,22 @@ def test_both_host_layers_make_the_same_c_calls_in_the_same_order():
     assert _collapse(jl_m) == want_m, jl_m
     assert _collapse(py_m) == want_m, py_m
     assert "fused_mgpu(" in jl and "_transportmatrix_mgpu(" in py  # both single-device builds hand a device list over to it
+    # ---- the pipelined one-phase build (slabs = S): result arrays at their upper bounds, then ONE call; both take the same bounds
+    jl_o = _julia_function("fused_onepass")
+    py_o = _python_function(api_src, "_transportmatrix_onepass")
+    jl_oc = [a or "otmb_host_alloc" for a in re.findall(r"sym\(:(otmb_\w+)\)|\boutarray\(|\bpinned_block\(", jl_o.split("else")[0])]
+    py_oc = [alias.get(a, a) for a in re.findall(r"\b(otmb_\w+|_out_array)\(", py_o)]
+    want_o = ["otmb_mgpu_set_reuse", "otmb_host_alloc", "otmb_mgpu_transportmatrix_onepass"]
+    assert _collapse(jl_oc) == want_o, jl_oc
+    assert _collapse(py_oc) == want_o, py_oc
+    assert "const PER_COLUMN_MAX = (7, 7, 5, 3, 3)" in SHIM and "PER_COLUMN_MAX = (7, 7, 5, 3, 3)" in api_src
+    assert "N * PER_COLUMN_MAX[m] + 1" in jl_o and "N * k + 1" in py_o
+    # the same default on both sides: 4 slabs from 2^18 wet cells and 8 levels on, never with reuse_fluxes or a device list
+    jl_d, py_d = _julia_function("default_slabs"), _python_function(api_src, "default_slabs")
+    for src in (jl_d, py_d):
+        assert "OTMB_HOST_SLABS" in src and '"4"' in src and "1 << 18" in src and "2 * s" in src and "reuse_fluxes" in src
+    jl_tm0 = _julia_function("transportmatrix")
+    assert "slabs = nothing" in SHIM and "fused_onepass(" in jl_tm0 and "_transportmatrix_onepass(" in _python_function(api_src, "transportmatrix")
     assert "otmb_mgpu_facefluxes" in _julia_function("facefluxes") and "otmb_mgpu_facefluxes" in _python_function(api_src, "_facefluxes_mgpu")
     # ---- precomputed operators: stand-ins + ignore_ops, ONE fused build, three adds with the library's `+`, left to right
     jl_tm = _julia_function("transportmatrix")

@@ -492,3 +492,135 @@ def test_rccl_transport_loads_and_initialises_on_one_gpu(oracle, monkeypatch):
     finally:
         api._mgpu.pop((0,), None)
         mg.close()
+
+
+# ---- the pipelined one-phase build (otmb_mgpu_transportmatrix_onepass; api.transportmatrix(..., slabs=S)) ----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("slabs,rho,upwind", [(1, "array", True), (2, "array", True), (4, "scalar", False), (8, "array", True)])
+def test_onepass_on_one_gpu_matches_whole_grid_oracle(oracle, slabs, rho, upwind):
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(24, 18, 11, seed=53 + slabs, rho=rho)
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm, upwind)
+    idx = api.makeindices(gm.v3D)
+    for operators in (True, False):
+        for rep in range(2):  # twice: the slabs' buffers and the pinned pool are reused
+            tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, upwind=upwind, slabs=slabs, operators=operators)
+            for m in MATS if operators else MATS[:1]:
+                assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/slabs={slabs}/rep={rep}")
+                assert tm[m].colptr[-1] == len(tm[m].rowval) + 1
+            if not operators:
+                assert all(tm[m] is None for m in MATS[1:])
+
+
+@pytest.mark.gpu
+def test_onepass_places_every_slab_behind_the_final_counts_of_the_slabs_above(oracle):
+    """κ = 0: every slab's T loses entries (exact-zero sums, src/matrixbuilding.jl:147) -- a slab's offsets are the running sums of the
+    FINAL counts above it, nothing is re-based afterwards."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(20, 16, 9, seed=41, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm, True, (0.0, 0.0, 0.0))
+    idx = api.makeindices(gm.v3D)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=0.0, κVML=0.0, κVdeep=0.0, slabs=3)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    assert tm["T"].nnz == tm["Tadv"].nnz < tm["TκH"].nnz + tm["Tadv"].nnz
+
+
+@pytest.mark.gpu
+def test_onepass_errors_release_every_slab(oracle):
+    """A failing slab in the middle of the pipeline: the slabs below it store nothing and return, the reference's error comes back with
+    the slab named, and the object builds the right matrices afterwards.  Too small an output array: OTMB_ERR_CAPACITY."""
+    import otmb_amd.api as api
+    from otmb_amd import capi, synthetic
+    from otmb_amd.capi import OtmbError
+
+    g = synthetic.make_grid(24, 18, 11, seed=36, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    kw = dict(mlotst=g.mlotst, gridmetrics=gm, indices=idx, slabs=4)
+    mg = api.mgpu([0, 0, 0, 0])
+    for where in (0, len(ref["Lwet"]) // 2, -1):  # first, a middle and the last slab
+        rho = g.rho.copy(order="F")
+        rho.ravel(order="F")[ref["Lwet"][where] - 1] = np.nan
+        with pytest.raises(OtmbError, match="ρ contains NaNs") as e:
+            api.transportmatrix(ϕ=rphi, ρ=rho, **kw)
+        assert "of 4" in str(e.value)
+        tm = api.transportmatrix(ϕ=rphi, ρ=g.rho, **kw)
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    # capacity: the C call with arrays one entry short for TκH
+    keep, passthrough = [], []
+    a = api._tm_args(rphi, g.mlotst, gm, idx, g.rho, g.kappaH, g.kappaVML, g.kappaVdeep, True, keep, passthrough)
+    N = int(idx["N"])
+    want = [len(rtm[m][1]) for m in MATS]
+    cap = [N * 7 + 1, N * 7 + 1, want[2] - 1, N * 3 + 1, N * 3 + 1]
+    cp = [np.zeros(N + 1, np.int64) for _ in range(5)]
+    rv = [np.zeros(c + 1, np.int64) for c in cap]   # (one entry more than the first call is told: the second call gets exactly enough)
+    nz = [np.zeros(c + 1, np.float64) for c in cap]
+    final = (C.c_int64 * 5)()
+    rc = capi.lib().otmb_mgpu_transportmatrix_onepass(mg.handle, C.byref(a), C.byref(capi.ptr_array(5, [x.ctypes.data for x in cp])),
+                                                      C.byref(capi.ptr_array(5, [x.ctypes.data for x in rv])),
+                                                      C.byref(capi.ptr_array(5, [x.ctypes.data for x in nz])), C.byref((C.c_int64 * 5)(*cap)), C.byref(final))
+    assert rc == 14, rc  # OTMB_ERR_CAPACITY
+    cap[2] = want[2]  # exactly enough
+    rc = capi.lib().otmb_mgpu_transportmatrix_onepass(mg.handle, C.byref(a), C.byref(capi.ptr_array(5, [x.ctypes.data for x in cp])),
+                                                      C.byref(capi.ptr_array(5, [x.ctypes.data for x in rv])),
+                                                      C.byref(capi.ptr_array(5, [x.ctypes.data for x in nz])), C.byref((C.c_int64 * 5)(*cap)), C.byref(final))
+    assert rc == capi.OK and list(final) == want, (rc, list(final), want)
+    for q, m in enumerate(MATS):
+        assert_csc_equal((cp[q], rv[q][: want[q]], nz[q][: want[q]]), rtm[m], m)
+
+
+@pytest.mark.gpu
+def test_onepass_with_the_reuse_promises_uploads_only_what_changed(oracle):
+    """A time loop (facefluxes, then transportmatrix) on three slabs of one device with both promises: a slice uploads ρ and mlotst only."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(24, 18, 11, seed=37, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    devices = [0, 0, 0]
+    mg = api.mgpu(devices)
+
+    def time_slice(**kw):
+        phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx, devices=devices)
+        b0 = mg.uploaded_bytes()
+        tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, devices=devices, slabs=3, **kw)
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/{kw}")
+        return mg.uploaded_bytes() - b0
+
+    full = time_slice()
+    first = time_slice(reuse_grid=True, reuse_fluxes=True)   # the first call with the promise still uploads the grid
+    both = time_slice(reuse_grid=True, reuse_fluxes=True)
+    nx, ny, nz = gm.v3D.shape
+    P = nx * ny
+    nze = nz + 2 * (len(devices) - 1)
+    assert both == nze * P * 8 + len(devices) * P * 8 < first < full, (both, first, full)
+
+
+@pytest.mark.gpu
+def test_onepass_at_the_headline_grid_matches_the_two_phase_path():
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(360, 300, 50, seed=20260501, rho="array")
+    gm = gridmetrics_of(g)
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    kw = dict(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML, κVdeep=g.kappaVdeep)
+    ref = api.transportmatrix(**kw)
+    for slabs in (4, 6):
+        tm = api.transportmatrix(slabs=slabs, **kw)
+        for m in MATS:
+            for a, b, what in zip(tuple(tm[m]), tuple(ref[m]), ("colptr", "rowval", "nzval")):
+                assert np.array_equal(a, b), (m, what, slabs)
