@@ -368,12 +368,13 @@ end
 # (a column holds at most 7 / 7 / 5 / 3 / 3 rows, src/matrixbuilding.jl:244-296, :348-415, :450-477), no nnz round trip, every slab's upload beside
 # the download of the slab above it.  The pinned blocks become Julia vectors of the FINAL lengths only after the call (no copy, one owner each).
 const PER_COLUMN_MAX = (7, 7, 5, 3, 3)
-# slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 wet cells and more, 8 levels and more) -- unless the fluxes
+# slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 ... 2^25 wet cells, 8 levels and more) -- unless the fluxes
 # are promised to be resident on the single-GPU context (reuse_fluxes) or a device list was given.  ENV["OTMB_HOST_SLABS"] overrides the 4.
 function default_slabs(N, nz, reuse_fluxes, devices)
     (devices === nothing && !reuse_fluxes) || return 0
     s = parse(Int, get(ENV, "OTMB_HOST_SLABS", "4"))
-    return (s > 0 && N >= (1 << 18) && nz >= 2 * s) ? s : 0
+    # (above 2^25 wet cells the upper-bound result arrays -- 400 B per wet cell -- pass 13 GB of pinned memory: left to an explicit `slabs =`)
+    return (s > 0 && (1 << 18) <= N < (1 << 25) && nz >= 2 * s) ? s : 0
 end
 function fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
                        usepinned::Bool, devices)

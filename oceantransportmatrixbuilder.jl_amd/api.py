@@ -415,14 +415,15 @@ def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVd
 
 
 def default_slabs(N, nz, reuse_fluxes, devices):
-    """slabs=None: the pipelined one-phase build on 4 slabs of the device for grids where the transfers dominate (2^18 wet cells and more, 8
+    """slabs=None: the pipelined one-phase build on 4 slabs of the device for grids where the transfers dominate (2^18 ... 2^25 wet cells, 8
     levels and more) -- unless the fluxes are promised to be resident on the single-GPU context (reuse_fluxes: nothing to upload beside
     the download then, the two-phase call is as fast) or a device list was given (`devices` keeps the two-phase protocol unless slabs is
     set).  ENV OTMB_HOST_SLABS overrides the 4 (0: always two-phase)."""
     if devices is not None or reuse_fluxes:
         return 0
     s = int(os.environ.get("OTMB_HOST_SLABS", "4"))
-    return s if (s > 0 and N >= (1 << 18) and nz >= 2 * s) else 0
+    # (above 2^25 wet cells the upper-bound result arrays -- 400 B per wet cell -- pass 13 GB of pinned memory: left to an explicit slabs=)
+    return s if (s > 0 and (1 << 18) <= N < (1 << 25) and nz >= 2 * s) else 0
 
 
 PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold (matrixbuilding.jl:244-296, :348-415, :450-477)

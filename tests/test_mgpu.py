@@ -609,6 +609,30 @@ def test_onepass_with_the_reuse_promises_uploads_only_what_changed(oracle):
 
 
 @pytest.mark.gpu
+def test_onepass_into_ordinary_host_memory_and_the_default_rule(oracle, monkeypatch):
+    """pinned results off: the upper-bound arrays are pageable and every slab's columns come home through its context's staging ring.
+    default_slabs: 4 from 2^18 wet cells and 8 levels on, never with reuse_fluxes, a device list or beyond 2^25 wet cells."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    assert api.default_slabs(3_000_000, 50, False, None) == 4 and api.default_slabs(3_000_000, 50, True, None) == 0
+    assert api.default_slabs(3_000_000, 50, False, [0, 1]) == 0 and api.default_slabs(100_000, 50, False, None) == 0
+    assert api.default_slabs(3_000_000, 7, False, None) == 0 and api.default_slabs(63_000_000, 75, False, None) == 0
+    monkeypatch.setenv("OTMB_HOST_SLABS", "0")
+    assert api.default_slabs(3_000_000, 50, False, None) == 0
+    monkeypatch.setenv("OTMB_HOST_SLABS", "6")
+    assert api.default_slabs(3_000_000, 50, False, None) == 6
+    monkeypatch.setattr(api, "PINNED_OUTPUTS", False)
+    g = synthetic.make_grid(70, 40, 12, seed=58, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, slabs=3)
+    for m in MATS:
+        assert_csc_equal(tuple(tm[m]), rtm[m], m)
+
+
+@pytest.mark.gpu
 def test_onepass_at_the_headline_grid_matches_the_two_phase_path():
     import otmb_amd.api as api
     from otmb_amd import synthetic
