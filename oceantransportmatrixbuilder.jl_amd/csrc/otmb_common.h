@@ -106,6 +106,7 @@ struct otmb_ctx {
     // staging for the host-pointer entry points
     std::vector<DevBuf> stage;
     OtmbXfer *xfer = nullptr;
+    DevBuf xfer_narrow;       // Int32 copies of the `narrow` items of a download (otmb_xfer.h)
     int xfer_threads = 0;     // host copy threads of this context's transfer engine; 0 = default (8, OTMB_XFER_THREADS); otmb_mgpu shares the cores among its slabs
     bool reuse_grid = false;  // otmb_ctx_set_reuse_grid: grid-constant host arrays are uploaded once (see include/otmb.h)
     i64 uploaded_bytes = 0;     // host -> device bytes of the host-pointer entry points (otmb_ctx_uploaded_bytes)

@@ -373,10 +373,11 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     TRY(otmb_transportmatrix_nnz(ctx, nnz));  // T's count can only shrink (entries that summed to exactly zero)
     for (int m = 0; m < 5; ++m) nnz_out[m] = nnz[m];
     std::vector<OtmbXferItem> down;
+    // row indices (<= N) and column offsets (<= nnz + 1) cross the link as Int32 where they provably fit (otmb_xfer.h: `narrow`)
     for (int m = 0; m < nm; ++m) {
-        down.push_back({dcp[m], colptr[m], (size_t)(N + 1) * 8});
+        down.push_back({dcp[m], colptr[m], (size_t)(N + 1) * 8, nnz_out[m] + 1 < ((int64_t)1 << 31)});
         if (nnz[m] > 0) {
-            down.push_back({drv[m], rowval[m], (size_t)nnz[m] * 8});
+            down.push_back({drv[m], rowval[m], (size_t)nnz[m] * 8, N < ((int64_t)1 << 31)});
             down.push_back({dnz[m], nzval[m], (size_t)nnz[m] * 8});
         }
     }

@@ -20,6 +20,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -709,10 +711,11 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         if ((r = otmb_transportmatrix_nnz(sl.ctx, sl.nnz))) return fail(r);
         std::vector<OtmbXferItem> down;
         const bool last = s + 1 == n;
+        const int small_rows = mg->N < ((i64)1 << 31);  // (otmb_xfer.h: `narrow`)
         for (int m = 1; m < nm; ++m) {
-            down.push_back({dcp[m], colptr[m] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8});
+            down.push_back({dcp[m], colptr[m] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, mg->nnz[m] + 1 < ((i64)1 << 31)});
             if (sl.nnz[m] > 0) {
-                down.push_back({drv[m], rowval[m] + sl.base[m], (size_t)sl.nnz[m] * 8});
+                down.push_back({drv[m], rowval[m] + sl.base[m], (size_t)sl.nnz[m] * 8, small_rows});
                 down.push_back({dnz[m], nzval[m] + sl.base[m], (size_t)sl.nnz[m] * 8});
             }
         }
@@ -729,9 +732,9 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         if (hipSetDevice(sl.device) != hipSuccess) { sl.status = OTMB_ERR_HIP; sl.msg = "hipSetDevice"; return; }
         const bool last = s + 1 == n;
         std::vector<OtmbXferItem> down;
-        down.push_back({sl.buf[B_COLPTR0].p, colptr[0] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8});
+        down.push_back({sl.buf[B_COLPTR0].p, colptr[0] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, mg->nnz[0] + 1 < ((i64)1 << 31)});
         if (sl.nnz[0] > 0) {
-            down.push_back({sl.buf[B_ROWVAL0].p, rowval[0] + tbase[s], (size_t)sl.nnz[0] * 8});
+            down.push_back({sl.buf[B_ROWVAL0].p, rowval[0] + tbase[s], (size_t)sl.nnz[0] * 8, mg->N < ((i64)1 << 31)});
             down.push_back({sl.buf[B_NZVAL0].p, nzval[0] + tbase[s], (size_t)sl.nnz[0] * 8});
         }
         const int32_t r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size());
@@ -796,6 +799,13 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
     int published = 0;
     bool broken = false;  // a slab above failed: nobody below it stores anything
     i64 next_base[5] = {0, 0, 0, 0, 0};
+    // OTMB_ONEPASS_TRACE=1: every slab's phase stamps (ms since the call began) on stderr -- where a time slice goes
+    const bool trace = getenv("OTMB_ONEPASS_TRACE") && getenv("OTMB_ONEPASS_TRACE")[0] == '1';
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::vector<std::array<double, 6>> stamps(n, std::array<double, 6>{{0, 0, 0, 0, 0, 0}});
+    std::mutex down_turn[16];
+    const bool down_turns = !(getenv("OTMB_ONEPASS_DOWN_TURNS") && getenv("OTMB_ONEPASS_DOWN_TURNS")[0] == '0');
     run_slabs(mg, [&](int s) {
         Slab &sl = *mg->slabs[s];
         int pred = -1;  // the nearest slab above me on MY device: I upload when it has
@@ -823,12 +833,15 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
         auto fail = [&](int32_t st) { sl.status = st; sl.msg = otmb_last_error(sl.ctx); };
         plan_slab(mg, s, a,
                   [&] {
-                      if (pred < 0) return;
-                      std::unique_lock<std::mutex> l(m);
-                      cv.wait(l, [&] { return uploaded[pred] != 0; });
+                      if (pred >= 0) {
+                          std::unique_lock<std::mutex> l(m);
+                          cv.wait(l, [&] { return uploaded[pred] != 0; });
+                      }
+                      stamps[s][0] = now_ms();
                   },
-                  leave_link);
+                  [&] { stamps[s][1] = now_ms(); leave_link(); });
         leave_link();  // (a slab that failed before its upload must not hold the link)
+        stamps[s][2] = now_ms();
         {   // my turn to place my columns: every slab above me has published
             std::unique_lock<std::mutex> l(m);
             cv.wait(l, [&] { return published >= s; });
@@ -838,6 +851,7 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
             }
             for (int q = 0; q < 5; ++q) sl.base[q] = next_base[q];
         }
+        stamps[s][3] = now_ms();
         if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); fail(OTMB_ERR_HIP); return publish(false); }
         for (int q = 0; q < nm; ++q)
             if (sl.base[q] + sl.nnz[q] > capacity[q]) {
@@ -863,17 +877,33 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
             return publish(false);
         }
         publish(true);  // (T's final count included: the slab below starts exactly where my entries end)
+        stamps[s][4] = now_ms();
         std::vector<OtmbXferItem> down;
         const bool last = s + 1 == n;
+        // row indices (<= N) and column offsets (<= capacity + 1) cross the link as Int32 where they provably fit (otmb_xfer.h: `narrow`)
+        const int small_rows = N < ((i64)1 << 31);
         for (int q = 0; q < nm; ++q) {
-            down.push_back({dcp[q], colptr[q] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8});
+            const int small_offs = capacity[q] + 1 < ((i64)1 << 31);
+            down.push_back({dcp[q], colptr[q] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, small_offs});
             if (sl.nnz[q] > 0) {
-                down.push_back({drv[q], rowval[q] + sl.base[q], (size_t)sl.nnz[q] * 8});
+                down.push_back({drv[q], rowval[q] + sl.base[q], (size_t)sl.nnz[q] * 8, small_rows});
                 down.push_back({dnz[q], nzval[q] + sl.base[q], (size_t)sl.nnz[q] * 8});
             }
         }
-        if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size()))) fail(r);
+        {   // One slab of a device copies home at a time: two download streams side by side slowed the NEXT slab's upload to 22 GB/s
+            // (profiles/r05/README.md section 9).  The turn ends with the slab's last DMA; its host threads unpack the ring afterwards.
+            // (experiment: OTMB_ONEPASS_DOWN_TURNS=0 lets the downloads overlap)
+            std::unique_lock<std::mutex> turn(down_turn[sl.device % 16], std::defer_lock);
+            if (down_turns) turn.lock();
+            const std::function<void()> hand_on = [&] { if (turn.owns_lock()) turn.unlock(); };
+            if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size(), &hand_on))) fail(r);
+        }
+        stamps[s][5] = now_ms();
     });
+    if (trace)
+        for (int s = 0; s < n; ++s)
+            fprintf(stderr, "onepass slab %d: upload %.2f-%.2f  planned %.2f  my turn %.2f  filled %.2f  home %.2f ms\n", s, stamps[s][0], stamps[s][1],
+                    stamps[s][2], stamps[s][3], stamps[s][4], stamps[s][5]);
     if ((rc = collect_status(mg))) return rc;
     for (int q = 0; q < 5; ++q) nnz_out[q] = mg->nnz[q] = (q < nm) ? next_base[q] : 0;
     return OTMB_OK;

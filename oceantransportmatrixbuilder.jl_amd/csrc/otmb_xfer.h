@@ -15,6 +15,11 @@ struct OtmbXferItem {
     void *dev;
     void *host;
     size_t bytes;
+    // (device -> host only) the array holds bytes / 8 Int64 values that the caller KNOWS to lie in [0, 2^31) -- row indices, column
+    // offsets: it crosses the link as Int32 (a narrowing kernel into a scratch buffer, half the bytes) and the host threads widen it
+    // into the Int64 array while the DMA engine is busy with the next pieces.  The host can widen 16 G entries/s with 8 threads
+    // (tools/micro/host_widen.cpp), the link moves 7 G Int64 entries/s.  Bit-identical by construction.
+    int narrow = 0;
 };
 
 class OtmbThreadPool {
@@ -42,9 +47,13 @@ struct OtmbXfer {
     char *pin = nullptr;  // NSLOT * chunk bytes of pinned host memory
     hipEvent_t ev[NSLOT] = {};
     OtmbThreadPool *pool = nullptr;
+    int narrow_ok = 1;  // OTMB_XFER_NARROW=0: `narrow` items travel as they are (A/B)
+    size_t narrow_min = (size_t)256 << 10;  // smaller arrays are not worth a kernel and a ring piece
     ~OtmbXfer();
 };
 
 // to_device: enqueue on ctx->stream; returns once every byte has been handed to the DMA engine (the caller's buffers may
 // be reused).  !to_device: returns when the host buffers are filled (the stream's earlier work is waited for).
-int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int n);
+// link_free (device -> host, optional): called once when this call's last DMA has finished -- possibly before the host threads have
+// unpacked the last ring pieces -- so that a caller that takes turns on the link can hand it on early.
+int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int n, const std::function<void()> *link_free = nullptr);

@@ -66,6 +66,8 @@ static int32_t xfer_init(otmb_ctx *ctx) {
     if (ctx->xfer) return OTMB_OK;
     OtmbXfer *x = new OtmbXfer();
     if (const char *e = getenv("OTMB_XFER_CHUNK_MB")) x->chunk = (size_t)(atoi(e) > 0 ? atoi(e) : 32) << 20;
+    if (const char *e = getenv("OTMB_XFER_NARROW")) x->narrow_ok = atoi(e) != 0;
+    if (const char *e = getenv("OTMB_XFER_NARROW_MIN_KB")) x->narrow_min = (size_t)(atoi(e) > 0 ? atoi(e) : 1) << 10;  // (tests: small arrays too)
     if (hipHostMalloc((void **)&x->pin, OtmbXfer::NSLOT * x->chunk) != hipSuccess) {
         x->pin = nullptr;
         delete x;
@@ -95,7 +97,21 @@ static void par_memcpy(OtmbThreadPool *pool, char *dst, const char *src, size_t 
     });
 }
 
-int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int n) {
+static void par_widen(OtmbThreadPool *pool, int64_t *dst, const int32_t *src, size_t count) {
+    const int parts = (count >= ((size_t)1 << 18)) ? pool->size() : 1;
+    const size_t per = ((count + parts - 1) / parts + 1023) & ~(size_t)1023;
+    pool->parallel_for(parts, [&](int p) {
+        const size_t a = (size_t)p * per, b = (a + per <= count) ? a + per : count;
+        for (size_t i = a; i < b; ++i) dst[i] = (int64_t)src[i];
+    });
+}
+
+__global__ __launch_bounds__(256) void narrow_i64_kernel(const int64_t *__restrict__ src, int32_t *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (int32_t)src[i];
+}
+
+int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int n, const std::function<void()> *link_free) {
     int32_t rc;
     if (to_device) {  // fault injection for the tests of the residency keys (a batch that never reaches the device must not be remembered)
         const char *e = getenv("OTMB_TEST_FAIL_UPLOAD");
@@ -103,20 +119,41 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
     }
     if ((rc = xfer_init(ctx))) return rc;
     OtmbXfer &x = *ctx->xfer;
-    struct Piece { char *dev, *host; size_t bytes; };
+    struct Piece { char *dev, *host; size_t bytes; bool widen; };
     std::vector<Piece> pieces;
+    std::vector<int> direct;  // (device -> host) copies that need no staging: issued BEHIND the first ring pieces, see below
+    // narrow items: one scratch buffer of Int32 for all of them, filled by one kernel each on the stream
+    size_t narrow_entries = 0;
+    if (!to_device && x.narrow_ok)
+        for (int q = 0; q < n; ++q)
+            if (items[q].narrow && items[q].bytes >= x.narrow_min) narrow_entries += items[q].bytes / 8;
+    if (narrow_entries) {
+        if ((rc = otmb_reserve(ctx, ctx->xfer_narrow, narrow_entries * 4))) return rc;
+        size_t at = 0;
+        for (int q = 0; q < n; ++q) {
+            if (!(items[q].narrow && items[q].bytes >= x.narrow_min)) continue;
+            const size_t cnt = items[q].bytes / 8;
+            int32_t *d32 = (int32_t *)ctx->xfer_narrow.p + at;
+            hipLaunchKernelGGL(narrow_i64_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)items[q].dev, d32, cnt);
+            for (size_t off = 0; off < cnt * 4; off += x.chunk)
+                pieces.push_back({(char *)d32 + off, (char *)items[q].host + 2 * off, (off + x.chunk <= cnt * 4) ? x.chunk : cnt * 4 - off, true});
+            at += cnt;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
     for (int q = 0; q < n; ++q) {
         if (!items[q].bytes) continue;
+        if (narrow_entries && items[q].narrow && items[q].bytes >= x.narrow_min) continue;  // (queued above)
         // small arrays: the runtime's own pageable path is fine; arrays inside pinned memory of otmb_host_alloc are the DMA's
         // own source / target: no staging, no host copy
         if (items[q].bytes < ((size_t)256 << 10) || otmb_host_is_pinned(ctx, items[q].host, items[q].bytes)) {
-            HIP_TRY(ctx, to_device ? hipMemcpyAsync(items[q].dev, items[q].host, items[q].bytes, hipMemcpyHostToDevice, ctx->stream)
-                                   : hipMemcpyAsync(items[q].host, items[q].dev, items[q].bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (to_device) HIP_TRY(ctx, hipMemcpyAsync(items[q].dev, items[q].host, items[q].bytes, hipMemcpyHostToDevice, ctx->stream));
+            else direct.push_back(q);
             continue;
         }
         for (size_t off = 0; off < items[q].bytes; off += x.chunk)
             pieces.push_back({(char *)items[q].dev + off, (char *)items[q].host + off,
-                              (off + x.chunk <= items[q].bytes) ? x.chunk : items[q].bytes - off});
+                              (off + x.chunk <= items[q].bytes) ? x.chunk : items[q].bytes - off, false});
     }
     const int np = (int)pieces.size(), NS = OtmbXfer::NSLOT;
     if (to_device) {
@@ -139,16 +176,33 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
         };
         for (; issued < np && issued < NS; ++issued)
             if ((rc = issue(issued))) return rc;
+        // the copies that go straight into pinned host memory queue up BEHIND the first ring pieces: the host threads unpack those
+        // (copy, or widen Int32 -> Int64) while the DMA engine works through these
+        for (int q : direct)
+            HIP_TRY(ctx, hipMemcpyAsync(items[q].host, items[q].dev, items[q].bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (link_free && np <= NS) {
+            // every DMA of this call is in the queue: wait for the last one, hand the link on, unpack afterwards
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (*link_free)();
+            for (int p = 0; p < np; ++p) {
+                const char *slot = x.pin + (size_t)(p % NS) * x.chunk;
+                if (pieces[p].widen) par_widen(x.pool, (int64_t *)pieces[p].host, (const int32_t *)slot, pieces[p].bytes / 4);
+                else par_memcpy(x.pool, pieces[p].host, slot, pieces[p].bytes);
+            }
+            return OTMB_OK;
+        }
         for (int p = 0; p < np; ++p) {
             const int s = p % NS;
             HIP_TRY(ctx, hipEventSynchronize(x.ev[s]));
-            par_memcpy(x.pool, pieces[p].host, x.pin + (size_t)s * x.chunk, pieces[p].bytes);
+            if (pieces[p].widen) par_widen(x.pool, (int64_t *)pieces[p].host, (const int32_t *)(x.pin + (size_t)s * x.chunk), pieces[p].bytes / 4);
+            else par_memcpy(x.pool, pieces[p].host, x.pin + (size_t)s * x.chunk, pieces[p].bytes);
             if (issued < np) {
                 if ((rc = issue(issued))) return rc;
                 ++issued;
             }
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the small direct copies
+        if (link_free) (*link_free)();
     }
     return OTMB_OK;
 }

@@ -648,3 +648,40 @@ def test_onepass_at_the_headline_grid_matches_the_two_phase_path():
         for m in MATS:
             for a, b, what in zip(tuple(tm[m]), tuple(ref[m]), ("colptr", "rowval", "nzval")):
                 assert np.array_equal(a, b), (m, what, slabs)
+
+
+@pytest.mark.gpu
+def test_index_arrays_cross_the_link_as_int32_and_come_back_the_same(oracle, monkeypatch):
+    """otmb_xfer's `narrow` items (row indices and column offsets travel as Int32, the host threads widen them): forced onto every array
+    (OTMB_XFER_NARROW_MIN_KB=1) with 1 MiB ring pieces, so that a matrix takes more pieces than the ring has slots -- the two-phase call on a
+    fresh context, otmb_mgpu plan / fetch and the pipelined one-phase build, pinned and ordinary result arrays -- against the oracle and
+    against the same calls with the arrays travelling as they are."""
+    import otmb_amd.api as api
+    from otmb_amd import capi, synthetic
+
+    g = synthetic.make_grid(130, 90, 30, seed=61, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    assert len(rtm["T"][1]) * 4 > 5 * (1 << 20)  # T's row indices as Int32: more than four pieces of 1 MiB
+    kw = dict(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho)
+    monkeypatch.setenv("OTMB_XFER_CHUNK_MB", "1")
+    for narrow in ("1", "0"):
+        monkeypatch.setenv("OTMB_XFER_NARROW", narrow)
+        monkeypatch.setenv("OTMB_XFER_NARROW_MIN_KB", "1")
+        for pinned in (True, False):
+            monkeypatch.setattr(api, "PINNED_OUTPUTS", pinned)
+            old = api._ctx.pop(0, None)  # a fresh single-GPU context reads the switches
+            api._ctx[0] = capi.Context(0)
+            try:
+                for name, extra in (("two-phase", dict(slabs=0)), ("mgpu", dict(devices=[0, 0, 0])), ("onepass", dict(slabs=3))):
+                    tm = api.transportmatrix(**kw, **extra)
+                    for m in MATS:
+                        assert_csc_equal(tuple(tm[m]), rtm[m], f"{m}/{name}/narrow={narrow}/pinned={pinned}")
+                    del tm
+            finally:
+                api._ctx.pop(0).close()
+                if old is not None:
+                    api._ctx[0] = old
+            for key in list(api._mgpu):
+                api._mgpu.pop(key).close()
