@@ -559,8 +559,25 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
         }
         (void)hipSetDevice(dev0);
     }
+    // Slabs that share a device take its link in turn: uploads deepest slab first (the chain's order), one slab downloading at a time -- the
+    // deepest slab's six arrays go home while the slab above it uploads (the link is full duplex; section 9 of profiles/r05/README.md).
+    std::mutex turn_m;
+    std::condition_variable turn_cv;
+    std::vector<char> ff_uploaded(n, 0);
+    std::mutex ff_down_turn[16];
     run_slabs(mg, [&](int s) {
         Slab &sl = *mg->slabs[s];
+        int succ = -1;  // the nearest slab BELOW me on my device: I upload when it has
+        for (int q = s + 1; q < n && succ < 0; ++q)
+            if (mg->slabs[q]->device == sl.device) succ = q;
+        bool left = false;
+        auto leave_link = [&] {
+            if (left) return;
+            left = true;
+            { std::lock_guard<std::mutex> l(turn_m); ff_uploaded[s] = 1; }
+            turn_cv.notify_all();
+        };
+        struct Leave { std::function<void()> f; ~Leave() { f(); } } leave_guard{leave_link};  // (whatever path this slab returns by)
         auto fail = [&](int32_t st) {
             sl.status = st;
             sl.msg = otmb_last_error(sl.ctx);
@@ -587,7 +604,13 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
         }
         OtmbXferItem up[3] = {{du, (char *)umo + (size_t)sl.k0 * P * es, Gl * es}, {dv, (char *)vmo + (size_t)sl.k0 * P * es, Gl * es},
                               {dw, (char *)wet3d + (size_t)sl.k0 * P, Gl}};
-        if ((r = otmb_xfer(sl.ctx, true, up, 3))) return fail(r);
+        if (succ >= 0) {
+            std::unique_lock<std::mutex> l(turn_m);
+            turn_cv.wait(l, [&] { return ff_uploaded[succ] != 0; });
+        }
+        r = otmb_xfer(sl.ctx, true, up, 3);
+        leave_link();
+        if (r) return fail(r);
         sl.uploaded += (i64)(2 * Gl * es + Gl);
         double *dp[6];
         for (int f = 0; f < 6; ++f) dp[f] = (double *)dphi[f];
@@ -626,7 +649,11 @@ int32_t otmb_mgpu_facefluxes(otmb_mgpu *mg, const void *umo, const void *vmo, in
         if (sl.hb) halo_ok &= hipMemcpyAsync((char *)dp[OTMB_TOP] + Gl * 8, dplane, (size_t)P * 8, hipMemcpyDeviceToDevice, sl.ctx->stream) == hipSuccess;
         std::vector<OtmbXferItem> down;
         for (int f = 0; f < 6; ++f) down.push_back({dp[f], phi[f] + (size_t)sl.k0 * P, Gl * 8});
-        if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size()))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
+        {
+            std::unique_lock<std::mutex> turn(ff_down_turn[sl.device % 16]);
+            const std::function<void()> hand_on = [&] { if (turn.owns_lock()) turn.unlock(); };
+            if ((r = otmb_xfer(sl.ctx, false, down.data(), (int)down.size(), &hand_on))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
+        }
         if ((r = otmb_facefluxes_slab_flags(sl.ctx, &sl.u_valid, &sl.v_valid))) { sl.status = r; sl.msg = otmb_last_error(sl.ctx); return; }
         if (halo_ok) {
             sl.phi_resident = true;
