@@ -176,10 +176,19 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
         };
         for (; issued < np && issued < NS; ++issued)
             if ((rc = issue(issued))) return rc;
-        // the copies that go straight into pinned host memory queue up BEHIND the first ring pieces: the host threads unpack those
-        // (copy, or widen Int32 -> Int64) while the DMA engine works through these
-        for (int q : direct)
-            HIP_TRY(ctx, hipMemcpyAsync(items[q].host, items[q].dev, items[q].bytes, hipMemcpyDeviceToHost, ctx->stream));
+        // The copies that go straight into pinned host memory queue up BEHIND the first ring pieces: the host threads unpack those
+        // (copy, or widen Int32 -> Int64) while the DMA engine works through these.  With more pieces than slots the direct copies are
+        // dealt out one per freed slot, so that the LAST things on the link are copies nobody has to unpack.
+        size_t next_direct = 0;
+        auto issue_direct = [&](size_t upto) -> int32_t {
+            for (; next_direct < upto && next_direct < direct.size(); ++next_direct) {
+                const int q = direct[next_direct];
+                HIP_TRY(ctx, hipMemcpyAsync(items[q].host, items[q].dev, items[q].bytes, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            return OTMB_OK;
+        };
+        const size_t per_slot = (np > NS) ? (direct.size() + (size_t)(np - NS)) / (size_t)(np - NS + 1) : direct.size();
+        if ((rc = issue_direct(np > NS ? per_slot : direct.size()))) return rc;
         if (link_free && np <= NS) {
             // every DMA of this call is in the queue: wait for the last one, hand the link on, unpack afterwards
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -199,9 +208,11 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
             if (issued < np) {
                 if ((rc = issue(issued))) return rc;
                 ++issued;
+                if ((rc = issue_direct(next_direct + per_slot))) return rc;
             }
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the small direct copies
+        if ((rc = issue_direct(direct.size()))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the direct copies
         if (link_free) (*link_free)();
     }
     return OTMB_OK;
