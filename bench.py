@@ -206,8 +206,8 @@ def end_to_end(g, gm, asm_N, reps=5, warm=2):
             "transportmatrix_c_abi_ms_reuse": 1e3 * res["reuse"][2], "value_reuse": asm_N / (res["reuse"][0] + res["reuse"][1]),
             "note": "host-pointer C ABI (what a Julia ccall passes): pageable host input arrays, five host CSC matrices out in pinned memory "
                     "of the library (otmb_host_alloc: the DMA writes them in place), PCIe both ways.  transportmatrix_ms: the default call -- "
-                    "pipelined over `slabs` depth slabs of the GPU, a slab uploading while the one above it copies its columns home "
-                    "(otmb_mgpu_transportmatrix_onepass); *_two_phase: slabs=0, otmb_transportmatrix_plan + _fetch (every upload before the "
+                    "pipelined over `slabs` depth slabs of the GPU, a slab uploading while the one above it copies its columns home, row indices "
+                    "and column offsets crossing the link as Int32 (otmb_mgpu_transportmatrix_onepass, OtmbXferItem.narrow); *_two_phase: slabs=0, otmb_transportmatrix_plan + _fetch (every upload before the "
                     "count, every download after it: rounds 1-4); c_abi_ms: inside the C calls; *_reuse: gridmetrics / indices uploaded once "
                     "(reuse_grid) and the face fluxes that facefluxes just computed not uploaded again (reuse_fluxes; two-phase)"}
 
