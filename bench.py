@@ -170,11 +170,12 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def end_to_end(g, gm, asm_N, reps=5, warm=2):
+def end_to_end(g, gm, asm_N, reps=5, warm=5):
     """What a Julia caller of the host-pointer C ABI sees (PCIe included; never `value`): facefluxesfrommasstransport +
     transportmatrix through otmb_amd.api on host arrays, median of `reps` time slices after `warm` warm-up slices (the first two slices of
     a loop allocate: device buffers, the pinned rings of the slab contexts, the pinned result blocks -- 123 and 31 ms against 23.4 ms from the
-    third on, tools/onepass_loop.py)."""
+    third on, tools/onepass_loop.py; and the default call spends its first five slices measuring which protocol this host is faster
+    with, api.Trial)."""
     import numpy as np
 
     import otmb_amd
@@ -201,6 +202,7 @@ def end_to_end(g, gm, asm_N, reps=5, warm=2):
     ff, tm, cabi = res["default"]
     return {"value": asm_N / (ff + tm), "unit": "wet-cells/s", "facefluxes_ms": 1e3 * ff, "transportmatrix_ms": 1e3 * tm,
             "transportmatrix_c_abi_ms": 1e3 * cabi, "slabs": api.default_slabs(asm_N, int(g.umo.data.shape[2]), False, None),
+            "default_protocol": ("pipelined" if api.Trial.of(0, int(asm_N)).now else "two-phase") + " (measured by the first five calls)",
             "transportmatrix_ms_two_phase": 1e3 * res["two_phase"][1], "value_two_phase": asm_N / (res["two_phase"][0] + res["two_phase"][1]),
             "facefluxes_ms_reuse": 1e3 * res["reuse"][0], "transportmatrix_ms_reuse": 1e3 * res["reuse"][1],
             "transportmatrix_c_abi_ms_reuse": 1e3 * res["reuse"][2], "value_reuse": asm_N / (res["reuse"][0] + res["reuse"][1]),

@@ -279,9 +279,20 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
         A = something(Tadv, r.Tadv); H = something(TκH, r.TκH); M = something(TκVML, r.TκVML); D = something(TκVdeep, r.TκVdeep)
         return (; T = spadd(spadd(spadd(A, H), M), D), Tadv = A, TκH = H, TκVML = M, TκVdeep = D)
     end
-    slabs = something(slabs, default_slabs(indices.N, size(gridmetrics.v3D, 3), reuse_fluxes, devices))
+    dev = parse(Int32, get(ENV, "OTMB_DEVICE", "0"))
+    if slabs === nothing
+        slabs = default_slabs(indices.N, size(gridmetrics.v3D, 3), reuse_fluxes, devices)
+        if slabs > 0   # the default's choice between the two protocols is measured (Trial)
+            tr = lock(() -> get!(() -> Trial(0, NaN, NaN, true), TRIALS, (Int(dev), Int(indices.N))), CALL_LOCK)
+            t0 = time()
+            r = pipelined!(tr) ?
+                fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, fill(dev, slabs)) :
+                fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, nothing)
+            record!(tr, time() - t0)
+            return r
+        end
+    end
     if slabs > 0
-        dev = parse(Int32, get(ENV, "OTMB_DEVICE", "0"))
         devs = devices === nothing ? fill(dev, clamp(Int(slabs), 1, size(gridmetrics.v3D, 3))) : devices
         return fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devs)
     end
@@ -368,6 +379,21 @@ end
 # (a column holds at most 7 / 7 / 5 / 3 / 3 rows, src/matrixbuilding.jl:244-296, :348-415, :450-477), no nnz round trip, every slab's upload beside
 # the download of the slab above it.  The pinned blocks become Julia vectors of the FINAL lengths only after the call (no copy, one owner each).
 const PER_COLUMN_MAX = (7, 7, 5, 3, 3)
+# The default call's choice between the pipelined and the two-phase protocol is MEASURED, per device and grid size, because it depends on the
+# host: the pipelined build needs the link to carry both directions at once and a few free host threads; where it does not get them it
+# has been seen slower than the two-phase call (27.9 against 23.6 ms; usually 20 against 25).  Calls 1-2 pipelined (they allocate), call 3
+# pipelined and timed, call 4 two-phase (allocates), call 5 two-phase and timed; from call 6 on whichever was faster.  An explicit
+# `slabs =` bypasses this.
+mutable struct Trial
+    n::Int; t1::Float64; t2::Float64; now::Bool
+end
+const TRIALS = Dict{Tuple{Int,Int},Trial}()
+function pipelined!(tr::Trial)
+    tr.n += 1
+    tr.now = tr.n <= 3 ? true : tr.n <= 5 ? false : (isnan(tr.t1) || isnan(tr.t2) || tr.t1 <= tr.t2)   # (a call that raised was not timed)
+    return tr.now
+end
+record!(tr::Trial, s) = (tr.n == 3 && (tr.t1 = s); tr.n == 5 && (tr.t2 = s); nothing)
 # slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 ... 2^25 wet cells, 8 levels and more) -- unless the fluxes
 # are promised to be resident on the single-GPU context (reuse_fluxes) or a device list was given.  ENV["OTMB_HOST_SLABS"] overrides the 4.
 function default_slabs(N, nz, reuse_fluxes, devices)

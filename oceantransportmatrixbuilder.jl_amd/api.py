@@ -366,8 +366,21 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     if any(x is not None for x in given.values()):
         # matrixbuilding.jl:140-143: operators passed in are used as they are; T = ((Tadv + TκH) + TκVML) + TκVdeep (:147)
         return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device, devices)
+    trial = None
     if slabs is None:
         slabs = default_slabs(int(indices["N"]), int(np.asarray(gridmetrics["v3D"]).shape[2]), reuse_fluxes, devices)
+        if slabs:
+            trial = Trial.of(int(device), int(indices["N"]))
+            slabs = slabs if trial.pipelined() else 0
+    if trial is not None:
+        import time as _time
+
+        t0 = _time.perf_counter()
+        tm = (_transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, [int(device)] * slabs, 0, reuse_grid, reuse_fluxes)
+              if slabs else
+              _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes, device, 0, None))
+        trial.record(_time.perf_counter() - t0)
+        return tm
     if slabs:
         nz_levels = int(np.asarray(gridmetrics["v3D"]).shape[2])
         devs = list(devices) if devices is not None else [int(device)] * max(1, min(int(slabs), nz_levels))
@@ -424,6 +437,36 @@ def default_slabs(N, nz, reuse_fluxes, devices):
     s = int(os.environ.get("OTMB_HOST_SLABS", "4"))
     # (above 2^25 wet cells the upper-bound result arrays -- 400 B per wet cell -- pass 13 GB of pinned memory: left to an explicit slabs=)
     return s if (s > 0 and (1 << 18) <= N < (1 << 25) and nz >= 2 * s) else 0
+
+
+class Trial:
+    """The default call's choice between the pipelined and the two-phase protocol is MEASURED, per device and grid size, because it depends
+    on the host: the pipelined build needs the link to carry both directions at once and a few free host threads; where it does not
+    get them it has been seen slower than the two-phase call (27.9 against 23.6 ms; usually 20 against 25: profiles/r05/README.md 9d).
+    Calls 1-2 pipelined (they allocate), call 3 pipelined and timed, call 4 two-phase (allocates), call 5 two-phase and timed; from
+    call 6 on whichever was faster.  An explicit slabs= bypasses this."""
+    _all = {}
+
+    def __init__(self):
+        self.n, self.t = 0, {True: None, False: None}
+
+    @classmethod
+    def of(cls, device, N):
+        return cls._all.setdefault((device, N), cls())
+
+    def pipelined(self):
+        self.n += 1
+        if self.n <= 3:
+            self.now = True
+        elif self.n <= 5:
+            self.now = False
+        else:  # (a call that raised was not timed: stay with the pipelined build)
+            self.now = self.t[True] is None or self.t[False] is None or self.t[True] <= self.t[False]
+        return self.now
+
+    def record(self, seconds):
+        if self.n in (3, 5):
+            self.t[self.now] = seconds
 
 
 PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold (matrixbuilding.jl:244-296, :348-415, :450-477)

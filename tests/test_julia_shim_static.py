@@ -251,7 +251,13 @@ def test_both_host_layers_make_the_same_c_calls_in_the_same_order():
     jl_d, py_d = _julia_function("default_slabs"), _python_function(api_src, "default_slabs")
     for src in (jl_d, py_d):
         assert "OTMB_HOST_SLABS" in src and '"4"' in src and "(1 << 18) <= N < (1 << 25)" in src and "2 * s" in src and "reuse_fluxes" in src
+    # ... and the same measured choice between the two protocols: pipelined for calls 1-3 (the third timed), two-phase for 4-5 (the fifth timed)
+    jl_p = _julia_function("pipelined!")
+    py_p = api_src[api_src.index("    def pipelined(self):"):api_src.index("    def record(self, seconds):")]
+    assert "tr.n <= 3 ? true : tr.n <= 5 ? false" in jl_p and "self.n <= 3" in py_p and "self.n <= 5" in py_p
+    assert "tr.n == 3 && (tr.t1 = s); tr.n == 5 && (tr.t2 = s)" in SHIM and "if self.n in (3, 5):" in api_src
     jl_tm0 = _julia_function("transportmatrix")
+    assert "pipelined!(tr) ?" in jl_tm0 and "trial.pipelined()" in _python_function(api_src, "transportmatrix")
     assert "slabs = nothing" in SHIM and "fused_onepass(" in jl_tm0 and "_transportmatrix_onepass(" in _python_function(api_src, "transportmatrix")
     assert "otmb_mgpu_facefluxes" in _julia_function("facefluxes") and "otmb_mgpu_facefluxes" in _python_function(api_src, "_facefluxes_mgpu")
     # ---- precomputed operators: stand-ins + ignore_ops, ONE fused build, three adds with the library's `+`, left to right

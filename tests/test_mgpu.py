@@ -685,3 +685,48 @@ def test_index_arrays_cross_the_link_as_int32_and_come_back_the_same(oracle, mon
                     api._ctx[0] = old
             for key in list(api._mgpu):
                 api._mgpu.pop(key).close()
+
+
+def test_the_default_protocol_is_chosen_by_measurement():
+    """api.Trial (no GPU): calls 1-3 pipelined (the third timed), 4-5 two-phase (the fifth timed), then the faster one; a trial whose timed
+    call raised stays with the pipelined build."""
+    import otmb_amd.api as api
+
+    for t_pipe, t_two, want in ((0.020, 0.025, True), (0.028, 0.024, False)):
+        tr, seq = api.Trial(), []
+        for call in range(9):
+            p = tr.pipelined()
+            seq.append(p)
+            tr.record(t_pipe if p else t_two)
+        assert seq[:5] == [True, True, True, False, False] and seq[5:] == [want] * 4, seq
+    tr = api.Trial()
+    for call in range(8):
+        p = tr.pipelined()
+        if call != 4:  # the timed two-phase call raised: nothing recorded
+            tr.record(0.02)
+    assert tr.pipelined() is True
+    assert api.Trial.of(3, 12345) is api.Trial.of(3, 12345) and api.Trial.of(3, 12345) is not api.Trial.of(3, 12346)
+
+
+@pytest.mark.gpu
+def test_default_calls_at_the_headline_grid_switch_protocols_and_stay_right():
+    """Eight default calls on the 1 degree grid go through both protocols (api.Trial); every one returns the two-phase call's matrices."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(360, 300, 50, seed=20260501, rho="array")
+    gm = gridmetrics_of(g)
+    idx = api.makeindices(gm.v3D)
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    kw = dict(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML, κVdeep=g.kappaVdeep)
+    ref = api.transportmatrix(slabs=0, **kw)
+    api.Trial._all.pop((0, int(idx["N"])), None)
+    used = []
+    for call in range(8):
+        tm = api.transportmatrix(**kw)
+        used.append(api.Trial.of(0, int(idx["N"])).now)
+        for m in MATS:
+            for a, b, what in zip(tuple(tm[m]), tuple(ref[m]), ("colptr", "rowval", "nzval")):
+                assert np.array_equal(a, b), (m, what, call)
+        del tm
+    assert used[:5] == [True, True, True, False, False] and used[5] == used[6] == used[7], used
