@@ -1,4 +1,6 @@
 """Shared test helpers: build the reference pipeline inputs for a synthetic grid."""
+import os
+
 import numpy as np
 
 import otmb_amd
@@ -59,3 +61,8 @@ def assert_csc_equal(a, b, what="", rtol=0.0):
         assert same.all(), f"{what}: nzval differs at {np.flatnonzero(~same)[:5]}: {a[2][~same][:5]} vs {b[2][~same][:5]}"
     else:
         np.testing.assert_allclose(a[2], b[2], rtol=rtol, atol=0.0, err_msg=what)
+
+
+# The suite is also run under the library's experiment switches (OTMB_COUNT_IN_FF=0, ...): tests ABOUT a switched-off feature skip, tests
+# that only note which kernels ran adapt
+COUNTS_ON = os.environ.get("OTMB_COUNT_IN_FF", "1") != "0"

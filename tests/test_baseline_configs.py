@@ -16,7 +16,7 @@ configs[3]      (the 0.25 degree grid cut in depth across 8 GPUs) needs 8 GPUs: 
 import numpy as np
 import pytest
 
-from helpers import MATS, assert_csc_equal, gridmetrics_of
+from helpers import COUNTS_ON, MATS, assert_csc_equal, gridmetrics_of
 
 pytestmark = pytest.mark.gpu
 
@@ -177,6 +177,7 @@ def test_large_grid_properties_and_subslab_oracle(oracle, workload, slab, protoc
     if workload == "quarterdeg":
         _subslab_oracle_check(oracle, dg, asm, 0, 1)
         _subslab_oracle_check(oracle, dg, asm, dg.nz - 1, dg.nz)
+    if workload == "quarterdeg" and COUNTS_ON:  # (otmb_step_dev needs the counts of its own facefluxes)
         # the fused step (otmb_step_dev: only ϕtop stored) into a second output set: the same matrices bit for bit, at full size
         nnz_two_call, first = list(asm.nnz), asm.out
         second = asm.new_output_set()
@@ -236,6 +237,7 @@ def test_access1deg_bolus_gm_velocity_matches_oracle(access1deg, oracle):
         np.testing.assert_allclose(h, r, rtol=1e-12, atol=1e-12 * typical, equal_nan=True, err_msg=name)
 
 
+@pytest.mark.skipif(not COUNTS_ON, reason="OTMB_COUNT_IN_FF=0: otmb_step_dev needs the counts of its own facefluxes")
 def test_access1deg_fused_step_matches_oracle_bit_for_bit(access1deg, access1deg_ref, oracle):
     """The fused device-resident step (otmb_step_dev: only ϕtop stored) on the whole 1 degree grid: the five matrices of the oracle."""
     from otmb_amd.device import DeviceAssembler

@@ -5,9 +5,9 @@ with the oracle bit for bit, and with the same library run with the counting pas
 import numpy as np
 import pytest
 
-from helpers import CASES, MATS, assert_csc_equal, gridmetrics_of, make_case
+from helpers import CASES, COUNTS_ON, MATS, assert_csc_equal, gridmetrics_of, make_case
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not COUNTS_ON, reason="OTMB_COUNT_IN_FF=0: the feature under test is switched off")]
 
 
 def _assembler(g, gm, upwind=True, count_in_ff=True, only_T=False):

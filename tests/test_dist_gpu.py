@@ -3,6 +3,7 @@ gloo (RCCL needs one GPU per rank; the transport layer is the only difference --
 and the concatenated result must equal the whole-grid oracle bit for bit."""
 import pytest
 
+from helpers import COUNTS_ON
 from test_dist_cpu import check_against_whole_grid, run_ranks
 
 pytestmark = pytest.mark.gpu
@@ -45,7 +46,7 @@ def test_hip_slabs_count_in_facefluxes(oracle, tmp_path, world, async_mode, case
     z = run_ranks(world, "hip", case, tmp_path, async_mode=async_mode, extra_env={"OTMB_TEST_KERNELS": "1"})
     check_against_whole_grid(oracle, z, case)
     for k in _kernels(tmp_path, world):
-        assert k.get("facefluxes_kernel", 0) > 0 and "tm_count_kernel" not in k and "push_mask_kernel" not in k, k
+        assert k.get("facefluxes_kernel", 0) > 0 and (("tm_count_kernel" not in k and "push_mask_kernel" not in k) or not COUNTS_ON), k
 
 
 def test_hip_slabs_count_in_facefluxes_centred_weighting(oracle, tmp_path):
@@ -53,7 +54,7 @@ def test_hip_slabs_count_in_facefluxes_centred_weighting(oracle, tmp_path):
     z = run_ranks(3, "hip", case, tmp_path, async_mode=True, extra_env={"OTMB_TEST_KERNELS": "1", "OTMB_TEST_CENTRED": "1"})
     check_against_whole_grid(oracle, z, case, upwind=False)
     for k in _kernels(tmp_path, 3):
-        assert "tm_count_kernel" not in k, k
+        assert "tm_count_kernel" not in k or not COUNTS_ON, k
 
 
 def test_hip_slabs_without_counts_still_count_for_themselves(oracle, tmp_path):
@@ -72,7 +73,7 @@ def test_hip_slabs_count_in_row_bands(oracle, tmp_path, pieces, rows):
     z = run_ranks(3, "hip", case, tmp_path, async_mode=True, pieces=pieces, extra_env={"OTMB_TEST_KERNELS": "1", "OTMB_FF_ROWS": rows})
     check_against_whole_grid(oracle, z, case)
     for k in _kernels(tmp_path, 3):
-        assert ("tm_count_kernel" not in k) == (rows == "4"), k
+        assert ("tm_count_kernel" not in k) == (rows == "4" and COUNTS_ON), k
 
 
 def _gpus():

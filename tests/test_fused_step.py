@@ -4,9 +4,9 @@ returns the six arrays, src/velocities.jl:245-254) -- and bit-identical to it: e
 import numpy as np
 import pytest
 
-from helpers import CASES, MATS, assert_csc_equal, gridmetrics_of, make_case
+from helpers import CASES, COUNTS_ON, MATS, assert_csc_equal, gridmetrics_of, make_case
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not COUNTS_ON, reason="OTMB_COUNT_IN_FF=0: otmb_step_dev needs the counts of its own facefluxes")]
 
 
 def _assembler(g, gm, upwind=True, only_T=False):

@@ -615,6 +615,7 @@ def test_onepass_into_ordinary_host_memory_and_the_default_rule(oracle, monkeypa
     import otmb_amd.api as api
     from otmb_amd import synthetic
 
+    monkeypatch.delenv("OTMB_HOST_SLABS", raising=False)
     assert api.default_slabs(3_000_000, 50, False, None) == 4 and api.default_slabs(3_000_000, 50, True, None) == 0
     assert api.default_slabs(3_000_000, 50, False, [0, 1]) == 0 and api.default_slabs(100_000, 50, False, None) == 0
     assert api.default_slabs(3_000_000, 7, False, None) == 0 and api.default_slabs(63_000_000, 75, False, None) == 0
@@ -709,11 +710,12 @@ def test_the_default_protocol_is_chosen_by_measurement():
 
 
 @pytest.mark.gpu
-def test_default_calls_at_the_headline_grid_switch_protocols_and_stay_right():
+def test_default_calls_at_the_headline_grid_switch_protocols_and_stay_right(monkeypatch):
     """Eight default calls on the 1 degree grid go through both protocols (api.Trial); every one returns the two-phase call's matrices."""
     import otmb_amd.api as api
     from otmb_amd import synthetic
 
+    monkeypatch.delenv("OTMB_HOST_SLABS", raising=False)
     g = synthetic.make_grid(360, 300, 50, seed=20260501, rho="array")
     gm = gridmetrics_of(g)
     idx = api.makeindices(gm.v3D)
