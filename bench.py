@@ -752,7 +752,10 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         if world > 1 or force_slab:
             out["config"]["ranks_over"] = backend  # the depth-slab path: "nccl" = RCCL (one rank per GPU)
         if world == 1 and host_grid is not None and not rehearsal:
-            out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
+            try:  # (an extra record must never cost the headline: the host-pointer legs allocate gigabytes of pinned memory and start threads)
+                out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
+            except Exception as e:
+                out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
         if world == 1 and host_grid is not None and not rehearsal and dev.type == "cuda":
             try:  # an extra record must never cost the headline
