@@ -341,10 +341,11 @@ def config2_bolus(g, gm, dev, local_rank, steps):
     alg = 33 * G + 16 * nx * ny
     ctx.close()
     return {"workload": f"bolus_GM_velocity on the {nx}x{ny}x{nz} grid (src/RediGM.jl:46-79; the reference's Redi/GM code never enters T)",
-            "kernels": "gm_slopes_kernel + gm_dyad_kernel", "ms": ms, "cells_per_s": G / (ms * 1e-3), "algorithmic_bytes": alg,
+            "kernels": "gm_fused_kernel (κGM·S through LDS; OTMB_GM_FUSED=0: gm_slopes_kernel + gm_dyad_kernel)", "ms": ms, "cells_per_s": G / (ms * 1e-3), "algorithmic_bytes": alg,
             "achieved_gbs": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "4 arrays in (ρ, Z3D, wet, 2-D distances), 2 out; the two κGM·S arrays between the kernels are written and read once more "
-                    "(74 B per cell of real traffic).  The transportmatrix of config 2 (3-D ρ) is this line's headline."}
+            "note": "4 arrays in (ρ, Z3D, wet, 2-D distances), 2 out; the two κGM·S arrays between the two steps stay in LDS.  Bound by its "
+                    "arithmetic (~25 Float64 divisions and a tanh per cell in dependent chains), not by its bytes.  The transportmatrix of "
+                    "config 2 (3-D ρ) is this line's headline."}
 
 
 def box_probe(dev):

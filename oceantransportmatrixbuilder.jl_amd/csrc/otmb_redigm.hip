@@ -70,6 +70,78 @@ __global__ __launch_bounds__(256) void gm_dyad_kernel(const double *__restrict__
     v[L] = b;
 }
 
+// Both steps in one kernel: a workgroup takes 64 consecutive columns of the plane, its eight waves an eighth of the levels each.  Every
+// thread computes κGM·S of its cells exactly as gm_slopes_kernel does and posts it in LDS ([2][nz][64] doubles: 51 KB at nz = 50); after one
+// barrier it takes the vertical dyad derivative of its own cells from there (the levels k - 1 / k + 1 may belong to the wave next to it).
+// The two (nx,ny,nz) arrays between the kernels -- written, then read three times over -- never exist: 178 MB instead of 350 MB of traffic at
+// 1 degree; what remains is the slopes' arithmetic (~25 Float64 divisions and a tanh per cell, in long dependent chains): 0.178-0.183 ->
+// 0.164-0.166 ms (4 / 8 / 16 waves per workgroup: 0.169 / 0.165 / 0.176 ms).  Same operations in the same order: bit-identical.
+#define GM_COLS 64
+#define GM_GROUPS 8
+__global__ __launch_bounds__(GM_COLS *GM_GROUPS) void gm_fused_kernel(const double *__restrict__ rho, const double *__restrict__ Z,
+                                                                      const uint8_t *__restrict__ wet, const double *__restrict__ dist_e,
+                                                                      const double *__restrict__ dist_n, int nx, int ny, int nz, i64 P,
+                                                                      double kappaGM, double maxslope, double *__restrict__ u,
+                                                                      double *__restrict__ v) {
+    extern __shared__ double gm_lds[];  // Ki: [nz][64], then Kj: [nz][64]
+    double *sKi = gm_lds, *sKj = gm_lds + (size_t)nz * GM_COLS;
+    const int lane = threadIdx.x & (GM_COLS - 1), grp = threadIdx.x / GM_COLS;
+    const i64 s = (i64)blockIdx.x * GM_COLS + lane;
+    const bool inside = s < P;
+    const int kper = (nz + GM_GROUPS - 1) / GM_GROUPS, k0 = grp * kper, k1 = (k0 + kper < nz) ? k0 + kper : nz;
+    const int j = inside ? (int)(s / nx) : 0, i = inside ? (int)(s - (i64)j * nx) : 0;
+    const double de = inside ? dist_e[s] : 0.0, dn = inside ? dist_n[s] : 0.0;
+    for (int k = k0; k < k1; ++k) {
+        double ki = __builtin_nan(""), kj = __builtin_nan("");
+        if (inside) {
+            const i64 L = (i64)k * P + s;
+            double si = __builtin_nan(""), sj = __builtin_nan("");
+            if (wet[L]) {
+                Cell c;
+                c.i = i; c.j = j; c.k = k; c.L = L; c.row0 = L - i;
+                const i64 N = nb_km1(c, P), S = nb_kp1(c, nz, P);
+                const i64 Ei = nb_ip1(c, nx), Ej = nb_jp1(c, nx, ny, OTMB_TRIPOLAR);
+                si = gm_triad(rho, Z, de, L, N, S, Ei, (k > 0) ? Ei - P : -1, (k + 1 < nz) ? Ei + P : -1);
+                sj = gm_triad(rho, Z, dn, L, N, S, Ej, (k > 0) ? Ej - P : -1, (k + 1 < nz) ? Ej + P : -1);
+            }
+            si = (si > maxslope) ? maxslope : ((si < -maxslope) ? -maxslope : si);
+            sj = (sj > maxslope) ? maxslope : ((sj < -maxslope) ? -maxslope : sj);
+            const double taper = 0.5 * (1 + tanh((0.004 - sqrt(si * si + sj * sj)) / 0.001));
+            ki = kappaGM * (taper * si);
+            kj = kappaGM * (taper * sj);
+        }
+        sKi[(size_t)k * GM_COLS + lane] = ki;
+        sKj[(size_t)k * GM_COLS + lane] = kj;
+    }
+    __syncthreads();
+    if (!inside) return;
+    for (int k = k0; k < k1; ++k) {
+        const i64 L = (i64)k * P + s;
+        double a = __builtin_nan(""), b = __builtin_nan("");
+        if (wet[L]) {
+            const double nanv = __builtin_nan("");
+            const double zI = Z[L], zN = (k > 0) ? Z[L - P] : nanv, zS = (k + 1 < nz) ? Z[L + P] : nanv;
+            const double dN = fabs(zN - zI), dS = fabs(zS - zI);
+            {   // gm_dyad on κGM·S_i
+                const double c = sKi[(size_t)k * GM_COLS + lane];
+                const double cn = (k > 0) ? sKi[(size_t)(k - 1) * GM_COLS + lane] : nanv, cs = (k + 1 < nz) ? sKi[(size_t)(k + 1) * GM_COLS + lane] : nanv;
+                const double x = (cn - c) / dN, y = (c - cs) / dS;
+                const bool wx = !isnan(x), wy = !isnan(y);
+                a = ((wx ? x : 0.0) + (wy ? y : 0.0)) / (double)((int)wx + (int)wy);
+            }
+            {
+                const double c = sKj[(size_t)k * GM_COLS + lane];
+                const double cn = (k > 0) ? sKj[(size_t)(k - 1) * GM_COLS + lane] : nanv, cs = (k + 1 < nz) ? sKj[(size_t)(k + 1) * GM_COLS + lane] : nanv;
+                const double x = (cn - c) / dN, y = (c - cs) / dS;
+                const bool wx = !isnan(x), wy = !isnan(y);
+                b = ((wx ? x : 0.0) + (wy ? y : 0.0)) / (double)((int)wx + (int)wy);
+            }
+        }
+        u[L] = a;
+        v[L] = b;
+    }
+}
+
 extern "C" int32_t otmb_bolus_gm_velocity_dev(otmb_ctx *ctx, const double *rho, const double *z3d, const uint8_t *wet3d,
                                               const double *dist_east, const double *dist_north, int64_t nx, int64_t ny,
                                               int64_t nz, int32_t topology, double kappa_gm, double maxslope, double *u,
@@ -82,6 +154,17 @@ extern "C" int32_t otmb_bolus_gm_velocity_dev(otmb_ctx *ctx, const double *rho, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 P = nx * ny, G = P * nz;
     int32_t rc;
+    const size_t lds = (size_t)2 * nz * GM_COLS * sizeof(double);
+    const char *sw = getenv("OTMB_GM_FUSED");  // (=0: the two streaming kernels, A/B and tests)
+    if (!(sw && sw[0] == '0') && lds <= (size_t)150 * 1024) {
+        if (lds > (size_t)48 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)gm_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KernelTimer kt(ctx, K_GM);
+        hipLaunchKernelGGL(gm_fused_kernel, dim3((unsigned)((P + GM_COLS - 1) / GM_COLS)), dim3(GM_COLS * GM_GROUPS), lds, ctx->stream, rho, z3d,
+                           wet3d, dist_east, dist_north, (int)nx, (int)ny, (int)nz, P, kappa_gm, maxslope, u, v);
+        HIP_TRY(ctx, hipGetLastError());
+        return OTMB_OK;
+    }
     if ((rc = otmb_reserve(ctx, ctx->tfix[1], (size_t)G * 8))) return rc;
     if ((rc = otmb_reserve(ctx, ctx->tfix[2], (size_t)G * 8))) return rc;
     double *Ki = (double *)ctx->tfix[1].p, *Kj = (double *)ctx->tfix[2].p;

@@ -48,3 +48,44 @@ def test_hip_bolus_bipolar_is_an_error(oracle):
     gi = api.makeindices(gm.v3D)
     with pytest.raises(OtmbError):
         api.bolus_GM_velocity(np.asfortranarray(gm.Z3D * 0 + 1030.0), gm, gi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(24, 18, 11), (70, 9, 3), (130, 40, 50), (65, 33, 75), (9, 7, 130)])
+def test_fused_bolus_kernel_equals_the_two_streaming_kernels_bit_for_bit(monkeypatch, shape):
+    """gm_fused_kernel (κGM·S through LDS, one barrier) does the same operations in the same order as gm_slopes_kernel + gm_dyad_kernel:
+    the same bits, NaNs included -- level counts that do not divide by the eight waves of a workgroup, one level per wave, more LDS
+    than the default limit (nz = 75: 77 KB), and a grid too deep for LDS (nz = 130: both calls take the streaming kernels)."""
+    import ctypes as C
+
+    import torch
+
+    from otmb_amd import capi
+
+    nx, ny, nz = shape
+    rng = np.random.default_rng(11)
+    P = nx * ny
+    wet = (rng.random((nz, P)) < 0.75)
+    wet[:, :3] = True
+    rho = 1025.0 + 0.01 * np.arange(nz)[:, None] + 0.05 * rng.standard_normal((nz, P))
+    rho[~wet] = np.nan
+    z3d = np.cumsum(5.0 + 3.0 * rng.random((nz, P)), axis=0)
+    z3d[rng.random((nz, P)) < 0.01] = np.nan  # NaN depths take part in the NaN-aware means as well
+    de, dn = 5e4 + 1e4 * rng.random(P), 5e4 + 1e4 * rng.random(P)
+    dev = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda().reshape(-1)
+    d_rho, d_z, d_de, d_dn = dev(rho), dev(z3d), dev(de), dev(dn)
+    d_wet = torch.from_numpy(wet.astype(np.uint8)).cuda().reshape(-1)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("OTMB_GM_FUSED", fused)
+        ctx = capi.Context(0)
+        u, v = torch.full_like(d_rho, 7.0), torch.full_like(d_rho, 7.0)
+        ctx.timing_enable(True)
+        ctx.check(capi.lib().otmb_bolus_gm_velocity_dev(ctx.handle, d_rho.data_ptr(), d_z.data_ptr(), d_wet.data_ptr(), d_de.data_ptr(), d_dn.data_ptr(),
+                                                        nx, ny, nz, 1, 600.0, 0.01, u.data_ptr(), v.data_ptr()))
+        ctx.synchronize()
+        out[fused] = (u.cpu().numpy().view(np.int64), v.cpu().numpy().view(np.int64))
+        ctx.close()
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    u = out["1"][0].view(np.float64).reshape(nz, P)
+    assert np.all(np.isnan(u[~wet])) and np.isfinite(u[wet]).any()
