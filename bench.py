@@ -164,7 +164,7 @@ def kernel_source_hash():
     """profiles/traffic.json holds counter traffic measured for ONE version of the dominant kernel: it is keyed to a hash of
     the kernel's sources and ignored (traffic: null) when they have changed since."""
     h = hashlib.sha256()
-    for f in ("otmb_transportmatrix.hip", "otmb_tm_column.h", "otmb_tm_dense.h", "otmb_facefluxes.hip"):
+    for f in ("otmb_transportmatrix.hip", "otmb_tm_column.h", "otmb_facefluxes.hip"):
         with open(os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

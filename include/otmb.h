@@ -110,13 +110,6 @@ int32_t otmb_host_pool_stats(int64_t *blocks_in_use, int64_t *bytes_in_use, int6
  * grid 70 -> 48 GB, its time unchanged (profiles/r04/README.md section 10).  Environment, read when a context is created, for
  * experiments only: OTMB_MARCH_ROWS, OTMB_MARCH_COLS (0 = whole rows).                                                       */
 int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band);
-/* Speed only, never results: which kernels build the matrices of transportmatrix.  dense = 0: GATHER -- one lane per wet
- * cell fetches its 6-neighbour stencil from global memory (tiles of 256 columns); dense = 1: DENSE-TILE MARCH -- a wave is
- * 62 consecutive cells of one grid row and walks down the levels: east / west neighbours are the neighbouring lanes, the
- * levels above / below stay in registers, every input is read once (land lanes idle); -1 (default): the library's choice
- * (the gather kernels: they measure faster on every grid tried).  depth_parts > 0: levels per column are
- * cut into that many pieces (more waves, shorter marches); 0 leaves it unchanged.  Same matrices bit for bit.      */
-int32_t otmb_ctx_set_formulation(otmb_ctx *ctx, int32_t dense, int32_t depth_parts);
 const char *otmb_last_error(const otmb_ctx *ctx);
 const char *otmb_status_string(int32_t status); /* the reference's error text for codes 1-8 */
 const char *otmb_version(void);
@@ -346,8 +339,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
  * holds at most 7, 7, 5, 3, 3 entries of T, Tadv, TκH, TκVML, TκVdeep): count -> scan -> fill are enqueued back
  * to back with no host round trip.  capacity[m] = entries rowval[m]/nzval[m] can hold; colptr[m] holds
  * n_wet+1.  otmb_transportmatrix_result synchronises, raises the reference's errors / OTMB_ERR_CAPACITY,
- * compacts T if entries cancelled and returns the five nnz.  (Environment OTMB_LOOKBACK=1 selects an
- * experimental single-kernel variant whose tile offsets come from a decoupled look-back.)
+ * compacts T if entries cancelled and returns the five nnz.
  * One exception to "no host round trip": the FIRST call for a grid (and the first after otmb_ctx_set_stream changed the stream)
  * builds the fill pass's tile order and waits for its number of heavy tiles -- one stream synchronisation per grid, not per step. */
 int32_t otmb_transportmatrix_dev(otmb_ctx *ctx, const otmb_tm_args *args, int64_t *const colptr[5],

@@ -85,7 +85,6 @@ SYMBOLS = {
     "otmb_mgpu_transportmatrix_onepass": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5),
                                                       C.POINTER(C.c_int64 * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
-    "otmb_ctx_set_formulation": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "otmb_last_error": (C.c_char_p, [_vp]),
     "otmb_status_string": (C.c_char_p, [C.c_int32]),
     "otmb_version": (C.c_char_p, []),
@@ -283,10 +282,6 @@ class Context:
     def set_tile_order(self, rows_per_band):
         """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = the library default (bands of 8 rows)."""
         self.check(self._lib.otmb_ctx_set_tile_order(self._h, int(rows_per_band)))
-
-    def set_formulation(self, dense, depth_parts=0):
-        """Speed only: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size."""
-        self.check(self._lib.otmb_ctx_set_formulation(self._h, int(dense), int(depth_parts)))
 
     def use_own_stream(self):
         self.check(self._lib.otmb_ctx_set_stream(self._h, _vp(0)))

@@ -28,7 +28,7 @@ struct SpPlan { const int64_t *I = nullptr, *J = nullptr; const double *V = null
 
 // kernel ids for the optional HIP-event timing (otmb_ctx_timing_*)
 enum {
-    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_TM_ONEPASS, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_TM_ORDER, K_DM_COUNT, K_DM_FILL, K_FF_BASES, K_NKERNELS
+    K_TM_COUNT = 0, K_TILESCAN, K_TM_FILL, K_TM_FINISH, K_FACEFLUXES, K_IDX_COUNT, K_IDX_WRITE, K_VELFLUX, K_GM, K_GRIDMETRICS, K_PUSHMASK, K_TM_ORDER, K_FF_BASES, K_NKERNELS
 };
 #define OTMB_TIMING_POOL 2048
 
@@ -38,7 +38,7 @@ struct otmb_ctx {
     hipStream_t stream = nullptr;  // own_stream or a borrowed one
     std::string err;
     // scratch for the scans / flags
-    DevBuf blocksums, blockoffs, flags, lookback, tcount, tfix[3];
+    DevBuf blocksums, blockoffs, flags, stamps, tcount, tfix[3];  // (stamps: diagnostic builds, OTMB_DBG_STAMPS)
     DevBuf sort[5];            // radix-sort keys/values/temporary of the general sparse() path
     DevBuf tm_sums, tm_offs;  // tile sums/offsets of the pending transportmatrix plan (must survive until fill)
     DevBuf mask;              // push mask derived by the library when the caller passes none
@@ -74,8 +74,6 @@ struct otmb_ctx {
         bool pieces_open = false;  // the last facefluxes call counted: a further row band of it (otmb_facefluxes_slab_counts_dev, first = 0) adds to the same buffer
     } ffc;
     const void *ffc_partial_mask = nullptr;  // the push_mask argument of the last counting facefluxes call: NOT written by it, never a counting pass's input
-    int formulation = -1;     // transportmatrix: 0 = gather kernels, 1 = dense-tile march, -1 = chosen by grid size (otmb_ctx_set_formulation)
-    int dense_kparts = 1;     // dense march: depth pieces per (row, segment)
     DevBuf lump[11];          // lump_and_spray scratch (otmb_lump.hip)
     DevBuf lump_host;         // staging of the host-pointer entry point
     bool lump_valid = false;
@@ -140,7 +138,7 @@ struct KernelTimer {
 #define OTMB_NFLAGS 16
 enum {
     FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
-    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_LOOKBACK_TIMEOUT, FLAG_CAPACITY,
+    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_RESERVED7, FLAG_CAPACITY,
     FLAG_T_CANCEL,  // some T entry summed to exactly zero: T was written with gaps and needs compaction
     FLAG_COUNT_MISMATCH,  // a tile's fill pass found other counts than its counting pass: push_mask does not describe ϕ
     OTMB_NFLAGS_TM = 12,            // words [0, OTMB_NFLAGS_TM) belong to transportmatrix and are reset by it

@@ -69,13 +69,11 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     c->device = device_id;
     if (const char *e = getenv("OTMB_MARCH_ROWS")) c->march_rows = atoi(e);  // experiments; otmb_ctx_set_tile_order is the API
     if (const char *e = getenv("OTMB_MARCH_COLS")) c->march_cols = atoi(e);  // experiments
-    if (const char *e = getenv("OTMB_DENSE")) c->formulation = atoi(e);        // experiments; otmb_ctx_set_formulation is the API
     if (const char *e = getenv("OTMB_FF_XCD")) c->ff_xcd_chunks = atoi(e);       // experiments (A/B in one library)
     if (const char *e = getenv("OTMB_FF_ROWS")) c->ff_rows = atoi(e);
     if (const char *e = getenv("OTMB_FF_LDS_SOUTH")) c->ff_lds_south = atoi(e);
     if (const char *e = getenv("OTMB_COUNT_ORDER")) c->count_order = atoi(e);
     if (const char *e = getenv("OTMB_DEAL_HEAVY")) c->deal_heavy = atoi(e);
-    if (const char *e = getenv("OTMB_DENSE_KPARTS")) c->dense_kparts = atoi(e);
     if (const char *e = getenv("OTMB_COUNT_IN_FF")) c->count_in_ff = atoi(e);  // A/B in one library
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -113,7 +111,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     otmb_tm_plan_free(ctx);
     otmb_xfer_free(ctx);
-    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->lookback, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4], &ctx->ffc_sums[0], &ctx->ffc_sums[1], &ctx->xfer_narrow})
+    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->stamps, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4], &ctx->ffc_sums[0], &ctx->ffc_sums[1], &ctx->xfer_narrow})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
@@ -148,13 +146,6 @@ int32_t otmb_ctx_use_default_stream(otmb_ctx *ctx) {
 int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band) {
     if (!ctx || rows_per_band < -1) return OTMB_ERR_INVALID_ARG;
     ctx->march_rows = rows_per_band;
-    return OTMB_OK;
-}
-
-int32_t otmb_ctx_set_formulation(otmb_ctx *ctx, int32_t dense, int32_t depth_parts) {
-    if (!ctx || dense < -1 || dense > 1 || depth_parts < 0) return OTMB_ERR_INVALID_ARG;
-    ctx->formulation = dense;
-    if (depth_parts > 0) ctx->dense_kparts = depth_parts;
     return OTMB_OK;
 }
 
@@ -202,8 +193,8 @@ int32_t otmb_ctx_timing_collect(otmb_ctx *ctx, double *ms_sum, int64_t *count, i
 const char *otmb_kernel_name(int32_t k) {
     static const char *names[K_NKERNELS] = {"tm_count_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_finish_colptr",
                                             "facefluxes_kernel", "indices_kernel<count>", "indices_kernel<write>",
-                                            "tm_kernel<onepass>", "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
-                                            "push_mask_kernel", "tm_order_kernels", "dm_count_kernel", "dm_fill_kernel", "ff_count_bases_kernel"};
+                                            "velocity_flux_kernel", "gm_slopes+gm_dyad", "gridmetrics2d+3d",
+                                            "push_mask_kernel", "tm_order_kernels", "ff_count_bases_kernel"};
     return (k >= 0 && k < K_NKERNELS) ? names[k] : "";
 }
 

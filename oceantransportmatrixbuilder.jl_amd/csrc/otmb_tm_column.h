@@ -48,9 +48,7 @@ struct TmParams {
     uint32_t *tilesums;    // [ntiles][5]  (COUNT writes)
     const i64 *tileoffs;   // [ntiles][5]  (FILL reads)
     const i64 *gsum;       // [groups][5] totals of the scan groups, when tileoffs are group-relative (else NULL)
-    u64 *status;           // [n_tiles] status words, then [n_tiles][5] inclusive prefixes (ONEPASS)
-    i64 n_tiles;
-    int *ticket;           // dynamic tile id (ONEPASS)
+    u64 *status;           // diagnostic builds only (OTMB_DBG_STAMPS): the stamp buffer
     int *flags;
     int *next_state;       // the NEXT asynchronous step's state block, zeroed by this fill (or NULL): no memset between steps
     const unsigned *order; // fill pass: tile taken by the q-th workgroup slot (march order), or NULL = wet-rank order
@@ -155,7 +153,7 @@ __device__ __forceinline__ double tm_replace(double x, double fill) {
     return (isnan(x) || __double_as_longlong(x) == __double_as_longlong(fill)) ? 0.0 : x;
 }
 // ---- THE value expressions of the three generators: one copy, used by the generic column builder (build_column) and by the
-// regular-cell arithmetic (column_compute) that both the gather kernel (fast_column) and the dense-march kernel call. -------------
+// regular-cell arithmetic (column_compute) of the gather kernel (fast_column). -------------
 #define FDIV(a, b) ((a) / (b))
 // pushTadvectionvalues! (src/matrixbuilding.jl:193-204): ρ̄ = (ρx + ρc) / 2; row x: -ϕ / (ρ̄ vx); diagonal: ϕ / (ρ̄ vc)
 __device__ __forceinline__ void adv_pair(double phi, double rx, double rc, double vx, double vc, double &off, double &dg) {
@@ -430,13 +428,12 @@ struct Stencil {
 };
 
 // The regular-cell arithmetic on a Stencil -- THE one copy of it (src/matrixbuilding.jl:193-204, :244-296, :348-415, :426-435,
-// :450-477): fast_column (gather kernel) fills the Stencil with loads, the dense-march kernel with registers / DPP / row loads.
+// :450-477): fast_column fills the Stencil with loads.
 // Accumulators start at -0.0: (-0.0) + x == x bit for bit for every x, which is exactly sparse()'s "first touch copies, later
-// ones add" without tracking the first touch.  RHOCHECK: the ρ-NaN check (:233) shares the (rarely taken) branch of the Tadv NaN
+// ones add" without tracking the first touch.  The ρ-NaN check (:233) shares the (rarely taken) branch of the Tadv NaN
 // check when the fill pass does it (p.rho_in_fill): a separate branch right after the loads splits the scheduling region and
 // cost 6 % of the kernel (collecting ALL error checks into one branch at the end measured 2 % slower than this).
 #define NEG0 (-0.0)
-template <bool RHOCHECK>
 __device__ __forceinline__ void column_compute(const TmParams &p, const Stencil &s, int i, int j, int k, i64 c, Column &col) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
@@ -481,7 +478,7 @@ __device__ __forceinline__ void column_compute(const TmParams &p, const Stencil 
         adv_pair(-fB, s.rB, rC, s.vB, vC, oB_, dB_);
         const bool bad = (aA & (isnan(oA_) | isnan(dA_))) | (aS & (isnan(oS_) | isnan(dS_))) | (aW & (isnan(oW_) | isnan(dW_))) |
                          (aE & (isnan(oE_) | isnan(dE_))) | (aN & (isnan(oN_) | isnan(dN_))) | (aB & (isnan(oB_) | isnan(dB_)));
-        const bool badrho = RHOCHECK && p.rho_in_fill && isnan(rC);
+        const bool badrho = p.rho_in_fill && isnan(rC);
         if (bad | badrho) {
             if (badrho) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
             if (bad) raise_flag(p.flags, FLAG_TADV_NAN);    // :39
@@ -574,13 +571,13 @@ template <int FUSED> __device__ __forceinline__ double ld_uv(const char *b, unsi
 __device__ __forceinline__ double ldd(const char *b, unsigned byteoff) { return *(const double *)(b + byteoff); }
 __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return ldd(b, byteoff); }
 __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(const i64 *)(b + byteoff); }
-// CHECKS: evaluate the two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN).
-// The count pass does them (fast_presence); the fill pass of the two-pass protocols skips them.
+// The two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN) are made with the counts
+// (fast_presence / facefluxes_kernel<COUNTS>), not here.
 // Returns whether Lwet3D holds c at the cell itself (the canonical-indices check, loaded with the stencil).
-template <bool CHECKS, int FUSED = 0>
+template <int FUSED = 0>
 __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
                                             i64 c, Column &col, Stamps &st) {
-    const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
+    const int nx = p.nx, ny = p.ny, nz = p.nz;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
     const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
     const unsigned nx8 = (unsigned)nx * 8u, P8 = (unsigned)p.P * 8u;
@@ -596,11 +593,7 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
               lA = ldi(tb.lw, oA), lB = ldi(tb.lw, oB);
     // each of the six flux arrays is read ONCE per cell (at one neighbour): streaming (non-temporal) loads, so that these lines do not
     // displace the v3D / ρ / Lwet3D lines that five neighbours share (A/B over several array placements: -3 % at 0.25 degree)
-#ifndef OTMB_PLAIN_PHI_LOADS
 #define LDPHI(b, o) __builtin_nontemporal_load((const double *)((b) + (o)))
-#else
-#define LDPHI(b, o) ldd(b, o)
-#endif
     double gE0, gW0, gS0, gN0, gA0, gB0;
     if (FUSED == 0) {
         gE0 = LDPHI(tb.pw, oE); gW0 = LDPHI(tb.pe, oW); gS0 = LDPHI(tb.pn, oS); gN0 = LDPHI(tb.ps, oN);
@@ -613,11 +606,6 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
         gN0 = ld_uv<FUSED>(tb.pv, oC);  // ϕsouth[N] = ϕnorth[c] (:219-224)
         gA0 = LDPHI(tb.pt, oC);         // ϕbottom[A] = ϕtop[c]  (:238-240)
         gB0 = LDPHI(tb.pt, oB);         // ϕtop[B]
-    }
-    double qW0 = 0, qE0 = 0, qS0 = 0, qN0 = 0, qB0 = 0, qT0 = 0;
-    if (CHECKS) {  // own fluxes, for the outgoing check
-        qW0 = ldd(tb.pw, oC); qE0 = ldd(tb.pe, oC); qS0 = ldd(tb.ps, oC); qN0 = ldd(tb.pn, oC); qB0 = ldd(tb.pb, oC);
-        qT0 = ldd(tb.pt, oC);
     }
     const double vC = ldv(tb.v, oC), vE = ldv(tb.v, oE), vW = ldv(tb.v, oW), vS = ldv(tb.v, oS), vN = ldv(tb.v, oN),
                  vA = ldv(tb.v, oA), vB = ldv(tb.v, oB);
@@ -657,15 +645,6 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
 
     STAMP(st, 2, 1);  // every stencil load is back
     if (!tb.rho) rC = rE = rW = rS = rN = rA = rB = p.rho_s;
-    if (CHECKS) {  // own pushes must land in a wet cell (see build_column); ρ (:233)
-        const bool wE = lE != 0, wW = lW != 0, wS = hS && lS != 0, wN = hN && lN != 0, wA = hA && lA != 0, wB = hB && lB != 0;
-        const double ow = sel_pos(qW0, up), oe = sel_neg(qE0, up), os = sel_pos(qS0, up), on = sel_neg(qN0, up);
-        const double ob = sel_pos(qB0, up), ot = hA ? sel_neg(qT0, up) : 0.0;
-        const bool bad = (nonzero(ow) & !wW) | (nonzero(oe) & !wE) | (nonzero(os) & !wS) | (nonzero(on) & !wN) |
-                         (nonzero(ob) & !wB) | (nonzero(ot) & !wA);
-        if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
-        if (isnan(rC)) raise_flag(p.flags, FLAG_RHO_NAN);  // :233
-    }
     if (FUSED != 0) {
         // what facefluxes stores: a flux between two wet cells is the transport with NaN / fill replaced by zero, any other is zero
         // (nofluxboundaries! on the emitting cell, :161-175; c itself is wet)
@@ -674,7 +653,7 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
         gS0 = (hS && lS != 0) ? tm_replace(gS0, p.fillv) : 0.0;
         gN0 = (hN && lN != 0) ? tm_replace(gN0, p.fillv) : 0.0;
     }
-    // the stencil as values, then THE arithmetic (column_compute: shared with the dense-march kernel)
+    // the stencil as values, then THE arithmetic
     Stencil s;
     s.lE = lE; s.lW = lW; s.lS = lS; s.lN = lN; s.lA = lA; s.lB = lB;
     s.gE = gE0; s.gW = gW0; s.gS = gS0; s.gN = gN0; s.gA = gA0; s.gB = gB0;
@@ -684,7 +663,7 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
     s.eW_c = eW_c; s.eE_c = eE_c; s.eS_c = eS_c; s.eN_c = eN_c; s.dW_c = dW_c; s.dE_c = dE_c; s.dS_c = dS_c; s.dN_c = dN_c;
     s.eE_w = eE_w; s.dE_w = dE_w; s.eW_e = eW_e; s.dW_e = dW_e; s.eN_s = eN_s; s.dN_s = dN_s; s.eS_n = eS_n; s.dS_n = dS_n;
     s.ar = ar; s.mld = mld; s.ztk = ztk; s.zta = zta; s.ztb = ztb;
-    column_compute<!CHECKS>(p, s, i, j, k, c, col);
+    column_compute(p, s, i, j, k, c, col);
     return lC == c;
 }
 
@@ -709,7 +688,6 @@ __device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase 
     const double ztk = p.zt[k], zta = p.zt[hA ? k - 1 : k], ztb = p.zt[hB ? k + 1 : k];
     const bool wE = mE & PM_WET, wW = mW & PM_WET, wS = hS && (mS & PM_WET), wN = hN && (mN & PM_WET), wA = hA && (mA & PM_WET),
                wB = hB && (mB & PM_WET);
-#ifndef OTMB_CHECKS_IN_FILL
     {   // the two input checks that need no arithmetic: own pushes land in wet cells (the reference indexes
         // Lwet3D[C𝑗] unconditionally, :247 etc.) and ρ is not NaN on wet cells (:233)
         const bool bad = ((mC & PM_W) && !wW) | ((mC & PM_E) && !wE) | ((mC & PM_S) && !wS) | ((mC & PM_N) && !wN) |
@@ -717,7 +695,6 @@ __device__ __forceinline__ void fast_presence(const TmParams &p, const TileBase 
         if (bad) raise_flag(p.flags, FLAG_FLUX_INTO_LAND);
         if (!p.rho_in_fill && tb.rho && isnan(ldd(tb.rho, oC))) raise_flag(p.flags, FLAG_RHO_NAN);
     }
-#endif
     // the east cell pushes through its west face, the cell above through its bottom face, ... (:244-296)
     const bool aE = wE && (mE & PM_W), aW = wW && (mW & PM_E), aS = wS && (mS & PM_N), aN = wN && (mN & PM_S);
     const bool aA = wA && (mA & PM_B), aB = wB && (mB & PM_T);

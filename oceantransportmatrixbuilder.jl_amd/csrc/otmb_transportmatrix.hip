@@ -7,11 +7,8 @@
 // (tile) per 256 consecutive wet cells = 256 consecutive columns of all five matrices.  Per tile:
 //   1. every thread builds its column in registers (otmb_tm_column.h);
 //   2. a packed 64-bit block scan gives each column's offset inside the tile for the five matrices;
-//   3. the tile's global offsets come from
-//        COUNT + tile scan + FILL   (two-phase C ABI: the caller allocates after plan), or
-//        ONEPASS                    (device-resident callers with known capacity): decoupled look-back
-//                                   over per-tile status words, so inputs are read once and outputs
-//                                   written once -- the algorithmic HBM traffic;
+//   3. the tile's global offsets come from the tile counts (counted by facefluxes for the fluxes it writes, by tm_count_kernel
+//      otherwise) + the tile scan: inputs are read once and outputs written once -- the algorithmic HBM traffic;
 //   4. entries are staged through LDS, per wave, and streamed out with 16-byte-per-lane non-temporal stores from scalar run
 //      bases (a column's entries are contiguous, a wave's 64 columns are one contiguous run in each matrix).
 #include <cstdlib>
@@ -19,7 +16,7 @@
 #include "otmb_tm_column.h"
 
 #ifndef TM_THREADS
-#define TM_THREADS 256  // measured: one-wave (64-thread) tiles are no faster in fill and much worse for look-back
+#define TM_THREADS 256  // measured: one-wave (64-thread) tiles are no faster in fill
 #endif
 #define TM_NF 5
 #ifndef TM_WAVES_PER_SIMD
@@ -39,9 +36,6 @@
 #define TM_WSTAGE (64 * TM_MAXROWS + 2)  // per-wave staging entries (+2: parity shift for 16-byte stores)
 #define TM_STAGE ((TM_THREADS / 64) * TM_WSTAGE)
 
-enum { MODE_FILL = 1, MODE_ONEPASS = 2 };
-
-struct DmGeomHost { int nseg = 0, nrowgrp = 0, kparts = 1; i64 nsl = 0; };  // dense-march launch geometry (otmb_tm_dense.h)
 struct TmPlan {
     otmb_tm_args args;  // device pointers
     i64 ntiles = 0;
@@ -50,24 +44,8 @@ struct TmPlan {
     bool onepass_pending = false;
     i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
-    bool dense = false;  // the plan's counting pass was the dense-march one: its fill must be too (same offsets table)
     bool rho_in_fill = false;  // the plan took its counts from facefluxes: no pass has looked at ρ yet, the fill pass does (:233)
-    DmGeomHost dm;
 };
-
-// look-back status word: [63:62] flag (0 empty, 1 tile aggregate, 2 inclusive prefix), [61:0] value.
-// One naturally aligned 8-byte word written by ONE agent-scope store and polled with agent-scope loads:
-// data and tag travel together, so no fence is needed and nothing depends on workgroup placement.
-#define ST_AGG (1ull << 62)
-#define ST_PFX (2ull << 62)
-#define LOOKBACK_SPIN_LIMIT (1 << 22)
-
-__device__ __forceinline__ void st_store(u64 *p, u64 v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 st_load(const u64 *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // A value every lane of the wave holds identically, moved to scalar registers.
 __device__ __forceinline__ i64 wave_uniform(i64 x) {
@@ -163,96 +141,11 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
 
 static_assert(TM_THREADS == (1 << FFC_TILE_SHIFT), "the counts in facefluxes are per tile of TM_THREADS columns");
 
-// ---- decoupled look-back (one-pass mode) ---------------------------------------------------------------------
-// One status word per tile: flag | the tile's five aggregates packed as in the block scan (55 bits).  A predecessor
-// therefore costs ONE load, whatever the number of matrices.  A tile whose inclusive prefixes are known stores them to
-// prefix[tile][0..4] with agent-scope (write-through) stores, drains them (s_waitcnt vmcnt(0)) and only then flips its
-// status word to ST_PFX; readers take the five prefixes with agent-scope loads after seeing the flag.  Called by ONE
-// wave of the tile; the exclusive prefixes land in s_prefix[0..4].
-__device__ __forceinline__ void tm_lookback(const TmParams &p, i64 tile, int lane, u64 all, i64 *s_prefix) {
-    const unsigned agg[5] = {(unsigned)(all & 0x7ff), (unsigned)((all >> 11) & 0x7ff), (unsigned)((all >> 22) & 0x7ff),
-                             (unsigned)((all >> 33) & 0x3ff), (unsigned)((all >> 43) & 0x3ff)};
-    u64 *status = p.status;
-    i64 *prefix = (i64 *)(p.status + p.n_tiles);
-    if (tile == 0) {
-        if (lane < TM_NF) {
-            i64 v = 0;
-#pragma unroll
-            for (int m = 0; m < TM_NF; ++m)
-                if (m == lane) v = agg[m];
-            st_store((u64 *)&prefix[lane], (u64)v);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_store(&status[0], ST_PFX | all);
-        if (lane < TM_NF) s_prefix[lane] = 0;
-        return;
-    }
-    if (lane == 0) st_store(&status[tile], ST_AGG | all);
-    i64 acc[TM_NF] = {0, 0, 0, 0, 0};
-    i64 look = tile - 1;  // nearest predecessor not yet accounted for
-    int spins = 0;
-    bool ok = true;
-    while (true) {
-        const i64 t = look - lane;  // lane 0 inspects the nearest predecessor
-        u64 sw = ST_AGG;             // positions before tile 0: empty aggregate (tile 0 always ends the walk)
-        if (t >= 0) {
-            sw = st_load(&status[t]);
-            while ((sw >> 62) == 0 && spins < LOOKBACK_SPIN_LIMIT) {
-                __builtin_amdgcn_s_sleep(1);
-                sw = st_load(&status[t]);
-                ++spins;
-            }
-        }
-        if (__any((sw >> 62) == 0)) {  // bounded spin expired: report, never hang
-            if (lane == 0) raise_flag(p.flags, FLAG_LOOKBACK_TIMEOUT);
-            ok = false;
-            break;
-        }
-        const u64 is_pfx = __ballot((sw >> 62) == 2);
-        const int first = is_pfx ? __builtin_ctzll(is_pfx) : 64;
-        // tiles nearer than the first prefix holder contribute their aggregates
-        const u64 mineagg = (lane < first) ? sw : 0;
-        int part[TM_NF] = {(int)(mineagg & 0x7ff), (int)((mineagg >> 11) & 0x7ff), (int)((mineagg >> 22) & 0x7ff),
-                           (int)((mineagg >> 33) & 0x3ff), (int)((mineagg >> 43) & 0x3ff)};
-#pragma unroll
-        for (int m = 0; m < TM_NF; ++m) {
-            int x = part[m];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-            acc[m] += x;
-        }
-        if (is_pfx) {  // the holder's inclusive prefixes end the walk
-            const i64 th = look - first;
-            i64 pv = 0;
-            if (lane < TM_NF) pv = (i64)st_load((const u64 *)&prefix[th * TM_NF + lane]);
-#pragma unroll
-            for (int m = 0; m < TM_NF; ++m) acc[m] += __shfl(pv, m);
-            break;
-        }
-        look -= 64;
-    }
-    if (ok) {
-        if (lane < TM_NF) {
-            i64 e = 0, v = 0;
-#pragma unroll
-            for (int m = 0; m < TM_NF; ++m)
-                if (m == lane) { e = acc[m]; v = acc[m] + agg[m]; }
-            st_store((u64 *)&prefix[tile * TM_NF + lane], (u64)v);
-            s_prefix[lane] = e;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_store(&status[tile], ST_PFX | all);
-    } else if (lane < TM_NF) {
-        s_prefix[lane] = 0;
-    }
-}
-
-template <int MODE, int FUSED = 0>  // FUSED: the fused step's fill pass (otmb_step_dev): five of the six fluxes re-derived from umo / vmo / ϕtop (1 Float64, 2 Float32)
+template <int FUSED = 0>  // FUSED: the fused step's fill pass (otmb_step_dev): five of the six fluxes re-derived from umo / vmo / ϕtop (1 Float64, 2 Float32)
 __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
     __shared__ unsigned s_presum[TM_NF];
-    __shared__ int s_tile;
     __shared__ __attribute__((aligned(16))) i64 s_stage[2 * TM_STAGE];  // rows, then value bits
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     Stamps st;
@@ -270,8 +163,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     // contiguous eighth of the tiles, so that a tile's south/north rows and the levels above/below, which
     // the same XCD touched a little earlier, are L2 hits instead of fabric re-reads.  Speed only: any
     // bijection is correct.
-    i64 tile = blockIdx.x;
-    if (MODE != MODE_ONEPASS) {
+    i64 tile;
+    {
         unsigned pos;
         if (!xcd_position(blockIdx.x, p.nt_order, p.nheavy, pos)) return;  // (the whole workgroup: no barrier has been reached)
         tile = pos;
@@ -280,28 +173,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #ifdef OTMB_DBG_STAMPS_ORDER  // diagnostic (tools/stamps.py): when is the tile id known (kernel arguments + tile order)
     STAMP(st, 6, 1);
 #endif
-    if (MODE == MODE_ONEPASS) {
-        // dynamic tile id: tiles start in ticket order, so every predecessor a tile waits for is already
-        // running or finished whatever order the hardware dispatches workgroups in
-        if (tid == 0) s_tile = atomicAdd(p.ticket, 1);
-        __syncthreads();
-        tile = s_tile;
-    }
-    // One-pass mode: the tile's five counts follow from the push mask alone (count_cell), so they are published
-    // FIRST and the look-back runs now, while the predecessors are still busy with their columns: nobody ever waits
-    // for anybody's arithmetic, and prefixes propagate within a few microseconds of a tile's start.
-    u64 early_all = 0;
-    if (MODE == MODE_ONEPASS) {
-        u64 x = count_cell(p, tile, tid);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-        if (lane == 0) wave_tot[wid] = x;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < TM_THREADS / 64; ++q) early_all += wave_tot[q];
-        __syncthreads();  // wave_tot is reused by the block scan below
-        if (wid == 0) tm_lookback(p, tile, lane, early_all, s_prefix);
-    }
     // The tile's reserved offsets (counting pass + scan) do not depend on anything this workgroup computes: their loads
     // are issued at the top (right after the index loads below), so that this memory round trip runs beside the Lwet and
     // stencil round trips instead of after the arithmetic (tools/stamps.py: the late fetch held every wave for ~15 % of its life).
@@ -320,7 +191,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 Lmax = p.lwet[wlast] - 1;
     unsigned pre_sum = 0;
     i64 pre_off = 0;
-    if (MODE == MODE_FILL && tid < TM_NF) {
+    if (tid < TM_NF) {
         pre_sum = p.tilesums[tile * TM_NF + tid];
         pre_off = p.tileoffs[tile * TM_NF + tid];
         if (p.gsum) {  // offsets are relative to the tile's scan group: add the totals of the groups before it, eight loads in flight
@@ -381,11 +252,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             bool canonical;
             const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
             {
-#ifdef OTMB_CHECKS_IN_FILL
-                if (regular) canonical = fast_column<true, FUSED>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
-#else
-                if (regular) canonical = fast_column<false, FUSED>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // the input checks ran with the counts
-#endif
+                if (regular) canonical = fast_column<FUSED>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // (the value-free input checks ran with the counts)
                 else {
                     canonical = ldi(tb.lw, oC) == c;
                     if (canonical) build_column(p, cell, c, col);
@@ -421,7 +288,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         if (lane >= d) incl += y;
     }
     if (lane == 63) wave_tot[wid] = incl;
-    if (MODE == MODE_FILL && tid < TM_NF) {  // the offsets fetched at the top travel through the scan's barrier
+    if (tid < TM_NF) {  // the offsets fetched at the top travel through the scan's barrier
         s_prefix[tid] = pre_off;
         s_presum[tid] = pre_sum;
     }
@@ -440,15 +307,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                              (unsigned)((all >> 33) & 0x3ff), (unsigned)((all >> 43) & 0x3ff)};
 
     // ---- 3. the tile's global offsets ----
-    if (MODE == MODE_ONEPASS && all != early_all) {  // the columns disagree with the mask-derived counts (see MODE_FILL)
-        if (tid == 0) raise_flag(p.flags, FLAG_COUNT_MISMATCH);
-        return;
-    }
-    if (MODE == MODE_ONEPASS) __syncthreads();  // s_prefix comes from the look-back of wave 0
     i64 g0[5];
 #pragma unroll
     for (int m = 0; m < TM_NF; ++m) g0[m] = s_prefix[m];  // entries of matrix m before this tile (this launch)
-    if (MODE == MODE_FILL) {
+    {
         // The space of this tile was reserved by the counting pass from the push mask.  A mask that does not
         // describe these ϕ / Lwet3D (stale, or not a makeindices result) would make the two passes disagree:
         // compare the tile's counts and write nothing on a mismatch.
@@ -467,7 +329,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #pragma unroll
             for (int m = 0; m < TM_NF; ++m)
                 if (m == tid) tot = g0[m] + agg[m];
-            if (MODE == MODE_ONEPASS || p.gsum) p.totals[tid] = tot;
+            if (p.gsum) p.totals[tid] = tot;
             i64 *cp = (tid == 0) ? p.colptr[0] : (tid == 1) ? p.colptr[1] : (tid == 2) ? p.colptr[2] : (tid == 3) ? p.colptr[3] : p.colptr[4];
             const i64 nb = (tid == 0) ? p.nnz_base[0] : (tid == 1) ? p.nnz_base[1] : (tid == 2) ? p.nnz_base[2] : (tid == 3) ? p.nnz_base[3] : p.nnz_base[4];
             if (tid == 0 || !p.only_t) cp[p.n_own] = nb + tot + 1;
@@ -501,16 +363,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     // The matrices are written once and read by nobody on the device: NON-TEMPORAL stores, so that 1 GB of output per 0.44 GB of input
     // does not push the stencil's lines (south / north rows, levels above / below: re-read by later tiles) out of the L2.  Together with
     // the march order: HBM reads back to the algorithmic bytes (7.5 GB fetched at 0.25 degree instead of 15.4 GB), -8 % time.
-#ifndef OTMB_PLAIN_STORES
 #define TM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
-#else
-#define TM_STORE(val, ptr) (*(ptr) = (val))
-#endif
-#ifdef OTMB_ALIGNED16
-    typedef i64x2 i64x2g;
-#else
     typedef i64x2 i64x2g __attribute__((aligned(8)));
-#endif
     // rows and value bits are staged in two arrays: an entry is two 8-byte LDS writes straight from the registers
     // that hold it, a pair of entries one 16-byte LDS read per array
     i64 *my_row = s_stage + wid * TM_WSTAGE;
@@ -520,20 +374,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
         // The run is streamed out with 16-byte stores (two entries per lane): 8-byte-per-lane stores are store-issue
         // bound per CU (measured: the write phase cost as much as loads + arithmetic).  The run starts at an arbitrary
         // 8-byte position; global_store_dwordx4 does not need more alignment than that, so pairs are simply counted from
-        // the run's first entry (an earlier version shifted the staging by the run's parity to keep the stores 16-byte
-        // aligned and paid two more 8-byte store instructions per matrix and array for the unpaired ends: +6 % time).
+        // the run's first entry (shifting the staging by the run's parity to keep the stores 16-byte aligned costs two more
+        // 8-byte store instructions per matrix and array for the unpaired ends: +6 % time, tools/experiments/).
         const i64 run0 = wave_uniform(g0[m]) + wb[m];
         i64 *rv = p.rowval[m] + run0;
         double *nz = p.nzval[m] + run0;
-#ifdef OTMB_ALIGNED16  // the earlier variant, kept for A/B runs
-        const unsigned par = (unsigned)(((unsigned long long)rv >> 3) & 1ull);
-        const bool wide = ((((unsigned long long)rv) ^ ((unsigned long long)nz)) & 15ull) == 0;  // same parity for both arrays
-#else
-        const unsigned par = 0;
-        const bool wide = true;
-#endif
         if (live) {
-            const unsigned q0 = par + ex[m] - wb[m];
+            const unsigned q0 = ex[m] - wb[m];
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 if ((pm[m] >> s) & 1u) {
@@ -559,39 +406,21 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             if (!room && lane == 0) raise_flag(p.flags, FLAG_CAPACITY);
         }
         if (room) {
-            const unsigned end = par + cnt;  // staged entries occupy LDS indices [par, end)
-            if (wide) {
-                char *rvb = (char *)(rv - par);
-                char *nzb = (char *)(nz - par);
-                for (unsigned base = 0; base < end; base += 128) {  // full pairs
-                    const unsigned u = base + 2 * lane;
-                    if ((u >= par) & (u + 1 < end)) {
-                        TM_STORE(*(const i64x2 *)(my_row + u), (i64x2g *)(rvb + u * 8u));
-                        TM_STORE(*(const i64x2 *)(my_val + u), (i64x2g *)(nzb + u * 8u));
-                    }
+            const unsigned end = cnt;  // staged entries occupy LDS indices [0, end)
+            char *rvb = (char *)rv;
+            char *nzb = (char *)nz;
+            for (unsigned base = 0; base < end; base += 128) {  // full pairs
+                const unsigned u = base + 2 * lane;
+                if (u + 1 < end) {
+                    TM_STORE(*(const i64x2 *)(my_row + u), (i64x2g *)(rvb + u * 8u));
+                    TM_STORE(*(const i64x2 *)(my_val + u), (i64x2g *)(nzb + u * 8u));
                 }
-                // the (at most two) entries without a partner: index 1 of an odd-parity run, and the last one if
-                // it sits at an even index
-#ifdef OTMB_ALIGNED16
-                const unsigned e = (lane == 0) ? 1u : end - 1;
-                const bool single = (lane == 0) ? ((par == 1) & (end > 1)) : ((lane == 1) & ((end & 1u) == 1u) & (end > par));
-                if (single) {
-                    *(i64 *)(rvb + e * 8u) = my_row[e];
-                    *(i64 *)(nzb + e * 8u) = my_val[e];
-                }
-#else
-                // an odd run's last entry: ONE 8-byte store instruction, lane 0 writes the row, lane 1 the value
-                if ((lane < 2) & ((end & 1u) == 1u)) {
-                    const unsigned e = end - 1;
-                    i64 *dst = (lane == 0) ? (i64 *)(rvb + e * 8u) : (i64 *)(nzb + e * 8u);
-                    TM_STORE((lane == 0) ? my_row[e] : my_val[e], dst);
-                }
-#endif
-            } else {
-                for (unsigned e = lane; e < cnt; e += 64) {
-                    rv[e] = my_row[par + e];
-                    ((i64 *)nz)[e] = my_val[par + e];
-                }
+            }
+            // an odd run's last entry: ONE 8-byte store instruction, lane 0 writes the row, lane 1 the value
+            if ((lane < 2) & ((end & 1u) == 1u)) {
+                const unsigned e = end - 1;
+                i64 *dst = (lane == 0) ? (i64 *)(rvb + e * 8u) : (i64 *)(nzb + e * 8u);
+                TM_STORE((lane == 0) ? my_row[e] : my_val[e], dst);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -602,7 +431,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #ifndef OTMB_DBG_STAMPS_ORDER
     STAMP(st, 6, 1);  // ... and acknowledged
 #endif
-    if (MODE == MODE_FILL && p.status && lane == 0) {
+    if (p.status && lane == 0) {
         u64 *o = p.status + ((u64)tile * (TM_THREADS / 64) + wid) * OTMB_NSTAMP;
         for (int q = 0; q < 7; ++q) o[q] = st.t[q];
         // HW_REG_HW_ID (4): wave slot / SIMD / CU / SH / SE;  HW_REG_XCC_ID (20): which XCD (each XCD has its own s_memtime base)
@@ -615,8 +444,6 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     }
 #endif
 }
-
-#include "otmb_tm_dense.h"
 
 // closing colptr entry of each matrix: nnz_base + nnz + 1 (values known on the host since the plan)
 __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
@@ -718,12 +545,8 @@ __device__ __forceinline__ unsigned order_key(const i64 *__restrict__ lwet, i64 
         i64 k1 = L1 / P, j1 = (L1 - k1 * P) / nx;
         if (j == ny - 1 || j1 == ny - 1 || k1 > k) return 0u;
     }
-#ifdef OTMB_MARCH_SOUTH_FIRST
-    return 1u + ((unsigned)(j / rows) * (unsigned)nblk + (unsigned)ic) * (unsigned)nz + (unsigned)k;
-#else
-    // bands from north to south
+    // bands from north to south (the seam row's neighbours at the START of an XCD's eighth: -5 % at 1 degree against south first)
     return 1u + ((unsigned)((ny - 1 - j) / rows) * (unsigned)nblk + (unsigned)ic) * (unsigned)nz + (unsigned)k;
-#endif
 }
 __global__ void order_hist(const i64 *__restrict__ lwet, i64 ntiles, i64 n, int nx, int ny, i64 P, int rows, int nz, int topo, int cols, unsigned *hist) {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -820,56 +643,6 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
 }
 
 
-// ---- dense-march formulation (otmb_tm_dense.h): when, and with what geometry --------------------------------------
-// ctx->formulation: 0 gather kernels, 1 dense march, -1 chosen here -- which today means the gather kernels on every grid:
-// measured on MI355X (profiles/r03/README.md) the march reads every input once (9.3 GB instead of the gather form's 15.4 GB
-// at 0.25 degree) with a third fewer load instructions, but executes 1.6 x the vector instructions (72 % of the lanes of
-// a non-empty wave hold wet cells, plus the march's bookkeeping) at two waves per SIMD (its level-to-level state costs
-// ~90 registers more than a gather tile), and a wave that both loads and stores waits for its previous level's stores at
-// every level (s_waitcnt vmcnt counts loads and stores in one queue): 9.3 ms against 6.4 ms.  It stays as a selectable,
-// bit-identical alternative.  nx < 3 grids (row-mates that coincide) always take the gather kernels' generic path.
-static bool use_dense(const otmb_ctx *ctx, const otmb_tm_args &a) {
-    if (a.nx < 3 || a.n_wet <= 0) return false;
-    return ctx->formulation == 1;
-}
-static int32_t dense_prepare(otmb_ctx *ctx, const otmb_tm_args &a, DmGeomHost &h, TmParams &p, DmGeom &g) {
-    h.nseg = (int)((a.nx + DM_W - 1) / DM_W);
-    h.nrowgrp = (int)((a.ny + DM_ROWS - 1) / DM_ROWS);
-    h.kparts = ctx->dense_kparts > 0 ? ctx->dense_kparts : 1;
-    if (h.kparts > a.nz) h.kparts = (int)a.nz;
-    h.nsl = a.nz * a.ny * h.nseg;
-    int32_t rc;
-    if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(h.nsl + 1) * DM_NF * sizeof(uint32_t)))) return rc;
-    if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(h.nsl + 1) * DM_NF * sizeof(i64) + otmb_scan_scratch(h.nsl, DM_NF) + 64))) return rc;
-    p.tilesums = (uint32_t *)ctx->tm_sums.p;
-    p.tileoffs = (const i64 *)ctx->tm_offs.p;
-    g.nseg = h.nseg; g.nrowgrp = h.nrowgrp; g.kparts = h.kparts;
-    // the two level bounds live behind the scan's scratch
-    g.kown = (const int *)((char *)ctx->tm_offs.p + (size_t)(h.nsl + 1) * DM_NF * sizeof(i64) + otmb_scan_scratch(h.nsl, DM_NF));
-    return OTMB_OK;
-}
-static void dense_launch_count(otmb_ctx *ctx, const otmb_tm_args &a, const DmGeomHost &h, const TmParams &p, const DmGeom &g, i64 *dtot) {
-    {
-        KernelTimer kt(ctx, K_DM_COUNT);
-        hipLaunchKernelGGL(dm_kown_kernel, dim3(1), dim3(64), 0, ctx->stream, (const i64 *)a.lwet, (i64)a.n_wet, a.nx * a.ny, (int)a.nz, (int *)g.kown);
-        hipLaunchKernelGGL(dm_count_kernel, dim3((unsigned)((h.nsl + 3) / 4)), dim3(256), 0, ctx->stream, p, g);
-    }
-    {
-        KernelTimer kt(ctx, K_TILESCAN);
-        otmb_launch_tilescan(ctx->stream, p.tilesums, (i64 *)ctx->tm_offs.p, dtot, h.nsl, DM_NF, (i64 *)ctx->tm_offs.p + (h.nsl + 1) * DM_NF);
-    }
-}
-static void dense_launch_fill(otmb_ctx *ctx, const DmGeomHost &h, const TmParams &p, const DmGeom &g, const i64 *dtot) {
-    KernelTimer kt(ctx, K_DM_FILL);
-    const i64 nunits = (i64)h.nseg * h.nrowgrp * h.kparts;
-    hipLaunchKernelGGL(dm_fill_kernel<false>, dim3((unsigned)nunits), dim3(256), 0, ctx->stream, p, g, dtot);
-    if (p.topo == OTMB_TRIPOLAR) {  // the seam row: one row group, its four waves are depth parts
-        DmGeom gs = g;
-        gs.nrowgrp = 1;
-        hipLaunchKernelGGL(dm_fill_kernel<true>, dim3((unsigned)(h.nseg * h.kparts)), dim3(256), 0, ctx->stream, p, gs, dtot);
-    }
-}
-
 // ---- host side ------------------------------------------------------------------------------
 static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
@@ -943,7 +716,6 @@ static int32_t check_flags(otmb_ctx *ctx, const int *f = nullptr, int ignore = 0
     if (!f) f = ctx->h_flags;
     const bool iA = (ignore >> OTMB_TADV) & 1, iH = (ignore >> OTMB_TKH) & 1, iM = (ignore >> OTMB_TKVML) & 1, iD = (ignore >> OTMB_TKVDEEP) & 1;
     if (f[FLAG_NONCANONICAL]) return otmb_fail(ctx, OTMB_ERR_NONCANONICAL_INDICES);
-    if (f[FLAG_LOOKBACK_TIMEOUT]) return otmb_fail(ctx, OTMB_ERR_HIP, "look-back spin limit reached");
     if (f[FLAG_COUNT_MISMATCH]) return otmb_fail(ctx, OTMB_ERR_PUSH_MASK);
     if (f[FLAG_RHO_NAN] && !iA) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // reference order: :233, loop, :39, :61, :90, :114
     if (f[FLAG_FLUX_INTO_LAND] && !iA) return otmb_fail(ctx, OTMB_ERR_FLUX_INTO_LAND);
@@ -1092,15 +864,9 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     int *dflags = (int *)ctx->flags.p;
     i64 *dtot = (i64 *)(dflags + OTMB_NFLAGS);
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // flag words and totals: one block
-    pl.dense = ntiles > 0 && use_dense(ctx, *a);
     pl.rho_in_fill = false;
     int fbuf = -1;
-    if (pl.dense) {
-        DmGeom g;
-        if ((rc = dense_prepare(ctx, *a, pl.dm, p, g))) return rc;
-        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
-        dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
-    } else if (ntiles > 0 && (fbuf = ffc_match(ctx, *a, pl)) >= 0) {
+    if (ntiles > 0 && (fbuf = ffc_match(ctx, *a, pl)) >= 0) {
         // the counts came with the fluxes (otmb_facefluxes_counts_dev): no counting pass
         pl.rho_in_fill = true;
         ffc_consume(ctx, fbuf, p, (i64 *)ctx->tm_offs.p, dtot, (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF, ntiles, true);
@@ -1167,14 +933,10 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     }
     int32_t rc;
     int *dflags = (int *)ctx->flags.p;
-    if (pl.dense) {
-        DmGeom g;
-        if ((rc = dense_prepare(ctx, pl.args, pl.dm, p, g))) return rc;  // (the buffers of the plan: nothing is reallocated)
-        dense_launch_fill(ctx, pl.dm, p, g, (const i64 *)(dflags + OTMB_NFLAGS));
-    } else if (pl.ntiles > 0) {
+    if (pl.ntiles > 0) {
         if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, p))) return rc;
         KernelTimer kt(ctx, K_TM_FILL);
-        hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(tm_kernel<0>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
     }
     if (pl.ntiles == 0) {  // (otherwise the fill kernel's last tile writes the closing colptr entries)
         KernelTimer kt(ctx, K_TM_FINISH);
@@ -1201,9 +963,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
 #ifdef OTMB_DBG_STAMPS
 // diagnostic build only: copy the stamp buffer of the last asynchronous fill pass to the host (tools/stamps.py)
 int32_t otmb_debug_stamps(otmb_ctx *ctx, uint64_t *host, int64_t n_words) {
-    if (!ctx || !host || !ctx->lookback.p || (size_t)n_words * 8 > ctx->lookback.cap) return OTMB_ERR_INVALID_ARG;
+    if (!ctx || !host || !ctx->stamps.p || (size_t)n_words * 8 > ctx->stamps.cap) return OTMB_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(host, ctx->lookback.p, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(host, ctx->stamps.p, (size_t)n_words * 8, hipMemcpyDeviceToHost));
     return OTMB_OK;
 }
 #endif
@@ -1266,21 +1028,10 @@ static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, in
     if ((rc = validate_args(ctx, a, fu.kind != 0))) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 ntiles = (a->n_wet + TM_THREADS - 1) / TM_THREADS;
-    // Default: COUNT -> tile scan -> FILL enqueued back to back with no host round trip (the totals stay on the
-    // device).  OTMB_LOOKBACK=1 selects the single-kernel decoupled look-back variant instead.
-#ifndef OTMB_DEFAULT_LOOKBACK
-#define OTMB_DEFAULT_LOOKBACK 0
-#endif
-    static const bool env_lookback = [] { const char *e = getenv("OTMB_LOOKBACK"); return e ? e[0] == '1' : (OTMB_DEFAULT_LOOKBACK != 0); }();
-    const bool dense = ntiles > 0 && use_dense(ctx, *a) && fu.kind == 0;   // (the fused step exists for the gather kernels only)
-    const bool use_lookback = env_lookback && !dense && fu.kind == 0;
-    const size_t stbytes = (size_t)(ntiles + 1) * (1 + TM_NF) * sizeof(u64);  // look-back words + prefixes (+ ticket)
-    if (use_lookback) {
-        if ((rc = otmb_reserve(ctx, ctx->lookback, stbytes + 64))) return rc;
-    } else if (!dense) {
-        if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
-        if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
-    }
+    // COUNT (or the counts that came with the fluxes) -> tile scan -> FILL enqueued back to back with no host round trip (the totals
+    // stay on the device).
+    if ((rc = otmb_reserve(ctx, ctx->tm_sums, (size_t)(ntiles + 1) * TM_NF * sizeof(uint32_t)))) return rc;
+    if ((rc = otmb_reserve(ctx, ctx->tm_offs, (size_t)(ntiles + 1) * TM_NF * sizeof(i64) + otmb_scan_scratch(ntiles, TM_NF)))) return rc;
     if (!ctx->plan) ctx->plan = new TmPlan();
     TmPlan &pl = *ctx->plan;
     pl.valid = false;
@@ -1327,22 +1078,6 @@ static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, in
         hipLaunchKernelGGL(tm_finish_colptr, dim3(1), dim3(64), 0, ctx->stream, p.colptr[0], p.colptr[1], p.colptr[2],
                            p.colptr[3], p.colptr[4], (i64)0, p.nnz_base[0], p.nnz_base[1], p.nnz_base[2], p.nnz_base[3],
                            p.nnz_base[4]);
-    } else if (dense) {
-        DmGeom g;
-        if ((rc = dense_prepare(ctx, *a, pl.dm, p, g))) return rc;
-        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
-        p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
-        dense_launch_count(ctx, *a, pl.dm, p, g, dtot);
-        dense_launch_fill(ctx, pl.dm, p, g, dtot);
-    } else if (use_lookback) {
-        if ((rc = ensure_push_mask(ctx, *a, p))) return rc;
-        p.rho_in_fill = 1;  // the one-pass kernel checks ρ where it loads it
-        p.status = (u64 *)ctx->lookback.p;
-        p.n_tiles = ntiles + 1;
-        p.ticket = (int *)((char *)ctx->lookback.p + stbytes);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->lookback.p, 0, stbytes + 64, ctx->stream));
-        KernelTimer kt(ctx, K_TM_ONEPASS);
-        hipLaunchKernelGGL(tm_kernel<MODE_ONEPASS>, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p);
     } else {
         p.rho_in_fill = 1;  // count and fill both run before the flags are read: check ρ where it is loaded anyway
         i64 *gsum = (i64 *)ctx->tm_offs.p + (ntiles + 1) * TM_NF;
@@ -1372,14 +1107,14 @@ static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, in
         }
         {
 #ifdef OTMB_DBG_STAMPS
-            if ((rc = otmb_reserve(ctx, ctx->lookback, (size_t)ntiles * (TM_THREADS / 64) * OTMB_NSTAMP * sizeof(u64)))) return rc;
-            p.status = (u64 *)ctx->lookback.p;
+            if ((rc = otmb_reserve(ctx, ctx->stamps, (size_t)ntiles * (TM_THREADS / 64) * OTMB_NSTAMP * sizeof(u64)))) return rc;
+            p.status = (u64 *)ctx->stamps.p;
 #endif
             if ((rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
             KernelTimer kt(ctx, K_TM_FILL);
-            if (fu.kind == 1) hipLaunchKernelGGL((tm_kernel<MODE_FILL, 1>), dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
-            else if (fu.kind == 2) hipLaunchKernelGGL((tm_kernel<MODE_FILL, 2>), dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
-            else hipLaunchKernelGGL(tm_kernel<MODE_FILL>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            if (fu.kind == 1) hipLaunchKernelGGL(tm_kernel<1>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            else if (fu.kind == 2) hipLaunchKernelGGL(tm_kernel<2>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            else hipLaunchKernelGGL(tm_kernel<0>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

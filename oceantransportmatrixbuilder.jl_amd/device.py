@@ -381,7 +381,7 @@ class DeviceAssembler:
         return self.fill()
 
     PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold
-    FILL_KERNELS = ("tm_kernel<fill>", "tm_kernel<onepass>", "dm_fill_kernel")  # the pass that writes the matrices, by formulation (otmb_kernel_name)
+    FILL_KERNELS = ("tm_kernel<fill>",)  # the pass that writes the matrices (otmb_kernel_name)
 
     def new_output_set(self):
         """A set of five CSC output buffers at their upper bound (for transportmatrix_onepass(out=...): a pipeline whose
@@ -418,7 +418,7 @@ class DeviceAssembler:
             return rec
 
         def timed(kernels, launch):
-            """mean duration of the pass: whichever of `kernels` ran (the fill pass has another name under the look-back / dense-march formulations)"""
+            """mean duration of the pass `kernels` names"""
             for _ in range(2):
                 launch()
             self.ctx.synchronize()

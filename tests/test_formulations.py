@@ -1,7 +1,5 @@
-"""The speed-only switches of transportmatrix must never change a result (run with -m gpu): the dense-tile march kernels
-(otmb_ctx_set_formulation) and every tile order of the gather kernels (otmb_ctx_set_tile_order) against the oracle, bit for bit,
-on the cases that stress them -- tripolar seam row, odd nx (a cell that is its own fold neighbour), nx just above the dense kernels'
-minimum, rows longer than one 62-cell segment, depth parts that do not divide the levels, scalar and 3-D ρ, upwind and centred."""
+"""The speed-only switches of transportmatrix must never change a result (run with -m gpu): every tile order of the fill pass
+(otmb_ctx_set_tile_order), every work mapping and the placement search against the oracle, bit for bit, in both protocols."""
 import os
 
 import numpy as np
@@ -10,14 +8,6 @@ import pytest
 from helpers import MATS, assert_csc_equal, gridmetrics_of, randomize_metrics
 
 pytestmark = pytest.mark.gpu
-
-GRIDS = [  # (nx, ny, nz, seed, rho, topology)
-    (36, 30, 10, 81, "array", "tripolar"),
-    (37, 11, 7, 82, "scalar", "tripolar"),   # odd nx: the centre cell of the seam row is its own north neighbour
-    (3, 5, 4, 83, "array", "tripolar"),      # the smallest nx the dense kernels take
-    (150, 9, 5, 84, "array", "bipolar"),     # three segments of 62 cells per row, the last one partial
-    (64, 8, 13, 85, "scalar", "tripolar"),   # a row of exactly 64 cells: segment boundary + periodic wrap in one wave
-]
 
 
 def _setup(oracle, case, upwind=True):
@@ -45,21 +35,6 @@ def _check(asm, rtm, what):
     got = asm.result_to_host()
     for m in MATS:
         assert_csc_equal(got[m], rtm[m], f"{what}/{m}")
-
-
-@pytest.mark.parametrize("case", GRIDS, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}-{c[4]}-{c[5]}")
-@pytest.mark.parametrize("upwind", [True, False])
-def test_dense_march_kernels_match_the_oracle(oracle, case, upwind):
-    asm, umo, vmo, rtm = _setup(oracle, case, upwind)
-    for parts in (1, 2, 3):
-        asm.ctx.set_formulation(1, parts)
-        asm.step(umo, vmo, 1e20)                      # asynchronous protocol (count -> scan -> fill back to back)
-        _check(asm, rtm, f"dense/{parts} parts/async")
-        asm.step(umo, vmo, 1e20, onepass=False)       # two-phase protocol (plan, then fill)
-        _check(asm, rtm, f"dense/{parts} parts/two-phase")
-    asm.ctx.set_formulation(0)
-    asm.step(umo, vmo, 1e20)
-    _check(asm, rtm, "gather")
 
 
 def test_every_tile_order_gives_the_same_matrices(oracle):
@@ -107,8 +82,8 @@ def test_choose_placement_never_changes_a_result(oracle):
     assert asm.choose_placement(umo, vmo, 1e20, candidates=1, min_output_bytes=0)["chosen"] is None
     assert "skipped" in asm.choose_placement(umo, vmo, 1e20, candidates=10 ** 9, min_output_bytes=0)
 
-@pytest.mark.skipif(any(os.environ.get(k) for k in ("OTMB_LOOKBACK", "OTMB_DENSE", "OTMB_MARCH_ROWS")),
-                    reason="counts the default formulation's kernels (the suite is also run under the library's experiment switches: tools/r04_call44.sh)")
+@pytest.mark.skipif(bool(os.environ.get("OTMB_MARCH_ROWS")),
+                    reason="counts the default tile order's kernels (the suite is also run under the library's experiment switches)")
 def test_tile_order_is_computed_once_per_grid(oracle):
     """The march order is a function of the grid: its three kernels run on the first step and again only when the band height changes
     (otmb_ctx_set_tile_order); the default (-1) is the march order, i.e. they do run."""
@@ -128,26 +103,6 @@ def test_tile_order_is_computed_once_per_grid(oracle):
     asm.ctx.set_tile_order(0)
     asm.step(umo, vmo, 1e20)
     assert "tm_order_kernels" not in asm.ctx.timing_collect()
-
-
-def test_dense_march_reports_the_reference_errors(oracle):
-    from otmb_amd.capi import OtmbError
-
-    asm, umo, vmo, rtm = _setup(oracle, GRIDS[0])
-    asm.ctx.set_formulation(1)
-    L = int(asm.lwet[asm.N // 2].item()) - 1
-    old = asm.rho[L].clone()
-    asm.rho[L] = float("nan")
-    with pytest.raises(OtmbError, match="ρ contains NaNs"):
-        asm.step(umo, vmo, 1e20)
-    asm.rho[L] = old
-    asm.step(umo, vmo, 1e20)
-    _check(asm, rtm, "dense after an error")
-    # exact cancellation in T (κ = 0: explicit zeros stay in the operators, T drops them, src/matrixbuilding.jl:147)
-    asm.kappa = (0.0, 0.0, 0.0)
-    asm.step(umo, vmo, 1e20)
-    got = asm.result_to_host()
-    assert len(got["T"][1]) == len(got["Tadv"][1]) and len(got["TκH"][1]) > 0 and not np.any(got["T"][2] == 0.0)
 
 
 @pytest.mark.parametrize("env", [

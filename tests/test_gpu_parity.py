@@ -168,8 +168,8 @@ def test_device_onepass_and_twophase_match_oracle(oracle, name):
             assert_csc_equal(got[m], rtm[m], f"{name}/{m}/onepass={onepass}")
 
 
-def test_onepass_many_tiles_lookback(oracle):
-    """A grid with several hundred tiles so that the decoupled look-back spans more than one 64-tile window."""
+def test_onepass_many_tiles(oracle):
+    """A grid with several hundred tiles: more than one wave of the tile scan, the march order in use."""
     import torch
 
     from helpers import gridmetrics_of
@@ -522,19 +522,6 @@ def test_set_grid_tensors_equals_set_grid(oracle):
                              edge_length=[dev(gm.edge_length_2D[d]) for d in HDIRS],
                              dist_nbr=[dev(gm.distance_to_neighbour_2D[d]) for d in HDIRS], area2d=dev(gm.area2D),
                              zt=dev(gm.zt), mlotst=dev(g.mlotst), rho=1035.0)
-
-
-def test_single_kernel_lookback_variant():
-    """OTMB_LOOKBACK=1 (experimental: one kernel, tile offsets by decoupled look-back) must give the same matrices.  The
-    library reads the switch once per process, hence the child process."""
-    import os
-    import subprocess
-    import sys
-
-    env = dict(os.environ, OTMB_LOOKBACK="1", OTMB_DENSE="0")  # (the look-back variant belongs to the gather formulation)
-    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lookback_worker.py")
-    r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "LOOKBACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("name", ["tiny_tripolar", "small_rho3d", "odd_nx_fold"])

@@ -8,11 +8,12 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "csrc")
 # preprocessor switches the product sources may test.  Every one of them leaves every stored value what the reference computes:
-# diagnostics (time stamps), alternative instruction selections / orders that are A/B-tested bit for bit, tunables.
+# diagnostics (time stamps) and tunables.  (Round 6: the never-default alternatives -- the dense-tile march formulation, the look-back
+# one-pass mode, OTMB_ALIGNED16 / _CHECKS_IN_FILL / _PLAIN_STORES / _PLAIN_PHI_LOADS / _MARCH_SOUTH_FIRST -- left the product for
+# tools/experiments/r06_removed_formulations.patch.)
 ALLOWED = {
     "OTMB_DBG_STAMPS", "OTMB_DBG_STAMPS_ORDER",  # s_memtime stamps of the fill pass's phases (tools/stamps.py): extra output, same matrices
-    "OTMB_PLAIN_STORES", "OTMB_PLAIN_PHI_LOADS", "OTMB_ALIGNED16", "OTMB_CHECKS_IN_FILL", "OTMB_MARCH_SOUTH_FIRST", "OTMB_DEFAULT_LOOKBACK",
-    "OTMB_MARCH_AUTO_ROWS", "OTMB_MARCH_AUTO_COLS", "TM_THREADS", "TM_WAVES_PER_SIMD", "TM_COUNT_TPB", "FF_KB", "FF_COUNTS_WAVES", "DM_WAVES_PER_SIMD", "DM_PREFETCH", "DM_LDS_METRICS",  # (dense march: registers vs LDS, bit-identical)
+    "OTMB_MARCH_AUTO_ROWS", "OTMB_MARCH_AUTO_COLS", "TM_THREADS", "TM_WAVES_PER_SIMD", "TM_COUNT_TPB", "FF_KB", "FF_COUNTS_WAVES",  # tunables
 }
 
 

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# NOTE (round 6): needs the dense-march formulation, which left the product: apply tools/experiments/r06_removed_formulations.patch first.
 """Variants of the library (built beforehand: tools/dense_ab.py --build name="flags" ...) timed one after the other on one
 device-generated grid:   python tools/dense_ab.py --run name1,name2 [--workload quarterdeg] [--dense 1] [--kparts 1]"""
 import argparse

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# NOTE (round 6): needs the dense-march formulation, which left the product: apply tools/experiments/r06_removed_formulations.patch first.
 """Gather kernels against the dense-tile march (otmb_ctx_set_formulation), one process, interleaved rounds:
     python tools/dense_scan.py [--workload quarterdeg] [--settings g,d1,d2,d3,d5] [--rounds 2] [--steps 8]
 g = gather (wet-rank tile order), gN = gather in march order with bands of N rows, dK = dense march with K depth parts."""

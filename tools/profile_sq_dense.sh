@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): needs the dense-march formulation, which left the product: apply tools/experiments/r06_removed_formulations.patch first.
 # SQ counters of the transportmatrix kernels for one formulation: tools/profile_sq_dense.sh <tag> <OTMB_DENSE value> [bench args]
 set -o pipefail
 TAG=$1; DENSE=$2; shift; shift
