@@ -47,7 +47,9 @@ typedef enum {
     OTMB_ERR_NONCANONICAL_INDICES = 13, /* Lwet3D is not what makeindices(v3D) returns */
     OTMB_ERR_CAPACITY = 14,
     OTMB_ERR_PUSH_MASK = 15,       /* args.push_mask does not describe args.phi / args.lwet3d (nothing was written) */
-    OTMB_ERR_ASYMMETRIC_PATTERN = 16 /* lump_and_spray: Graphs.SimpleGraph's ArgumentError for a one-directional T pattern */
+    OTMB_ERR_ASYMMETRIC_PATTERN = 16, /* lump_and_spray: Graphs.SimpleGraph's ArgumentError for a one-directional T pattern */
+    OTMB_ERR_GIVEN_FOREIGN = 17    /* otmb_tm_args.given: an operator that is NOT what this library derives for these arguments was handed to an
+                                    * entry point that cannot add it (the asynchronous and the multi-slab builds): use otmb_transportmatrix_plan[_dev] */
 } otmb_status;
 
 /* gridmetrics.gridtopology (src/gridtopology.jl:1-16) */
@@ -291,6 +293,14 @@ int32_t otmb_fluxes2velocity(otmb_ctx *ctx, const void *phi_i, const void *phi_j
  *      *_operator_sparse_entries generators (:221-299, :337-418, :438-479), sparse() x4 and
  *      T = Tadv + TκH + TκVML + TκVdeep (:147), fused: each wet cell's column of all five
  *      matrices is produced directly in CSC order.                                          */
+/* A SparseMatrixCSC{Float64,Int64} by its three arrays, 1-based as Julia stores them: colptr (columns + 1), rowval / nzval (nnz). */
+typedef struct {
+    const int64_t *colptr;
+    const int64_t *rowval;
+    const double *nzval;
+    int64_t nnz;
+} otmb_csc;
+
 typedef struct {
     int64_t nx, ny, nz;
     int32_t topology;            /* otmb_topology */
@@ -322,7 +332,38 @@ typedef struct {
                                   * builds it, so nothing it alone would have raised is raised: "Tadv contains NaNs.", "ρ contains
                                   * NaNs" and a flux into land for Tadv, "TκH / TκVML / TκVdeep contains NaNs." for the others.  The
                                   * matrices of ignored operators and T are still written and are the caller's to discard.       */
+    int32_t skip_ops;            /* extension: bit m (m = OTMB_T .. OTMB_TKVDEEP): the caller does not WANT matrix m -- it is evaluated where T needs
+                                  * it but neither counted, written nor copied home (its nnz comes out 0, its outputs may be NULL).  only_t is
+                                  * skip_ops = the four operator bits.  buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120)
+                                  * are this call with every bit but one set, and ignore_ops for the operators they do not build.               */
+    otmb_csc given[5];           /* given[m].colptr != NULL (m = OTMB_TADV .. OTMB_TKVDEEP; given[OTMB_T] stays zero): transportmatrix's
+                                  * Tadv = / TκH = / TκVML = / TκVdeep = keyword (src/matrixbuilding.jl:133-143) -- the caller PASSES operator m
+                                  * (N x N; device arrays for the _dev entry points, host arrays for the others).  As in the reference it
+                                  * is then NOT built: not counted, not stored, not copied home (nnz[m] comes back 0, the outputs of m may be
+                                  * NULL: the caller returns the very object it passed, :149), nothing it alone would raise is raised (as
+                                  * ignore_ops), and T = ((Tadv + TκH) + TκVML) + TκVdeep (:147) is formed with the GIVEN matrix:
+                                  *  - TκH / TκVdeep are functions of the grid and κ alone.  A given one whose three arrays are bit for bit
+                                  *    what this library derives for these gridmetrics / indices / κ ("derived": checked on the device by
+                                  *    one pass that compares instead of stores, the verdict kept per context and operator until one of
+                                  *    the arrays it names changes -- otmb_ctx_forget_given) is re-derived in registers by the fill pass:
+                                  *    its 16 nnz + 8 (N + 1) bytes are neither read nor written (29 % of the fill pass's bytes at 1 degree
+                                  *    for TκH + TκVdeep, 40 % of the bytes a host caller waits for).
+                                  *  - any other given matrix (another κ, another pattern, Tadv, TκVML) is "foreign": the built operators
+                                  *    are written as usual and T is formed by the device sparse add (otmb_spadd_*_dev: left fold, exact
+                                  *    zeros dropped) from the given arrays where they lie.  Two-phase entry points only
+                                  *    (otmb_transportmatrix_plan[_dev] + fill / fetch: the plan's nnz[0] is then the sum of the four
+                                  *    operands' counts); the asynchronous and multi-slab builds return OTMB_ERR_GIVEN_FOREIGN.
+                                  * In a depth-slab launch (otmb_transportmatrix_set_slab) given[m] names the slab's columns: colptr
+                                  * its n_wet + 1 entries (global numbering), rowval / nzval the entries from colptr[0] on, nnz their number. */
 } otmb_tm_args;
+/* The verdicts on otmb_tm_args.given are keyed to array ADDRESSES (the given matrix's and the gridmetrics / indices arrays') and κ.
+ * A device-resident caller that rewrites one of those arrays in place calls this before the next transportmatrix; the host-pointer
+ * entry points do it themselves whenever they upload such an array (i.e. always, unless otmb_ctx_set_reuse_grid promises otherwise). */
+int32_t otmb_ctx_forget_given(otmb_ctx *ctx);
+/* Diagnostics: how the last plan / _dev call on this context treated operator m: 0 not given, 1 given and derived, 2 given and foreign. */
+int32_t otmb_ctx_given_state(const otmb_ctx *ctx, int32_t m);
+/* ... and how many comparing passes the context has run so far (a time loop with resident arrays runs ONE). */
+int64_t otmb_ctx_given_checks(const otmb_ctx *ctx);
 
 /* Two-phase protocol so the CALLER allocates the outputs (Julia owns its SparseMatrixCSC buffers).
  * plan: the nnz of the four operator matrices (exact: their patterns depend on the wet mask, the flux

@@ -76,9 +76,14 @@ function context()
     return ctx[]
 end
 
+# OTMB_ERR_GIVEN_FOREIGN: an operator that was passed in is not what the library derives for this grid and κ, and the build that was asked
+# (pipelined / multi-slab) cannot add it: transportmatrix falls back to the two-phase call, which can
+struct GivenForeign <: Exception end
+
 # status -> the reference's own exception types and texts (include/otmb.h, otmb_status)
 function check(rc::Int32)
     rc == 0 && return
+    rc == 17 && throw(GivenForeign())
     msg = unsafe_string(ccall(sym(:otmb_last_error), Cstring, (Ptr{Cvoid},), ctx[]))
     rc == 8 && throw(AssertionError(msg))      # velocities.jl:199-200
     rc == 11 && throw(ArgumentError(msg))
@@ -88,6 +93,7 @@ end
 
 function check_mgpu(mg::Ptr{Cvoid}, rc::Int32)
     rc == 0 && return
+    rc == 17 && throw(GivenForeign())
     msg = unsafe_string(ccall(sym(:otmb_mgpu_last_error), Cstring, (Ptr{Cvoid},), mg))
     rc == 8 && throw(AssertionError(msg))
     rc == 11 && throw(ArgumentError(msg))
@@ -166,6 +172,13 @@ function facefluxesfrommasstransport(; umo, vmo, gridmetrics, indices, pinned = 
     return facefluxes(umo, vmo, gridmetrics, indices; FillValue, pinned, devices)
 end
 
+# mirror of otmb_csc (include/otmb.h): a SparseMatrixCSC{Float64,Int64} by its three vectors
+struct Csc
+    colptr::Ptr{Int64}; rowval::Ptr{Int64}; nzval::Ptr{Float64}
+    nnz::Int64
+end
+const NOCSC = Csc(C_NULL, C_NULL, C_NULL, 0)
+
 # mirror of otmb_tm_args (include/otmb.h); isbits, passed by reference
 struct TmArgs
     nx::Int64; ny::Int64; nz::Int64
@@ -181,7 +194,9 @@ struct TmArgs
     kappa_h::Float64; kappa_vml::Float64; kappa_vdeep::Float64
     push_mask::Ptr{UInt16}        # device-resident callers only; C_NULL here (host arrays)
     only_t::Int32                 # extension: 1 = materialise T alone
-    ignore_ops::Int32             # bit m: operator m was passed in by the caller -- nothing it alone would raise is raised
+    ignore_ops::Int32             # bit m: nothing operator m alone would raise is raised
+    skip_ops::Int32               # bit m: matrix m is not wanted -- neither counted, written nor copied home (buildT*)
+    given::NTuple{5,Csc}          # operators the caller passes (Tadv = / TκH = / TκVML = / TκVdeep = keywords): not built, added as they are
 end
 
 # Output arrays in pinned host memory of the library (otmb_host_alloc): the DMA writes them in place -- no staging copy, no page
@@ -262,45 +277,84 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
     # reuse_grid = true (extension): the caller promises that gridmetrics / indices are the arrays of the previous call,
     #   unmodified (a loop over time slices); they are then not copied to the GPU again (otmb_ctx_set_reuse_grid)
     # reuse_fluxes = true (extension): ϕ is what facefluxes* returned last, unmodified: its device copy is used
-    if !(isnothing(Tadv) && isnothing(TκH) && isnothing(TκVML) && isnothing(TκVdeep))
-        # precomputed operators (matrixbuilding.jl:133-147).  The same sequence of C calls as api.py's
-        # _transportmatrix_with_given: one fused build whose errors for the GIVEN operators are switched off (ignore_ops: the
-        # reference never builds them, so it never looks at ϕ / ρ when Tadv is given, nor at mlotst when TκVML is -- harmless
-        # stand-ins take their place), then the three adds of :147 with the library's `+`.
-        given = (Tadv, TκH, TκVML, TκVdeep)
-        ignore = sum(Int32(1) << m for m in 1:4 if !isnothing(given[m]))
+    given = (nothing, Tadv, TκH, TκVML, TκVdeep)    # by matrix: T, Tadv, TκH, TκVML, TκVdeep
+    if any(!isnothing, given)
+        # matrixbuilding.jl:140-143: an operator that is passed in is NOT built -- nothing it alone would read is read (ϕ / ρ for Tadv, mlotst
+        # for TκVML: harmless stand-ins take their place), it is returned as the very object passed (:149), and
+        # T = ((Tadv + TκH) + TκVML) + TκVdeep (:147) is formed with it (otmb_tm_args.given): a TκH / TκVdeep that is bit for bit what the
+        # library derives for this grid and κ is re-derived in registers -- neither uploaded again (reuse_grid), counted, stored nor copied
+        # home; any other matrix makes T the device sparse add of the four operands (the two-phase call: see the fallback below).
+        for (m, A) in enumerate(given)
+            (A === nothing || size(A) == (indices.N, indices.N)) || throw(ArgumentError("$(MATNAMES[m]) is $(size(A, 1))x$(size(A, 2)), expected $(indices.N)x$(indices.N)"))
+        end
         if !isnothing(Tadv)
             z = zeros(size(gridmetrics.v3D))
             ϕ = (east = z, west = z, north = z, south = z, top = z, bottom = z)
             ρ = 1035.0
         end
-        r = fused(ϕ, something(mlotst, fill(NaN, size(gridmetrics.v3D)[1:2])), gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, true,
-                  false, false, Int32(ignore), pinned, devices)
-        A = something(Tadv, r.Tadv); H = something(TκH, r.TκH); M = something(TκVML, r.TκVML); D = something(TκVdeep, r.TκVdeep)
-        return (; T = spadd(spadd(spadd(A, H), M), D), Tadv = A, TκH = H, TκVML = M, TκVdeep = D)
+        mlotst = something(mlotst, fill(NaN, size(gridmetrics.v3D)[1:2]))
+        operators = true    # (the built operators are operands of T and are returned)
+    else
+        given = nothing
     end
     dev = parse(Int32, get(ENV, "OTMB_DEVICE", "0"))
-    if slabs === nothing
-        slabs = default_slabs(indices.N, size(gridmetrics.v3D, 3), reuse_fluxes, devices)
-        if slabs > 0   # the default's choice between the two protocols is measured (Trial)
-            tr = lock(() -> get!(() -> Trial(0, NaN, NaN, true), TRIALS, (Int(dev), Int(indices.N))), CALL_LOCK)
-            t0 = time()
-            r = pipelined!(tr) ?
-                fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, fill(dev, slabs)) :
-                fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, nothing)
-            record!(tr, time() - t0)
-            return r
+    two_phase() = fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, false, false, Int32(0), pinned, nothing, given)
+    fkey = foreign_key(given)
+    (given !== nothing && devices === nothing && lock(() -> fkey in FOREIGN_SEEN, CALL_LOCK)) && return two_phase()   # known to need the sparse adds
+    try
+        if slabs === nothing
+            slabs = default_slabs(indices.N, size(gridmetrics.v3D, 3), reuse_fluxes, devices)
+            if slabs > 0   # the default's choice between the two protocols is measured (Trial), per kind of call
+                key = (Int(dev), Int(indices.N), operators, !(ρ isa Number), reuse_grid, given === nothing ? () : Tuple(m for m in 2:5 if given[m] !== nothing))
+                tr = lock(() -> get!(() -> Trial(0, NaN, NaN, true, 0), TRIALS, key), CALL_LOCK)
+                t0 = time()
+                r = pipelined!(tr) ?
+                    fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, fill(dev, slabs), given) :
+                    fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, nothing, given)
+                record!(tr, time() - t0)
+                return r
+            end
         end
+        if slabs > 0
+            devs = devices === nothing ? fill(dev, clamp(Int(slabs), 1, size(gridmetrics.v3D, 3))) : devices
+            return fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devs, given)
+        end
+        return fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devices, given)
+    catch e
+        (e isa GivenForeign && given !== nothing) || rethrow()
+        # a given operator is not what the library derives (another κ, another pattern, Tadv, TκVML): T is then the device sparse add of
+        # four materialised operands, which the single-context two-phase call does; remembered for the next time slice
+        lock(() -> push!(FOREIGN_SEEN, fkey), CALL_LOCK)
+        return two_phase()
     end
-    if slabs > 0
-        devs = devices === nothing ? fill(dev, clamp(Int(slabs), 1, size(gridmetrics.v3D, 3))) : devices
-        return fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devs)
-    end
-    return fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devices)
 end
+const MATNAMES = ("T", "Tadv", "TκH", "TκVML", "TκVdeep")
+const FOREIGN_SEEN = Set{Any}()
+foreign_key(given) = given === nothing ? nothing : Tuple((m, UInt(pointer(given[m].nzval)), length(given[m].rowval)) for m in 2:5 if given[m] !== nothing)
+
+# buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120; unexported there and here): ONE operator, by the fused build
+# with every other matrix switched off (otmb_tm_args.skip_ops) and nothing the others alone would raise raised (ignore_ops); what the other
+# operators would read and this one does not gets harmless stand-ins, as the reference never looks at it.  These are what a caller passes back
+# as `TκH = ...` / `TκVdeep = ...` in a loop over time slices.
+function build_operator(m::Int; gridmetrics, indices, ϕ = nothing, ρ = 1035.0, mlotst = nothing, κ = (500.0, 0.1, 1.0e-5), upwind = true)
+    if ϕ === nothing
+        z = zeros(size(gridmetrics.v3D))
+        ϕ = (east = z, west = z, north = z, south = z, top = z, bottom = z)
+    end
+    mlotst = something(mlotst, fill(NaN, size(gridmetrics.v3D)[1:2]))
+    others = Int32(0x1e & ~(1 << (m - 1)))
+    r = fused(ϕ, mlotst, gridmetrics, indices, ρ, κ[1], κ[2], κ[3], upwind, true, false, false, others, PINNED_RESULTS[], nothing, nothing,
+              Int32(0x1f & ~(1 << (m - 1))))
+    return r[m]
+end
+buildTadv(; ϕ, gridmetrics, indices, ρ, upwind = true) = build_operator(2; gridmetrics, indices, ϕ, ρ, upwind)
+buildTκH(; gridmetrics, indices, ρ = 1035.0, κH) = build_operator(3; gridmetrics, indices, κ = (κH, 0.1, 1.0e-5))
+buildTκVML(; mlotst, gridmetrics, indices, κVML) = build_operator(4; gridmetrics, indices, mlotst, κ = (500.0, κVML, 1.0e-5))
+buildTκVdeep(; mlotst = nothing, gridmetrics, indices, κVdeep) = build_operator(5; gridmetrics, indices, κ = (500.0, 0.1, κVdeep))
 
 # the arguments of one build, flattened for the C ABI; `keep` holds every converted array alive across the calls
-function tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops::Int32)
+function tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops::Int32, given = nothing,
+                skip_ops::Int32 = Int32(0))
     (; v3D, thkcello, edge_length_2D, distance_to_neighbour_2D, area2D, zt, gridtopology) = gridmetrics
     nx, ny, nz = size(v3D)
     ph = [asis(getproperty(ϕ, d)) for d in (:east, :west, :north, :south, :top, :bottom)]   # as they are: reuse_fluxes knows them by address
@@ -310,13 +364,17 @@ function tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwin
     lw = indices.Lwet isa Vector{Int64} ? indices.Lwet : Vector{Int64}(indices.Lwet)
     el = [asis(edge_length_2D[d]) for d in HDIRS]; dn = [asis(distance_to_neighbour_2D[d]) for d in HDIRS]
     ar = asis(area2D); z = zt isa Vector{Float64} ? zt : Vector{Float64}(zt); ml = f64(Array(mlotst))
-    keep = (ph, v, thk, rho3, lw3, lw, el, dn, ar, z, ml)
+    # operators the caller passes: the three vectors of a SparseMatrixCSC{Float64,Int64} as they are (grid constants of a time loop: under the
+    # reuse_grid promise the library recognises them by address and neither uploads nor compares them again)
+    gv = given === nothing ? nothing : map(A -> A === nothing ? nothing : SparseMatrixCSC{Float64,Int64}(A), given)
+    csc = ntuple(m -> (gv === nothing || gv[m] === nothing) ? NOCSC : Csc(pointer(gv[m].colptr), pointer(gv[m].rowval), pointer(gv[m].nzval), length(gv[m].rowval)), 5)
+    keep = (ph, v, thk, rho3, lw3, lw, el, dn, ar, z, ml, gv)
     a = TmArgs(nx, ny, nz, topologykind(gridtopology), Int32(upwind), indices.N,
         ntuple(i -> pointer(ph[i]), 6), pointer(v), pointer(thk),
         ρ isa Number ? Ptr{Float64}(C_NULL) : pointer(rho3), ρ isa Number ? Float64(ρ) : 0.0,
         pointer(lw3), pointer(lw), ntuple(i -> pointer(el[i]), 4), ntuple(i -> pointer(dn[i]), 4),
         pointer(ar), pointer(z), pointer(ml), Float64(κH), Float64(κVML), Float64(κVdeep), Ptr{UInt16}(C_NULL),
-        Int32(operators ? 0 : 1), ignore_ops)
+        Int32(operators ? 0 : 1), ignore_ops, skip_ops, csc)
     return a, keep
 end
 
@@ -324,54 +382,72 @@ end
 # of its own: a COPY of the first `k` entries -- no view into the pinned parent, hence no lifetime to tie (round 3 tied it with a
 # WeakKeyDict, whose Array keys compare by CONTENT: two equal trimmed views collided and one parent was freed under its matrix).
 trim(x, k) = length(x) == k ? x : x[1:k]
-function wrap(N, colptr, rowval, nzval, final, operators)
-    mats = Any[(operators || m == 1) ? SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], trim(rowval[m], final[m]), trim(nzval[m], final[m])) : nothing
+# an operator that was passed in comes back as the very object passed (matrixbuilding.jl:149); what was not asked for is `nothing`
+wanted(m, operators, given, skip_ops = Int32(0)) = (operators || m == 1) && (given === nothing || given[m] === nothing) && (skip_ops >> (m - 1)) & 1 == 0
+function wrap(N, colptr, rowval, nzval, final, operators, given = nothing, skip_ops = Int32(0))
+    mats = Any[(given !== nothing && given[m] !== nothing) ? given[m] :
+               wanted(m, operators, given, skip_ops) ? SparseMatrixCSC{Float64,Int64}(N, N, colptr[m], trim(rowval[m], final[m]), trim(nzval[m], final[m])) : nothing
                for m in 1:5]
     return (; T = mats[1], Tadv = mats[2], TκH = mats[3], TκVML = mats[4], TκVdeep = mats[5])
 end
+# Which engine served the previous host-pointer transportmatrix of a device: the single-GPU context (:ctx) or an otmb_mgpu (its device
+# list).  reuse_grid is the caller's promise about THE PREVIOUS CALL, but each engine checks it against ITS OWN previous call: after a change
+# of engine (the Trial changes it by itself) the promise is not forwarded -- the new engine's residency keys may describe arrays the caller
+# has edited since, legitimately passing reuse_grid = false in between.
+const LAST_ENGINE = Dict{Int,Any}()
+function reuse_grid_for(device, engine, reuse_grid)
+    same = get(LAST_ENGINE, Int(device), nothing) == engine
+    LAST_ENGINE[Int(device)] = engine
+    return reuse_grid && same
+end
+ptr_or_null(x, ::Type{T}) where {T} = x === nothing ? Ptr{T}(C_NULL) : Ptr{T}(pointer(x))
 
 # otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch
 function fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
-               usepinned::Bool, devices)
+               usepinned::Bool, devices, given = nothing, skip_ops::Int32 = Int32(0))
     devices === nothing || return fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes,
-                                              ignore_ops, usepinned, devices)
+                                              ignore_ops, usepinned, devices, given)
     lock(CALL_LOCK) do
+        reuse_grid = reuse_grid_for(parse(Int, get(ENV, "OTMB_DEVICE", "0")), :ctx, reuse_grid)
         check(ccall(sym(:otmb_ctx_set_reuse_grid), Int32, (Ptr{Cvoid}, Int32), context(), Int32(reuse_grid)))
         check(ccall(sym(:otmb_ctx_set_reuse_fluxes), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(reuse_fluxes)))
-        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops)
+        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops, given, skip_ops)
         N = indices.N
         nnz = zeros(Int64, 5)
         GC.@preserve keep check(ccall(sym(:otmb_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), ctx[], Ref(a), nnz))
-        colptr = [outarray(Int64, usepinned, N + 1) for _ in 1:5]
-        rowval = [outarray(Int64, usepinned, nnz[m]) for m in 1:5]
-        nzval = [outarray(Float64, usepinned, nnz[m]) for m in 1:5]
+        want = [wanted(m, operators, given, skip_ops) for m in 1:5]   # (what is not handed out -- a given operator, a skipped matrix -- gets no arrays)
+        colptr = [want[m] ? outarray(Int64, usepinned, N + 1) : nothing for m in 1:5]
+        rowval = [want[m] ? outarray(Int64, usepinned, nnz[m]) : nothing for m in 1:5]
+        nzval = [want[m] ? outarray(Float64, usepinned, nnz[m]) : nothing for m in 1:5]
         final = zeros(Int64, 5)
-        cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
-        GC.@preserve colptr rowval nzval check(ccall(sym(:otmb_transportmatrix_fetch), Int32,
+        cp = [ptr_or_null(x, Int64) for x in colptr]; rv = [ptr_or_null(x, Int64) for x in rowval]; nz = [ptr_or_null(x, Float64) for x in nzval]
+        GC.@preserve keep colptr rowval nzval check(ccall(sym(:otmb_transportmatrix_fetch), Int32,
             (Ptr{Cvoid}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}), ctx[], cp, rv, nz, final))
         check(ccall(sym(:otmb_ctx_set_reuse_fluxes), Int32, (Ptr{Cvoid}, Int32), ctx[], Int32(0)))
-        return wrap(N, colptr, rowval, nzval, final, operators)
+        return wrap(N, colptr, rowval, nzval, final, operators, given, skip_ops)
     end
 end
 
 # otmb_mgpu_set_reuse -> otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs, one per listed GPU
 function fused_mgpu(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
-                    usepinned::Bool, devices)
+                    usepinned::Bool, devices, given = nothing)
     lock(CALL_LOCK) do
         mg = mgpu_of(devices)
+        reuse_grid = reuse_grid_for(first(devices), Tuple(Int(d) for d in devices), reuse_grid)
         check_mgpu(mg, ccall(sym(:otmb_mgpu_set_reuse), Int32, (Ptr{Cvoid}, Int32, Int32), mg, Int32(reuse_grid), Int32(reuse_fluxes)))
-        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops)
+        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops, given)
         N = indices.N
         nnz = zeros(Int64, 5)
         GC.@preserve keep check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_plan), Int32, (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Int64}), mg, Ref(a), nnz))
-        colptr = [outarray(Int64, usepinned, N + 1) for _ in 1:5]
-        rowval = [outarray(Int64, usepinned, nnz[m]) for m in 1:5]
-        nzval = [outarray(Float64, usepinned, nnz[m]) for m in 1:5]
+        want = [wanted(m, operators, given) for m in 1:5]
+        colptr = [want[m] ? outarray(Int64, usepinned, N + 1) : nothing for m in 1:5]
+        rowval = [want[m] ? outarray(Int64, usepinned, nnz[m]) : nothing for m in 1:5]
+        nzval = [want[m] ? outarray(Float64, usepinned, nnz[m]) : nothing for m in 1:5]
         final = zeros(Int64, 5)
-        cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
-        GC.@preserve colptr rowval nzval check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_fetch), Int32,
+        cp = [ptr_or_null(x, Int64) for x in colptr]; rv = [ptr_or_null(x, Int64) for x in rowval]; nz = [ptr_or_null(x, Float64) for x in nzval]
+        GC.@preserve keep colptr rowval nzval check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_fetch), Int32,
             (Ptr{Cvoid}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}), mg, cp, rv, nz, final))
-        return wrap(N, colptr, rowval, nzval, final, operators)
+        return wrap(N, colptr, rowval, nzval, final, operators, given)
     end
 end
 
@@ -379,21 +455,47 @@ end
 # (a column holds at most 7 / 7 / 5 / 3 / 3 rows, src/matrixbuilding.jl:244-296, :348-415, :450-477), no nnz round trip, every slab's upload beside
 # the download of the slab above it.  The pinned blocks become Julia vectors of the FINAL lengths only after the call (no copy, one owner each).
 const PER_COLUMN_MAX = (7, 7, 5, 3, 3)
-# The default call's choice between the pipelined and the two-phase protocol is MEASURED, per device and grid size, because it depends on the
-# host: the pipelined build needs the link to carry both directions at once and a few free host threads; where it does not get them it
-# has been seen slower than the two-phase call (27.9 against 23.6 ms; usually 20 against 25).  Calls 1-2 pipelined (they allocate), call 3
-# pipelined and timed, call 4 two-phase (allocates), call 5 two-phase and timed; from call 6 on whichever was faster.  An explicit
-# `slabs =` bypasses this.
+# The default call's choice between the pipelined and the two-phase protocol is MEASURED, because it depends on the host: the pipelined build
+# needs the link to carry both directions at once and a few free host threads; where it does not get them it has been seen slower than the
+# two-phase call (27.9 against 23.6 ms; usually 20 against 25).  One trial per KIND of call (device, grid size, operators or T alone, scalar
+# or 3-D ρ, the reuse_grid promise, which operators are passed in).  Calls 1-2 pipelined (they allocate), 3-4 pipelined and timed, 5 two-phase
+# (allocates), 6-7 two-phase and timed; from call 8 on whichever was faster (the minimum of its two samples).  The verdict is not for life:
+# every 64th call runs the protocol that lost and refreshes its time, and a chosen protocol that takes more than 1.3 x its recorded time
+# three calls in a row (a host that got busy) starts the trial over.  An explicit `slabs =` bypasses this.  (Mirror of api.Trial.)
 mutable struct Trial
-    n::Int; t1::Float64; t2::Float64; now::Bool
+    n::Int; t1::Float64; t2::Float64; now::Bool; slow::Int
 end
-const TRIALS = Dict{Tuple{Int,Int},Trial}()
+const TRIALS = Dict{Any,Trial}()
+const REMEASURE_EVERY = 64
+decided(tr::Trial) = !isnan(tr.t1) && !isnan(tr.t2)
 function pipelined!(tr::Trial)
-    tr.n += 1
-    tr.now = tr.n <= 3 ? true : tr.n <= 5 ? false : (isnan(tr.t1) || isnan(tr.t2) || tr.t1 <= tr.t2)   # (a call that raised was not timed)
-    return tr.now
+    lock(CALL_LOCK) do
+        tr.n += 1
+        best = !decided(tr) || tr.t1 <= tr.t2                                   # (a call that raised was not timed: stay with the pipelined build)
+        tr.now = tr.n <= 4 ? true : tr.n <= 7 ? false : (decided(tr) && tr.n % REMEASURE_EVERY == 0) ? !best : best
+        return tr.now
+    end
 end
-record!(tr::Trial, s) = (tr.n == 3 && (tr.t1 = s); tr.n == 5 && (tr.t2 = s); nothing)
+function record!(tr::Trial, s)
+    lock(CALL_LOCK) do
+        mine() = tr.now ? tr.t1 : tr.t2
+        set!(x) = tr.now ? (tr.t1 = x) : (tr.t2 = x)
+        if tr.n in (3, 4, 6, 7)
+            set!(isnan(mine()) ? s : min(mine(), s))
+        elseif tr.n > 7 && decided(tr)
+            if tr.n % REMEASURE_EVERY == 0
+                set!(s)
+            elseif s > 1.3 * mine()
+                tr.slow += 1
+                tr.slow >= 3 && (tr.n = 2; tr.t1 = NaN; tr.t2 = NaN; tr.slow = 0)   # this host is not what it was: measure both again
+            else
+                tr.slow = 0
+                set!(s < mine() ? s : 0.9 * mine() + 0.1 * s)
+            end
+        end
+        nothing
+    end
+end
 # slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 ... 2^25 wet cells, 8 levels and more) -- unless the fluxes
 # are promised to be resident on the single-GPU context (reuse_fluxes) or a device list was given.  ENV["OTMB_HOST_SLABS"] overrides the 4.
 function default_slabs(N, nz, reuse_fluxes, devices)
@@ -403,14 +505,15 @@ function default_slabs(N, nz, reuse_fluxes, devices)
     return (s > 0 && (1 << 18) <= N < (1 << 25) && nz >= 2 * s) ? s : 0
 end
 function fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
-                       usepinned::Bool, devices)
+                       usepinned::Bool, devices, given = nothing)
     lock(CALL_LOCK) do
         mg = mgpu_of(devices)
+        reuse_grid = reuse_grid_for(first(devices), Tuple(Int(d) for d in devices), reuse_grid)
         check_mgpu(mg, ccall(sym(:otmb_mgpu_set_reuse), Int32, (Ptr{Cvoid}, Int32, Int32), mg, Int32(reuse_grid), Int32(reuse_fluxes)))
-        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops)
+        a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops, given)
         N = indices.N
-        cap = Int64[(operators || m == 1) ? N * PER_COLUMN_MAX[m] + 1 : 0 for m in 1:5]
-        colptr = [outarray(Int64, usepinned, N + 1) for _ in 1:5]
+        cap = Int64[wanted(m, operators, given) ? N * PER_COLUMN_MAX[m] + 1 : 0 for m in 1:5]   # (nothing for a given operator: it is not handed out)
+        colptr = [outarray(Int64, usepinned, cap[m] > 0 ? N + 1 : 0) for m in 1:5]
         final = zeros(Int64, 5)
         if usepinned
             rvb = Ptr{Cvoid}[]; nzb = Ptr{Cvoid}[]
@@ -434,7 +537,7 @@ function fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep
                 (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
             foreach(m -> (resize!(rowval[m], final[m]); resize!(nzval[m], final[m])), 1:5)  # (ordinary vectors shrink in place)
         end
-        return wrap(N, colptr, rowval, nzval, final, operators)
+        return wrap(N, colptr, rowval, nzval, final, operators, given)
     end
 end
 

@@ -11,6 +11,7 @@ with ccall).  Arrays are numpy, Fortran-ordered, Julia shapes; indices stay 1-ba
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -293,9 +294,10 @@ def bolus_GM_velocity(ρ, gridmetrics, indices, *, κGM=600, maxslope=0.01, devi
     return u, v
 
 
-def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, grid_passthrough=None):
+def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, grid_passthrough=None, given=None):
     """grid_passthrough (list): receives False for every grid-constant array that had to be converted (copied) on the way
-    to the C ABI -- a temporary's address says nothing about its content, so reuse_grid must not rely on it."""
+    to the C ABI -- a temporary's address says nothing about its content, so reuse_grid must not rely on it.
+    given: {name: SparseMatrixCSC or None} -- operators the caller passes (otmb_tm_args.given)."""
     if grid_passthrough is None:
         grid_passthrough = []
 
@@ -337,6 +339,18 @@ def _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, k
     ml, _ = data_and_props(mlotst)
     a.mlotst = hold(_f64(ml))
     a.kappa_h, a.kappa_vml, a.kappa_vdeep = float(kH), float(kVML), float(kVdeep)
+    N = int(indices["N"])
+    for m, name in enumerate(MATS):
+        A = None if given is None else given.get(name)
+        if A is None:
+            continue
+        if A.shape != (N, N):
+            raise ValueError(f"{name} is {A.shape[0]}x{A.shape[1]}, expected {N}x{N}")
+        # (TκH / TκVdeep are grid constants of a time loop: their arrays fall under the reuse_grid promise like gridmetrics / indices)
+        a.given[m].colptr = hold(grid(A.colptr, lambda x: np.ascontiguousarray(x, dtype=np.int64)))
+        a.given[m].rowval = hold(grid(A.rowval, lambda x: np.ascontiguousarray(x, dtype=np.int64)))
+        a.given[m].nzval = hold(grid(A.nzval, lambda x: np.ascontiguousarray(x, dtype=np.float64)))
+        a.given[m].nnz = int(len(A.rowval))
     return a
 
 
@@ -363,45 +377,94 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     kVML = κVML if kappaVML is None else kappaVML
     kVdeep = κVdeep if kappaVdeep is None else kappaVdeep
     given = dict(Tadv=Tadv, TκH=TκH, TκVML=TκVML, TκVdeep=TκVdeep)
-    if any(x is not None for x in given.values()):
-        # matrixbuilding.jl:140-143: operators passed in are used as they are; T = ((Tadv + TκH) + TκVML) + TκVdeep (:147)
-        return _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, (kH, kVML, kVdeep), upwind, device, devices)
-    trial = None
-    if slabs is None:
-        slabs = default_slabs(int(indices["N"]), int(np.asarray(gridmetrics["v3D"]).shape[2]), reuse_fluxes, devices)
-        if slabs:
-            trial = Trial.of(int(device), int(indices["N"]))
-            slabs = slabs if trial.pipelined() else 0
-    if trial is not None:
-        import time as _time
+    if all(x is None for x in given.values()):
+        given = None
+    else:
+        # matrixbuilding.jl:140-143: an operator that is passed in is NOT built -- nothing it alone would read is read (ϕ / ρ for Tadv,
+        # mlotst for TκVML: harmless stand-ins take their place), it is returned as the very object passed (:149), and
+        # T = ((Tadv + TκH) + TκVML) + TκVdeep (:147) is formed with it (otmb_tm_args.given)
+        shape = np.asarray(gridmetrics["v3D"]).shape
+        if given["Tadv"] is not None:
+            z = np.zeros(shape, dtype=np.float64, order="F")
+            phi, rho = {k: z for k in PHI_ORDER}, 1035.0
+        if mlotst is None:
+            mlotst = np.full(shape[:2], np.nan)
+        operators = True  # (the built operators are operands of T and are returned)
+    common = (phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators)
+    fkey = _foreign_key(given)
+    if fkey in _foreign_seen and devices is None:  # known to need the sparse-add path: straight to the call that has it
+        return _transportmatrix_fused(*common, reuse_grid, reuse_fluxes, device, 0, None, given)
+    try:
+        trial = None
+        if slabs is None:
+            slabs = default_slabs(int(indices["N"]), int(np.asarray(gridmetrics["v3D"]).shape[2]), reuse_fluxes, devices)
+            if slabs:
+                trial = Trial.of(int(device), int(indices["N"]), operators, np.ndim(rho) != 0, reuse_grid, given)
+                slabs = slabs if trial.pipelined() else 0
+        if trial is not None:
+            import time as _time
 
-        t0 = _time.perf_counter()
-        tm = (_transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, [int(device)] * slabs, 0, reuse_grid, reuse_fluxes)
-              if slabs else
-              _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes, device, 0, None))
-        trial.record(_time.perf_counter() - t0)
-        return tm
-    if slabs:
-        nz_levels = int(np.asarray(gridmetrics["v3D"]).shape[2])
-        devs = list(devices) if devices is not None else [int(device)] * max(1, min(int(slabs), nz_levels))
-        return _transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devs, 0, reuse_grid, reuse_fluxes)
-    return _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes,
-                                  device, 0, devices)
+            t0 = _time.perf_counter()
+            tm = (_transportmatrix_onepass(*common, [int(device)] * slabs, 0, reuse_grid, reuse_fluxes, given) if slabs else
+                  _transportmatrix_fused(*common, reuse_grid, reuse_fluxes, device, 0, None, given))
+            trial.record(_time.perf_counter() - t0)
+            return tm
+        if slabs:
+            nz_levels = int(np.asarray(gridmetrics["v3D"]).shape[2])
+            devs = list(devices) if devices is not None else [int(device)] * max(1, min(int(slabs), nz_levels))
+            return _transportmatrix_onepass(*common, devs, 0, reuse_grid, reuse_fluxes, given)
+        return _transportmatrix_fused(*common, reuse_grid, reuse_fluxes, device, 0, devices, given)
+    except capi.OtmbError as e:
+        if e.status != capi.GIVEN_FOREIGN or given is None:
+            raise
+        # a given operator is not what the library derives for this grid and κ (another κ, another pattern, Tadv, TκVML): T is then the
+        # device sparse add of four materialised operands, which the single-context two-phase call does
+        _foreign_seen.add(fkey)
+        return _transportmatrix_fused(*common, False, False, device if devices is None else list(devices)[0], 0, None, given)
+
+
+_foreign_seen = set()  # given-operator sets that the pipelined / multi-slab builds refused (OTMB_ERR_GIVEN_FOREIGN): next time straight to the two-phase call
+
+
+def _foreign_key(given):
+    if given is None:
+        return None
+    return tuple((name, A.nzval.ctypes.data, len(A.rowval)) for name, A in given.items() if A is not None and hasattr(A.nzval, "ctypes"))
+
+
+def _result(N, colptr, rowval, nzval, final, operators, given, skip_ops=0):
+    """NT(T, Tadv, TκH, TκVML, TκVdeep): the built matrices wrapped at their final counts, a given operator as the very object passed
+    (matrixbuilding.jl:149), None for what was not asked for (operators = False)."""
+    out = {}
+    for m, name in enumerate(MATS):
+        if given is not None and given.get(name) is not None:
+            out[name] = given[name]
+        elif (operators or m == 0) and not (skip_ops >> m) & 1:
+            out[name] = SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]])
+        else:
+            out[name] = None
+    return NT(**out)
+
+
+def _wanted(m, operators, given, skip_ops=0):
+    return (operators or m == 0) and not (given is not None and given.get(MATS[m]) is not None) and not (skip_ops >> m) & 1
 
 
 def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, reuse_grid, reuse_fluxes, device,
-                           ignore_ops, devices=None):
+                           ignore_ops, devices=None, given=None, skip_ops=0):
     """otmb_ctx_set_reuse_grid -> otmb_ctx_set_reuse_fluxes -> otmb_transportmatrix_plan -> otmb_transportmatrix_fetch."""
     if devices is not None:
         return _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
-                                     reuse_grid, reuse_fluxes)
+                                     reuse_grid, reuse_fluxes, given)
     ctx = context(device)
     keep, passthrough = [], []
-    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough, given)
+    reuse_grid = _reuse_grid_for(device, "ctx", reuse_grid)
     ctx.set_reuse_grid(bool(reuse_grid) and all(passthrough))  # converted temporaries have no identity to rely on
     ctx.set_reuse_fluxes(bool(reuse_fluxes))
     a.only_t = 0 if operators else 1
     a.ignore_ops = int(ignore_ops)
+    a.skip_ops = int(skip_ops)
     nnz = (C.c_int64 * 5)()
     import time as _time
 
@@ -410,21 +473,20 @@ def _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVd
     last_call_seconds["plan"] = _time.perf_counter() - t0
     N = int(indices["N"])
     t0 = _time.perf_counter()
-    colptr = [_out_array(ctx, N + 1, np.int64) for _ in range(5)]
-    rowval = [_out_array(ctx, int(nnz[m]), np.int64) for m in range(5)]
-    nzval = [_out_array(ctx, int(nnz[m]), np.float64) for m in range(5)]
+    want = [_wanted(m, operators, given, skip_ops) for m in range(5)]
+    colptr = [_out_array(ctx, N + 1, np.int64) if want[m] else None for m in range(5)]
+    rowval = [_out_array(ctx, int(nnz[m]), np.int64) if want[m] else None for m in range(5)]
+    nzval = [_out_array(ctx, int(nnz[m]), np.float64) if want[m] else None for m in range(5)]
     last_call_seconds["alloc"] = _time.perf_counter() - t0
-    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
-    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
-    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    ptrs = lambda arrs: capi.ptr_array(5, [None if x is None else x.ctypes.data for x in arrs])
+    cp, rv, nz = ptrs(colptr), ptrs(rowval), ptrs(nzval)
     final = (C.c_int64 * 5)()
     t0 = _time.perf_counter()
     ctx.check(capi.lib().otmb_transportmatrix_fetch(ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
     last_call_seconds["fetch"] = _time.perf_counter() - t0
     ctx.set_reuse_fluxes(False)
     # plan's count for T is the union-pattern bound; entries that summed to exactly zero are dropped (:147)
-    return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
-                 for m, name in enumerate(MATS)})
+    return _result(N, colptr, rowval, nzval, final, operators, given, skip_ops)
 
 
 def default_slabs(N, nz, reuse_fluxes, devices):
@@ -440,46 +502,97 @@ def default_slabs(N, nz, reuse_fluxes, devices):
 
 
 class Trial:
-    """The default call's choice between the pipelined and the two-phase protocol is MEASURED, per device and grid size, because it depends
-    on the host: the pipelined build needs the link to carry both directions at once and a few free host threads; where it does not
-    get them it has been seen slower than the two-phase call (27.9 against 23.6 ms; usually 20 against 25: profiles/r05/README.md 9d).
-    Calls 1-2 pipelined (they allocate), call 3 pipelined and timed, call 4 two-phase (allocates), call 5 two-phase and timed; from
-    call 6 on whichever was faster.  An explicit slabs= bypasses this."""
+    """The default call's choice between the pipelined and the two-phase protocol is MEASURED, because it depends on the host: the pipelined
+    build needs the link to carry both directions at once and a few free host threads; where it does not get them it has been seen slower
+    than the two-phase call (27.9 against 23.6 ms; usually 20 against 25: profiles/r05/README.md 9d).  One trial per KIND of call -- device,
+    grid size, operators or T alone, scalar or 3-D ρ, the reuse_grid promise, which operators are passed in -- since each of those changes the
+    bytes either protocol moves.  Schedule: calls 1-2 pipelined (they allocate), 3-4 pipelined and timed, 5 two-phase (allocates), 6-7
+    two-phase and timed; from call 8 on whichever was faster (the minimum of its two samples).  The verdict is not for life: every
+    REMEASURE_EVERY-th call runs the protocol that lost and refreshes its time, and a chosen protocol that takes more than SLOW_FACTOR x its
+    recorded time SLOW_STREAK calls in a row (a host that got busy) starts the trial over.  Thread-safe.  An explicit slabs= bypasses it."""
     _all = {}
+    _lock = threading.Lock()
+    REMEASURE_EVERY, SLOW_FACTOR, SLOW_STREAK = 64, 1.3, 3
 
     def __init__(self):
-        self.n, self.t = 0, {True: None, False: None}
+        self.n, self.t, self.now, self.slow = 0, {True: None, False: None}, True, 0
 
     @classmethod
-    def of(cls, device, N):
-        return cls._all.setdefault((device, N), cls())
+    def key(cls, device, N, operators=True, rho3d=False, reuse_grid=False, given=None):
+        g = tuple(name for name in MATS if given is not None and given.get(name) is not None)
+        return (int(device), int(N), bool(operators), bool(rho3d), bool(reuse_grid), g)
+
+    @classmethod
+    def of(cls, device, N, operators=True, rho3d=False, reuse_grid=False, given=None):
+        with cls._lock:
+            return cls._all.setdefault(cls.key(device, N, operators, rho3d, reuse_grid, given), cls())
+
+    @classmethod
+    def peek(cls, device, N, operators=True, rho3d=False, reuse_grid=False, given=None):
+        """The trial of this kind of call if one exists (bench.py reports its verdict), else None."""
+        return cls._all.get(cls.key(device, N, operators, rho3d, reuse_grid, given))
+
+    def decided(self):
+        return self.t[True] is not None and self.t[False] is not None
 
     def pipelined(self):
-        self.n += 1
-        if self.n <= 3:
-            self.now = True
-        elif self.n <= 5:
-            self.now = False
-        else:  # (a call that raised was not timed: stay with the pipelined build)
-            self.now = self.t[True] is None or self.t[False] is None or self.t[True] <= self.t[False]
-        return self.now
+        with self._lock:
+            self.n += 1
+            if self.n <= 4:
+                self.now = True
+            elif self.n <= 7:
+                self.now = False
+            elif not self.decided():  # (a call that raised was not timed: stay with the pipelined build)
+                self.now = True
+            else:
+                best = self.t[True] <= self.t[False]
+                self.now = (not best) if (self.n % self.REMEASURE_EVERY == 0) else best
+            return self.now
 
     def record(self, seconds):
-        if self.n in (3, 5):
-            self.t[self.now] = seconds
+        with self._lock:
+            if self.n in (3, 4, 6, 7):
+                self.t[self.now] = seconds if self.t[self.now] is None else min(self.t[self.now], seconds)
+            elif self.n > 7 and self.decided():
+                if self.n % self.REMEASURE_EVERY == 0:
+                    self.t[self.now] = seconds
+                    return
+                if seconds > self.SLOW_FACTOR * self.t[self.now]:
+                    self.slow += 1
+                    if self.slow >= self.SLOW_STREAK:  # this host is not what it was: measure both again (no warm-ups needed: the blocks are pooled)
+                        self.n, self.t, self.slow = 2, {True: None, False: None}, 0
+                else:
+                    self.slow = 0
+                    self.t[self.now] = min(self.t[self.now], seconds) if seconds < self.t[self.now] else 0.9 * self.t[self.now] + 0.1 * seconds
+
+
+# Which engine served the previous host-pointer transportmatrix of a device: the single-device context ("ctx") or an otmb_mgpu (its device
+# tuple).  reuse_grid is the caller's promise about "the previous call" -- but each engine checks it against ITS OWN previous call.  When the
+# engine changes (the Trial does that by itself), the new engine's residency keys may describe arrays the caller has edited since, legitimately
+# passing reuse_grid = False in between: the promise is therefore not forwarded to an engine that did not serve the previous call (ADVICE r05).
+_last_engine = {}
+_engine_lock = threading.Lock()
+
+
+def _reuse_grid_for(device, engine, reuse_grid):
+    with _engine_lock:
+        same = _last_engine.get(int(device)) == engine
+        _last_engine[int(device)] = engine
+    return bool(reuse_grid) and same
 
 
 PER_COLUMN_MAX = (7, 7, 5, 3, 3)  # rows a column of T, Tadv, TκH, TκVML, TκVdeep can hold (matrixbuilding.jl:244-296, :348-415, :450-477)
 
 
 def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
-                          reuse_grid=False, reuse_fluxes=False):
+                          reuse_grid=False, reuse_fluxes=False, given=None):
     """otmb_mgpu_set_reuse -> otmb_mgpu_transportmatrix_plan -> otmb_mgpu_transportmatrix_fetch: the same build cut into depth slabs,
     one per listed GPU."""
     mg = mgpu(devices)
     ctx = context(list(devices)[0])  # (pinned result arrays only: the pool is the process's, every device's DMA reaches it)
     keep, passthrough = [], []
-    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough, given)
+    reuse_grid = _reuse_grid_for(list(devices)[0], tuple(int(d) for d in devices), reuse_grid)
     mg.check(capi.lib().otmb_mgpu_set_reuse(mg.handle, int(bool(reuse_grid) and all(passthrough)), int(bool(reuse_fluxes))))
     a.only_t = 0 if operators else 1
     a.ignore_ops = int(ignore_ops)
@@ -490,22 +603,21 @@ def _transportmatrix_mgpu(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVde
     mg.check(capi.lib().otmb_mgpu_transportmatrix_plan(mg.handle, C.byref(a), C.byref(nnz)))
     last_call_seconds["plan"] = _time.perf_counter() - t0
     N = int(indices["N"])
-    colptr = [_out_array(ctx, N + 1, np.int64) for _ in range(5)]
-    rowval = [_out_array(ctx, int(nnz[m]), np.int64) for m in range(5)]
-    nzval = [_out_array(ctx, int(nnz[m]), np.float64) for m in range(5)]
-    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
-    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
-    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    want = [_wanted(m, operators, given) for m in range(5)]
+    colptr = [_out_array(ctx, N + 1, np.int64) if want[m] else None for m in range(5)]
+    rowval = [_out_array(ctx, int(nnz[m]), np.int64) if want[m] else None for m in range(5)]
+    nzval = [_out_array(ctx, int(nnz[m]), np.float64) if want[m] else None for m in range(5)]
+    ptrs = lambda arrs: capi.ptr_array(5, [None if x is None else x.ctypes.data for x in arrs])
+    cp, rv, nz = ptrs(colptr), ptrs(rowval), ptrs(nzval)
     final = (C.c_int64 * 5)()
     t0 = _time.perf_counter()
     mg.check(capi.lib().otmb_mgpu_transportmatrix_fetch(mg.handle, C.byref(cp), C.byref(rv), C.byref(nz), C.byref(final)))
     last_call_seconds["fetch"] = _time.perf_counter() - t0
-    return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
-                 for m, name in enumerate(MATS)})
+    return _result(N, colptr, rowval, nzval, final, operators, given)
 
 
 def _transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, operators, devices, ignore_ops,
-                             reuse_grid=False, reuse_fluxes=False):
+                             reuse_grid=False, reuse_fluxes=False, given=None):
     """otmb_mgpu_set_reuse -> result arrays at their upper bounds -> otmb_mgpu_transportmatrix_onepass: no nnz round trip, every slab's upload
     beside the download of the slab above it.  The matrices' rowval / nzval are the first nnz entries of those arrays."""
     import time as _time
@@ -513,71 +625,42 @@ def _transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, k
     mg = mgpu(devices)
     ctx = context(list(devices)[0])
     keep, passthrough = [], []
-    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough)
+    a = _tm_args(phi, mlotst, gridmetrics, indices, rho, kH, kVML, kVdeep, upwind, keep, passthrough, given)
+    reuse_grid = _reuse_grid_for(list(devices)[0], tuple(int(d) for d in devices), reuse_grid)
     mg.check(capi.lib().otmb_mgpu_set_reuse(mg.handle, int(bool(reuse_grid) and all(passthrough)), int(bool(reuse_fluxes))))
     a.only_t = 0 if operators else 1
     a.ignore_ops = int(ignore_ops)
     N = int(indices["N"])
-    cap = [N * k + 1 if (operators or m == 0) else 0 for m, k in enumerate(PER_COLUMN_MAX)]
-    colptr = [_out_array(ctx, N + 1, np.int64) for _ in range(5)]
-    rowval = [_out_array(ctx, cap[m], np.int64) for m in range(5)]
-    nzval = [_out_array(ctx, cap[m], np.float64) for m in range(5)]
-    cp = capi.ptr_array(5, [x.ctypes.data for x in colptr])
-    rv = capi.ptr_array(5, [x.ctypes.data for x in rowval])
-    nz = capi.ptr_array(5, [x.ctypes.data for x in nzval])
+    want = [_wanted(m, operators, given) for m in range(5)]
+    cap = [N * k + 1 if want[m] else 0 for m, k in enumerate(PER_COLUMN_MAX)]
+    colptr = [_out_array(ctx, N + 1, np.int64) if want[m] else None for m in range(5)]
+    rowval = [_out_array(ctx, cap[m], np.int64) if want[m] else None for m in range(5)]
+    nzval = [_out_array(ctx, cap[m], np.float64) if want[m] else None for m in range(5)]
+    ptrs = lambda arrs: capi.ptr_array(5, [None if x is None else x.ctypes.data for x in arrs])
+    cp, rv, nz = ptrs(colptr), ptrs(rowval), ptrs(nzval)
     caps, final = (C.c_int64 * 5)(*cap), (C.c_int64 * 5)()
     t0 = _time.perf_counter()
     mg.check(capi.lib().otmb_mgpu_transportmatrix_onepass(mg.handle, C.byref(a), C.byref(cp), C.byref(rv), C.byref(nz), C.byref(caps), C.byref(final)))
     last_call_seconds["plan"], last_call_seconds["fetch"] = _time.perf_counter() - t0, 0.0
-    return NT(**{name: (SparseMatrixCSC(N, N, colptr[m], rowval[m][: final[m]], nzval[m][: final[m]]) if (operators or m == 0) else None)
-                 for m, name in enumerate(MATS)})
-
-
-def _transportmatrix_with_given(given, phi, mlotst, gridmetrics, indices, rho, kappa, upwind, device, devices=None):
-    """transportmatrix with precomputed operators (matrixbuilding.jl:133-147).  The same sequence of C calls as the Julia
-    shim (julia/OceanTransportMatrixBuilderAMD.jl; tests/test_julia_shim_static.py compares the two): one fused build whose
-    errors for the GIVEN operators are switched off (otmb_tm_args.ignore_ops -- the reference never builds them, so it never
-    looks at ϕ / ρ when Tadv is given, nor at mlotst when TκVML is: harmless stand-ins take their place), then the three
-    sparse adds of :147 with the library's `+` (otmb_spadd: union pattern, exact-zero sums dropped)."""
-    shape = np.asarray(gridmetrics["v3D"]).shape
-    ignore = sum(1 << m for m, name in enumerate(MATS) if m > 0 and given[name] is not None)
-    if given["Tadv"] is not None:
-        z = np.zeros(shape, dtype=np.float64, order="F")
-        phi = {k: z for k in PHI_ORDER}
-        rho = 1035.0
-    if mlotst is None:
-        mlotst = np.full(shape[:2], np.nan)
-    N = int(indices["N"])
-    for name, A in given.items():
-        if A is not None and A.shape != (N, N):
-            raise ValueError(f"{name} is {A.shape[0]}x{A.shape[1]}, expected {N}x{N}")
-    r = _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, *kappa, upwind, True, False, False, device, ignore, devices)
-    if devices is not None:
-        device = list(devices)[0]  # (the three adds run on the first listed device)
-    ops = [given[name] if given[name] is not None else r[name] for name in MATS[1:]]
-    T = spadd(spadd(spadd(ops[0], ops[1], device=device), ops[2], device=device), ops[3], device=device)
-    return NT(T=T, Tadv=ops[0], TκH=ops[1], TκVML=ops[2], TκVdeep=ops[3])
+    return _result(N, colptr, rowval, nzval, final, operators, given)
 
 
 def _build_operator(which, *, gridmetrics, indices, phi=None, rho=1035.0, mlotst=None, kappa=(500.0, 0.1, 1.0e-5), upwind=True,
                     device=0):
-    import torch
-
-    from .device import DeviceAssembler
-
-    asm = DeviceAssembler(device)
+    """buildTadv / buildTκH / buildTκVML / buildTκVdeep (src/matrixbuilding.jl:31-120): ONE operator, by the fused build with every other
+    matrix switched off (otmb_tm_args.skip_ops: neither counted, written nor copied home) and nothing the others alone would raise raised
+    (ignore_ops).  What the other operators would read and this one does not gets harmless stand-ins, as the reference never looks at it."""
+    m = MATS.index(which)
     shape = np.asarray(gridmetrics["v3D"]).shape
-    ml = np.full(shape[:2], np.nan) if mlotst is None else mlotst
-    asm.set_grid(gridmetrics, ml, rho, *kappa, upwind=upwind)
-    if asm.N != int(indices["N"]):
-        raise ValueError("indices do not belong to gridmetrics.v3D")
     if phi is None:
-        dphi = [torch.zeros(asm.G, dtype=torch.float64, device=asm.device) for _ in range(6)]
-    else:
-        dphi = [asm._t(np.asarray(phi[k])) for k in PHI_ORDER]
-    I, J, V = asm.sparse_entries(which, dphi)
-    cp, rv, nz = asm.sparse(I, J, V, asm.N, asm.N)
-    return SparseMatrixCSC(asm.N, asm.N, cp.cpu().numpy(), rv.cpu().numpy(), nz.cpu().numpy())
+        z = np.zeros(shape, dtype=np.float64, order="F")
+        phi = {k: z for k in PHI_ORDER}
+    if mlotst is None:
+        mlotst = np.full(shape[:2], np.nan)
+    others = 0x1e & ~(1 << m)
+    r = _transportmatrix_fused(phi, mlotst, gridmetrics, indices, rho, *kappa, upwind, True, False, False, device, others, None, None,
+                               0x1f & ~(1 << m))
+    return r[which]
 
 
 def buildTadv(*, ϕ=None, phi=None, gridmetrics, indices, ρ=None, rho=None, upwind=True, device=0):

@@ -9,8 +9,9 @@ OK = 0
 STATUS_NAMES = {
     1: "RHO_NAN", 2: "TADV_NAN", 3: "TKH_NAN", 4: "TKVML_NAN", 5: "TKVDEEP_NAN", 6: "FLUX_INTO_LAND",
     7: "UNKNOWN_TOPOLOGY", 8: "ALL_MISSING", 9: "ALLOC", 10: "HIP", 11: "INVALID_ARG", 12: "NO_PLAN",
-    13: "NONCANONICAL_INDICES", 14: "CAPACITY", 15: "PUSH_MASK", 16: "ASYMMETRIC_PATTERN",
+    13: "NONCANONICAL_INDICES", 14: "CAPACITY", 15: "PUSH_MASK", 16: "ASYMMETRIC_PATTERN", 17: "GIVEN_FOREIGN",
 }
+GIVEN_FOREIGN = 17
 PHI_ORDER = ("east", "west", "north", "south", "top", "bottom")  # OTMB_EAST..OTMB_BOTTOM
 HDIRS = ("west", "east", "south", "north")  # OTMB_DIR_*
 MATS = ("T", "Tadv", "TκH", "TκVML", "TκVdeep")  # OTMB_T..OTMB_TKVDEEP
@@ -31,6 +32,11 @@ class OtmbError(RuntimeError):
         self.step = step  # asynchronous pipelines: 0-based index of the first step that failed
 
 
+class Csc(C.Structure):
+    """otmb_csc: a SparseMatrixCSC{Float64,Int64} by its three arrays (1-based)."""
+    _fields_ = [("colptr", C.c_void_p), ("rowval", C.c_void_p), ("nzval", C.c_void_p), ("nnz", C.c_int64)]
+
+
 class TmArgs(C.Structure):
     _fields_ = [
         ("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
@@ -43,6 +49,8 @@ class TmArgs(C.Structure):
         ("push_mask", C.c_void_p),
         ("only_t", C.c_int32),
         ("ignore_ops", C.c_int32),
+        ("skip_ops", C.c_int32),  # bit m: matrix m is not wanted (neither counted, written nor copied home)
+        ("given", Csc * 5),  # operators the caller passes (transportmatrix's Tadv = / TκH = / TκVML = / TκVdeep = keywords)
     ]
 
 
@@ -85,6 +93,9 @@ SYMBOLS = {
     "otmb_mgpu_transportmatrix_onepass": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5),
                                                       C.POINTER(C.c_int64 * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_ctx_forget_given": (C.c_int32, [_vp]),
+    "otmb_ctx_given_state": (C.c_int32, [_vp, C.c_int32]),
+    "otmb_ctx_given_checks": (C.c_int64, [_vp]),
     "otmb_last_error": (C.c_char_p, [_vp]),
     "otmb_status_string": (C.c_char_p, [C.c_int32]),
     "otmb_version": (C.c_char_p, []),
@@ -282,6 +293,14 @@ class Context:
     def set_tile_order(self, rows_per_band):
         """Speed only: 0 = tiles in wet-rank order, R > 0 = march order in bands of R rows, -1 = the library default (bands of 8 rows)."""
         self.check(self._lib.otmb_ctx_set_tile_order(self._h, int(rows_per_band)))
+
+    def forget_given(self):
+        """The verdicts on given operators (otmb_tm_args.given) are keyed to array addresses: call after rewriting such an array in place."""
+        self.check(self._lib.otmb_ctx_forget_given(self._h))
+
+    def given_state(self, m):
+        """How the last plan / _dev call treated operator m (index into MATS): 0 not given, 1 given and derived, 2 given and foreign."""
+        return int(self._lib.otmb_ctx_given_state(self._h, int(m)))
 
     def use_own_stream(self):
         self.check(self._lib.otmb_ctx_set_stream(self._h, _vp(0)))

@@ -99,6 +99,22 @@ struct otmb_ctx {
     std::vector<TmStepResult> tm_hist;  // verdict and nnz of every step since the previous otmb_transportmatrix_result
     bool tm_hist_final = false;      // tm_hist describes a finished pipeline (cleared by the next otmb_transportmatrix_dev)
     TmPlan *plan = nullptr;
+    // ---- otmb_tm_args.given: is a given TκH / TκVdeep bit for bit what the fill pass derives?  One verdict per operator, keyed to every
+    // array address and scalar the answer depends on, and to an epoch that otmb_ctx_forget_given (and every host upload of such an array) bumps.
+    struct GivenVerdict {
+        bool valid = false, derived = false;
+        uint64_t epoch = 0;
+        otmb_csc g = {nullptr, nullptr, nullptr, 0};
+        const void *lwet3d = nullptr, *lwet = nullptr, *v3d = nullptr, *thk = nullptr, *edge[4] = {nullptr, nullptr, nullptr, nullptr},
+                   *dist[4] = {nullptr, nullptr, nullptr, nullptr}, *area = nullptr, *zt = nullptr;
+        int64_t nx = 0, ny = 0, nz = 0, n_wet = 0, wet_base = 0;
+        int topo = -1;
+        double kappa = 0.0;
+    } given_verdict[5];
+    uint64_t given_epoch = 1;
+    int given_state[5] = {0, 0, 0, 0, 0};  // the last plan's treatment of operator m: 0 not given, 1 derived, 2 foreign (otmb_ctx_given_state)
+    long given_checks = 0;                 // comparing passes run so far (tests: the verdict is cached)
+    DevBuf given_tmp[6];                   // temporaries of the foreign path's sparse adds: two (colptr, rowval, nzval) triples
     CooPlan coo;
     SpPlan sp;
     // staging for the host-pointer entry points
@@ -138,7 +154,7 @@ struct KernelTimer {
 #define OTMB_NFLAGS 16
 enum {
     FLAG_RHO_NAN = 0, FLAG_TADV_NAN, FLAG_TKH_NAN, FLAG_TKVML_NAN, FLAG_TKVDEEP_NAN,
-    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_RESERVED7, FLAG_CAPACITY,
+    FLAG_FLUX_INTO_LAND, FLAG_NONCANONICAL, FLAG_GIVEN_MISMATCH /* the comparing pass (otmb_tm_args.given): an entry differs */, FLAG_CAPACITY,
     FLAG_T_CANCEL,  // some T entry summed to exactly zero: T was written with gaps and needs compaction
     FLAG_COUNT_MISMATCH,  // a tile's fill pass found other counts than its counting pass: push_mask does not describe ϕ
     OTMB_NFLAGS_TM = 12,            // words [0, OTMB_NFLAGS_TM) belong to transportmatrix and are reset by it
@@ -161,7 +177,7 @@ int32_t otmb_reserve(otmb_ctx *ctx, DevBuf &b, size_t bytes);
 #define FFC_BAD_FLUX (1ull << 63)         // some cell of the tile pushes a non-zero flux into land / out of the grid
 #define FFC_BAD_TABLE (1ull << 62)        // the bases table was built for another wave geometry
 void otmb_launch_tilescan_packed(hipStream_t s, unsigned long long *packed, const unsigned long long *stat, uint32_t *sums, i64 *offs, i64 *tot, i64 *gsum, i64 ntiles,
-                                 int *flags, int only_t, bool all_levels);  // otmb_scan.hip
+                                 int *flags, unsigned long long keep, bool all_levels);  // otmb_scan.hip (keep: count fields of the matrices that are materialised)
 int32_t otmb_launch_push_mask(otmb_ctx *ctx, const double *const phi[6], const int64_t *lwet3d, int64_t first, int64_t count,
                               uint16_t *push_mask);  // otmb_facefluxes.hip
 int32_t otmb_facefluxes_top_counts(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t src_is_f32, const uint8_t *wetflags, double fill,
@@ -172,7 +188,7 @@ void otmb_tm_plan_invalidate(otmb_ctx *ctx);                         // otmb_tra
 void otmb_xfer_free(otmb_ctx *ctx);                                  // otmb_host.hip
 bool otmb_host_is_pinned(const otmb_ctx *ctx, const void *p, size_t bytes);  // otmb_host.hip: inside a block of otmb_host_alloc
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
-bool otmb_tm_plan_only_t(otmb_ctx *ctx);                              // otmb_transportmatrix.hip
+unsigned otmb_tm_plan_skip(otmb_ctx *ctx);                            // otmb_transportmatrix.hip: matrices (bit m) the pending plan does not hand out
 
 #define HIP_TRY(ctx, call)                                                              \
     do {                                                                                \

@@ -54,6 +54,7 @@ const char *otmb_status_string(int32_t s) {
         case OTMB_ERR_CAPACITY: return "output capacity too small";
         case OTMB_ERR_PUSH_MASK: return "push_mask does not describe these face fluxes and wet mask";
         case OTMB_ERR_ASYMMETRIC_PATTERN: return "ArgumentError: Adjacency / distance matrices must be symmetric";
+        case OTMB_ERR_GIVEN_FOREIGN: return "a given operator is not what the library derives for these arguments: use the two-phase protocol";
         default: return "unknown status";
     }
 }
@@ -111,7 +112,7 @@ void otmb_ctx_destroy(otmb_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     otmb_tm_plan_free(ctx);
     otmb_xfer_free(ctx);
-    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->stamps, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4], &ctx->ffc_sums[0], &ctx->ffc_sums[1], &ctx->xfer_narrow})
+    for (DevBuf *b : {&ctx->blocksums, &ctx->blockoffs, &ctx->flags, &ctx->ring, &ctx->stamps, &ctx->tcount, &ctx->tfix[0], &ctx->tfix[1], &ctx->tfix[2], &ctx->tm_sums, &ctx->tm_offs, &ctx->sort[0], &ctx->sort[1], &ctx->sort[2], &ctx->sort[3], &ctx->sort[4], &ctx->ffc_sums[0], &ctx->ffc_sums[1], &ctx->xfer_narrow, &ctx->given_tmp[0], &ctx->given_tmp[1], &ctx->given_tmp[2], &ctx->given_tmp[3], &ctx->given_tmp[4], &ctx->given_tmp[5]})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
@@ -148,6 +149,15 @@ int32_t otmb_ctx_set_tile_order(otmb_ctx *ctx, int32_t rows_per_band) {
     ctx->march_rows = rows_per_band;
     return OTMB_OK;
 }
+
+int32_t otmb_ctx_forget_given(otmb_ctx *ctx) {
+    if (!ctx) return OTMB_ERR_INVALID_ARG;
+    ctx->given_epoch += 1;
+    return OTMB_OK;
+}
+
+int32_t otmb_ctx_given_state(const otmb_ctx *ctx, int32_t m) { return (ctx && m >= 0 && m < 5) ? ctx->given_state[m] : -1; }
+int64_t otmb_ctx_given_checks(const otmb_ctx *ctx) { return ctx ? (int64_t)ctx->given_checks : -1; }
 
 int32_t otmb_ctx_synchronize(otmb_ctx *ctx) {
     if (!ctx) return OTMB_ERR_INVALID_ARG;

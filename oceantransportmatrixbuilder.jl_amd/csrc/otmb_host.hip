@@ -10,7 +10,8 @@
 enum {
     ST_PHI0 = 0, ST_V = 6, ST_THK, ST_RHO, ST_LW, ST_EDGE0, ST_DIST0 = ST_EDGE0 + 4, ST_AREA = ST_DIST0 + 4, ST_ZT,
     ST_ML, ST_UMO, ST_VMO, ST_WET, ST_LWET, ST_COLPTR0, ST_ROWVAL0 = ST_COLPTR0 + 5, ST_NZVAL0 = ST_ROWVAL0 + 5,
-    ST_COUNT = ST_NZVAL0 + 5
+    ST_GIVEN0 = ST_NZVAL0 + 5,  // operators the caller passes (otmb_tm_args.given): colptr, rowval, nzval of m = 1 .. 4
+    ST_COUNT = ST_GIVEN0 + 12
 };
 
 static int32_t stage(otmb_ctx *ctx, int slot, size_t bytes, void **dptr) {
@@ -37,19 +38,23 @@ struct Uploads {
     }
 };
 // kind: 0 = uploaded every call; 1 = grid constant (otmb_ctx_set_reuse_grid); 2 = a face-flux array (otmb_ctx_set_reuse_fluxes:
-// resident when the slot still holds what otmb_facefluxes computed and copied to this very host array)
+// resident when the slot still holds what otmb_facefluxes computed and copied to this very host array); 3 = an array of a GIVEN operator
+// (otmb_tm_args.given: TκH / TκVdeep are grid constants of a time loop, so they fall under the reuse_grid promise like kind 1).
+// Whenever a kind-1 or kind-3 array is actually copied, the verdicts on given operators are forgotten (they are keyed to device addresses,
+// and the content behind those addresses has just changed or cannot be known to be the same).
 static int32_t upload(otmb_ctx *ctx, Uploads &up, int slot, const void *h, size_t bytes, const void **dptr, int kind = 0) {
     void *d = nullptr;
     int32_t rc = stage(ctx, slot, bytes, &d);
     if (rc) return rc;
     if (ctx->stage_key.size() < (size_t)ST_COUNT) ctx->stage_key.resize(ST_COUNT);
     otmb_ctx::StageKey &key = ctx->stage_key[slot];
-    const bool promised = (kind == 1 && ctx->reuse_grid) || (kind == 2 && ctx->reuse_fluxes);
+    const bool promised = ((kind == 1 || kind == 3) && ctx->reuse_grid) || (kind == 2 && ctx->reuse_fluxes);
     const bool resident = promised && key.host == h && key.bytes == bytes && bytes > 0;
     if (bytes && !resident) {
         up.items.push_back({d, const_cast<void *>(h), bytes});
         ctx->uploaded_bytes += (i64)bytes;
         up.ctx = ctx; up.slots.push_back(slot); up.done = false;
+        if (kind == 1 || kind == 3) ctx->given_epoch += 1;
     }
     key.host = (promised || resident) ? h : nullptr;
     key.bytes = bytes;
@@ -347,6 +352,17 @@ int32_t otmb_transportmatrix_plan(otmb_ctx *ctx, const otmb_tm_args *a, int64_t 
     TRY(upload(ctx, up, ST_AREA, a->area2d, P * 8, &p, 1)); d.area2d = (const double *)p;
     TRY(upload(ctx, up, ST_ZT, a->zt, (size_t)a->nz * 8, &p, 1)); d.zt = (const double *)p;
     TRY(upload(ctx, up, ST_ML, a->mlotst, P * 8, &p)); d.mlotst = (const double *)p;
+    // operators the caller passes (transportmatrix's Tadv = / TκH = / ... keywords): their arrays go up like grid constants
+    for (int m = 1; m < 5; ++m) {
+        const otmb_csc &g = a->given[m];
+        if (!g.colptr) continue;
+        if (g.nnz < 0 || (g.nnz > 0 && (!g.rowval || !g.nzval))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "given operator: arrays / nnz");
+        if (g.colptr[a->n_wet] - g.colptr[0] != g.nnz) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "given operator: colptr does not end at nnz (is it N x N?)");
+        const int s0 = ST_GIVEN0 + 3 * (m - 1);
+        TRY(upload(ctx, up, s0, g.colptr, (size_t)(a->n_wet + 1) * 8, &p, 3)); d.given[m].colptr = (const int64_t *)p;
+        TRY(upload(ctx, up, s0 + 1, g.rowval, (size_t)g.nnz * 8, &p, 3)); d.given[m].rowval = (const int64_t *)p;
+        TRY(upload(ctx, up, s0 + 2, g.nzval, (size_t)g.nnz * 8, &p, 3)); d.given[m].nzval = (const double *)p;
+    }
     TRY(flush(ctx, up));
     return otmb_transportmatrix_plan_dev(ctx, &d, nnz);
 }
@@ -360,9 +376,11 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t *dcp[5], *drv[5];
     double *dnz[5];
-    const int nm = otmb_tm_plan_only_t(ctx) ? 1 : 5;  // T alone (otmb_tm_args.only_t): the operators' outputs may be NULL
+    // matrices that are not handed out (T alone: otmb_tm_args.only_t; operators the caller passed: otmb_tm_args.given): their outputs may be NULL
+    const unsigned skip = otmb_tm_plan_skip(ctx);
     for (int m = 0; m < 5; ++m) { dcp[m] = nullptr; drv[m] = nullptr; dnz[m] = nullptr; }
-    for (int m = 0; m < nm; ++m) {
+    for (int m = 0; m < 5; ++m) {
+        if ((skip >> m) & 1u) continue;
         if (!colptr[m] || (nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         void *d;
         TRY(stage(ctx, ST_COLPTR0 + m, (size_t)(N + 1) * 8, &d)); dcp[m] = (int64_t *)d;
@@ -374,7 +392,8 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     for (int m = 0; m < 5; ++m) nnz_out[m] = nnz[m];
     std::vector<OtmbXferItem> down;
     // row indices (<= N) and column offsets (<= nnz + 1) cross the link as Int32 where they provably fit (otmb_xfer.h: `narrow`)
-    for (int m = 0; m < nm; ++m) {
+    for (int m = 0; m < 5; ++m) {
+        if ((skip >> m) & 1u) continue;
         down.push_back({dcp[m], colptr[m], (size_t)(N + 1) * 8, nnz_out[m] + 1 < ((int64_t)1 << 31)});
         if (nnz[m] > 0) {
             down.push_back({drv[m], rowval[m], (size_t)nnz[m] * 8, N < ((int64_t)1 << 31)});

@@ -63,7 +63,9 @@ struct Rccl {
 };
 
 enum { B_PHI0 = 0, B_V = 6, B_THK, B_RHO, B_LW, B_LWET, B_EDGE0, B_DIST0 = B_EDGE0 + 4, B_AREA = B_DIST0 + 4, B_ZT, B_ML, B_UMO, B_VMO,
-       B_WET, B_PLANE, B_COLPTR0, B_ROWVAL0 = B_COLPTR0 + 5, B_NZVAL0 = B_ROWVAL0 + 5, B_COUNT = B_NZVAL0 + 5 };
+       B_WET, B_PLANE, B_COLPTR0, B_ROWVAL0 = B_COLPTR0 + 5, B_NZVAL0 = B_ROWVAL0 + 5,
+       B_GIVEN0 = B_NZVAL0 + 5,  // the slab's columns of the operators the caller passes (otmb_tm_args.given): colptr, rowval, nzval of m = 1 .. 4
+       B_COUNT = B_GIVEN0 + 12 };
 
 struct Slab {
     otmb_ctx *ctx = nullptr;
@@ -100,7 +102,7 @@ __global__ void shift_i64_kernel(i64 *p, i64 n, i64 delta) {
 // :90, :114), behind the library's own input checks -- as oceantransportmatrixbuilder.jl_amd/dist.py ranks them
 int status_rank(int32_t st) {
     static const int order[] = {OTMB_ERR_NONCANONICAL_INDICES, OTMB_ERR_HIP, OTMB_ERR_PUSH_MASK, OTMB_ERR_RHO_NAN, OTMB_ERR_FLUX_INTO_LAND,
-                                OTMB_ERR_TADV_NAN, OTMB_ERR_TKH_NAN, OTMB_ERR_TKVML_NAN, OTMB_ERR_TKVDEEP_NAN, OTMB_ERR_CAPACITY};
+                                OTMB_ERR_TADV_NAN, OTMB_ERR_TKH_NAN, OTMB_ERR_TKVML_NAN, OTMB_ERR_TKVDEEP_NAN, OTMB_ERR_CAPACITY, OTMB_ERR_GIVEN_FOREIGN};
     for (int q = 0; q < (int)(sizeof order / sizeof order[0]); ++q)
         if (order[q] == st) return q;
     return 99;
@@ -248,7 +250,8 @@ void fail_plane(otmb_mgpu *mg, int to) {  // a slab that cannot produce its plan
 
 // One slab's share of a plan: stage its levels [k0 - ha, k1 + hb) of the host arrays on its device (what is resident under the reuse
 // promises is not uploaded again), then count.  Leaves sl.nnz / sl.status.  before_upload / after_upload bracket the upload batch.
-void plan_slab(otmb_mgpu *mg, int s, const otmb_tm_args *a, const std::function<void()> &before_upload, const std::function<void()> &after_upload) {
+void plan_slab(otmb_mgpu *mg, int s, const otmb_tm_args *a, const std::function<void()> &before_upload, const std::function<void()> &after_upload,
+               bool one_phase = false) {
     const i64 P = a->nx * a->ny;
     Slab &sl = *mg->slabs[s];
     // The residency keys are written when an upload is QUEUED: a slab that fails before its batch has reached the device (a later
@@ -282,7 +285,11 @@ void plan_slab(otmb_mgpu *mg, int s, const otmb_tm_args *a, const std::function<
         if (sl.buf[B].p != before) k = Slab::Key();  // the buffer was (re)allocated: whatever it held is gone
         const bool promised = (kind == 1 && mg->reuse_grid) || (kind == 2 && mg->reuse_fluxes);
         const bool resident = promised && k.host == host && k.bytes == bytes && k.e0 == e0 && bytes > 0;
-        if (!resident && bytes) { up.push_back({*out, const_cast<void *>(host), bytes}); sl.uploaded += (i64)bytes; }
+        if (!resident && bytes) {
+            up.push_back({*out, const_cast<void *>(host), bytes});
+            sl.uploaded += (i64)bytes;
+            if (kind == 1) otmb_ctx_forget_given(sl.ctx);  // (verdicts on given operators are keyed to addresses whose content has just changed)
+        }
         k.host = (promised || resident) ? host : nullptr;
         k.bytes = bytes;
         k.e0 = e0;
@@ -328,6 +335,25 @@ void plan_slab(otmb_mgpu *mg, int s, const otmb_tm_args *a, const std::function<
     d.mlotst = (const double *)p;
     if ((r = put(B_ZT, a->zt + e0, (size_t)nze * 8, 1, &p)) > 0) return fail(r);
     d.zt = (const double *)p;
+    // operators the caller passes (otmb_tm_args.given): this slab's columns -- colptr entries [wet_base, wet_base + n_own] (global numbering)
+    // and the entries they delimit; grid constants of a time loop, so they fall under the reuse_grid promise
+    for (int m = 1; m < 5; ++m) {
+        const otmb_csc &g = a->given[m];
+        if (!g.colptr) continue;
+        const i64 lo = g.colptr[sl.wet_base] - 1, hi = g.colptr[sl.wet_base + sl.n_own] - 1;
+        if (g.nnz < 0 || lo < 0 || hi < lo || hi > g.nnz || (g.nnz > 0 && (!g.rowval || !g.nzval))) {
+            otmb_fail(sl.ctx, OTMB_ERR_INVALID_ARG, "given operator: colptr / nnz (is it N x N?)");
+            return fail(OTMB_ERR_INVALID_ARG);
+        }
+        const int b0 = B_GIVEN0 + 3 * (m - 1);
+        if ((r = put(b0, g.colptr + sl.wet_base, (size_t)(sl.n_own + 1) * 8, 1, &p)) > 0) return fail(r);
+        d.given[m].colptr = (const int64_t *)p;
+        if ((r = put(b0 + 1, g.rowval + lo, (size_t)(hi - lo) * 8, 1, &p)) > 0) return fail(r);
+        d.given[m].rowval = (const int64_t *)p;
+        if ((r = put(b0 + 2, g.nzval + lo, (size_t)(hi - lo) * 8, 1, &p)) > 0) return fail(r);
+        d.given[m].nzval = (const double *)p;
+        d.given[m].nnz = hi - lo;
+    }
     if (before_upload) before_upload();  // (the pipelined build lets the slabs of one device take the link in turn)
     r = up.empty() ? OTMB_OK : otmb_xfer(sl.ctx, true, up.data(), (int)up.size());
     if (after_upload) after_upload();
@@ -340,6 +366,20 @@ void plan_slab(otmb_mgpu *mg, int s, const otmb_tm_args *a, const std::function<
     on_device = true;  // (errors from here on are the reference's own: the arrays ARE where the keys say)
     if ((r = otmb_transportmatrix_set_slab(sl.ctx, sl.wet_base))) return fail(r);
     if ((r = otmb_transportmatrix_plan_dev(sl.ctx, &d, sl.nnz))) return fail(r);
+    // a given operator that is not what the library derives makes T a sparse add over whole columns of four matrices, sized by the sum of
+    // their counts: with more than one slab, or in the one-phase build (whose T array is sized 7N), that is not built here -- the
+    // two-phase call on one context does it (the host layers fall back to it)
+    if (mg->slabs.size() > 1 || one_phase)
+        for (int m = 1; m < 5; ++m)
+            if (otmb_ctx_given_state(sl.ctx, m) == 2) { otmb_fail(sl.ctx, OTMB_ERR_GIVEN_FOREIGN); return fail(OTMB_ERR_GIVEN_FOREIGN); }
+}
+
+// matrices (bit m) a build with these arguments hands out: not T's operators when only T is wanted, never an operator the caller passed
+unsigned wanted_mask(const otmb_tm_args &a) {
+    unsigned w = (a.only_t ? 1u : 0x1fu) & ~((unsigned)a.skip_ops & 0x1fu);
+    for (int m = 1; m < 5; ++m)
+        if (a.given[m].colptr) w &= ~(1u << m);
+    return w;
 }
 
 }  // namespace
@@ -711,9 +751,10 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
                                         int64_t nnz_out[5]) {
     if (!mg || !colptr || !rowval || !nzval || !nnz_out) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null argument");
     if (!mg->planned) return mg_fail(mg, OTMB_ERR_NO_PLAN);
-    const int nm = mg->args.only_t ? 1 : 5, n = (int)mg->slabs.size();
-    for (int m = 0; m < nm; ++m)
-        if (!colptr[m] || (mg->nnz[m] > 0 && (!rowval[m] || !nzval[m]))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
+    const unsigned want = wanted_mask(mg->args);
+    const int n = (int)mg->slabs.size();
+    for (int m = 0; m < 5; ++m)
+        if (((want >> m) & 1u) && (!colptr[m] || (mg->nnz[m] > 0 && (!rowval[m] || !nzval[m])))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
     mg->planned = false;  // a plan is consumed by its fetch (not by a call that is refused for its arguments)
     // phase 1: every slab fills its column range on its device and copies the four operators home (their counts are exact
     // since the plan); T's final count is only known now (entries that summed to exactly zero, src/matrixbuilding.jl:147)
@@ -725,7 +766,8 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         int64_t *dcp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *drv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         double *dnz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         void *p;
-        for (int m = 0; m < nm; ++m) {
+        for (int m = 0; m < 5; ++m) {
+            if (!((want >> m) & 1u)) continue;
             if ((r = reserve(sl, B_COLPTR0 + m, (size_t)(sl.n_own + 1) * 8, &p))) return fail(r);
             dcp[m] = (int64_t *)p;
             if ((r = reserve(sl, B_ROWVAL0 + m, (size_t)sl.nnz[m] * 8, &p))) return fail(r);
@@ -739,7 +781,8 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         std::vector<OtmbXferItem> down;
         const bool last = s + 1 == n;
         const int small_rows = mg->N < ((i64)1 << 31);  // (otmb_xfer.h: `narrow`)
-        for (int m = 1; m < nm; ++m) {
+        for (int m = 1; m < 5; ++m) {
+            if (!((want >> m) & 1u)) continue;
             down.push_back({dcp[m], colptr[m] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, mg->nnz[m] + 1 < ((i64)1 << 31)});
             if (sl.nnz[m] > 0) {
                 down.push_back({drv[m], rowval[m] + sl.base[m], (size_t)sl.nnz[m] * 8, small_rows});
@@ -777,7 +820,7 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
     for (int m = 0; m < 5; ++m) {
         i64 tot = 0;
         for (Slab *sl : mg->slabs) tot += sl->nnz[m];
-        nnz_out[m] = mg->nnz[m] = (m < nm) ? tot : 0;
+        nnz_out[m] = mg->nnz[m] = ((want >> m) & 1u) ? tot : 0;
     }
     return OTMB_OK;
 }
@@ -800,9 +843,10 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
     if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null input array");
     const i64 P = a->nx * a->ny, G = P * a->nz, N = a->n_wet;
     if (N < 0 || N > G || (N > 0 && !a->lwet)) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "lwet / n_wet");
-    const int nm = a->only_t ? 1 : 5, n = (int)mg->slabs.size();
-    for (int m = 0; m < nm; ++m)
-        if (!colptr[m] || capacity[m] < 0 || (capacity[m] > 0 && (!rowval[m] || !nzval[m]))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
+    const unsigned want = wanted_mask(*a);
+    const int n = (int)mg->slabs.size();
+    for (int m = 0; m < 5; ++m)
+        if (((want >> m) & 1u) && (!colptr[m] || capacity[m] < 0 || (capacity[m] > 0 && (!rowval[m] || !nzval[m])))) return mg_fail(mg, OTMB_ERR_INVALID_ARG, "null output");
     mg->planned = false;
     std::vector<i64> counts(a->nz, 0);
     {
@@ -866,7 +910,7 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
                       }
                       stamps[s][0] = now_ms();
                   },
-                  [&] { stamps[s][1] = now_ms(); leave_link(); });
+                  [&] { stamps[s][1] = now_ms(); leave_link(); }, true);
         leave_link();  // (a slab that failed before its upload must not hold the link)
         stamps[s][2] = now_ms();
         {   // my turn to place my columns: every slab above me has published
@@ -880,8 +924,8 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
         }
         stamps[s][3] = now_ms();
         if (hipSetDevice(sl.device) != hipSuccess) { otmb_fail(sl.ctx, OTMB_ERR_HIP, "hipSetDevice"); fail(OTMB_ERR_HIP); return publish(false); }
-        for (int q = 0; q < nm; ++q)
-            if (sl.base[q] + sl.nnz[q] > capacity[q]) {
+        for (int q = 0; q < 5; ++q)
+            if (((want >> q) & 1u) && sl.base[q] + sl.nnz[q] > capacity[q]) {
                 otmb_fail(sl.ctx, OTMB_ERR_CAPACITY);
                 fail(OTMB_ERR_CAPACITY);
                 return publish(false);
@@ -890,7 +934,8 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
         int64_t *dcp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *drv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         double *dnz[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         void *p;
-        for (int q = 0; q < nm; ++q) {
+        for (int q = 0; q < 5; ++q) {
+            if (!((want >> q) & 1u)) continue;
             if ((r = reserve(sl, B_COLPTR0 + q, (size_t)(sl.n_own + 1) * 8, &p))) { fail(r); return publish(false); }
             dcp[q] = (int64_t *)p;
             if ((r = reserve(sl, B_ROWVAL0 + q, (size_t)sl.nnz[q] * 8, &p))) { fail(r); return publish(false); }
@@ -909,7 +954,8 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
         const bool last = s + 1 == n;
         // row indices (<= N) and column offsets (<= capacity + 1) cross the link as Int32 where they provably fit (otmb_xfer.h: `narrow`)
         const int small_rows = N < ((i64)1 << 31);
-        for (int q = 0; q < nm; ++q) {
+        for (int q = 0; q < 5; ++q) {
+            if (!((want >> q) & 1u)) continue;
             const int small_offs = capacity[q] + 1 < ((i64)1 << 31);
             down.push_back({dcp[q], colptr[q] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, small_offs});
             if (sl.nnz[q] > 0) {
@@ -932,7 +978,7 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
             fprintf(stderr, "onepass slab %d: upload %.2f-%.2f  planned %.2f  my turn %.2f  filled %.2f  home %.2f ms\n", s, stamps[s][0], stamps[s][1],
                     stamps[s][2], stamps[s][3], stamps[s][4], stamps[s][5]);
     if ((rc = collect_status(mg))) return rc;
-    for (int q = 0; q < 5; ++q) nnz_out[q] = mg->nnz[q] = (q < nm) ? next_base[q] : 0;
+    for (int q = 0; q < 5; ++q) nnz_out[q] = mg->nnz[q] = ((want >> q) & 1u) ? next_base[q] : 0;
     return OTMB_OK;
 }
 

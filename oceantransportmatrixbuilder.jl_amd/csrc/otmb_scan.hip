@@ -90,7 +90,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups5(const uint32_t 
 __global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups5_packed(unsigned long long *__restrict__ packed,
                                                                          const unsigned long long *__restrict__ stat, uint32_t *__restrict__ sums,
                                                                          i64 *__restrict__ offs, i64 *__restrict__ gsum, i64 ntiles,
-                                                                         int *__restrict__ flags, int only_t) {
+                                                                         int *__restrict__ flags, unsigned long long keep) {
     __shared__ uint32_t wave_tot[5][SCAN_THREADS / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const i64 t = (i64)blockIdx.x * SCAN_THREADS + threadIdx.x;
@@ -101,12 +101,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void tilescan_groups5_packed(unsigned
     }
     if (w & FFC_BAD_FLUX) { if (flags[FLAG_FLUX_INTO_LAND] == 0) atomicExch(&flags[FLAG_FLUX_INTO_LAND], 1); }
     if (w & FFC_BAD_TABLE) { if (flags[FLAG_COUNT_MISMATCH] == 0) atomicExch(&flags[FLAG_COUNT_MISMATCH], 1); }
+    w &= keep;  // (matrices that are not materialised -- T alone, given operators -- count nothing: TmParams.skip)
     uint32_t mine[5], x[5];
     mine[0] = (uint32_t)(w & 0x7ff);
-    mine[1] = only_t ? 0u : (uint32_t)((w >> 11) & 0x7ff);
-    mine[2] = only_t ? 0u : (uint32_t)((w >> 22) & 0x7ff);
-    mine[3] = only_t ? 0u : (uint32_t)((w >> 33) & 0x3ff);
-    mine[4] = only_t ? 0u : (uint32_t)((w >> 43) & 0x3ff);
+    mine[1] = (uint32_t)((w >> 11) & 0x7ff);
+    mine[2] = (uint32_t)((w >> 22) & 0x7ff);
+    mine[3] = (uint32_t)((w >> 33) & 0x3ff);
+    mine[4] = (uint32_t)((w >> 43) & 0x3ff);
 #pragma unroll
     for (int f = 0; f < 5; ++f) {
         if (t < ntiles) sums[t * 5 + f] = mine[f];
@@ -256,9 +257,9 @@ void otmb_launch_tilescan_groups(hipStream_t s, const uint32_t *sums, i64 *offs,
 // Tile counts from facefluxes (one packed word per tile): level 1 always; all_levels adds the group bases to offs and leaves the
 // totals in tot, as otmb_launch_tilescan does (the two-phase plan, and grids of more groups than the fill pass adds up itself).
 void otmb_launch_tilescan_packed(hipStream_t s, unsigned long long *packed, const unsigned long long *stat, uint32_t *sums, i64 *offs, i64 *tot, i64 *gsum, i64 ntiles,
-                                 int *flags, int only_t, bool all_levels) {
+                                 int *flags, unsigned long long keep, bool all_levels) {
     const i64 ngroups = (ntiles + SCAN_THREADS - 1) / SCAN_THREADS;
-    hipLaunchKernelGGL(tilescan_groups5_packed, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, packed, stat, sums, offs, gsum, ntiles, flags, only_t);
+    hipLaunchKernelGGL(tilescan_groups5_packed, dim3((unsigned)ngroups), dim3(SCAN_THREADS), 0, s, packed, stat, sums, offs, gsum, ntiles, flags, keep);
     if (!all_levels) return;
     hipLaunchKernelGGL(tilescan_top, dim3(1), dim3(SCAN_THREADS), 0, s, gsum, tot, ngroups, 5);
     if (ngroups > 1) {

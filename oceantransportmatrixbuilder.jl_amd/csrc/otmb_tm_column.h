@@ -32,7 +32,9 @@ struct TmParams {
     const double *area, *zt, *ml;
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
-    int only_t;        // build T alone: the operators are evaluated but neither counted nor written (otmb_tm_args.only_t)
+    unsigned skip;     // bit m: matrix m is evaluated (T is the sum of all four) but neither counted nor written -- otmb_tm_args.only_t (bits 1-4),
+                       // a given operator that the fill pass re-derives (otmb_tm_args.given), T itself when a foreign given operator makes it a sparse add
+    u64 keep;          // the packed count word's fields of the matrices that ARE counted (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10)
     int rho_in_fill;   // the ρ-NaN check (:233) is done by the fill pass (which loads ρ anyway) instead of the counting pass:
                        // set when both passes run before the flags are read (otmb_transportmatrix_dev)
     i64 P, G;

@@ -45,7 +45,28 @@ struct TmPlan {
     i64 wet_base = 0;
     i64 nnz_base[5] = {0, 0, 0, 0, 0};
     bool rho_in_fill = false;  // the plan took its counts from facefluxes: no pass has looked at ρ yet, the fill pass does (:233)
+    // otmb_tm_args.given: operators the caller passes (bit m).  derived: bit for bit what the fill pass computes -- re-derived in registers, not
+    // materialised; foreign: any other matrix -- T is then the device sparse add of the four operands (two-phase protocol only)
+    unsigned given = 0, derived = 0, foreign = 0;
+    unsigned skip = 0;         // matrices the kernels neither count nor write (TmParams.skip)
+    bool want_t = true;        // the caller wants T (otmb_tm_args.skip_ops bit 0 clear)
+    i64 built_nnz[5] = {0, 0, 0, 0, 0};  // (foreign) the counts of the matrices the kernel writes; nnz[0] is then the sparse adds' bound
 };
+
+// fields of the packed count word (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10) that belong to the matrices NOT in `skip`
+static u64 keep_mask(unsigned skip) {
+    static const u64 field[5] = {0x7ffull, 0x7ffull << 11, 0x7ffull << 22, 0x3ffull << 33, 0x3ffull << 43};
+    u64 k = 0;
+    for (int m = 0; m < 5; ++m)
+        if (!((skip >> m) & 1u)) k |= field[m];
+    return k;
+}
+static unsigned given_mask(const otmb_tm_args &a) {
+    unsigned g = 0;
+    for (int m = 1; m < 5; ++m)
+        if (a.given[m].colptr) g |= 1u << m;
+    return g;
+}
 
 // A value every lane of the wave holds identically, moved to scalar registers.
 __device__ __forceinline__ i64 wave_uniform(i64 x) {
@@ -93,9 +114,8 @@ __device__ __forceinline__ u64 count_cell(const TmParams &p, i64 tile, int tid) 
     } else {
         general_presence(p, cell, padv, phh, pml, pdp);
     }
-    if (p.only_t) return (u64)__popc(padv | phh | pml | pdp);
-    return (u64)__popc(padv | phh | pml | pdp) | ((u64)__popc(padv) << 11) | ((u64)__popc(phh) << 22) | ((u64)__popc(pml) << 33) |
-           ((u64)__popc(pdp) << 43);
+    return ((u64)__popc(padv | phh | pml | pdp) | ((u64)__popc(padv) << 11) | ((u64)__popc(phh) << 22) | ((u64)__popc(pml) << 33) |
+            ((u64)__popc(pdp) << 43)) & p.keep;  // (matrices that are not materialised count nothing: TmParams.skip)
 }
 
 #ifndef TM_COUNT_TPB
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 live = true;
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
                 nU = __popc(uni);
-                if (!p.only_t) { nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp); }
+                nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
                 {
 #pragma unroll
                     for (int s = 0; s < NSLOT; ++s)
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                         col.tv[s] = t_value(col, s);
                         if (((uni >> s) & 1u) && col.tv[s] != 0.0) pT |= 1u << s;
                     }
-                    if (pT != uni) raise_flag(p.flags, FLAG_T_CANCEL);
+                    if (pT != uni && !(p.skip & 1u)) raise_flag(p.flags, FLAG_T_CANCEL);
                 }
             }
         }
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 
     STAMP(st, 3, 0);  // the column's arithmetic is done
     // ---- 2. packed block scan: T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10 bits ----
-    const u64 mine = (u64)nU | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43);
+    const u64 mine = ((u64)nU | ((u64)nA << 11) | ((u64)nH << 22) | ((u64)nM << 33) | ((u64)nD << 43)) & p.keep;  // (matrices that are not materialised: TmParams.skip)
     u64 incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             if (p.gsum) p.totals[tid] = tot;
             i64 *cp = (tid == 0) ? p.colptr[0] : (tid == 1) ? p.colptr[1] : (tid == 2) ? p.colptr[2] : (tid == 3) ? p.colptr[3] : p.colptr[4];
             const i64 nb = (tid == 0) ? p.nnz_base[0] : (tid == 1) ? p.nnz_base[1] : (tid == 2) ? p.nnz_base[2] : (tid == 3) ? p.nnz_base[3] : p.nnz_base[4];
-            if (tid == 0 || !p.only_t) cp[p.n_own] = nb + tot + 1;
+            if (!((p.skip >> tid) & 1u)) cp[p.n_own] = nb + tot + 1;
         }
     }
 
@@ -344,13 +364,15 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     if (live) {
 #pragma unroll
         for (int m = 0; m < TM_NF; ++m)
-            if (m == 0 || !p.only_t) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;  // (non-temporal here: no gain)
+            if (!((p.skip >> m) & 1u)) p.colptr[m][w] = p.nnz_base[m] + g0[m] + ex[m] + 1;  // (non-temporal here: no gain)
     }
     // the vertical operators only ever hold the rows above, self and below (:438-479): lets the compiler drop
     // the other five slot tests of their staging loops
     const unsigned vslots = (1u << S_A) | (1u << S_SELF) | (1u << S_B);
-    const unsigned ops = p.only_t ? 0u : ~0u;  // T alone: nothing of the operators is staged or stored
-    const unsigned pm[5] = {pT, col.padv & ops, col.phh & ops, col.pml & vslots & ops, col.pdp & vslots & ops};
+    // matrices that are not materialised (T alone; a given operator): nothing of them is staged or stored
+    const unsigned on0 = (p.skip & 1u) ? 0u : ~0u, on1 = (p.skip & 2u) ? 0u : ~0u, on2 = (p.skip & 4u) ? 0u : ~0u, on3 = (p.skip & 8u) ? 0u : ~0u,
+                   on4 = (p.skip & 16u) ? 0u : ~0u;
+    const unsigned pm[5] = {pT & on0, col.padv & on1, col.phh & on2, col.pml & vslots & on3, col.pdp & vslots & on4};
     // wave-uniform quantities go to scalar registers: the run's base pointers are then SGPR pairs, the stores
     // take the `global_store vaddr32, vdata, sbase` form and the copy loop is a scalar loop
     const u64 ubefore = (u64)wave_uniform((i64)before);
@@ -393,7 +415,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             // T after an exact cancellation (rare): the column keeps its reserved (union) width, its entries are left-aligned
             // and the unused slots carry row 0 -- which is how the compaction (tfix_*) finds a column's real length, for
             // any step of an asynchronous pipeline, from the step's own output arrays
-            if (m == 0 && (unsigned)__popc(pT) != nU) {
+            if (m == 0 && on0 && (unsigned)__popc(pT) != nU) {
                 for (unsigned e = __popc(pT); e < nU; ++e) { my_row[q0 + e] = 0; my_val[q0 + e] = 0; }
             }
         }
@@ -445,10 +467,91 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 #endif
 }
 
+// ---- otmb_tm_args.given: the COMPARING pass ------------------------------------------------------------------------------------
+// Is a given operator bit for bit what the fill pass would write?  One thread per column builds the column exactly as tm_kernel does
+// (fast_column / build_column: the one copy of the arithmetic) and, for every operator m in g.check, reads the given matrix's column:
+// same length, same rows in the same order, same value BITS (-0.0 is not +0.0, a NaN equals itself).  The given arrays may be a depth
+// slab's slice: column w holds entries [colptr[w] - colptr[0], colptr[w + 1] - colptr[0]) of rowval / nzval.  Nothing is stored but
+// the verdict: bit m of flags[FLAG_GIVEN_MISMATCH].  Once per grid and κ (the verdict is cached), so plain wet-rank order, no staging.
+struct GivenCmp {
+    const i64 *cp[5], *ri[5], *vx[5];  // the given matrices' colptr / rowval / nzval (value bits)
+    i64 nnz[5];
+    unsigned check;
+};
+__global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_given_kernel(const TmParams p, const GivenCmp g) {
+    const int tid = threadIdx.x;
+    const i64 w0 = (i64)blockIdx.x * TM_THREADS, w = w0 + tid;
+    if (w0 >= p.n_own) return;
+    const bool valid = w < p.n_own;
+    const i64 wlast = (w0 + TM_THREADS - 1 < p.n_own) ? w0 + TM_THREADS - 1 : p.n_own - 1;
+    const i64 wcl = valid ? w : wlast;
+    const i64 L = p.lwet[wcl] - 1;
+    const i64 Lnext = (wcl + 1 < p.n_own) ? p.lwet[wcl + 1] - 1 : p.G;
+    const i64 Lmin = p.lwet[w0] - 1, Lmax = p.lwet[wlast] - 1;
+    const i64 base_elem = (Lmin > p.P) ? Lmin - p.P : 0;
+    const bool span_ok = (Lmax + p.P - base_elem) < (1ll << 28) && Lmin >= 0 && Lmax < p.G && Lmin <= Lmax;
+    if (!valid) return;
+    if (!span_ok || L < Lmin || L > Lmax || Lnext <= L) {  // not a makeindices result: nothing can be derived from it
+        atomicOr(&p.flags[FLAG_GIVEN_MISMATCH], (int)g.check);
+        return;
+    }
+    TileBase tb;
+    tb.lw = (const char *)(p.lw + base_elem);
+    tb.v = (const char *)(p.v + base_elem);
+    tb.thk = (const char *)(p.thk + base_elem);
+    tb.rho = p.rho ? (const char *)(p.rho + base_elem) : nullptr;
+    tb.pt = (const char *)(p.phi[OTMB_TOP] + base_elem);
+    tb.pe = (const char *)(p.phi[OTMB_EAST] + base_elem);
+    tb.pw = (const char *)(p.phi[OTMB_WEST] + base_elem);
+    tb.pn = (const char *)(p.phi[OTMB_NORTH] + base_elem);
+    tb.ps = (const char *)(p.phi[OTMB_SOUTH] + base_elem);
+    tb.pb = (const char *)(p.phi[OTMB_BOTTOM] + base_elem);
+    tb.pu = tb.pv = tb.mk = nullptr;
+    Column col;
+    Stamps st;
+    const i64 c = p.wet_base + w + 1;
+    const Cell cell = cell_of(L, p.nx, p.ny, p.P);
+    const unsigned oC = (unsigned)(L - base_elem) * 8u;
+    const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
+    bool canonical;
+    if (regular) canonical = fast_column<0>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);
+    else {
+        canonical = ldi(tb.lw, oC) == c;
+        if (canonical) build_column(p, cell, c, col);
+    }
+    if (!canonical) {
+        atomicOr(&p.flags[FLAG_GIVEN_MISMATCH], (int)g.check);
+        return;
+    }
+    const unsigned vslots = (1u << S_A) | (1u << S_SELF) | (1u << S_B);
+    const unsigned pm[5] = {0u, col.padv, col.phh, col.pml & vslots, col.pdp & vslots};
+    unsigned bad = 0;
+#pragma unroll
+    for (int m = 1; m < TM_NF; ++m) {
+        if (!((g.check >> m) & 1u)) continue;
+        const i64 c0 = g.cp[m][0];
+        const i64 lo = g.cp[m][w] - c0, hi = g.cp[m][w + 1] - c0;
+        bool ok = lo >= 0 && hi <= g.nnz[m] && hi - lo == (i64)__popc(pm[m]);
+        if (w == p.n_own - 1) ok &= hi == g.nnz[m];
+        if (ok) {
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) {
+                if ((pm[m] >> sl) & 1u) {
+                    const i64 q = lo + (i64)__popc(pm[m] & col.bef[sl]);
+                    const double v = (m == 1) ? col.adv[sl] : (m == 2) ? col.hh[sl] : (m == 3) ? col.ml[sl] : col.dp[sl];
+                    ok &= (g.ri[m][q] == col.idx[sl]) & (g.vx[m][q] == __double_as_longlong(v));
+                }
+            }
+        }
+        if (!ok) bad |= 1u << m;
+    }
+    if (bad) atomicOr(&p.flags[FLAG_GIVEN_MISMATCH], (int)bad);
+}
+
 // closing colptr entry of each matrix: nnz_base + nnz + 1 (values known on the host since the plan)
 __global__ void tm_finish_colptr(i64 *c0, i64 *c1, i64 *c2, i64 *c3, i64 *c4, i64 N, i64 t0, i64 t1, i64 t2, i64 t3, i64 t4) {
     if (threadIdx.x == 0) {
-        c0[N] = t0 + 1;
+        if (c0) c0[N] = t0 + 1;
         if (c1) c1[N] = t1 + 1;
         if (c2) c2[N] = t2 + 1;
         if (c3) c3[N] = t3 + 1;
@@ -653,7 +756,8 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.area = a.area2d; p.zt = a.zt; p.ml = a.mlotst;
     p.kH = a.kappa_h; p.kML = a.kappa_vml; p.kDeep = a.kappa_vdeep;
     p.nx = (int)a.nx; p.ny = (int)a.ny; p.nz = (int)a.nz; p.topo = a.topology; p.upwind = a.upwind;
-    p.only_t = a.only_t != 0;
+    p.skip = pl ? pl->skip : ((a.only_t ? 0x1eu : 0u) | ((unsigned)a.skip_ops & 0x1fu));
+    p.keep = keep_mask(p.skip);
     p.P = a.nx * a.ny; p.G = p.P * a.nz;
     p.n_own = a.n_wet;
     if (pl) {
@@ -701,7 +805,7 @@ static int ffc_match(const otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &p
 static void ffc_consume(otmb_ctx *ctx, int buf, const TmParams &p, i64 *offs, i64 *dtot, i64 *gsum, i64 ntiles, bool all_levels) {
     KernelTimer kt(ctx, K_TILESCAN);
     otmb_launch_tilescan_packed(ctx->stream, (unsigned long long *)ctx->ffc_sums[buf].p, (const unsigned long long *)ctx->ffc.stat, p.tilesums, offs, dtot, gsum, ntiles, p.flags,
-                                p.only_t, all_levels);
+                                p.keep, all_levels);
     ctx->ffc.valid = false;
     ctx->ffc_dirty[buf] = false;
 }
@@ -709,6 +813,107 @@ static void ffc_consume(otmb_ctx *ctx, int buf, const TmParams &p, i64 *offs, i6
 __global__ __launch_bounds__(256) void rho_nan_kernel(const double *__restrict__ rho, const i64 *__restrict__ lwet, i64 n, int *flags) {
     const i64 w = (i64)blockIdx.x * 256 + threadIdx.x;
     if (w < n && isnan(rho[lwet[w] - 1])) raise_flag(flags, FLAG_RHO_NAN);
+}
+
+// ---- otmb_tm_args.given (host side) ---------------------------------------------------------------------------------------------
+static bool verdict_matches(const otmb_ctx::GivenVerdict &v, const otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, int m) {
+    if (!v.valid || v.epoch != ctx->given_epoch) return false;
+    const otmb_csc &g = a.given[m];
+    if (v.g.colptr != g.colptr || v.g.rowval != g.rowval || v.g.nzval != g.nzval || v.g.nnz != g.nnz) return false;
+    if (v.lwet3d != a.lwet3d || v.lwet != a.lwet || v.v3d != a.v3d || v.nx != a.nx || v.ny != a.ny || v.nz != a.nz || v.n_wet != a.n_wet ||
+        v.wet_base != pl.wet_base || v.topo != a.topology)
+        return false;
+    if (m == OTMB_TKH) {
+        if (v.thk != a.thkcello || v.kappa != a.kappa_h) return false;
+        for (int d = 0; d < 4; ++d)
+            if (v.edge[d] != a.edge_length[d] || v.dist[d] != a.dist_nbr[d]) return false;
+    } else {
+        if (v.area != a.area2d || v.zt != a.zt || v.kappa != a.kappa_vdeep) return false;
+    }
+    return true;
+}
+static void verdict_store(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, int m, bool derived) {
+    otmb_ctx::GivenVerdict &v = ctx->given_verdict[m];
+    v.valid = true; v.derived = derived; v.epoch = ctx->given_epoch; v.g = a.given[m];
+    v.lwet3d = a.lwet3d; v.lwet = a.lwet; v.v3d = a.v3d; v.thk = a.thkcello; v.area = a.area2d; v.zt = a.zt;
+    for (int d = 0; d < 4; ++d) { v.edge[d] = a.edge_length[d]; v.dist[d] = a.dist_nbr[d]; }
+    v.nx = a.nx; v.ny = a.ny; v.nz = a.nz; v.n_wet = a.n_wet; v.wet_base = pl.wet_base; v.topo = a.topology;
+    v.kappa = (m == OTMB_TKH) ? a.kappa_h : a.kappa_vdeep;
+}
+// the comparing pass over the operators in `check`; *derived: those that are bit for bit what the fill pass writes.  Synchronises.
+static int32_t verify_given(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, unsigned check, unsigned *derived) {
+    *derived = 0;
+    if (a.n_wet == 0) {  // a 0 x 0 matrix: derived iff it is empty
+        for (int m = 1; m < 5; ++m)
+            if (((check >> m) & 1u) && a.given[m].nnz == 0) *derived |= 1u << m;
+        return OTMB_OK;
+    }
+    TmPlan tmp;
+    tmp.wet_base = pl.wet_base;
+    tmp.skip = 0;
+    TmParams p;
+    fill_params(p, a, ctx, &tmp);
+    // TκH / TκVdeep do not look at the fluxes: the six ϕ pointers name v3D (G readable Float64), so that this pass can run for callers
+    // whose ϕ arrays do not exist (otmb_step_dev) or are about to be overwritten
+    for (int f = 0; f < 6; ++f) p.phi[f] = a.v3d;
+    int *dflags = (int *)ctx->flags.p;
+    p.flags = dflags;
+    GivenCmp g;
+    memset(&g, 0, sizeof g);
+    g.check = check;
+    for (int m = 1; m < 5; ++m) {
+        g.cp[m] = (const i64 *)a.given[m].colptr; g.ri[m] = (const i64 *)a.given[m].rowval; g.vx[m] = (const i64 *)a.given[m].nzval;
+        g.nnz[m] = a.given[m].nnz;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));
+    const i64 ntiles = (a.n_wet + TM_THREADS - 1) / TM_THREADS;
+    hipLaunchKernelGGL(tm_given_kernel, dim3((unsigned)ntiles), dim3(TM_THREADS), 0, ctx->stream, p, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // (whatever the columns' arithmetic flagged is the real pass's to report)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *derived = check & ~(unsigned)ctx->h_flags[FLAG_GIVEN_MISMATCH];
+    ctx->given_checks += 1;
+    return OTMB_OK;
+}
+// Which operators does the caller pass, and how is each treated?  Sets pl.given / derived / foreign / skip and ctx->given_state.
+static int32_t classify_given(otmb_ctx *ctx, const otmb_tm_args &a, TmPlan &pl) {
+    pl.given = given_mask(a);
+    pl.derived = pl.foreign = 0;
+    for (int m = 0; m < 5; ++m) { ctx->given_state[m] = 0; pl.built_nnz[m] = 0; }
+    pl.skip = (a.only_t ? 0x1eu : 0u) | ((unsigned)a.skip_ops & 0x1fu);
+    pl.want_t = !(pl.skip & 1u);
+    if (a.given[OTMB_T].colptr) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "given[OTMB_T]: T is never passed in (src/matrixbuilding.jl:133-138)");
+    if (!pl.given) return OTMB_OK;
+    unsigned check = 0;
+    for (int m = 1; m < 5; ++m) {
+        if (!((pl.given >> m) & 1u)) continue;
+        const otmb_csc &g = a.given[m];
+        if (g.nnz < 0 || (g.nnz > 0 && (!g.rowval || !g.nzval))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "given operator: arrays / nnz");
+        if (m == OTMB_TKH || m == OTMB_TKVDEEP) {  // functions of the grid and κ alone: worth a verdict that is kept
+            if (verdict_matches(ctx->given_verdict[m], ctx, a, pl, m)) {
+                if (ctx->given_verdict[m].derived) pl.derived |= 1u << m;
+            } else {
+                check |= 1u << m;
+            }
+        }
+    }
+    if (check) {
+        unsigned d = 0;
+        int32_t rc;
+        if ((rc = verify_given(ctx, a, pl, check, &d))) return rc;
+        for (int m = 1; m < 5; ++m)
+            if ((check >> m) & 1u) verdict_store(ctx, a, pl, m, (d >> m) & 1u);
+        pl.derived |= d;
+    }
+    pl.foreign = pl.given & ~pl.derived;
+    if (pl.foreign && pl.want_t && (pl.skip & 0x1eu & ~pl.given))
+        return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "only_t / skip_ops with a foreign given operator: T is then a sum of materialised matrices");
+    // nothing given is built; with a foreign operand T is not the kernel's business either (it is the device sparse add of the four)
+    pl.skip |= pl.given | (pl.foreign ? 1u : 0u);
+    for (int m = 1; m < 5; ++m)
+        if ((pl.given >> m) & 1u) ctx->given_state[m] = ((pl.derived >> m) & 1u) ? 1 : 2;
+    return OTMB_OK;
 }
 
 // ignore: otmb_tm_args.ignore_ops -- errors that only an operator the caller already has would have raised
@@ -740,7 +945,8 @@ static int32_t validate_args(otmb_ctx *ctx, const otmb_tm_args *a, bool top_only
     if (!a->v3d || !a->thkcello || !a->lwet3d || !a->area2d || !a->zt || !a->mlotst)
         return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null input array");
     if (a->n_wet < 0 || a->n_wet > G || (a->n_wet > 0 && !a->lwet)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "lwet / n_wet");
-    if (!a->rho && a->rho_scalar != a->rho_scalar && a->n_wet > 0 && !((a->ignore_ops >> OTMB_TADV) & 1)) return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // :233
+    if (!a->rho && a->rho_scalar != a->rho_scalar && a->n_wet > 0 && !((a->ignore_ops >> OTMB_TADV) & 1) && !a->given[OTMB_TADV].colptr)
+        return otmb_fail(ctx, OTMB_ERR_RHO_NAN);  // :233 (buildTadv's check: not reached when Tadv is passed in, :140)
     return OTMB_OK;
 }
 
@@ -825,6 +1031,43 @@ static int32_t fold_pending(otmb_ctx *ctx) {
     return ret;
 }
 
+// The foreign path of otmb_tm_args.given: T = ((Tadv + TκH) + TκVML) + TκVdeep (:147) from four materialised operands -- the ones the fill
+// pass has just written into the caller's arrays and the GIVEN ones where they lie -- by SparseArrays' `+` on the device (otmb_spadd.hip:
+// per column a sorted merge, a missing operand is +0.0, exact-zero results are dropped), left to right, through two temporaries.
+static int32_t foreign_sum(otmb_ctx *ctx, TmPlan &pl, const TmParams &p) {
+    const otmb_tm_args &a = pl.args;
+    const i64 n = a.n_wet;
+    if (pl.wet_base != 0 || pl.nnz_base[0] != 0) return otmb_fail(ctx, OTMB_ERR_GIVEN_FOREIGN, "depth slab");
+    otmb_csc op[5];
+    for (int m = 1; m < 5; ++m) {
+        if ((pl.given >> m) & 1u) op[m] = a.given[m];
+        else { op[m].colptr = p.colptr[m]; op[m].rowval = p.rowval[m]; op[m].nzval = p.nzval[m]; op[m].nnz = pl.built_nnz[m]; }
+    }
+    int32_t rc;
+    otmb_csc acc = op[1];
+    for (int step = 2; step < 5; ++step) {
+        int64_t k = 0;
+        if ((rc = otmb_spadd_plan_dev(ctx, n, acc.colptr, acc.rowval, acc.nzval, op[step].colptr, op[step].rowval, op[step].nzval, &k))) return rc;
+        i64 *Cp, *Ci;
+        double *Cx;
+        if (step == 4) {  // the last add lands in the caller's T arrays (planned at the sum of the operands' counts: k cannot exceed it)
+            if (k > pl.nnz[0]) return otmb_fail(ctx, OTMB_ERR_CAPACITY, "T");
+            Cp = p.colptr[0]; Ci = p.rowval[0]; Cx = p.nzval[0];
+        } else {
+            DevBuf *t = &ctx->given_tmp[(step - 2) * 3];
+            if ((rc = otmb_reserve(ctx, t[0], (size_t)(n + 1) * 8)) || (rc = otmb_reserve(ctx, t[1], (size_t)(k > 0 ? k : 1) * 8)) ||
+                (rc = otmb_reserve(ctx, t[2], (size_t)(k > 0 ? k : 1) * 8)))
+                return rc;
+            Cp = (i64 *)t[0].p; Ci = (i64 *)t[1].p; Cx = (double *)t[2].p;
+        }
+        if ((rc = otmb_spadd_fill_dev(ctx, n, acc.colptr, acc.rowval, acc.nzval, op[step].colptr, op[step].rowval, op[step].nzval, Cp, Ci, Cx))) return rc;
+        acc.colptr = Cp; acc.rowval = Ci; acc.nzval = Cx; acc.nnz = k;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pl.nnz[0] = acc.nnz;
+    return OTMB_OK;
+}
+
 void otmb_tm_plan_free(otmb_ctx *ctx) {
     delete ctx->plan;
     ctx->plan = nullptr;
@@ -835,7 +1078,12 @@ void otmb_tm_plan_invalidate(otmb_ctx *ctx) {
     if (ctx->plan) ctx->plan->valid = false;
 }
 
-bool otmb_tm_plan_only_t(otmb_ctx *ctx) { return ctx->plan && ctx->plan->args.only_t != 0; }
+// matrices (bit m) the pending plan does not hand out: neither counted nor written -- T alone, given operators
+unsigned otmb_tm_plan_skip(otmb_ctx *ctx) {
+    if (!ctx->plan) return 0u;
+    const TmPlan &pl = *ctx->plan;
+    return (pl.foreign && pl.want_t) ? (pl.skip & ~1u) : pl.skip;  // (a foreign build's T is written by the sparse adds)
+}
 
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N) {
     if (!ctx->plan || !ctx->plan->valid) return otmb_fail(ctx, OTMB_ERR_NO_PLAN);
@@ -859,6 +1107,7 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
     TmPlan &pl = *ctx->plan;
     pl.args = *a;
     pl.ntiles = ntiles;
+    if ((rc = classify_given(ctx, *a, pl))) return rc;  // (may run the comparing pass: before anything of this plan is on the stream)
     TmParams p;
     fill_params(p, *a, ctx, &pl);
     int *dflags = (int *)ctx->flags.p;
@@ -894,8 +1143,15 @@ int32_t otmb_transportmatrix_plan_dev(otmb_ctx *ctx, const otmb_tm_args *a, int6
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_TM_STATE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if ((rc = check_flags(ctx, nullptr, a->ignore_ops))) return rc;
-    for (int m = 0; m < 5; ++m) nnz[m] = pl.nnz[m] = ctx->h_tot[m];
+    if ((rc = check_flags(ctx, nullptr, a->ignore_ops | (int)pl.given))) return rc;
+    for (int m = 0; m < 5; ++m) nnz[m] = pl.nnz[m] = pl.built_nnz[m] = ctx->h_tot[m];  // (0 for what is not materialised)
+    if (pl.foreign && pl.want_t) {
+        // T = ((Tadv + TκH) + TκVML) + TκVdeep by the device sparse add (:147): its pattern is the union of the four operands', at most the
+        // sum of their counts -- what the caller's T arrays must hold until otmb_transportmatrix_nnz gives the final count
+        i64 bound = 0;
+        for (int m = 1; m < 5; ++m) bound += ((pl.given >> m) & 1u) ? a->given[m].nnz : pl.built_nnz[m];
+        nnz[0] = pl.nnz[0] = bound;
+    }
     pl.valid = true;
     return OTMB_OK;
 }
@@ -926,7 +1182,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     fill_params(p, pl.args, ctx, &pl);
     p.rho_in_fill = pl.rho_in_fill ? 1 : 0;
     for (int m = 0; m < 5; ++m) {
-        const bool wanted = (m == 0) || !pl.args.only_t;
+        const bool wanted = !((pl.skip >> m) & 1u) || (m == 0 && pl.foreign && pl.want_t);  // (T of a foreign build: written by the sparse adds below)
         if (wanted && (!colptr[m] || (pl.nnz[m] > 0 && (!rowval[m] || !nzval[m])))) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         p.colptr[m] = wanted ? (i64 *)colptr[m] : nullptr; p.rowval[m] = wanted ? (i64 *)rowval[m] : nullptr;
         p.nzval[m] = wanted ? nzval[m] : nullptr;
@@ -951,7 +1207,9 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     // a plan is consumed by its fill: T's final count may be smaller than the reserved (union) one, so a second fill into
     // buffers sized from otmb_transportmatrix_nnz would overflow them -- plan again instead
     pl.valid = false;
-    if ((rc = check_flags(ctx, nullptr, pl.args.ignore_ops))) return rc;
+    if ((rc = check_flags(ctx, nullptr, pl.args.ignore_ops | (int)pl.given))) return rc;
+    if (pl.foreign && pl.want_t) return foreign_sum(ctx, pl, p);
+    if (pl.skip & 1u) return OTMB_OK;  // (no T: nothing to compact)
     if (ctx->h_flags[FLAG_T_CANCEL]) {
         i64 actual = pl.nnz[0];
         if ((rc = t_fixup(ctx, pl.args.n_wet, pl.nnz_base[0], pl.nnz[0], p.colptr[0], p.rowval[0], p.nzval[0], &actual))) return rc;
@@ -1037,11 +1295,15 @@ static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, in
     pl.valid = false;
     pl.args = *a;
     pl.ntiles = ntiles;
+    // operators the caller passes (otmb_tm_args.given): a derived one is re-derived in registers (the FIRST call for a grid and κ runs the
+    // comparing pass and waits for its verdict: one stream synchronisation, like the tile order); a foreign one needs the two-phase protocol
+    if ((rc = classify_given(ctx, *a, pl))) return rc;
+    if (pl.foreign && pl.want_t) return otmb_fail(ctx, OTMB_ERR_GIVEN_FOREIGN);
     TmParams p;
     fill_params(p, *a, ctx, &pl);
     p.umo = fu.umo; p.vmo = fu.vmo; p.fillv = fu.fill; p.fused = fu.kind;
     for (int m = 0; m < 5; ++m) {
-        const bool wanted = (m == 0) || !a->only_t;
+        const bool wanted = !((pl.skip >> m) & 1u);
         if (wanted && (!colptr[m] || !rowval[m] || !nzval[m])) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "null output");
         if (wanted && capacity[m] <= 0) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "capacity");
         p.colptr[m] = wanted ? (i64 *)colptr[m] : nullptr; p.rowval[m] = wanted ? (i64 *)rowval[m] : nullptr;
@@ -1119,7 +1381,7 @@ static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, in
     }
     HIP_TRY(ctx, hipGetLastError());
     if (p.next_state) ctx->ring_clean |= 1ull << slot_after;
-    ctx->tm_rec.push_back({p.colptr[0], p.rowval[0], p.nzval[0], (i64)a->n_wet, p.nnz_base[0], (int)a->ignore_ops});
+    ctx->tm_rec.push_back({p.colptr[0], p.rowval[0], p.nzval[0], (i64)a->n_wet, p.nnz_base[0], (int)a->ignore_ops | (int)pl.given});
     ctx->tm_next += 1;
     pl.onepass_pending = true;
     return OTMB_OK;

@@ -156,9 +156,36 @@ class DeviceAssembler:
         self.upwind = bool(upwind)
         self.makeindices()
 
+    # ---- operators the caller passes (transportmatrix's Tadv = / TκH = / TκVML = / TκVdeep = keywords, src/matrixbuilding.jl:133-143) ----
+    def set_given(self, **ops):
+        """ops: name -> (colptr, rowval, nzval) device tensors (int64, int64, float64; rowval / nzval exactly nnz long) or None.  A passed
+        operator is not built (otmb_tm_args.given): a TκH / TκVdeep that is bit for bit what the library derives for this grid and κ is
+        re-derived in registers by the fill pass -- neither read, written nor counted; any other matrix makes T a device sparse add (two-phase
+        protocol only: transportmatrix(); the asynchronous calls raise GIVEN_FOREIGN)."""
+        given = dict(getattr(self, "given", {}) or {})
+        for name, triple in ops.items():
+            if name not in MATS[1:]:
+                raise ValueError(f"{name}: not an operator of transportmatrix")
+            if triple is None:
+                given.pop(name, None)
+                continue
+            cp, rv, nz = (t.contiguous() for t in triple)
+            if cp.dtype != torch.int64 or rv.dtype != torch.int64 or nz.dtype != torch.float64 or cp.numel() != self.N + 1 or rv.numel() != nz.numel():
+                raise ValueError(f"{name}: (colptr int64 [N + 1], rowval int64 [nnz], nzval float64 [nnz]) device tensors are required")
+            given[name] = (cp, rv, nz)
+        self.given = given
+        self._given_key = None
+
+    def _given_versions(self):
+        ts = [self.lwet3d, self.lwet, self.v3d, self.thk, self.area, self.zt, *self.edge, *self.dist]
+        for name in MATS[1:]:
+            ts += list(self.given.get(name, ()))
+        return tuple((t.data_ptr(), t._version) for t in ts) + tuple(self.kappa)
+
     def makeindices(self):
         """otmb_makeindices_dev on the resident v3D (src/matrixbuilding.jl:10-24)."""
-        self._mask_key = None  # (fluxes of an earlier facefluxes call no longer come with counts / a mask for THESE indices)
+        self._mask_key = None
+        self.given, self._given_key = {}, None  # (operators of another grid)  # (fluxes of an earlier facefluxes call no longer come with counts / a mask for THESE indices)
         self.lwet3d = self._empty(self.G, torch.int64)
         self.lwet = self._empty(self.G, torch.int64)
         self.wet3d = torch.empty(self.G, dtype=torch.uint8, device=self.device)
@@ -296,9 +323,7 @@ class DeviceAssembler:
             self._count_tables()
         self._mask_key = None
         a = self._args([self.phi_top] * 6)
-        cp = capi.ptr_array(5, [out[m][0].data_ptr() for m in MATS])
-        rv = capi.ptr_array(5, [out[m][1].data_ptr() for m in MATS])
-        nz = capi.ptr_array(5, [out[m][2].data_ptr() for m in MATS])
+        cp, rv, nz = self._out_ptrs(out)
         caps = (C.c_int64 * 5)(*[self.N * k + 1 for k in self.PER_COLUMN_MAX])
         self._note("_ff_seq")
         self.ctx.check(self.lib.otmb_step_dev(self.ctx.handle, umo.data_ptr(), vmo.data_ptr(), int(umo.dtype == torch.float32), float(fill),
@@ -349,7 +374,21 @@ class DeviceAssembler:
         fresh = getattr(self, "_mask_key", None) is not None and self._mask_key == self._phi_key(phi)
         a.push_mask = self.push_mask.data_ptr() if fresh else None
         a.only_t = 1 if getattr(self, "only_T", False) else 0  # extension: materialise T alone (outputs of the operators unused)
+        if getattr(self, "given", None):
+            for m, name in enumerate(MATS):
+                if name in self.given:
+                    cp, rv, nz = self.given[name]
+                    a.given[m].colptr, a.given[m].rowval, a.given[m].nzval, a.given[m].nnz = cp.data_ptr(), rv.data_ptr(), nz.data_ptr(), rv.numel()
+            key = self._given_versions()  # the library keys its verdicts to addresses: any in-place edit (torch bumps _version) makes it look again
+            if key != self._given_key:
+                self.ctx.forget_given()
+                self._given_key = key
         return a
+
+    def _out_ptrs(self, out):
+        """The three pointer arrays of an output set; NULL for an operator the caller passes (nothing of it is written)."""
+        skip = set(getattr(self, "given", None) or ())
+        return tuple(capi.ptr_array(5, [None if m in skip else out[m][q].data_ptr() for m in MATS]) for q in range(3))
 
     def plan(self, phi):
         a = self._args(phi)
@@ -366,9 +405,7 @@ class DeviceAssembler:
                             torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.int64, device=self.device),
                             torch.empty(max(self.nnz[k], 1) + self.nnz[k] // 64, dtype=torch.float64, device=self.device))
                         for k, m in enumerate(MATS)}
-        cp = capi.ptr_array(5, [self.out[m][0].data_ptr() for m in MATS])
-        rv = capi.ptr_array(5, [self.out[m][1].data_ptr() for m in MATS])
-        nz = capi.ptr_array(5, [self.out[m][2].data_ptr() for m in MATS])
+        cp, rv, nz = self._out_ptrs(self.out)
         self.ctx.check(self.lib.otmb_transportmatrix_fill_dev(self.ctx.handle, C.byref(cp), C.byref(rv), C.byref(nz)))
         final = (C.c_int64 * 5)()
         self.ctx.check(self.lib.otmb_transportmatrix_nnz(self.ctx.handle, C.byref(final)))
@@ -463,9 +500,7 @@ class DeviceAssembler:
         if out is None:
             out = self.out
         a = self._args(phi)
-        cp = capi.ptr_array(5, [out[m][0].data_ptr() for m in MATS])
-        rv = capi.ptr_array(5, [out[m][1].data_ptr() for m in MATS])
-        nz = capi.ptr_array(5, [out[m][2].data_ptr() for m in MATS])
+        cp, rv, nz = self._out_ptrs(out)
         caps = (C.c_int64 * 5)(*[self.N * k + 1 for k in self.PER_COLUMN_MAX])
         self.ctx.check(self.lib.otmb_transportmatrix_dev(self.ctx.handle, C.byref(a), C.byref(cp), C.byref(rv),
                                                          C.byref(nz), C.byref(caps)))
@@ -585,15 +620,16 @@ class DeviceAssembler:
     def algorithmic_bytes(self):
         """bytes the assembly must move with all five matrices returned
         (inputs read once, outputs written once; intermediate traffic is overhead and not counted)."""
-        n3d = 9 + (1 if self.rho is not None else 0)
-        b = 8 * self.G * n3d + 80 * self.nx * self.ny + 8 * self.nz
-        b += sum(16 * z + 8 * (self.N + 1) for z in self.nnz)
-        return b
+        r, w = self.algorithmic_bytes_split()
+        return r + w
 
     def algorithmic_bytes_split(self):
-        """(bytes read, bytes written) of algorithmic_bytes()."""
+        """(bytes read, bytes written) of algorithmic_bytes().  An operator the caller passes and the fill pass re-derives (set_given) is
+        neither read nor written: its 16 nnz + 8 (N + 1) bytes are not part of the pass."""
         n3d = 9 + (1 if self.rho is not None else 0)
-        return 8 * self.G * n3d + 80 * self.nx * self.ny + 8 * self.nz, sum(16 * z + 8 * (self.N + 1) for z in self.nnz)
+        skip = set(getattr(self, "given", None) or ())
+        return (8 * self.G * n3d + 80 * self.nx * self.ny + 8 * self.nz,
+                sum(16 * z + 8 * (self.N + 1) for m, z in zip(MATS, self.nnz) if m not in skip))
 
     def fill_pass_stream_mix(self):
         """What an ideal streaming kernel reaches over the fill pass's OWN arrays (otmb_ctx_stream_mix): its ten 3-D inputs (+ the 2-D

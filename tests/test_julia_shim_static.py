@@ -37,15 +37,22 @@ def julia_kind(t):
     t = t.strip()
     m = re.fullmatch(r"NTuple\{(\d+),\s*(.+)\}", t)
     if m:
-        return [julia_kind(m.group(2))[0]] * int(m.group(1))
+        return julia_kind(m.group(2)) * int(m.group(1))
+    if t == "Csc":  # mirror of otmb_csc: its own fields, checked by test_csc_struct_matches_header_and_ctypes_mirror
+        return CSC_KINDS
     if t.startswith("Ptr{") or t in ("Cstring",):
         return ["ptr"]
     return [{"Int32": "i32", "Int64": "i64", "Float64": "f64", "Cvoid": "void", "UInt8": "u8"}[t]]
 
 
+CSC_KINDS = ["ptr", "ptr", "ptr", "i64"]  # otmb_csc: colptr, rowval, nzval, nnz
+
+
 def ctypes_kind(t):
     if t is None:
         return ["void"]
+    if isinstance(t, type) and issubclass(t, C.Structure):
+        return [k for _, ft in t._fields_ for k in ctypes_kind(ft)]
     if isinstance(t, type) and issubclass(t, C.Array):
         return ctypes_kind(t._type_) * t._length_
     if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
@@ -101,11 +108,22 @@ def test_tmargs_struct_matches_header_and_ctypes_mirror():
         base, names = m.group(1), m.group(2)
         for n in names.split(","):
             mm = re.fullmatch(r"\s*(\*?)\s*(\w+)(?:\[(\d+)\])?\s*", n)
-            kind = "ptr" if mm.group(1) else c_kind(base)
-            hfields.append((mm.group(2), [kind] * int(mm.group(3) or 1)))
+            kinds = ["ptr"] if mm.group(1) else CSC_KINDS if base == "otmb_csc" else [c_kind(base)]
+            hfields.append((mm.group(2), kinds * int(mm.group(3) or 1)))
     assert [n for n, _ in hfields] == [n for n, _ in fields]
     for (name, hk), (_, jt) in zip(hfields, fields):
         assert hk == julia_kind(jt), name
+
+
+def test_csc_struct_matches_header_and_ctypes_mirror():
+    from otmb_amd import capi
+
+    body = re.search(r"struct Csc\n(.*?)\nend", SHIM, re.S).group(1)
+    fields = [tuple(x.strip() for x in decl.split("::")) for line in body.splitlines() for decl in line.split("#")[0].split(";") if decl.strip()]
+    assert [n for n, _ in fields] == [n for n, _ in capi.Csc._fields_] == ["colptr", "rowval", "nzval", "nnz"]
+    assert [k for _, t in fields for k in julia_kind(t)] == CSC_KINDS == ctypes_kind(capi.Csc)
+    h = re.search(r"typedef struct \{([^}]*)\} otmb_csc;", HEADER).group(1)
+    assert re.findall(r"(\*?)\s*(\w+);", h) == [("*", "colptr"), ("*", "rowval"), ("*", "nzval"), ("", "nnz")]
 
 
 def test_every_ccall_matches_its_c_prototype():
@@ -251,22 +269,43 @@ def test_both_host_layers_make_the_same_c_calls_in_the_same_order():
     jl_d, py_d = _julia_function("default_slabs"), _python_function(api_src, "default_slabs")
     for src in (jl_d, py_d):
         assert "OTMB_HOST_SLABS" in src and '"4"' in src and "(1 << 18) <= N < (1 << 25)" in src and "2 * s" in src and "reuse_fluxes" in src
-    # ... and the same measured choice between the two protocols: pipelined for calls 1-3 (the third timed), two-phase for 4-5 (the fifth timed)
+    # ... and the same measured choice between the two protocols: pipelined for calls 1-4 (3 and 4 timed), two-phase for 5-7 (6 and 7 timed), the
+    # loser measured again every 64th call, three slow calls in a row start the trial over
     jl_p = _julia_function("pipelined!")
     py_p = api_src[api_src.index("    def pipelined(self):"):api_src.index("    def record(self, seconds):")]
-    assert "tr.n <= 3 ? true : tr.n <= 5 ? false" in jl_p and "self.n <= 3" in py_p and "self.n <= 5" in py_p
-    assert "tr.n == 3 && (tr.t1 = s); tr.n == 5 && (tr.t2 = s)" in SHIM and "if self.n in (3, 5):" in api_src
+    assert "tr.n <= 4 ? true : tr.n <= 7 ? false" in jl_p and "self.n <= 4" in py_p and "self.n <= 7" in py_p
+    assert "tr.n % REMEASURE_EVERY == 0" in jl_p and "self.n % self.REMEASURE_EVERY == 0" in py_p
+    jl_r = _julia_function("record!")
+    assert "tr.n in (3, 4, 6, 7)" in jl_r and "if self.n in (3, 4, 6, 7):" in api_src
+    assert "s > 1.3 * mine()" in jl_r and "tr.slow >= 3" in jl_r and "SLOW_FACTOR, SLOW_STREAK = 64, 1.3, 3" in api_src
+    assert "const REMEASURE_EVERY = 64" in SHIM
+    # ... one trial per kind of call, and the reuse_grid promise is not forwarded to an engine that did not serve the previous call
+    assert "(Int(dev), Int(indices.N), operators, !(ρ isa Number), reuse_grid," in _julia_function("transportmatrix")
+    assert "(int(device), int(N), bool(operators), bool(rho3d), bool(reuse_grid), g)" in api_src
+    for fn, pyfn in (("fused", "_transportmatrix_fused"), ("fused_mgpu", "_transportmatrix_mgpu"), ("fused_onepass", "_transportmatrix_onepass")):
+        assert "reuse_grid = reuse_grid_for(" in _julia_function(fn) and "reuse_grid = _reuse_grid_for(" in _python_function(api_src, pyfn), fn
     jl_tm0 = _julia_function("transportmatrix")
     assert "pipelined!(tr) ?" in jl_tm0 and "trial.pipelined()" in _python_function(api_src, "transportmatrix")
     assert "slabs = nothing" in SHIM and "fused_onepass(" in jl_tm0 and "_transportmatrix_onepass(" in _python_function(api_src, "transportmatrix")
     assert "otmb_mgpu_facefluxes" in _julia_function("facefluxes") and "otmb_mgpu_facefluxes" in _python_function(api_src, "_facefluxes_mgpu")
-    # ---- precomputed operators: stand-ins + ignore_ops, ONE fused build, three adds with the library's `+`, left to right
+    # ---- operators the caller passes (src/matrixbuilding.jl:133-147): stand-ins for what only they would read, otmb_tm_args.given through the
+    # SAME builds as the default call, the objects passed come back, and a GIVEN_FOREIGN refusal falls back to the two-phase call, remembered
     jl_tm = _julia_function("transportmatrix")
-    py_given = _python_function(api_src, "_transportmatrix_with_given")
-    for src, fused_name in ((jl_tm, "fused("), (py_given, "_transportmatrix_fused(")):
-        assert src.count(fused_name) >= 1 and "spadd(spadd(spadd(" in src.replace(" ", ""), fused_name
-        assert "ignore" in src and "1035.0" in src
-    assert "1 << m" in py_given and "Int32(1) << m" in jl_tm
+    py_tm = _python_function(api_src, "transportmatrix")
+    for src in (jl_tm, py_tm):
+        assert "1035.0" in src and "NaN" in src.replace("np.nan", "NaN")
+    assert "e isa GivenForeign" in jl_tm and "e.status != capi.GIVEN_FOREIGN" in py_tm
+    assert "push!(FOREIGN_SEEN, fkey)" in jl_tm and "_foreign_seen.add(fkey)" in py_tm
+    assert "rc == 17 && throw(GivenForeign())" in SHIM and "GIVEN_FOREIGN = 17" in open(os.path.join(ROOT, "oceantransportmatrixbuilder.jl_amd", "capi.py"), encoding="utf-8").read()
+    assert "OTMB_ERR_GIVEN_FOREIGN = 17" in HEADER
+    assert "Csc(pointer(gv[m].colptr), pointer(gv[m].rowval), pointer(gv[m].nzval), length(gv[m].rowval))" in _julia_function("tmargs")
+    assert "given[m] !== nothing) ? given[m]" in _julia_function("wrap") and "out[name] = given[name]" in _python_function(api_src, "_result")
+    # ---- buildTadv / buildTκH / buildTκVML / buildTκVdeep (:31-120): the fused build with every other matrix switched off (skip_ops, ignore_ops)
+    jl_b, py_b = _julia_function("build_operator"), _python_function(api_src, "_build_operator")
+    assert "0x1e & ~(1 << (m - 1))" in jl_b and "0x1f & ~(1 << (m - 1))" in jl_b and "0x1e & ~(1 << m)" in py_b and "0x1f & ~(1 << m)" in py_b
+    assert "fused(" in jl_b and "_transportmatrix_fused(" in py_b
+    for name in ("buildTadv", "buildTκH", "buildTκVML", "buildTκVdeep"):
+        assert re.search(r"^" + name + r"\(;", SHIM, re.M) and re.search(r"^def " + name + r"\(", api_src, re.M), name
     jl_spadd = _julia_function("spadd")
     assert re.findall(r"sym\(:(otmb_\w+)\)", jl_spadd) == ["otmb_spadd"]
     assert re.findall(r"\b(otmb_\w+)\(", _python_function(api_src, "spadd")) == ["otmb_spadd"]

@@ -689,29 +689,79 @@ def test_index_arrays_cross_the_link_as_int32_and_come_back_the_same(oracle, mon
 
 
 def test_the_default_protocol_is_chosen_by_measurement():
-    """api.Trial (no GPU): calls 1-3 pipelined (the third timed), 4-5 two-phase (the fifth timed), then the faster one; a trial whose timed
-    call raised stays with the pipelined build."""
+    """api.Trial (no GPU): calls 1-4 pipelined (3 and 4 timed), 5-7 two-phase (6 and 7 timed), then the faster one by the minimum of its
+    two samples; a trial whose timed calls raised stays with the pipelined build; every 64th call re-measures the loser; a protocol that
+    turns slow three calls in a row starts the trial over; one trial per kind of call."""
     import otmb_amd.api as api
 
     for t_pipe, t_two, want in ((0.020, 0.025, True), (0.028, 0.024, False)):
         tr, seq = api.Trial(), []
-        for call in range(9):
+        for call in range(12):
             p = tr.pipelined()
             seq.append(p)
             tr.record(t_pipe if p else t_two)
-        assert seq[:5] == [True, True, True, False, False] and seq[5:] == [want] * 4, seq
+        assert seq[:7] == [True] * 4 + [False] * 3 and seq[7:] == [want] * 5, seq
     tr = api.Trial()
-    for call in range(8):
+    for call in range(10):
         p = tr.pipelined()
-        if call != 4:  # the timed two-phase call raised: nothing recorded
+        if call not in (5, 6):  # the timed two-phase calls raised: nothing recorded
             tr.record(0.02)
     assert tr.pipelined() is True
-    assert api.Trial.of(3, 12345) is api.Trial.of(3, 12345) and api.Trial.of(3, 12345) is not api.Trial.of(3, 12346)
+    # an outlier in one of the two samples does not decide: the minimum does
+    tr = api.Trial()
+    for call, t in enumerate((0.1, 0.03, 0.020, 0.031, 0.05, 0.025, 0.026)):
+        tr.pipelined()
+        tr.record(t)
+    assert tr.t == {True: 0.020, False: 0.025} and tr.pipelined() is True
+    # the verdict is revisited: call 64 runs the loser and refreshes its time -- which can change the choice
+    tr = api.Trial()
+    seq = []
+    for call in range(1, 70):
+        p = tr.pipelined()
+        seq.append(p)
+        tr.record((0.020 if p else 0.025) if call < 64 else (0.030 if p else 0.018))
+    assert seq[7:63] == [True] * 56 and seq[63] is False and seq[64:] == [False] * 5, seq[60:]
+    # a host that got busy: three slow calls in a row start the trial over (both protocols timed again, no warm-up calls)
+    tr = api.Trial()
+    for call in range(10):
+        p = tr.pipelined()
+        tr.record(0.020 if p else 0.025)
+    for _ in range(3):
+        assert tr.pipelined() is True
+        tr.record(0.040)
+    assert not tr.decided()
+    seq = []
+    for call in range(6):
+        p = tr.pipelined()
+        seq.append(p)
+        tr.record(0.040 if p else 0.030)
+    assert seq == [True, True, False, False, False, False], seq
+    # one trial per kind of call
+    T = api.Trial
+    assert T.of(3, 12345) is T.of(3, 12345) and T.of(3, 12345) is not T.of(3, 12346)
+    assert T.of(3, 12345) is not T.of(3, 12345, operators=False) and T.of(3, 12345) is not T.of(3, 12345, rho3d=True)
+    assert T.of(3, 12345) is not T.of(3, 12345, reuse_grid=True) and T.of(3, 12345) is not T.of(3, 12345, given={"TκH": object()})
+    assert T.peek(3, 999) is None and T.peek(3, 12345) is T.of(3, 12345)
+
+
+def test_reuse_grid_is_not_forwarded_to_an_engine_that_did_not_serve_the_previous_call():
+    """reuse_grid is the caller's promise about THE PREVIOUS CALL; an engine (single context / otmb_mgpu) checks it against its
+    OWN previous call, so after a change of engine the promise stays behind (no GPU: the bookkeeping only)."""
+    import otmb_amd.api as api
+
+    api._last_engine.pop(7, None)
+    assert api._reuse_grid_for(7, (7, 7, 7, 7), True) is False   # first call on the device: nothing can be resident
+    assert api._reuse_grid_for(7, (7, 7, 7, 7), True) is True
+    assert api._reuse_grid_for(7, "ctx", True) is False          # the Trial switched engines: the context's keys are from long ago
+    assert api._reuse_grid_for(7, "ctx", True) is True
+    assert api._reuse_grid_for(7, "ctx", False) is False
+    assert api._reuse_grid_for(7, (7, 7, 7, 7), True) is False   # ... and back
+    assert api._reuse_grid_for(7, (7, 7), True) is False         # another cut is another engine
 
 
 @pytest.mark.gpu
 def test_default_calls_at_the_headline_grid_switch_protocols_and_stay_right(monkeypatch):
-    """Eight default calls on the 1 degree grid go through both protocols (api.Trial); every one returns the two-phase call's matrices."""
+    """Ten default calls on the 1 degree grid go through both protocols (api.Trial); every one returns the two-phase call's matrices."""
     import otmb_amd.api as api
     from otmb_amd import synthetic
 
@@ -722,13 +772,13 @@ def test_default_calls_at_the_headline_grid_switch_protocols_and_stay_right(monk
     phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
     kw = dict(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML, κVdeep=g.kappaVdeep)
     ref = api.transportmatrix(slabs=0, **kw)
-    api.Trial._all.pop((0, int(idx["N"])), None)
+    api.Trial._all.pop(api.Trial.key(0, int(idx["N"]), rho3d=True), None)
     used = []
-    for call in range(8):
+    for call in range(10):
         tm = api.transportmatrix(**kw)
-        used.append(api.Trial.of(0, int(idx["N"])).now)
+        used.append(api.Trial.of(0, int(idx["N"]), rho3d=True).now)
         for m in MATS:
             for a, b, what in zip(tuple(tm[m]), tuple(ref[m]), ("colptr", "rowval", "nzval")):
                 assert np.array_equal(a, b), (m, what, call)
         del tm
-    assert used[:5] == [True, True, True, False, False] and used[5] == used[6] == used[7], used
+    assert used[:7] == [True] * 4 + [False] * 3 and used[7] == used[8] == used[9], used
