@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--rho", default="array", choices=["array", "scalar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--end-to-end-large", action="store_true",
+                    help="workloads generated on the device (quarterdeg): copy the grid down once and run the host-pointer end_to_end legs on it "
+                         "(what a Julia caller waits for at BASELINE.json configs[2]; ~60 GB of host memory)")
     ap.add_argument("--seed", type=int, default=20260501)
     ap.add_argument("--extra-configs", default="quarterdeg,tenthdeg",
                     help="after the headline workload (N = 1 only): BASELINE.json configs[2] (0.25 degree, the HBM-roofline run) and configs[4]'s "
@@ -109,6 +112,124 @@ def spawn_ranks(args):
     return max(abs(rc) for rc in rcs) or (0 if line else 1)
 
 
+class Watchdog:
+    """A multi-rank run must END -- with a verdict -- whatever a collective does on first contact with a node: while armed, a phase that
+    takes longer than its limit prints which rank was in which phase and ends THIS process with a non-zero status (os._exit: a thread
+    stuck inside a collective cannot be unwound), which the launcher (torchrun, or bench.py's own spawn_ranks) turns into the end of
+    the whole job.  OTMB_BENCH_PREFLIGHT_S (default 120) bounds the bring-up phases, OTMB_BENCH_WATCHDOG_S (default 1500) the rest."""
+
+    def __init__(self, rank):
+        import threading
+
+        self.rank, self.lock, self.timer, self.threading = rank, threading.Lock(), None, threading
+        self.absent = None  # callable -> the ranks that have not reported in yet (first_contact sets it once a store exists)
+
+    def arm(self, phase, seconds):
+        self.disarm()
+
+        def expire():
+            who = ""
+            try:
+                if self.absent is not None:
+                    who = f"; ranks that never reached this phase: {self.absent()}"
+            except Exception:
+                pass
+            print(f"bench.py: rank {self.rank} did not finish '{phase}' within {seconds:.0f} s{who} -- giving up (exit 3)", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        with self.lock:
+            self.timer = self.threading.Timer(seconds, expire)
+            self.timer.daemon = True
+            self.timer.start()
+
+    def disarm(self):
+        with self.lock:
+            if self.timer is not None:
+                self.timer.cancel()
+                self.timer = None
+
+
+def first_contact(dist, torch, world, rank, dev, backend, plane_elems, rehearsal, dog):
+    """Evidence a multi-rank line must carry about ITS OWN communicator: how many ranks answered an all_reduce, which
+    library / version carried it, and what the one exchange of the path costs here -- a (nx, ny) plane of ϕtop from rank r to rank r - 1
+    (the facefluxes chain, src/velocities.jl:236-243 across depth slabs), whole and in the row bands it is handed over in.  Every phase
+    runs under the watchdog.  Returns the record (every rank computes it; rank 0 prints it)."""
+    limit = float(os.environ.get("OTMB_BENCH_PREFLIGHT_S", "120"))
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    rec = {"backend": backend, "world": world}
+    # every rank signs in through the rendezvous store first, so that a watchdog that fires can NAME the ranks that never arrived
+    if os.environ.get("OTMB_BENCH_TEST_STALL_RANK") == str(rank):  # fault injection (tests/test_bench_cpu.py): this rank never joins
+        time.sleep(10 ** 6)
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"otmb_bench_signed_in_{rank}", "1")
+        dog.absent = lambda: [r for r in range(world) if not store.check([f"otmb_bench_signed_in_{r}"])]
+    except Exception:
+        store = None
+    dog.arm("preflight: all_reduce of ones", limit)
+    ones = torch.ones(1, dtype=torch.float64, device=cdev)
+    dist.all_reduce(ones)
+    if cdev.type == "cuda":
+        torch.cuda.synchronize(cdev)
+    rec["ranks_seen"] = int(round(float(ones.item())))
+    try:
+        v = torch.cuda.nccl.version() if backend == "nccl" else None
+        rec["library"] = ("RCCL " + ".".join(str(x) for x in v)) if v else ("gloo (torch %s)" % torch.__version__)
+    except Exception as e:
+        rec["library"] = f"unknown ({type(e).__name__})"
+    rec["hip"] = getattr(torch.version, "hip", None)
+    for k in ("NCCL_DEBUG", "NCCL_P2P_DISABLE", "NCCL_SOCKET_IFNAME", "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        if k in os.environ:
+            rec.setdefault("env", {})[k] = os.environ[k]
+    # the chain's hand-off: rank r sends a plane to r - 1 (deepest slab first), timed between barriers; then the same in 4 row bands
+    from otmb_amd import dist as odist
+
+    comm = odist.Comm()
+    pieces = int(os.environ.get("OTMB_CHAIN_PIECES", "0")) or (4 if plane_elems >= (1 << 19) else 1)
+    if world > 1:
+        dog.arm("preflight: point-to-point plane hand-off", limit)
+        send = torch.full((plane_elems,), float(rank), dtype=torch.float64, device=dev)
+        recv = torch.empty(plane_elems, dtype=torch.float64, device=dev)
+
+        def hand_off(nparts):
+            step = (plane_elems + nparts - 1) // nparts
+            hs, hr = [], []
+            for q in range(nparts):
+                a, b = q * step, min(plane_elems, (q + 1) * step)
+                if rank + 1 < world:
+                    hr.append(comm.irecv(recv[a:b], rank + 1))
+                if rank > 0:
+                    hs.append(comm.isend(send[a:b], rank - 1))
+            for h in hr:
+                comm.wait_recv(h)
+            for h in hs:
+                comm.wait_send(h)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+
+        out = {}
+        for nparts in sorted({1, pieces}):
+            hand_off(nparts)  # (first use of every pair's channel: connection set-up is not what a step pays)
+            ts = []
+            for _ in range(5):
+                dist.barrier()
+                t0 = time.perf_counter()
+                hand_off(nparts)
+                ts.append(time.perf_counter() - t0)
+            t = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[str(nparts)] = 1e3 * float(t.item())
+        ok = bool(rank + 1 >= world or float(recv[0].item()) == float(rank + 1))
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        rec["plane_hand_off"] = {"bytes": 8 * plane_elems, "pieces": pieces, "ms_by_pieces": out, "payload_intact": bool(okt.item() == 1.0),
+                                 "ms_per_piece": out[str(pieces)] / pieces,
+                                 "what": "every rank r > 0 sends one (nx, ny) Float64 plane to rank r - 1 at once (non-blocking send / receive pairs, "
+                                         "as dist.SlabRunner posts them), median of 5 between barriers, max over ranks"}
+    dog.disarm()
+    return rec
+
+
 def cpu_baseline(g, gm, workload, reps=5):
     """The oracle (single-thread C restatement of the reference algorithm: push COO -> sparse() x4 ->
     3 sparse adds) timed on this box's host cores over the same workload: 1 warm-up + median of `reps`
@@ -170,12 +291,14 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def end_to_end(g, gm, asm_N, reps=5, warm=5):
+def end_to_end(g, gm, asm_N, reps=5, warm=8, large=False):
     """What a Julia caller of the host-pointer C ABI sees (PCIe included; never `value`): facefluxesfrommasstransport +
     transportmatrix through otmb_amd.api on host arrays, median of `reps` time slices after `warm` warm-up slices (the first two slices of
     a loop allocate: device buffers, the pinned rings of the slab contexts, the pinned result blocks -- 123 and 31 ms against 23.4 ms from the
-    third on, tools/onepass_loop.py; and the default call spends its first five slices measuring which protocol this host is faster
-    with, api.Trial)."""
+    third on, tools/onepass_loop.py; and the default call spends its first seven slices measuring which protocol this host is faster
+    with, api.Trial).
+    given_ops: the reference's own time-loop idiom (src/matrixbuilding.jl:133-147) -- TκH and TκVdeep, functions of the grid and κ alone, are
+    built ONCE (buildTκH / buildTκVdeep) and passed back to every transportmatrix call, which then builds, and copies home, Tadv, TκVML and T only."""
     import numpy as np
 
     import otmb_amd
@@ -186,23 +309,60 @@ def end_to_end(g, gm, asm_N, reps=5, warm=5):
     # default: what `transportmatrix(; ϕ, ...)` does with no extension keyword -- on a grid of this size the pipelined one-phase build on 4
     # depth slabs of the GPU (api.default_slabs; otmb_mgpu_transportmatrix_onepass); two_phase: slabs=0, the plan -> allocate -> fetch call of
     # rounds 1-4; reuse: both reuse promises (then always two-phase: nothing is left to upload beside the download)
-    for name, kw in (("default", {}), ("two_phase", {"slabs": 0}), ("reuse", {"reuse_grid": True, "reuse_fluxes": True})):
+    t0 = time.perf_counter()
+    H = api.buildTκH(gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH)
+    D = api.buildTκVdeep(mlotst=g.mlotst, gridmetrics=gm, indices=idx, κVdeep=g.kappaVdeep)
+    build_ms = 1e3 * (time.perf_counter() - t0)
+    given = {"TκH": H, "TκVdeep": D}
+    legs = (("default", {}), ("two_phase", {"slabs": 0}), ("reuse", {"reuse_grid": True, "reuse_fluxes": True}),
+            ("given", dict(given, reuse_grid=True)), ("given_no_promise", dict(given)), ("given_reuse", dict(given, reuse_grid=True, reuse_fluxes=True)))
+    if large:  # (the 0.25 degree grid: a time slice moves 25 GB -- the legs that answer the questions asked of it, fewer repetitions)
+        legs = (legs[0], legs[1], legs[3])
+    pinned = {}
+    for name, kw in legs:
         ts = []
-        for rep in range(reps + warm):
+        # (explicit protocols need two allocating slices, the measured default seven: api.Trial)
+        for rep in range(reps + (warm if "slabs" not in kw else min(warm, 2))):
             t0 = time.perf_counter()
             phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
             t1 = time.perf_counter()
             tm = api.transportmatrix(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML,
                                      κVdeep=g.kappaVdeep, **kw)
             t2 = time.perf_counter()
-            if rep >= warm:
-                ts.append((t1 - t0, t2 - t1, api.last_call_seconds["plan"] + api.last_call_seconds["fetch"]))
+            ts.append((t1 - t0, t2 - t1, api.last_call_seconds["plan"] + api.last_call_seconds["fetch"]))
+            pinned[name] = {k: int(api.last_call_seconds[k]) for k in ("result_bytes_pinned", "result_bytes_used") if k in api.last_call_seconds}
+            api.last_call_seconds.pop("result_bytes_pinned", None)
+            api.last_call_seconds.pop("result_bytes_used", None)
             del tm, phi  # (a time-slice loop drops the previous matrices: their pinned blocks return to the context's pool)
-        res[name] = tuple(float(np.median([x[q] for x in ts])) for q in range(3))
+        res[name] = tuple(float(np.median([x[q] for x in ts[-reps:]])) for q in range(3))
+    if large:
+        for name in ("reuse", "given_no_promise", "given_reuse"):
+            res[name] = (float("nan"),) * 3
     ff, tm, cabi = res["default"]
+
+    def protocol(**kw):
+        tr = api.Trial.peek(0, int(asm_N), rho3d=np.ndim(g.rho) != 0, **kw)
+        return "two-phase (rule)" if tr is None else ("pipelined" if tr.now else "two-phase") + " (measured by the first seven calls)"
+
+    lib = __import__("otmb_amd.capi", fromlist=["lib"]).lib()
+    given_rec = {
+        "what": "transportmatrix(; ϕ, ..., TκH = H, TκVdeep = D, reuse_grid = true): the two grid-constant operators are built once "
+                "(buildTκH / buildTκVdeep: build_operators_ms) and passed back every time slice, as src/matrixbuilding.jl:133-143 offers -- "
+                "neither uploaded again, built, nor copied home; the very objects come back; T, Tadv, TκVML are the full call's bit for bit",
+        "build_operators_ms": build_ms, "facefluxes_ms": 1e3 * res["given"][0], "transportmatrix_ms": 1e3 * res["given"][1],
+        "transportmatrix_c_abi_ms": 1e3 * res["given"][2], "value": asm_N / (res["given"][0] + res["given"][1]),
+        "protocol": protocol(reuse_grid=True, given=given),
+        "transportmatrix_ms_no_promise": 1e3 * res["given_no_promise"][1], "value_no_promise": asm_N / (res["given_no_promise"][0] + res["given_no_promise"][1]),
+        "no_promise": "the same call without reuse_grid: the two operators (and the grid) are uploaded and compared again every call",
+        "transportmatrix_ms_reuse_fluxes": 1e3 * res["given_reuse"][1], "value_reuse_fluxes": asm_N / (res["given_reuse"][0] + res["given_reuse"][1]),
+        "comparing_passes": int(lib.otmb_ctx_given_checks(api.context(0).handle)),
+    }
     return {"value": asm_N / (ff + tm), "unit": "wet-cells/s", "facefluxes_ms": 1e3 * ff, "transportmatrix_ms": 1e3 * tm,
             "transportmatrix_c_abi_ms": 1e3 * cabi, "slabs": api.default_slabs(asm_N, int(g.umo.data.shape[2]), False, None),
-            "default_protocol": ("pipelined" if api.Trial.of(0, int(asm_N)).now else "two-phase") + " (measured by the first five calls)",
+            "default_protocol": protocol(), "given_ops": given_rec,
+            "result_bytes": {"default": pinned.get("default"), "given": pinned.get("given"),
+                             "note": "pinned host bytes of one result set of the pipelined call (capacities: the wet mask's bounds, the previous slice's "
+                                     "counts + 25 / 50 % for Tadv / TκVML) against the bytes the matrices use; rounds 4-5 pinned 25 N entries for 19.2 N"},
             "transportmatrix_ms_two_phase": 1e3 * res["two_phase"][1], "value_two_phase": asm_N / (res["two_phase"][0] + res["two_phase"][1]),
             "facefluxes_ms_reuse": 1e3 * res["reuse"][0], "transportmatrix_ms_reuse": 1e3 * res["reuse"][1],
             "transportmatrix_c_abi_ms_reuse": 1e3 * res["reuse"][2], "value_reuse": asm_N / (res["reuse"][0] + res["reuse"][1]),
@@ -224,6 +384,7 @@ def extra_configs_in_children(args):
     for wl in [w for w in args.extra_configs.split(",") if w and w != args.workload]:
         key = names.get(wl, "config_" + wl)
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--extra-configs", "", "--no-cpu-baseline", "--no-end-to-end",
+               *(["--end-to-end-large"] if wl == "quarterdeg" and not args.no_end_to_end else []),
                "--steps", str(min(args.steps, 10)), "--warmup", "2", "--repeats", "2", "--rho", args.rho, "--seed", str(args.seed),
                "--placement-candidates", str(args.placement_candidates)]
         rec = {"workload": wl}
@@ -238,7 +399,8 @@ def extra_configs_in_children(args):
                 rec.update({"grid": d["config"]["workload"].split("grid ")[1].split(",")[0], "wet_cells": d["config"]["wet_cells"], "nnz": d["config"]["nnz"],
                             "protocol": d["config"]["protocol"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
                             "value": d["value"], "unit": d["unit"], "repeats": d["repeats"], "roofline": d["roofline"], "kernels_ms": d["kernels_ms"],
-                            "step_gbs": d["step_gbs"], "placement": d.get("placement"), "fused_step": d.get("fused_step"), "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
+                            "step_gbs": d["step_gbs"], "placement": d.get("placement"), "fused_step": d.get("fused_step"), "given_ops_step": d.get("given_ops_step"),
+                            "end_to_end": d.get("end_to_end"), "measured_by": "a fresh process: " + " ".join(cmd[1:6])})
         except subprocess.TimeoutExpired:
             rec["error"] = "child timed out"
         except Exception as e:  # an extra record must never cost the headline
@@ -444,6 +606,7 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
 
     import otmb_amd
     from otmb_amd import synthetic
+    from otmb_amd.capi import MATS
     from otmb_amd.device import DeviceAssembler
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -470,12 +633,26 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         sys.stdout.flush()
         saved_stdout_fd = os.dup(1)
         os.dup2(2, 1)
+        import datetime
+
+        dog = Watchdog(rank)
+        limit = float(os.environ.get("OTMB_BENCH_PREFLIGHT_S", "120"))
+        dog.arm("init_process_group (" + backend + ")", limit + 30)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=limit))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=max(limit, 300)))
+        dog.disarm()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
+    comm_rec = None
+    if world > 1 or force_slab:
+        nx_, ny_ = synthetic.PRESETS[args.workload][:2]
+        comm_rec = first_contact(dist, torch, world, rank, dev, backend, nx_ * ny_, rehearsal, dog)
+        if comm_rec["ranks_seen"] != world:
+            print(f"bench.py: rank {rank}: all_reduce saw {comm_rec['ranks_seen']} of {world} ranks", file=sys.stderr, flush=True)
+            os._exit(4)
+        dog.arm("the measurement", float(os.environ.get("OTMB_BENCH_WATCHDOG_S", "1500")))
 
     def make_backend(lr):
         if slab_backend_factory is not None:
@@ -606,6 +783,53 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
                 asm.step_fused_async(umo, vmo, fill)
 
             fused_available = args.protocol == "async" and args.workload != "tenthdeg" and nx >= 3
+            given_available = args.protocol == "async" and args.workload != "tenthdeg"
+
+            def given_steps(self, args, barrier):
+                full_nnz = list(asm.nnz)
+                full_r, full_w = asm.algorithmic_bytes_split()
+                ops = {}
+                for m in ("TκH", "TκVdeep"):  # this grid's own operators, as a caller keeps them: exact-length copies of the last step's
+                    k = asm.nnz[MATS.index(m)]
+                    cp, rv, nz = asm.out[m]
+                    ops[m] = (cp.clone(), rv[:k].clone(), nz[:k].clone())
+                asm.set_given(**ops)
+                try:
+                    for _ in range(max(args.warmup, 2)):
+                        asm.step_async(umo, vmo, fill)
+                    asm.finish()
+                    states = [asm.ctx.given_state(MATS.index(m)) for m in ("TκH", "TκVdeep")]
+                    reps = []
+                    for _ in range(min(args.repeats, 3)):
+                        barrier()
+                        t0 = time.perf_counter()
+                        for _ in range(args.steps):
+                            asm.step_async(umo, vmo, fill)
+                        asm.finish()
+                        barrier()
+                        reps.append(time.perf_counter() - t0)
+                    asm.ctx.timing_enable(True)
+                    for _ in range(args.steps):
+                        asm.step_async(umo, vmo, fill)
+                    asm.finish()
+                    gk = asm.ctx.timing_collect()
+                    asm.ctx.timing_enable(False)
+                    r, w = asm.algorithmic_bytes_split()
+                    gms = 1e3 * float(np.median(reps)) / args.steps
+                    fill_ms = gk["tm_kernel<fill>"][0] / gk["tm_kernel<fill>"][1]
+                    same = asm.nnz[0] == full_nnz[0] and asm.nnz[1] == full_nnz[1] and asm.nnz[3] == full_nnz[3]
+                    return {"what": "transportmatrix with TκH and TκVdeep GIVEN (otmb_tm_args.given; src/matrixbuilding.jl:133-147), device resident, two-call "
+                                    "path; an extra record, NOT the headline: the two operators are neither counted, written nor read -- the fill pass "
+                                    "re-derives their values in registers (verdict of ONE comparing pass, cached) and T is the same bit for bit",
+                            "given_state": dict(zip(("TκH", "TκVdeep"), ("derived" if q == 1 else "foreign" if q == 2 else "not given" for q in states))),
+                            "ms_per_step": gms, "wet_cells_per_s": asm.N / (gms * 1e-3), "kernels_ms": {k: round(v[0] / v[1], 5) for k, v in gk.items()},
+                            "fill_bytes": {"read": r, "written": w, "total": r + w, "full_build_total": full_r + full_w},
+                            "fill_gbs": (r + w) / (fill_ms * 1e-3) / 1e9, "fill_frac_of_hbm_peak": (r + w) / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "nnz_T_Tadv_TkVML_as_in_the_full_build": bool(same), "comparing_passes": int(asm.lib.otmb_ctx_given_checks(asm.ctx.handle))}
+                finally:
+                    asm.set_given(TκH=None, TκVdeep=None)
+                    asm.step_async(umo, vmo, fill)  # (the full build again: the roofline record below reads this object's nnz and matrices)
+                    asm.finish()
 
         runner = _Single()
 
@@ -681,6 +905,16 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         except Exception as e:  # an extra record must never cost the headline
             fused = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # The reference's time-loop shortcut on the device (otmb_tm_args.given): TκH and TκVdeep of this grid passed back to every step -- derived
+    # (one comparing pass, then cached), so the fill pass neither counts nor writes them.  An EXTRA record (never `value`: the headline returns
+    # all five matrices); measured like the headline, two-call path (facefluxes -> transportmatrix).
+    given_step = None
+    if getattr(runner, "given_available", False) and not rehearsal:
+        try:
+            given_step = runner.given_steps(args, barrier)
+        except Exception as e:  # an extra record must never cost the headline
+            given_step = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # N > 1: BASELINE.json configs[3] (the fixed 0.25 degree grid cut into N depth slabs) beside the headline, unless it IS the headline
     config4 = None
     c4_workload = os.environ.get("OTMB_BENCH_CONFIG4_WORKLOAD", "quarterdeg")  # (tests rehearse this leg on a small grid)
@@ -690,6 +924,14 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             config4 = slab_config(c4_workload, args, world, rank, dev, local_rank, rehearsal, backend, make_backend)
         except Exception as e:  # every rank raises the same pipeline errors (dist.SlabRunner.finish), so nobody is left in a collective
             config4 = {"workload": c4_workload, "error": f"{type(e).__name__}: {e}"[:300]}
+    kernels_by_rank = None
+    if dist.is_initialized() and (world > 1 or force_slab):
+        mine = {k: v[0] / v[1] for k, v in ktimes.items()}
+        allk = [None] * world
+        dist.all_gather_object(allk, mine)
+        names = sorted({k for d_ in allk for k in d_})
+        kernels_by_rank = {k: {"min": round(min(d_.get(k, float("inf")) for d_ in allk), 5), "max": round(max(d_.get(k, 0.0) for d_ in allk), 5)}
+                           for k in names}
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         n_total = runner.n_wet_total
@@ -748,16 +990,39 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         }
         if fused is not None:
             out["fused_step"] = fused
+        if given_step is not None:
+            out["given_ops_step"] = given_step
         if world == 1 and not force_slab and not rehearsal:
             out["placement"] = placement
         if world > 1 or force_slab:
             out["config"]["ranks_over"] = backend  # the depth-slab path: "nccl" = RCCL (one rank per GPU)
+            out["config"]["ranks_seen"] = comm_rec["ranks_seen"]  # an all_reduce of ones over the group, before anything was measured
+            out["comm"] = comm_rec
+            out["kernels_ms_over_ranks"] = kernels_by_rank
+            if world > 1 and kernels_by_rank and comm_rec.get("plane_hand_off"):
+                # what a weak-scaled step should cost: the slowest rank's own kernels + one hand-off per chain piece
+                own = sum(v["max"] for k, v in kernels_by_rank.items() if k in ("facefluxes_kernel", "tilescan_kernel", "tm_kernel<fill>", "tm_count_kernel"))
+                out["comm"]["expected_step_ms"] = own + comm_rec["plane_hand_off"]["ms_by_pieces"][str(comm_rec["plane_hand_off"]["pieces"])]
+                out["comm"]["expected_step_note"] = "slowest rank's facefluxes + scan + fill (HIP events) + one plane hand-off; the measured ms_per_step above it is orchestration and skew"
         if world == 1 and host_grid is not None and not rehearsal:
             try:  # (an extra record must never cost the headline: the host-pointer legs allocate gigabytes of pinned memory and start threads)
                 out["end_to_end"] = None if args.no_end_to_end else end_to_end(*host_grid, n_total)
             except Exception as e:
                 out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(*host_grid, args.workload)
+        if world == 1 and host_grid is None and args.end_to_end_large and not rehearsal and not force_slab:
+            try:  # (after everything that reads the assembler's matrices: it is released first -- the host-pointer engines stage the grid themselves)
+                import gc
+
+                from otmb_amd import synthetic_device as _sd
+
+                hg = _sd.host_copy(dg)
+                del asm, runner
+                gc.collect()
+                torch.cuda.empty_cache()
+                out["end_to_end"] = end_to_end(*hg, n_total, reps=3, warm=8, large=True)
+            except Exception as e:
+                out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and host_grid is not None and not rehearsal and dev.type == "cuda":
             try:  # an extra record must never cost the headline
                 out["config2"] = config2_bolus(*host_grid, dev, local_rank, min(args.steps, 10))
@@ -779,8 +1044,12 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         if saved_stdout_fd is not None:
             os.dup2(2, 1)  # anything the communicator says while shutting down goes to stderr too
     if dist.is_initialized():
+        if world > 1 or force_slab:
+            dog.arm("the closing barrier", 120.0)
         dist.barrier()
         dist.destroy_process_group()
+        if world > 1 or force_slab:
+            dog.disarm()
 
 
 if __name__ == "__main__":

@@ -482,6 +482,13 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
  * nnz round trip.  OTMB_ERR_CAPACITY when an array is too small.                                                          */
 int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *args, int64_t *const colptr[5], int64_t *const rowval[5],
                                           double *const nzval[5], const int64_t capacity[5], int64_t nnz_out[5]);
+/* Capacities that always suffice for otmb_mgpu_transportmatrix_onepass / otmb_transportmatrix_dev, from the wet mask ALONE (indices.wet3D
+ * bytes; pure host arithmetic on all cores, no GPU, no context; once per grid): a column holds a row per wet neighbour of its cell (+ the
+ * diagonal), whatever the fluxes are (src/velocities.jl:167-173 zeroes every flux towards land) -- so cap[OTMB_T] = cap[OTMB_TADV] = the union
+ * pattern's count, cap[OTMB_TKH] and cap[OTMB_TKVDEEP] the horizontal / vertical neighbour counts (exact but for coinciding row-mates on
+ * the tripolar seam), cap[OTMB_TKVML] = cap[OTMB_TKVDEEP].  About 24.6 N on an ocean grid against the 7 + 7 + 5 + 3 + 3 = 25 N of the per-column
+ * maxima: what varies from time slice to time slice (Tadv: 3.9 N, TκVML: 0.6 N) is bounded by the host layers from the PREVIOUS slice's counts. */
+int32_t otmb_static_capacity(const uint8_t *wet3d, int64_t nx, int64_t ny, int64_t nz, int32_t topology, int64_t cap[5]);
 
 /* ---- makegridmetrics(; areacello, volcello, lon, lat, lev, lon_vertices, lat_vertices) -- the array work of
  *      src/gridcellgeometry.jl:265-311 (device pointers; vertex permutation :158-178 and topology detection

@@ -94,6 +94,7 @@ end
 function check_mgpu(mg::Ptr{Cvoid}, rc::Int32)
     rc == 0 && return
     rc == 17 && throw(GivenForeign())
+    rc == 14 && throw(CapacityExceeded())
     msg = unsafe_string(ccall(sym(:otmb_mgpu_last_error), Cstring, (Ptr{Cvoid},), mg))
     rc == 8 && throw(AssertionError(msg))
     rc == 11 && throw(ArgumentError(msg))
@@ -496,13 +497,62 @@ function record!(tr::Trial, s)
         nothing
     end
 end
-# slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 ... 2^25 wet cells, 8 levels and more) -- unless the fluxes
+# slabs = nothing: 4 slabs of the device for grids where the transfers dominate (2^18 wet cells and more, 8 levels and more) -- unless the fluxes
 # are promised to be resident on the single-GPU context (reuse_fluxes) or a device list was given.  ENV["OTMB_HOST_SLABS"] overrides the 4.
 function default_slabs(N, nz, reuse_fluxes, devices)
     (devices === nothing && !reuse_fluxes) || return 0
     s = parse(Int, get(ENV, "OTMB_HOST_SLABS", "4"))
-    # (above 2^25 wet cells the upper-bound result arrays -- 400 B per wet cell -- pass 13 GB of pinned memory: left to an explicit `slabs =`)
-    return (s > 0 && (1 << 18) <= N < (1 << 25) && nz >= 2 * s) ? s : 0
+    # (round 6: no upper limit any more -- the result vectors are sized from the wet mask and the previous slice's counts, ~6 % over what is used,
+    # where rounds 4-5 pinned 7N / 7N / 5N / 3N / 3N entries, +30 %, and left grids above 2^25 wet cells to the two-phase call)
+    return (s > 0 && N >= (1 << 18) && nz >= 2 * s) ? s : 0
+end
+# Capacities of the one-phase build's result vectors (mirror of api._capacity_bounds / _capacities): otmb_static_capacity -- entries that always
+# suffice, from the wet mask alone, once per indices object -- and, for what varies between time slices (Tadv, TκVML), the previous slice's
+# counts with a margin; a slice that outgrows them (OTMB_ERR_CAPACITY) is built again at the mask's bounds.
+const STATIC_CAP = Dict{Any,Vector{Int64}}()
+const PREV_NNZ = Dict{Any,Vector{Int64}}()
+const GROWTH = (1.0, 1.25, 1.0, 1.5, 1.0)
+function capacity_bounds(indices, gridmetrics)
+    key = (objectid(indices.wet3D), size(indices.wet3D), topologykind(gridmetrics.gridtopology))
+    bound = get!(STATIC_CAP, key) do
+        wet = Array{UInt8,3}(indices.wet3D)
+        out = zeros(Int64, 5)
+        rc = ccall(sym(:otmb_static_capacity), Int32, (Ptr{UInt8}, Int64, Int64, Int64, Int32, Ptr{Int64}), wet, size(wet)..., key[3], out)
+        rc == 0 || error("otmb_static_capacity failed (status $rc)")
+        out
+    end
+    return key, bound
+end
+capacities(key, bound) = haskey(PREV_NNZ, key) ? Int64[min(bound[m], floor(Int64, PREV_NNZ[key][m] * GROWTH[m]) + 4096) for m in 1:5] : copy(bound)
+struct CapacityExceeded <: Exception end
+# one otmb_mgpu_transportmatrix_onepass call into result vectors of `cap` entries (under CALL_LOCK): pinned blocks become Julia vectors of the
+# FINAL lengths only after the call (no copy, one owner each); nothing owns them if the call throws
+function onepass_call(mg, a, keep, N, cap, usepinned)
+    colptr = [outarray(Int64, usepinned, cap[m] > 0 ? N + 1 : 0) for m in 1:5]
+    final = zeros(Int64, 5)
+    if usepinned
+        rvb = Ptr{Cvoid}[]; nzb = Ptr{Cvoid}[]
+        try
+            for m in 1:5
+                push!(rvb, pinned_block(Int64, cap[m])); push!(nzb, pinned_block(Float64, cap[m]))
+            end
+            cp = [pointer(x) for x in colptr]; rv = [Ptr{Int64}(b) for b in rvb]; nz = [Ptr{Float64}(b) for b in nzb]
+            GC.@preserve keep colptr check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_onepass), Int32,
+                (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
+        catch
+            foreach(b -> ccall(host_free_fn[], Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, b), vcat(rvb, nzb))  # nothing owns these blocks yet
+            rethrow()
+        end
+        rowval = [adopt(Int64, rvb[m], Int(final[m])) for m in 1:5]
+        nzval = [adopt(Float64, nzb[m], Int(final[m])) for m in 1:5]
+    else
+        rowval = [Vector{Int64}(undef, cap[m]) for m in 1:5]; nzval = [Vector{Float64}(undef, cap[m]) for m in 1:5]
+        cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
+        GC.@preserve keep colptr rowval nzval check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_onepass), Int32,
+            (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
+        foreach(m -> (resize!(rowval[m], final[m]); resize!(nzval[m], final[m])), 1:5)  # (ordinary vectors shrink in place)
+    end
+    return colptr, rowval, nzval, final
 end
 function fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, ignore_ops::Int32,
                        usepinned::Bool, devices, given = nothing)
@@ -512,31 +562,20 @@ function fused_onepass(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep
         check_mgpu(mg, ccall(sym(:otmb_mgpu_set_reuse), Int32, (Ptr{Cvoid}, Int32, Int32), mg, Int32(reuse_grid), Int32(reuse_fluxes)))
         a, keep = tmargs(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, ignore_ops, given)
         N = indices.N
-        cap = Int64[wanted(m, operators, given) ? N * PER_COLUMN_MAX[m] + 1 : 0 for m in 1:5]   # (nothing for a given operator: it is not handed out)
-        colptr = [outarray(Int64, usepinned, cap[m] > 0 ? N + 1 : 0) for m in 1:5]
-        final = zeros(Int64, 5)
-        if usepinned
-            rvb = Ptr{Cvoid}[]; nzb = Ptr{Cvoid}[]
+        ckey, bound = capacity_bounds(indices, gridmetrics)
+        local colptr, rowval, nzval, final
+        for attempt in 0:1
+            cs = attempt == 0 ? capacities(ckey, bound) : bound
+            cap = Int64[wanted(m, operators, given) ? cs[m] + 1 : 0 for m in 1:5]   # (nothing for a given operator: it is not handed out)
             try
-                for m in 1:5
-                    push!(rvb, pinned_block(Int64, cap[m])); push!(nzb, pinned_block(Float64, cap[m]))
-                end
-                cp = [pointer(x) for x in colptr]; rv = [Ptr{Int64}(b) for b in rvb]; nz = [Ptr{Float64}(b) for b in nzb]
-                GC.@preserve keep colptr check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_onepass), Int32,
-                    (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
-            catch
-                foreach(b -> ccall(host_free_fn[], Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, b), vcat(rvb, nzb))  # nothing owns these blocks yet
-                rethrow()
+                colptr, rowval, nzval, final = onepass_call(mg, a, keep, N, cap, usepinned)
+                break
+            catch e
+                (e isa CapacityExceeded && attempt == 0) || rethrow()
+                delete!(PREV_NNZ, ckey)     # this slice outgrew the previous one's counts: once more at the mask's bounds
             end
-            rowval = [adopt(Int64, rvb[m], Int(final[m])) for m in 1:5]
-            nzval = [adopt(Float64, nzb[m], Int(final[m])) for m in 1:5]
-        else
-            rowval = [Vector{Int64}(undef, cap[m]) for m in 1:5]; nzval = [Vector{Float64}(undef, cap[m]) for m in 1:5]
-            cp = [pointer(x) for x in colptr]; rv = [pointer(x) for x in rowval]; nz = [pointer(x) for x in nzval]
-            GC.@preserve keep colptr rowval nzval check_mgpu(mg, ccall(sym(:otmb_mgpu_transportmatrix_onepass), Int32,
-                (Ptr{Cvoid}, Ptr{TmArgs}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64}), mg, Ref(a), cp, rv, nz, cap, final))
-            foreach(m -> (resize!(rowval[m], final[m]); resize!(nzval[m], final[m])), 1:5)  # (ordinary vectors shrink in place)
         end
+        all(m -> wanted(m, operators, given), 1:5) && (PREV_NNZ[ckey] = copy(final))
         return wrap(N, colptr, rowval, nzval, final, operators, given)
     end
 end

@@ -497,8 +497,9 @@ def default_slabs(N, nz, reuse_fluxes, devices):
     if devices is not None or reuse_fluxes:
         return 0
     s = int(os.environ.get("OTMB_HOST_SLABS", "4"))
-    # (above 2^25 wet cells the upper-bound result arrays -- 400 B per wet cell -- pass 13 GB of pinned memory: left to an explicit slabs=)
-    return s if (s > 0 and (1 << 18) <= N < (1 << 25) and nz >= 2 * s) else 0
+    # (round 6: no upper limit any more -- the result arrays are sized from the wet mask and the previous slice's counts, ~6 % over what is used,
+    # where rounds 4-5 pinned 7N / 7N / 5N / 3N / 3N entries, +30 %, and left grids above 2^25 wet cells to the two-phase call)
+    return s if (s > 0 and N >= (1 << 18) and nz >= 2 * s) else 0
 
 
 class Trial:
@@ -632,17 +633,60 @@ def _transportmatrix_onepass(phi, mlotst, gridmetrics, indices, rho, kH, kVML, k
     a.ignore_ops = int(ignore_ops)
     N = int(indices["N"])
     want = [_wanted(m, operators, given) for m in range(5)]
-    cap = [N * k + 1 if want[m] else 0 for m, k in enumerate(PER_COLUMN_MAX)]
-    colptr = [_out_array(ctx, N + 1, np.int64) if want[m] else None for m in range(5)]
-    rowval = [_out_array(ctx, cap[m], np.int64) if want[m] else None for m in range(5)]
-    nzval = [_out_array(ctx, cap[m], np.float64) if want[m] else None for m in range(5)]
+    ckey, bound = _capacity_bounds(indices, gridmetrics)
     ptrs = lambda arrs: capi.ptr_array(5, [None if x is None else x.ctypes.data for x in arrs])
-    cp, rv, nz = ptrs(colptr), ptrs(rowval), ptrs(nzval)
-    caps, final = (C.c_int64 * 5)(*cap), (C.c_int64 * 5)()
-    t0 = _time.perf_counter()
-    mg.check(capi.lib().otmb_mgpu_transportmatrix_onepass(mg.handle, C.byref(a), C.byref(cp), C.byref(rv), C.byref(nz), C.byref(caps), C.byref(final)))
+    for attempt in (0, 1):
+        # result arrays at capacities that suffice: the wet mask's bounds, and for what varies between time slices (Tadv, TκVML) the previous
+        # slice's counts with a margin -- a slice that outgrows them (OTMB_ERR_CAPACITY) is built again at the mask's bounds
+        cap = [(c + 1 if want[m] else 0) for m, c in enumerate(_capacities(ckey, bound) if attempt == 0 else bound)]
+        colptr = [_out_array(ctx, N + 1, np.int64) if want[m] else None for m in range(5)]
+        rowval = [_out_array(ctx, cap[m], np.int64) if want[m] else None for m in range(5)]
+        nzval = [_out_array(ctx, cap[m], np.float64) if want[m] else None for m in range(5)]
+        cp, rv, nz = ptrs(colptr), ptrs(rowval), ptrs(nzval)
+        caps, final = (C.c_int64 * 5)(*cap), (C.c_int64 * 5)()
+        t0 = _time.perf_counter()
+        rc = capi.lib().otmb_mgpu_transportmatrix_onepass(mg.handle, C.byref(a), C.byref(cp), C.byref(rv), C.byref(nz), C.byref(caps), C.byref(final))
+        if rc == capi.CAPACITY and attempt == 0:
+            _prev_nnz.pop(ckey, None)
+            del colptr, rowval, nzval
+            continue
+        mg.check(rc)
+        break
     last_call_seconds["plan"], last_call_seconds["fetch"] = _time.perf_counter() - t0, 0.0
+    last_call_seconds["result_bytes_pinned"] = sum(16 * c for c in cap) + 8 * (N + 1) * sum(want)
+    last_call_seconds["result_bytes_used"] = sum(16 * int(final[m]) for m in range(5) if want[m]) + 8 * (N + 1) * sum(want)
+    if all(want):
+        _prev_nnz[ckey] = [int(x) for x in final]
     return _result(N, colptr, rowval, nzval, final, operators, given)
+
+
+_static_cap = {}  # (address of indices.wet3D, shape, topology) -> otmb_static_capacity's five bounds
+_prev_nnz = {}    # the same key -> the five counts of the previous full build on that grid
+GROWTH = (1.0, 1.25, 1.0, 1.5, 1.0)  # margins over the previous slice's counts (T, TκH, TκVdeep: the mask's bounds are exact enough already)
+
+
+def _capacity_bounds(indices, gridmetrics):
+    """otmb_static_capacity of this grid (host arithmetic, once per indices object): entries that always suffice, from the wet mask alone."""
+    wet = np.asfortranarray(indices["wet3D"]).view(np.uint8)
+    topo = _topology_kind(gridmetrics)
+    key = (wet.ctypes.data, wet.shape, topo)
+    if key not in _static_cap:
+        if len(_static_cap) > 64:
+            _static_cap.clear()
+            _prev_nnz.clear()
+        out = (C.c_int64 * 5)()
+        rc = capi.lib().otmb_static_capacity(wet.ctypes.data, *wet.shape, topo, C.byref(out))
+        if rc != capi.OK:
+            raise capi.OtmbError(rc, "otmb_static_capacity")
+        _static_cap[key] = ([int(x) for x in out], wet)  # (the array is kept: its address is the key)
+    return key, _static_cap[key][0]
+
+
+def _capacities(key, bound):
+    prev = _prev_nnz.get(key)
+    if prev is None:
+        return list(bound)
+    return [min(b, int(p * g) + 4096) for b, p, g in zip(bound, prev, GROWTH)]
 
 
 def _build_operator(which, *, gridmetrics, indices, phi=None, rho=1035.0, mlotst=None, kappa=(500.0, 0.1, 1.0e-5), upwind=True,

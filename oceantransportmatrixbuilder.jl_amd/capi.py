@@ -12,6 +12,7 @@ STATUS_NAMES = {
     13: "NONCANONICAL_INDICES", 14: "CAPACITY", 15: "PUSH_MASK", 16: "ASYMMETRIC_PATTERN", 17: "GIVEN_FOREIGN",
 }
 GIVEN_FOREIGN = 17
+CAPACITY = 14
 PHI_ORDER = ("east", "west", "north", "south", "top", "bottom")  # OTMB_EAST..OTMB_BOTTOM
 HDIRS = ("west", "east", "south", "north")  # OTMB_DIR_*
 MATS = ("T", "Tadv", "TκH", "TκVML", "TκVdeep")  # OTMB_T..OTMB_TKVDEEP
@@ -92,6 +93,7 @@ SYMBOLS = {
     "otmb_mgpu_transportmatrix_fetch": (C.c_int32, [_vp, C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(C.c_int64 * 5)]),
     "otmb_mgpu_transportmatrix_onepass": (C.c_int32, [_vp, C.POINTER(TmArgs), C.POINTER(_vp * 5), C.POINTER(_vp * 5), C.POINTER(_vp * 5),
                                                       C.POINTER(C.c_int64 * 5), C.POINTER(C.c_int64 * 5)]),
+    "otmb_static_capacity": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int64 * 5)]),
     "otmb_ctx_set_tile_order": (C.c_int32, [_vp, C.c_int32]),
     "otmb_ctx_forget_given": (C.c_int32, [_vp]),
     "otmb_ctx_given_state": (C.c_int32, [_vp, C.c_int32]),

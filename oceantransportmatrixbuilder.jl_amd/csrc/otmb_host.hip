@@ -1,6 +1,7 @@
 // otmb_host.hip -- HOST-pointer entry points (what Julia's ccall hands over): stage the caller's
 // arrays through device buffers owned by the context, run the _dev path, copy the results back
 // into the caller's buffers.  No CPU compute path exists here: without a GPU these calls fail.
+#include <algorithm>
 #include <mutex>
 
 #include "otmb_common.h"
@@ -73,6 +74,7 @@ struct HostBlock { void *p = nullptr; size_t cap = 0; bool used = false; };
 struct HostPool {
     std::mutex m;
     std::vector<HostBlock> blocks;
+    size_t peak = 0;  // most bytes the pool has held at once (in use + idle)
 };
 HostPool &host_pool() {
     static HostPool *pool = new HostPool();  // intentionally leaked: must outlive every static destructor and atexit hook
@@ -404,6 +406,37 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     return otmb_ctx_synchronize(ctx);
 }
 
+// Capacities from the wet mask alone (include/otmb.h): per wet cell its wet horizontal / vertical neighbours; one level per work item.
+int32_t otmb_static_capacity(const uint8_t *wet3d, int64_t nx, int64_t ny, int64_t nz, int32_t topology, int64_t cap[5]) {
+    if (!wet3d || !cap || nx < 1 || ny < 1 || nz < 1 || (topology != OTMB_BIPOLAR && topology != OTMB_TRIPOLAR)) return OTMB_ERR_INVALID_ARG;
+    const i64 P = nx * ny;
+    std::vector<i64> nh(nz, 0), nv(nz, 0), nd(nz, 0);  // horizontal / vertical neighbour entries, diagonals (of TκH | of TκVdeep | of the union)
+    std::vector<i64> dh(nz, 0), dv(nz, 0);
+    OtmbThreadPool pool(std::min<int>(16, std::max<int>(1, (int)std::thread::hardware_concurrency())));
+    pool.parallel_for((int)nz, [&](int k) {
+        const uint8_t *w = wet3d + (size_t)k * P, *wa = k > 0 ? w - P : nullptr, *wb = k + 1 < nz ? w + P : nullptr;
+        i64 h = 0, v = 0, d = 0, ddh = 0, ddv = 0;
+        for (i64 j = 0; j < ny; ++j) {
+            const uint8_t *r = w + j * nx, *rs = j > 0 ? r - nx : nullptr, *rn = j + 1 < ny ? r + nx : nullptr;
+            for (i64 i = 0; i < nx; ++i) {
+                if (!r[i]) continue;
+                const int e = r[i + 1 < nx ? i + 1 : 0] != 0, ww = r[i > 0 ? i - 1 : nx - 1] != 0, s = rs ? rs[i] != 0 : 0;
+                const int n = rn ? rn[i] != 0 : (topology == OTMB_TRIPOLAR ? r[nx - 1 - i] != 0 : 0);
+                const int a = wa ? wa[j * nx + i] != 0 : 0, b = wb ? wb[j * nx + i] != 0 : 0;
+                h += e + ww + s + n; v += a + b;
+                ddh += (e + ww + s + n) > 0; ddv += (a + b) > 0; d += (e + ww + s + n + a + b) > 0;
+            }
+        }
+        nh[k] = h; nv[k] = v; nd[k] = d; dh[k] = ddh; dv[k] = ddv;
+    });
+    i64 H = 0, V = 0, D = 0, DH = 0, DV = 0;
+    for (i64 k = 0; k < nz; ++k) { H += nh[k]; V += nv[k]; D += nd[k]; DH += dh[k]; DV += dv[k]; }
+    cap[OTMB_T] = cap[OTMB_TADV] = H + V + D;
+    cap[OTMB_TKH] = H + DH;
+    cap[OTMB_TKVML] = cap[OTMB_TKVDEEP] = V + DV;
+    return OTMB_OK;
+}
+
 // bytes the host-pointer entry points have copied to the device since the context was created (diagnostics / tests: what the
 // reuse flags save)
 int64_t otmb_ctx_uploaded_bytes(const otmb_ctx *ctx) { return ctx ? ctx->uploaded_bytes : -1; }
@@ -454,10 +487,13 @@ int32_t otmb_host_free(otmb_ctx *, void *p) {
         for (auto &b : hp.blocks)
             if (b.p == p && b.used) { b.used = false; p = nullptr; }
         if (p) return OTMB_ERR_INVALID_ARG;  // not a block of otmb_host_alloc (or freed twice)
-        // keep at most 4 GiB of idle pinned memory
-        size_t idle = 0;
-        for (auto &b : hp.blocks) idle += b.used ? 0 : b.cap;
-        for (size_t q = 0; q < hp.blocks.size() && idle > ((size_t)4 << 30);) {
+        // keep at most 4 GiB of idle pinned memory -- or, on grids whose result sets are larger than that, 1.25 x the most that was ever in use
+        // at once (a 0.25 degree time-slice loop drops and re-requests 20 GB of result blocks per call: pinning them again costs seconds)
+        size_t idle = 0, used = 0;
+        for (auto &b : hp.blocks) (b.used ? used : idle) += b.cap;
+        if (used + idle > hp.peak) hp.peak = used + idle;
+        const size_t keep = std::max((size_t)4 << 30, hp.peak + hp.peak / 4 > used ? hp.peak + hp.peak / 4 - used : (size_t)0);
+        for (size_t q = 0; q < hp.blocks.size() && idle > keep;) {
             if (!hp.blocks[q].used) {
                 idle -= hp.blocks[q].cap;
                 release.push_back(hp.blocks[q].p);

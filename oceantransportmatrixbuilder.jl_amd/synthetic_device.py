@@ -88,3 +88,21 @@ def assembler_for(dg, device_index=0, upwind=True):
                          edge_length=dg.edge_length, dist_nbr=dg.dist_nbr, area2d=dg.area2d, zt=dg.zt, mlotst=dg.mlotst,
                          rho=dg.rho, kappaH=dg.kappaH, kappaVML=dg.kappaVML, kappaVdeep=dg.kappaVdeep, upwind=upwind)
     return asm
+
+
+def host_copy(dg):
+    """The device-generated grid as HOST arrays in the shapes the host API takes (bench.py's end_to_end leg on the 0.25 degree grid, where
+    building the 3-D fields on the host would take minutes): (g, gm) with g.umo / g.vmo Cubes, g.rho, g.mlotst, the κ and gm the gridmetrics
+    NamedTuple whose 3-D members are copied down once.  Whole grids only (k0 == 0, k1 == nz)."""
+    assert dg.k0 == 0 and dg.k1 == dg.nz
+    shape = (dg.nx, dg.ny, dg.nz)
+
+    def h3(t):
+        return np.asfortranarray(t.cpu().numpy().reshape(shape, order="F"))
+
+    gm = NT(**{k: v for k, v in dg.gm.items()})
+    gm["v3D"], gm["thkcello"], gm["zt"] = h3(dg.v3d), h3(dg.thkcello), np.ascontiguousarray(dg.zt_host, dtype=np.float64)
+    g = NT(umo=Cube(h3(dg.umo), _FillValue=dg.fill), vmo=Cube(h3(dg.vmo), _FillValue=dg.fill),
+           rho=h3(dg.rho) if torch.is_tensor(dg.rho) else float(dg.rho), mlotst=np.asfortranarray(dg.mlotst_host, dtype=np.float64),
+           kappaH=dg.kappaH, kappaVML=dg.kappaVML, kappaVdeep=dg.kappaVdeep)
+    return g, gm

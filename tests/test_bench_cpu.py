@@ -28,6 +28,14 @@ def test_bench_spawns_its_ranks_and_prints_one_json_line(gpus, scaling):
     assert f"cut into {gpus} depth slabs" in d["config"]["workload"]
     nz = 10 * gpus if scaling == "weak" else 10
     assert f"36x30x{nz}" in d["config"]["workload"]
+    # the line's own evidence about its communicator: every rank answered an all_reduce, who carried it, and what the one
+    # exchange of the path -- a plane of ϕtop to the slab above -- costs here, whole and in row bands
+    assert d["config"]["ranks_seen"] == gpus and d["config"]["ranks_over"] == "gloo"
+    cm = d["comm"]
+    assert cm["backend"] == "gloo" and cm["world"] == gpus and cm["library"].startswith("gloo")
+    ho = cm["plane_hand_off"]
+    assert ho["bytes"] == 8 * 36 * 30 and ho["payload_intact"] is True and ho["ms_by_pieces"]["1"] > 0 and ho["ms_per_piece"] > 0
+    assert isinstance(d["kernels_ms_over_ranks"], dict)  # (the CPU checker backend launches no kernels: empty here, min / max per kernel on GPUs)
     # the strong-scaled sub-record (BASELINE.json configs[3]; here on the small grid) rides along unless it is the headline itself
     if scaling == "weak":
         c4 = d["config4"]
@@ -35,6 +43,22 @@ def test_bench_spawns_its_ranks_and_prints_one_json_line(gpus, scaling):
         assert c4["wet_cells"] > 0 and c4["ms_per_step"] > 0
     else:
         assert "config4" not in d
+
+
+def test_a_rank_that_never_arrives_ends_the_run_with_its_name():
+    """First contact with a node must end with a verdict, not a hang: a rank that never joins the first collective trips the other
+    ranks' watchdog (OTMB_BENCH_PREFLIGHT_S), which names the absent rank and exits non-zero; the launcher stops everybody."""
+    import time
+
+    env = dict(os.environ, OTMB_BENCH_TEST_STALL_RANK="1", OTMB_BENCH_PREFLIGHT_S="6")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--workload", "small", "--steps", "2",
+                        "--warmup", "1", "--repeats", "1", "--extra-configs", ""], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "did not finish 'preflight: all_reduce of ones' within 6 s" in r.stderr and "ranks that never reached this phase: [1]" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_traffic_json_is_keyed_to_the_kernel_sources():

@@ -256,19 +256,24 @@ def test_both_host_layers_make_the_same_c_calls_in_the_same_order():
     assert _collapse(py_m) == want_m, py_m
     assert "fused_mgpu(" in jl and "_transportmatrix_mgpu(" in py  # both single-device builds hand a device list over to it
     # ---- the pipelined one-phase build (slabs = S): result arrays at their upper bounds, then ONE call; both take the same bounds
-    jl_o = _julia_function("fused_onepass")
+    jl_o = _julia_function("fused_onepass") + _julia_function("onepass_call").split("    else\n")[0]
     py_o = _python_function(api_src, "_transportmatrix_onepass")
-    jl_oc = [a or "otmb_host_alloc" for a in re.findall(r"sym\(:(otmb_\w+)\)|\boutarray\(|\bpinned_block\(", jl_o.split("else")[0])]
+    jl_oc = [a or "otmb_host_alloc" for a in re.findall(r"sym\(:(otmb_\w+)\)|\boutarray\(|\bpinned_block\(", jl_o)]
     py_oc = [alias.get(a, a) for a in re.findall(r"\b(otmb_\w+|_out_array)\(", py_o)]
     want_o = ["otmb_mgpu_set_reuse", "otmb_host_alloc", "otmb_mgpu_transportmatrix_onepass"]
     assert _collapse(jl_oc) == want_o, jl_oc
     assert _collapse(py_oc) == want_o, py_oc
-    assert "const PER_COLUMN_MAX = (7, 7, 5, 3, 3)" in SHIM and "PER_COLUMN_MAX = (7, 7, 5, 3, 3)" in api_src
-    assert "N * PER_COLUMN_MAX[m] + 1" in jl_o and "N * k + 1" in py_o
+    # ... into result vectors sized alike: the wet mask's bounds (otmb_static_capacity, once per indices object), the previous slice's counts
+    # with the same margins for what varies, one retry at the mask's bounds when a slice outgrows them
+    assert "const GROWTH = (1.0, 1.25, 1.0, 1.5, 1.0)" in SHIM and "GROWTH = (1.0, 1.25, 1.0, 1.5, 1.0)" in api_src
+    assert "otmb_static_capacity" in _julia_function("capacity_bounds") and "otmb_static_capacity" in _python_function(api_src, "_capacity_bounds")
+    assert "PREV_NNZ[key][m] * GROWTH[m]) + 4096" in SHIM and "int(p * g) + 4096" in _python_function(api_src, "_capacities")
+    assert "e isa CapacityExceeded && attempt == 0" in jl_o and "rc == capi.CAPACITY and attempt == 0" in py_o
+    assert "cs[m] + 1" in jl_o and "c + 1 if want[m] else 0" in py_o
     # the same default on both sides: 4 slabs from 2^18 wet cells and 8 levels on, never with reuse_fluxes or a device list
     jl_d, py_d = _julia_function("default_slabs"), _python_function(api_src, "default_slabs")
     for src in (jl_d, py_d):
-        assert "OTMB_HOST_SLABS" in src and '"4"' in src and "(1 << 18) <= N < (1 << 25)" in src and "2 * s" in src and "reuse_fluxes" in src
+        assert "OTMB_HOST_SLABS" in src and '"4"' in src and "N >= (1 << 18)" in src and "2 * s" in src and "reuse_fluxes" in src and "1 << 25" not in src
     # ... and the same measured choice between the two protocols: pipelined for calls 1-4 (3 and 4 timed), two-phase for 5-7 (6 and 7 timed), the
     # loser measured again every 64th call, three slow calls in a row start the trial over
     jl_p = _julia_function("pipelined!")

@@ -326,3 +326,35 @@ def test_oracle_reproduces_lump_fixtures(oracle, path):
     assert np.array_equal(LUMP[1], z["lump_rowval"]) and np.array_equal(LUMP[2], z["lump_nzval"])
     assert np.array_equal(SPRAY[0], z["spray_colptr"]) and np.array_equal(SPRAY[1], z["spray_rowval"])
     assert np.array_equal(vol_c, z["vol_c"]) and np.array_equal(LUMP[0], np.arange(1, N + 2))
+
+
+def test_static_capacity_bounds_every_matrix_and_is_exact_where_the_mask_decides(oracle):
+    """otmb_static_capacity (pure host arithmetic in the product library: runs without a GPU): from the wet mask alone, counts that every
+    build on that grid stays under -- whatever the fluxes, κ and mixed layer -- and that ARE TκH's, TκVdeep's and the union pattern's counts
+    wherever no two row-mates coincide (no tripolar seam aliasing, nx >= 3)."""
+    import ctypes as C
+
+    from helpers import CASES, make_case
+    from otmb_amd import capi
+
+    lib = capi.lib()
+    for name in CASES:
+        g, gm = make_case(name)
+        idx = oracle.makeindices(gm.v3D)
+        wet = np.asfortranarray(idx["wet3D"]).view(np.uint8)
+        cap = (C.c_int64 * 5)()
+        assert lib.otmb_static_capacity(wet.ctypes.data, *wet.shape, int(gm.gridtopology.kind), C.byref(cap)) == 0
+        phi = oracle.facefluxes(np.asarray(g.umo.data, dtype=np.float64), np.asarray(g.vmo.data, dtype=np.float64), idx["wet3D"],
+                                float(g.umo.properties["_FillValue"]), gm.gridtopology.kind)
+        for upwind in (True, False):
+            tm = oracle.transportmatrix(phi, gm, idx, g.rho, g.mlotst, g.kappaH, g.kappaVML, g.kappaVdeep, upwind)
+            got = [len(tm[m][1]) for m in ("T", "Tadv", "TκH", "TκVML", "TκVdeep")]
+            assert all(c >= n for c, n in zip(cap, got)), (name, list(cap), got)
+            assert cap[4] == got[4], (name, "TκVdeep")
+            if name in ("tiny_bipolar",):  # (no fold: nothing coincides)
+                assert cap[2] == got[2], (name, "TκH")
+                if upwind is False:
+                    assert cap[0] >= got[0]
+    bad = (C.c_int64 * 5)()
+    assert lib.otmb_static_capacity(None, 3, 3, 3, 0, C.byref(bad)) != 0
+    assert lib.otmb_static_capacity(wet.ctypes.data, *wet.shape, 2, C.byref(bad)) != 0  # UnknownGridTopology has no neighbours to count
