@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--end-to-end-large", action="store_true",
                     help="workloads generated on the device (quarterdeg): copy the grid down once and run the host-pointer end_to_end legs on it "
                          "(what a Julia caller waits for at BASELINE.json configs[2]; ~60 GB of host memory)")
+    ap.add_argument("--given-ops", action="store_true",
+                    help="profiling aid, never the driver's run: EVERY step of this process passes TκH and TκVdeep in (otmb_tm_args.given), so that a "
+                         "rocprofv3 run of it averages the fill pass of that path alone (the default run measures it as the extra record given_ops_step)")
     ap.add_argument("--seed", type=int, default=20260501)
     ap.add_argument("--extra-configs", default="quarterdeg,tenthdeg",
                     help="after the headline workload (N = 1 only): BASELINE.json configs[2] (0.25 degree, the HBM-roofline run) and configs[4]'s "
@@ -783,7 +786,7 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
                 asm.step_fused_async(umo, vmo, fill)
 
             fused_available = args.protocol == "async" and args.workload != "tenthdeg" and nx >= 3
-            given_available = args.protocol == "async" and args.workload != "tenthdeg"
+            given_available = args.protocol == "async" and args.workload != "tenthdeg" and not args.given_ops and not under_profiler()
 
             def given_steps(self, args, barrier):
                 full_nnz = list(asm.nnz)
@@ -832,6 +835,14 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
                     asm.finish()
 
         runner = _Single()
+        if args.given_ops:  # (profiling aid: see the flag) this grid's own two grid-constant operators, passed back to every step from here on
+            asm.step(umo, vmo, fill)
+            ops = {}
+            for m in ("TκH", "TκVdeep"):
+                k = asm.nnz[MATS.index(m)]
+                cp, rv, nz_ = asm.out[m]
+                ops[m] = (cp.clone(), rv[:k].clone(), nz_[:k].clone())
+            asm.set_given(**ops)
 
     def barrier():
         if dist.is_initialized():
@@ -956,7 +967,7 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
                 mix = (br + bw) / (br / rd + bw / wr)
                 roof["box"] = {"read_gbs": rd, "write_gbs": wr, "mix_ceiling": mix, "frac_of_box": achieved / mix,
                                "bytes_read": br, "bytes_written": bw}
-                if dom.startswith("tm_kernel") and hasattr(runner, "stream_mix"):
+                if dom.startswith("tm_kernel") and hasattr(runner, "stream_mix") and not args.given_ops:
                     # ... and of what an ideal streaming kernel reaches over the fill pass's OWN arrays, where they lie (destroys the matrices:
                     # everything that reads them has run).  The two plain streams above are the same on fast and slow boxes (profiles/r05).
                     sm = runner.stream_mix()  # {columns per slice: GB/s}; 256 = the fill pass's own tile
@@ -978,7 +989,8 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: synthetic ACCESS-ESM1-5-like tripolar grid {shape}"
-                            f", facefluxes + full transportmatrix (5 CSC matrices), rho={args.rho}, upwind",
+                            f", facefluxes + full transportmatrix (5 CSC matrices), rho={args.rho}, upwind"
+                            + (" -- PROFILING RUN with TκH and TκVdeep passed in (--given-ops): 3 matrices built, not the headline" if args.given_ops else ""),
                 "wet_cells": n_total, "nnz": dict(zip(("T", "Tadv", "TkH", "TkVML", "TkVdeep"), runner.nnz)),
                 "seed": args.seed, "protocol": getattr(runner, "protocol", args.protocol),
             },

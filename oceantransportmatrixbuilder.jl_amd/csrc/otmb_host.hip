@@ -2,7 +2,9 @@
 // arrays through device buffers owned by the context, run the _dev path, copy the results back
 // into the caller's buffers.  No CPU compute path exists here: without a GPU these calls fail.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
+#include <thread>
 
 #include "otmb_common.h"
 #include "otmb_xfer.h"
@@ -161,9 +163,55 @@ int32_t otmb_facefluxes(otmb_ctx *ctx, const void *umo, const void *vmo, int32_t
     }
     TRY(flush(ctx, up));
     TRY(otmb_facefluxes_dev(ctx, du, dv, src_is_f32, (const uint8_t *)dw, fill, nx, ny, nz, topology, dphi));
-    std::vector<OtmbXferItem> down;
-    for (int f = 0; f < 6; ++f) down.push_back({dphi[f], phi[f], G * 8});
-    TRY(download(ctx, down));
+    // Three of the six arrays are SHIFTED COPIES of the other three -- that is how the reference defines them: ϕwest[c] = ϕeast[i₋₁(c)]
+    // (periodic; src/velocities.jl:206-211), ϕsouth[c] = ϕnorth[j₋₁(c)], zero on the first row (:219-224), ϕbottom[k] = ϕtop[k + 1], zero at
+    // the sea floor level (:238-240) -- so only ϕeast, ϕnorth and ϕtop cross the link (130 of 259 MB at 1 degree) and host threads lay the
+    // other three down beside the next array's DMA: plain memcpy, bit-identical by construction (the device holds all six, for reuse_fluxes).
+    // OTMB_FF_SHIFT_ON_HOST=0: all six are copied (A/B).
+    static const bool shift_on_host = [] { const char *e = getenv("OTMB_FF_SHIFT_ON_HOST"); return !(e && e[0] == '0'); }();
+    if (shift_on_host) {
+        const int src_of[3] = {OTMB_EAST, OTMB_NORTH, OTMB_TOP}, dst_of[3] = {OTMB_WEST, OTMB_SOUTH, OTMB_BOTTOM};
+        const size_t P = (size_t)(nx * ny), X = (size_t)nx;
+        const int nt = G < ((size_t)1 << 16) ? 1 : std::max(2, ctx->xfer_threads > 0 ? ctx->xfer_threads : 8);  // (small grids: inline)
+        std::vector<std::thread> workers;
+        int32_t rc = OTMB_OK;
+        for (int q = 0; q < 3 && rc == OTMB_OK; ++q) {
+            OtmbXferItem it = {dphi[src_of[q]], phi[src_of[q]], G * 8};
+            rc = otmb_xfer(ctx, false, &it, 1);  // (returns when the array is in the caller's memory)
+            if (rc) break;
+            const double *src = phi[src_of[q]];
+            double *dst = phi[dst_of[q]];
+            for (int t = 0; t < nt; ++t) {
+                auto work = [=] {
+                    if (q == 0) {          // west: every row rotated by one cell
+                        const size_t rows = G / X, a = rows * t / nt, b = rows * (t + 1) / nt;
+                        for (size_t r = a; r < b; ++r) {
+                            dst[r * X] = src[r * X + X - 1];
+                            if (X > 1) memcpy(dst + r * X + 1, src + r * X, (X - 1) * 8);
+                        }
+                    } else if (q == 1) {   // south: every level moved up by one row, +0.0 on the first
+                        const size_t a = (size_t)nz * t / nt, b = (size_t)nz * (t + 1) / nt;
+                        for (size_t k = a; k < b; ++k) {
+                            memset(dst + k * P, 0, X * 8);
+                            if (P > X) memcpy(dst + k * P + X, src + k * P, (P - X) * 8);
+                        }
+                    } else {               // bottom: the level below's top, +0.0 at the deepest level
+                        const size_t n = G - P, a = n * t / nt, b = n * (t + 1) / nt;
+                        if (b > a) memcpy(dst + a, src + P + a, (b - a) * 8);
+                        if (t == nt - 1) memset(dst + n, 0, P * 8);
+                    }
+                };
+                if (nt == 1) work();
+                else workers.emplace_back(work);
+            }
+        }
+        for (auto &w : workers) w.join();
+        if (rc) return rc;
+    } else {
+        std::vector<OtmbXferItem> down;
+        for (int f = 0; f < 6; ++f) down.push_back({dphi[f], phi[f], G * 8});
+        TRY(download(ctx, down));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // the staging slots still hold the six arrays: a transportmatrix_plan that is handed these very host arrays back can skip
     // their upload (otmb_ctx_set_reuse_fluxes: the caller's promise that it has not modified them)

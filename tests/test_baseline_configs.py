@@ -311,3 +311,53 @@ def test_access1deg_velocity_fluxes_bgrid_and_device_gridmetrics_at_full_size(ac
         np.testing.assert_allclose(back(asm.dist_edge[k], shp[:2]), rgm.distance_to_edge_2D[d], rtol=1e-12)
         np.testing.assert_allclose(back(asm.dist[k], shp[:2]), rgm.distance_to_neighbour_2D[d], rtol=1e-12, equal_nan=True)
     assert asm.N == int(wet.sum())
+
+
+def test_quarterdeg_host_call_pipelined_equals_two_phase_and_given_operators(oracle):
+    """BASELINE.json configs[2] through the HOST-pointer API (what a Julia caller runs on the 0.25 degree grid, 63.5 M wet cells): the
+    pipelined default (4 depth slabs of the GPU, result arrays sized from the wet mask and -- second slice -- the previous slice's counts)
+    returns the two-phase call's five matrices bit for bit on all fifteen arrays, and with TκH / TκVdeep passed back (the TMIP loop's
+    idiom, src/matrixbuilding.jl:133-147) the same T, Tadv and TκVML, the two objects themselves, and fewer pinned bytes."""
+    import gc
+
+    import torch
+
+    import otmb_amd.api as api
+    from otmb_amd import synthetic_device
+
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    avail_kb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
+    if free < 120e9 or avail_kb < 160e6:
+        pytest.skip(f"needs 120 GB of free HBM and 160 GB of host memory ({free / 1e9:.0f} GB, {avail_kb / 1e6:.0f} GB available)")
+    dg = synthetic_device.make_device_grid("quarterdeg", torch.device("cuda", 0))
+    g, gm = synthetic_device.host_copy(dg)
+    del dg
+    torch.cuda.empty_cache()
+    idx = api.makeindices(gm.v3D)
+    assert idx["N"] > 60_000_000 and api.default_slabs(idx["N"], 75, False, None) == 4
+    phi = api.facefluxesfrommasstransport(umo=g.umo, vmo=g.vmo, gridmetrics=gm, indices=idx)
+    kw = dict(ϕ=phi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, κH=g.kappaH, κVML=g.kappaVML, κVdeep=g.kappaVdeep)
+    two = api.transportmatrix(slabs=0, **kw)
+    pinned = []
+    for call in range(2):  # the first slice at the mask's bounds, the second at the first one's counts + margin
+        pipe = api.transportmatrix(slabs=4, **kw)
+        pinned.append((api.last_call_seconds["result_bytes_pinned"], api.last_call_seconds["result_bytes_used"]))
+        for m in MATS:
+            for a, b, what in zip(tuple(pipe[m]), tuple(two[m]), ("colptr", "rowval", "nzval")):
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.int64), b.view(np.int64)), (m, what, call)
+        del pipe
+        gc.collect()
+    assert pinned[1][0] < pinned[0][0] and pinned[1][1] == pinned[0][1] and pinned[1][0] < 1.08 * pinned[1][1], pinned
+    H, D = two.TκH, two.TκVdeep
+    for call in range(2):
+        giv = api.transportmatrix(slabs=4, TκH=H, TκVdeep=D, reuse_grid=call > 0, **kw)
+        assert giv.TκH is H and giv.TκVdeep is D
+        for m in ("T", "Tadv", "TκVML"):
+            for a, b, what in zip(tuple(giv[m]), tuple(two[m]), ("colptr", "rowval", "nzval")):
+                assert np.array_equal(a.view(np.int64), b.view(np.int64)), (m, what, "given", call)
+        assert api.last_call_seconds["result_bytes_pinned"] < 0.7 * pinned[1][0]
+        del giv
+        gc.collect()
+    del two, H, D, phi
+    gc.collect()

@@ -618,7 +618,7 @@ def test_onepass_into_ordinary_host_memory_and_the_default_rule(oracle, monkeypa
     monkeypatch.delenv("OTMB_HOST_SLABS", raising=False)
     assert api.default_slabs(3_000_000, 50, False, None) == 4 and api.default_slabs(3_000_000, 50, True, None) == 0
     assert api.default_slabs(3_000_000, 50, False, [0, 1]) == 0 and api.default_slabs(100_000, 50, False, None) == 0
-    assert api.default_slabs(3_000_000, 7, False, None) == 0 and api.default_slabs(63_000_000, 75, False, None) == 0
+    assert api.default_slabs(3_000_000, 7, False, None) == 0 and api.default_slabs(63_000_000, 75, False, None) == 4  # (round 6: no upper limit)
     monkeypatch.setenv("OTMB_HOST_SLABS", "0")
     assert api.default_slabs(3_000_000, 50, False, None) == 0
     monkeypatch.setenv("OTMB_HOST_SLABS", "6")
@@ -631,6 +631,40 @@ def test_onepass_into_ordinary_host_memory_and_the_default_rule(oracle, monkeypa
     tm = api.transportmatrix(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, slabs=3)
     for m in MATS:
         assert_csc_equal(tuple(tm[m]), rtm[m], m)
+
+
+@pytest.mark.gpu
+def test_onepass_result_arrays_follow_the_previous_slice_and_recover_when_it_is_outgrown(oracle):
+    """The pipelined call's result arrays: the wet mask's bounds on the first slice (otmb_static_capacity), then the previous slice's counts
+    + 25 / 50 % for Tadv / TκVML -- fewer pinned bytes, the same matrices -- and a slice that outgrows them (OTMB_ERR_CAPACITY inside) is
+    built again at the mask's bounds without the caller noticing."""
+    import otmb_amd.api as api
+    from otmb_amd import synthetic
+
+    g = synthetic.make_grid(70, 40, 12, seed=59, rho="array")
+    gm = gridmetrics_of(g)
+    ref, rphi, rtm = _reference(oracle, g, gm)
+    idx = api.makeindices(gm.v3D)
+    kw = dict(ϕ=rphi, mlotst=g.mlotst, gridmetrics=gm, indices=idx, ρ=g.rho, slabs=3)
+    key, bound = api._capacity_bounds(idx, gm)
+    nnz = [len(rtm[m][1]) for m in MATS]
+    assert all(b >= n for b, n in zip(bound, nnz)) and bound[4] == nnz[4] and sum(bound) < 25 * ref["N"]
+    api._prev_nnz.pop(key, None)
+    sizes = []
+    for call in range(3):
+        tm = api.transportmatrix(**kw)
+        sizes.append((api.last_call_seconds["result_bytes_pinned"], api.last_call_seconds["result_bytes_used"]))
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], f"call {call}: {m}")
+    assert api._prev_nnz[key] == nnz
+    assert sizes[1][0] < sizes[0][0] and sizes[1] == sizes[2] and sizes[1][0] >= sizes[1][1] and sizes[1][0] < 1.15 * sizes[1][1] + 5 * 16 * 4097, sizes
+    # the previous slice is outgrown: pretend it had a tenth of the advective entries
+    api._prev_nnz[key] = [nnz[0], max(1, (nnz[1] - 8000) // 10), nnz[2], nnz[3], nnz[4]]
+    if api._capacities(key, bound)[1] < nnz[1]:
+        tm = api.transportmatrix(**kw)
+        for m in MATS:
+            assert_csc_equal(tuple(tm[m]), rtm[m], f"after the retry: {m}")
+        assert api._prev_nnz[key] == nnz
 
 
 @pytest.mark.gpu

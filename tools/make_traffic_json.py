@@ -20,8 +20,9 @@ dst = sys.argv[1]
 os.makedirs(dst, exist_ok=True)
 # kernel name patterns of the PMC summary -> the names bench.py uses (round 5: the fill pass is tm_kernel<1, 0>, the fused step's variants
 # -- tm_kernel<1, 1 | 2> and the ϕtop-only facefluxes, whose last template argument is true -- get their own entries)
-names = {"tm_kernel<1>": "tm_kernel<fill>", "tm_kernel<1, 0>": "tm_kernel<fill>", "tm_kernel<1, 1>": "tm_kernel<fill, fused>",
-         "tm_kernel<1, 2>": "tm_kernel<fill, fused>", "tm_count_kernel": "tm_count_kernel"}
+# (round 6: one template argument is left -- tm_kernel<0> is the fill pass, <1> / <2> the fused step's with Float64 / Float32 transports)
+names = {"tm_kernel<0>": "tm_kernel<fill>", "tm_kernel<1>": "tm_kernel<fill, fused>", "tm_kernel<2>": "tm_kernel<fill, fused>",
+         "tm_count_kernel": "tm_count_kernel"}
 
 
 def ff_name(k):
