@@ -98,6 +98,8 @@ struct otmb_ctx {
     struct TmStepResult { int32_t status; i64 nnz[5]; };
     std::vector<TmStepResult> tm_hist;  // verdict and nnz of every step since the previous otmb_transportmatrix_result
     bool tm_hist_final = false;      // tm_hist describes a finished pipeline (cleared by the next otmb_transportmatrix_dev)
+    int gm_lds_limit = -1;    // bolus_GM_velocity: LDS bytes the fused kernel may use (-1: not queried yet; 0: use the two streaming kernels)
+    size_t gm_lds_set = 0;    // ... and the dynamic-LDS size its function attribute currently allows
     TmPlan *plan = nullptr;
     // ---- otmb_tm_args.given: is a given TκH / TκVdeep bit for bit what the fill pass derives?  One verdict per operator, keyed to every
     // array address and scalar the answer depends on, and to an epoch that otmb_ctx_forget_given (and every host upload of such an array) bumps.
@@ -188,6 +190,7 @@ void otmb_tm_plan_invalidate(otmb_ctx *ctx);                         // otmb_tra
 void otmb_xfer_free(otmb_ctx *ctx);                                  // otmb_host.hip
 bool otmb_host_is_pinned(const otmb_ctx *ctx, const void *p, size_t bytes);  // otmb_host.hip: inside a block of otmb_host_alloc
 int32_t otmb_tm_plan_query(otmb_ctx *ctx, int64_t *nnz, int64_t *N);  // otmb_transportmatrix.hip
+bool otmb_tm_plan_foreign(otmb_ctx *ctx);                             // otmb_transportmatrix.hip: T of the last plan came out of the sparse adds
 unsigned otmb_tm_plan_skip(otmb_ctx *ctx);                            // otmb_transportmatrix.hip: matrices (bit m) the pending plan does not hand out
 
 #define HIP_TRY(ctx, call)                                                              \

@@ -789,6 +789,9 @@ extern "C" int32_t otmb_push_mask_dev(otmb_ctx *ctx, const double *const phi[6],
         if (!phi[f]) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "phi");
     if (first < 0 || count < 0 || count >= (1ll << 39)) return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // (an array that held the token of a counting facefluxes call and now receives a mask for cells of its own is an ordinary push mask
+    // again -- a partial one if only halo planes are written, but then the counts are still pending and take precedence)
+    if (push_mask == ctx->ffc_partial_mask && !ctx->ffc.valid) ctx->ffc_partial_mask = nullptr;
     int32_t rc = otmb_launch_push_mask(ctx, phi, lwet3d, first, count, push_mask);
     if (rc) return rc;
     HIP_TRY(ctx, hipGetLastError());

@@ -295,8 +295,14 @@ int32_t otmb_makegridmetrics(otmb_ctx *ctx, const double *volcello, const double
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)(nx * ny), G = P * (size_t)nz;
     otmb_tm_plan_invalidate(ctx);
-    // (every staging slot used here is forgotten afterwards: none of them holds what its residency key may say)
+    // (every staging slot used here is forgotten BEFORE it is touched: none of them holds what its residency key may say, whichever way
+    // this function returns -- an early return used to leave keys that named host arrays whose device copies were gone)
     const int in_slots[6] = {ST_RHO, ST_ML, ST_UMO, ST_VMO, ST_LW, ST_LWET};
+    if (ctx->stage_key.size() < (size_t)ST_COUNT) ctx->stage_key.resize(ST_COUNT);
+    for (int q : in_slots) ctx->stage_key[q] = otmb_ctx::StageKey();
+    for (int q : {(int)ST_AREA, (int)ST_V, (int)ST_THK, (int)ST_PHI0, ST_PHI0 + 1, ST_PHI0 + 2, ST_PHI0 + 3, ST_PHI0 + 4}) ctx->stage_key[q] = otmb_ctx::StageKey();
+    for (int d = 0; d < 4; ++d) ctx->stage_key[ST_EDGE0 + d] = ctx->stage_key[ST_DIST0 + d] = otmb_ctx::StageKey();
+    ctx->given_epoch += 1;  // (grid-constant slots are rewritten: verdicts on given operators are keyed to them)
     const void *dvol, *darea, *dlon, *dlat, *dlonv, *dlatv;
     Uploads up;
     TRY(upload(ctx, up, ST_RHO, volcello, G * 8, &dvol));
@@ -441,10 +447,12 @@ int32_t otmb_transportmatrix_fetch(otmb_ctx *ctx, int64_t *const colptr[5], int6
     TRY(otmb_transportmatrix_nnz(ctx, nnz));  // T's count can only shrink (entries that summed to exactly zero)
     for (int m = 0; m < 5; ++m) nnz_out[m] = nnz[m];
     std::vector<OtmbXferItem> down;
-    // row indices (<= N) and column offsets (<= nnz + 1) cross the link as Int32 where they provably fit (otmb_xfer.h: `narrow`)
+    // row indices (<= N) cross the link as Int32 where they provably fit, column offsets as one byte per column -- a column of the matrices the
+    // fill pass writes holds at most 7 entries (otmb_xfer.h: `narrow`); T out of the sparse adds of a foreign build has no such bound
+    const bool t_foreign = otmb_tm_plan_foreign(ctx);
     for (int m = 0; m < 5; ++m) {
         if ((skip >> m) & 1u) continue;
-        down.push_back({dcp[m], colptr[m], (size_t)(N + 1) * 8, nnz_out[m] + 1 < ((int64_t)1 << 31)});
+        down.push_back({dcp[m], colptr[m], (size_t)(N + 1) * 8, (m == 0 && t_foreign) ? (nnz_out[m] + 1 < ((int64_t)1 << 31) ? 1 : 0) : 2});
         if (nnz[m] > 0) {
             down.push_back({drv[m], rowval[m], (size_t)nnz[m] * 8, N < ((int64_t)1 << 31)});
             down.push_back({dnz[m], nzval[m], (size_t)nnz[m] * 8});

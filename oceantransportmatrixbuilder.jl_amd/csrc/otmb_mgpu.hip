@@ -783,7 +783,7 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         const int small_rows = mg->N < ((i64)1 << 31);  // (otmb_xfer.h: `narrow`)
         for (int m = 1; m < 5; ++m) {
             if (!((want >> m) & 1u)) continue;
-            down.push_back({dcp[m], colptr[m] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, mg->nnz[m] + 1 < ((i64)1 << 31)});
+            down.push_back({dcp[m], colptr[m] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, 2});  // (<= 7 entries per column: one byte each)
             if (sl.nnz[m] > 0) {
                 down.push_back({drv[m], rowval[m] + sl.base[m], (size_t)sl.nnz[m] * 8, small_rows});
                 down.push_back({dnz[m], nzval[m] + sl.base[m], (size_t)sl.nnz[m] * 8});
@@ -802,7 +802,9 @@ int32_t otmb_mgpu_transportmatrix_fetch(otmb_mgpu *mg, int64_t *const colptr[5],
         if (hipSetDevice(sl.device) != hipSuccess) { sl.status = OTMB_ERR_HIP; sl.msg = "hipSetDevice"; return; }
         const bool last = s + 1 == n;
         std::vector<OtmbXferItem> down;
-        down.push_back({sl.buf[B_COLPTR0].p, colptr[0] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, mg->nnz[0] + 1 < ((i64)1 << 31)});
+        // (T of a foreign build -- one slab only -- comes out of the sparse adds: no bound on a column's entries, Int32 offsets where they fit)
+        down.push_back({sl.buf[B_COLPTR0].p, colptr[0] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8,
+                        otmb_tm_plan_foreign(sl.ctx) ? (mg->nnz[0] + 1 < ((i64)1 << 31) ? 1 : 0) : 2});
         if (sl.nnz[0] > 0) {
             down.push_back({sl.buf[B_ROWVAL0].p, rowval[0] + tbase[s], (size_t)sl.nnz[0] * 8, mg->N < ((i64)1 << 31)});
             down.push_back({sl.buf[B_NZVAL0].p, nzval[0] + tbase[s], (size_t)sl.nnz[0] * 8});
@@ -952,12 +954,11 @@ int32_t otmb_mgpu_transportmatrix_onepass(otmb_mgpu *mg, const otmb_tm_args *a, 
         stamps[s][4] = now_ms();
         std::vector<OtmbXferItem> down;
         const bool last = s + 1 == n;
-        // row indices (<= N) and column offsets (<= capacity + 1) cross the link as Int32 where they provably fit (otmb_xfer.h: `narrow`)
+        // row indices (<= N) cross the link as Int32 where they provably fit, column offsets as one byte per column (otmb_xfer.h: `narrow`)
         const int small_rows = N < ((i64)1 << 31);
         for (int q = 0; q < 5; ++q) {
             if (!((want >> q) & 1u)) continue;
-            const int small_offs = capacity[q] + 1 < ((i64)1 << 31);
-            down.push_back({dcp[q], colptr[q] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, small_offs});
+            down.push_back({dcp[q], colptr[q] + sl.wet_base, (size_t)(sl.n_own + (last ? 1 : 0)) * 8, 2});
             if (sl.nnz[q] > 0) {
                 down.push_back({drv[q], rowval[q] + sl.base[q], (size_t)sl.nnz[q] * 8, small_rows});
                 down.push_back({dnz[q], nzval[q] + sl.base[q], (size_t)sl.nnz[q] * 8});

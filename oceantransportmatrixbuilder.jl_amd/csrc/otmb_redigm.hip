@@ -155,15 +155,29 @@ extern "C" int32_t otmb_bolus_gm_velocity_dev(otmb_ctx *ctx, const double *rho, 
     const i64 P = nx * ny, G = P * nz;
     int32_t rc;
     const size_t lds = (size_t)2 * nz * GM_COLS * sizeof(double);
-    const char *sw = getenv("OTMB_GM_FUSED");  // (=0: the two streaming kernels, A/B and tests)
-    if (!(sw && sw[0] == '0') && lds <= (size_t)150 * 1024) {
-        if (lds > (size_t)48 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)gm_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        KernelTimer kt(ctx, K_GM);
-        hipLaunchKernelGGL(gm_fused_kernel, dim3((unsigned)((P + GM_COLS - 1) / GM_COLS)), dim3(GM_COLS * GM_GROUPS), lds, ctx->stream, rho, z3d,
-                           wet3d, dist_east, dist_north, (int)nx, (int)ny, (int)nz, P, kappa_gm, maxslope, u, v);
-        HIP_TRY(ctx, hipGetLastError());
-        return OTMB_OK;
+    // the fused kernel keeps κGM·S of a block of columns in LDS: as many levels as the DEVICE's opt-in limit holds (queried once per context,
+    // like the switch OTMB_GM_FUSED=0 -- the two streaming kernels, A/B and tests); if it cannot be launched the two-kernel path below runs
+    if (ctx->gm_lds_limit < 0) {
+        int lim = 0;
+        ctx->gm_lds_limit = (hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && lim > 0) ? lim : 64 * 1024;
+        const char *sw = getenv("OTMB_GM_FUSED");
+        if (sw && sw[0] == '0') ctx->gm_lds_limit = 0;
+    }
+    if (lds <= (size_t)ctx->gm_lds_limit) {
+        bool ok = true;
+        if (lds > (size_t)48 * 1024 && lds > ctx->gm_lds_set) {
+            ok = hipFuncSetAttribute((const void *)gm_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            if (ok) ctx->gm_lds_set = lds;
+        }
+        if (ok) {
+            KernelTimer kt(ctx, K_GM);
+            hipLaunchKernelGGL(gm_fused_kernel, dim3((unsigned)((P + GM_COLS - 1) / GM_COLS)), dim3(GM_COLS * GM_GROUPS), lds, ctx->stream, rho, z3d,
+                               wet3d, dist_east, dist_north, (int)nx, (int)ny, (int)nz, P, kappa_gm, maxslope, u, v);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        if (ok) return OTMB_OK;
+        (void)hipGetLastError();
+        ctx->gm_lds_limit = 0;  // (not on this device: the streaming pair from now on)
     }
     if ((rc = otmb_reserve(ctx, ctx->tfix[1], (size_t)G * 8))) return rc;
     if ((rc = otmb_reserve(ctx, ctx->tfix[2], (size_t)G * 8))) return rc;

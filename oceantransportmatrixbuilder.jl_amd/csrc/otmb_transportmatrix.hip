@@ -1078,6 +1078,7 @@ void otmb_tm_plan_invalidate(otmb_ctx *ctx) {
     if (ctx->plan) ctx->plan->valid = false;
 }
 
+bool otmb_tm_plan_foreign(otmb_ctx *ctx) { return ctx->plan && ctx->plan->foreign && ctx->plan->want_t; }
 // matrices (bit m) the pending plan does not hand out: neither counted nor written -- T alone, given operators
 unsigned otmb_tm_plan_skip(otmb_ctx *ctx) {
     if (!ctx->plan) return 0u;

@@ -19,6 +19,9 @@ struct OtmbXferItem {
     // offsets: it crosses the link as Int32 (a narrowing kernel into a scratch buffer, half the bytes) and the host threads widen it
     // into the Int64 array while the DMA engine is busy with the next pieces.  The host can widen 16 G entries/s with 8 threads
     // (tools/micro/host_widen.cpp), the link moves 7 G Int64 entries/s.  Bit-identical by construction.
+    // narrow = 2 (device -> host only): the array holds COLUMN OFFSETS whose consecutive differences the caller KNOWS to lie in [0, 255] (a column
+    // of the five matrices holds at most 7 entries): the first offset and one BYTE per column cross the link (an eighth of the Int32 form) and the
+    // host threads rebuild the Int64 offsets by a prefix sum.  Bit-identical by construction; OTMB_XFER_NARROW=0 / =1 switch it off.
     int narrow = 0;
 };
 
@@ -47,7 +50,7 @@ struct OtmbXfer {
     char *pin = nullptr;  // NSLOT * chunk bytes of pinned host memory
     hipEvent_t ev[NSLOT] = {};
     OtmbThreadPool *pool = nullptr;
-    int narrow_ok = 1;  // OTMB_XFER_NARROW=0: `narrow` items travel as they are (A/B)
+    int narrow_ok = 2;  // OTMB_XFER_NARROW=0: `narrow` items travel as they are; =1: column offsets as Int32 like row indices (A/B); 2: offsets as byte differences
     size_t narrow_min = (size_t)256 << 10;  // smaller arrays are not worth a kernel and a ring piece
     ~OtmbXfer();
 };

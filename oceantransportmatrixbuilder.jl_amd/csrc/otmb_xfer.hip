@@ -66,7 +66,7 @@ static int32_t xfer_init(otmb_ctx *ctx) {
     if (ctx->xfer) return OTMB_OK;
     OtmbXfer *x = new OtmbXfer();
     if (const char *e = getenv("OTMB_XFER_CHUNK_MB")) x->chunk = (size_t)(atoi(e) > 0 ? atoi(e) : 32) << 20;
-    if (const char *e = getenv("OTMB_XFER_NARROW")) x->narrow_ok = atoi(e) != 0;
+    if (const char *e = getenv("OTMB_XFER_NARROW")) x->narrow_ok = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char *e = getenv("OTMB_XFER_NARROW_MIN_KB")) x->narrow_min = (size_t)(atoi(e) > 0 ? atoi(e) : 1) << 10;  // (tests: small arrays too)
     if (hipHostMalloc((void **)&x->pin, OtmbXfer::NSLOT * x->chunk) != hipSuccess) {
         x->pin = nullptr;
@@ -106,6 +106,36 @@ static void par_widen(OtmbThreadPool *pool, int64_t *dst, const int32_t *src, si
     });
 }
 
+// dst[0 .. count - 2] = src[i + 1] - src[i] as bytes; the host rebuilds out[i + 1] = out[i] + dst[i] from out[0] = first
+static void par_offsets(OtmbThreadPool *pool, int64_t *dst, const uint8_t *diffs, size_t count, int64_t first) {
+    if (count == 0) return;
+    const size_t nd = count - 1;
+    const int parts = (nd >= ((size_t)1 << 18)) ? pool->size() : 1;
+    const size_t per = ((nd + parts - 1) / parts + 1023) & ~(size_t)1023;
+    std::vector<int64_t> sums(parts + 1, 0);
+    pool->parallel_for(parts, [&](int p) {  // pass 1: every slice's total
+        const size_t a = (size_t)p * per, b = (a + per <= nd) ? a + per : nd;
+        int64_t t = 0;
+        for (size_t i = a; i < b; ++i) t += diffs[i];
+        sums[p + 1] = t;
+    });
+    for (int p = 0; p < parts; ++p) sums[p + 1] += sums[p];
+    dst[0] = first;
+    pool->parallel_for(parts, [&](int p) {  // pass 2: the offsets
+        const size_t a = (size_t)p * per, b = (a + per <= nd) ? a + per : nd;
+        int64_t run = first + sums[p];
+        for (size_t i = a; i < b; ++i) { run += diffs[i]; dst[i + 1] = run; }
+    });
+}
+// n offsets -> pieces of `per` differences each: [the piece's first offset, 8 bytes][its differences, one byte each], `stride` bytes apart
+__global__ __launch_bounds__(256) void offsets_to_bytes_kernel(const int64_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n, size_t per, size_t stride) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t p = i / per, r = i - p * per;
+    if (r == 0) *(int64_t *)(dst + p * stride) = src[i];
+    if (i + 1 < n) dst[p * stride + 8 + r] = (uint8_t)(src[i + 1] - src[i]);
+}
+
 __global__ __launch_bounds__(256) void narrow_i64_kernel(const int64_t *__restrict__ src, int32_t *__restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = (int32_t)src[i];
@@ -119,31 +149,51 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
     }
     if ((rc = xfer_init(ctx))) return rc;
     OtmbXfer &x = *ctx->xfer;
-    struct Piece { char *dev, *host; size_t bytes; bool widen; };
+    struct Piece { char *dev, *host; size_t bytes; int widen; size_t count; };  // widen: 0 copy, 1 Int32 -> Int64, 2 first offset + byte differences -> Int64 offsets (ONE piece)
     std::vector<Piece> pieces;
     std::vector<int> direct;  // (device -> host) copies that need no staging: issued BEHIND the first ring pieces, see below
     // narrow items: one scratch buffer of Int32 for all of them, filled by one kernel each on the stream
     size_t narrow_entries = 0;
+    // offsets items (narrow == 2): pieces of `per` byte differences behind their own first offset, one ring slot each.  (With OTMB_XFER_NARROW=1
+    // they travel as they are: Int32 would need a bound on the offsets themselves, which a 0.1 degree matrix passes.)
+    const size_t per = x.chunk - 4096;
+    auto stride_of = [&](size_t cnt) { return (cnt - 1 > per) ? x.chunk : ((8 + (cnt > 1 ? cnt - 1 : 0) + 4095) & ~(size_t)4095); };
+    auto as_bytes = [&](const OtmbXferItem &it) { return it.narrow == 2 && x.narrow_ok >= 2; };
+    auto is_narrow = [&](const OtmbXferItem &it) { return it.bytes >= x.narrow_min && (it.narrow == 1 || as_bytes(it)); };
+    auto byte_pieces = [&](size_t cnt) { return cnt > 1 ? (cnt - 1 + per - 1) / per : (size_t)1; };
     if (!to_device && x.narrow_ok)
         for (int q = 0; q < n; ++q)
-            if (items[q].narrow && items[q].bytes >= x.narrow_min) narrow_entries += items[q].bytes / 8;
+            if (is_narrow(items[q])) narrow_entries += as_bytes(items[q]) ? byte_pieces(items[q].bytes / 8) * (stride_of(items[q].bytes / 8) / 4) + 2 : items[q].bytes / 8;
     if (narrow_entries) {
         if ((rc = otmb_reserve(ctx, ctx->xfer_narrow, narrow_entries * 4))) return rc;
         size_t at = 0;
         for (int q = 0; q < n; ++q) {
-            if (!(items[q].narrow && items[q].bytes >= x.narrow_min)) continue;
+            if (!is_narrow(items[q])) continue;
             const size_t cnt = items[q].bytes / 8;
             int32_t *d32 = (int32_t *)ctx->xfer_narrow.p + at;
+            if (as_bytes(items[q])) {
+                at = (at + 1) & ~(size_t)1;  // (8-byte aligned: every piece starts with its first offset)
+                uint8_t *d8 = (uint8_t *)((int32_t *)ctx->xfer_narrow.p + at);
+                const size_t stride = stride_of(cnt);
+                hipLaunchKernelGGL(offsets_to_bytes_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)items[q].dev, d8, cnt, per, stride);
+                const size_t np_ = byte_pieces(cnt);
+                for (size_t p = 0; p < np_; ++p) {
+                    const size_t a = p * per, b = (a + per + 1 <= cnt) ? a + per + 1 : cnt;  // offsets [a, b): b - a - 1 differences
+                    pieces.push_back({(char *)d8 + p * stride, (char *)((int64_t *)items[q].host + a), 8 + (b - a - 1), 2, b - a});
+                }
+                at += np_ * (stride / 4);
+                continue;
+            }
             hipLaunchKernelGGL(narrow_i64_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)items[q].dev, d32, cnt);
             for (size_t off = 0; off < cnt * 4; off += x.chunk)
-                pieces.push_back({(char *)d32 + off, (char *)items[q].host + 2 * off, (off + x.chunk <= cnt * 4) ? x.chunk : cnt * 4 - off, true});
+                pieces.push_back({(char *)d32 + off, (char *)items[q].host + 2 * off, (off + x.chunk <= cnt * 4) ? x.chunk : cnt * 4 - off, 1, 0});
             at += cnt;
         }
         HIP_TRY(ctx, hipGetLastError());
     }
     for (int q = 0; q < n; ++q) {
         if (!items[q].bytes) continue;
-        if (narrow_entries && items[q].narrow && items[q].bytes >= x.narrow_min) continue;  // (queued above)
+        if (narrow_entries && is_narrow(items[q])) continue;  // (queued above)
         // small arrays: the runtime's own pageable path is fine; arrays inside pinned memory of otmb_host_alloc are the DMA's
         // own source / target: no staging, no host copy
         if (items[q].bytes < ((size_t)256 << 10) || otmb_host_is_pinned(ctx, items[q].host, items[q].bytes)) {
@@ -153,7 +203,7 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
         }
         for (size_t off = 0; off < items[q].bytes; off += x.chunk)
             pieces.push_back({(char *)items[q].dev + off, (char *)items[q].host + off,
-                              (off + x.chunk <= items[q].bytes) ? x.chunk : items[q].bytes - off, false});
+                              (off + x.chunk <= items[q].bytes) ? x.chunk : items[q].bytes - off, 0, 0});
     }
     const int np = (int)pieces.size(), NS = OtmbXfer::NSLOT;
     if (to_device) {
@@ -195,7 +245,8 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
             (*link_free)();
             for (int p = 0; p < np; ++p) {
                 const char *slot = x.pin + (size_t)(p % NS) * x.chunk;
-                if (pieces[p].widen) par_widen(x.pool, (int64_t *)pieces[p].host, (const int32_t *)slot, pieces[p].bytes / 4);
+                if (pieces[p].widen == 2) par_offsets(x.pool, (int64_t *)pieces[p].host, (const uint8_t *)slot + 8, pieces[p].count, *(const int64_t *)slot);
+                else if (pieces[p].widen) par_widen(x.pool, (int64_t *)pieces[p].host, (const int32_t *)slot, pieces[p].bytes / 4);
                 else par_memcpy(x.pool, pieces[p].host, slot, pieces[p].bytes);
             }
             return OTMB_OK;
@@ -203,8 +254,10 @@ int32_t otmb_xfer(otmb_ctx *ctx, bool to_device, const OtmbXferItem *items, int 
         for (int p = 0; p < np; ++p) {
             const int s = p % NS;
             HIP_TRY(ctx, hipEventSynchronize(x.ev[s]));
-            if (pieces[p].widen) par_widen(x.pool, (int64_t *)pieces[p].host, (const int32_t *)(x.pin + (size_t)s * x.chunk), pieces[p].bytes / 4);
-            else par_memcpy(x.pool, pieces[p].host, x.pin + (size_t)s * x.chunk, pieces[p].bytes);
+            const char *slot = x.pin + (size_t)s * x.chunk;
+            if (pieces[p].widen == 2) par_offsets(x.pool, (int64_t *)pieces[p].host, (const uint8_t *)slot + 8, pieces[p].count, *(const int64_t *)slot);
+            else if (pieces[p].widen) par_widen(x.pool, (int64_t *)pieces[p].host, (const int32_t *)slot, pieces[p].bytes / 4);
+            else par_memcpy(x.pool, pieces[p].host, slot, pieces[p].bytes);
             if (issued < np) {
                 if ((rc = issue(issued))) return rc;
                 ++issued;

@@ -38,6 +38,16 @@ for f in glob.glob(root + "/**/*results.json", recursive=True):
             inst[nm].append(x.get("value"))
         for nm, vals in inst.items():
             per[kname][nm].append(vals)
+    if "--per-dispatch" in sys.argv:  # one row per dispatch and counter: the instances' sum, min / max SHARE, busiest over mean
+        for kname, cs in per.items():
+            k = out.setdefault("per_dispatch", {}).setdefault(kname[:80], {})
+            for nm, disp in cs.items():
+                rows = []
+                for v in disp:
+                    tot = float(sum(v)) or 1.0
+                    rows.append({"instances": len(v), "sum": tot, "min_share": min(v) / tot, "max_share": max(v) / tot, "max_over_mean": max(v) * len(v) / tot,
+                                 "stdev_over_mean": (sum((x - tot / len(v)) ** 2 for x in v) / len(v)) ** 0.5 / (tot / len(v))})
+                k[nm] = rows
     for kname, cs in per.items():
         k = out["kernels"].setdefault(kname[:80], {})
         for nm, disp in cs.items():
