@@ -32,6 +32,12 @@ struct TmParams {
     const double *area, *zt, *ml;
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
+    // (round 6) a given TκH that the comparing pass found DERIVED: its values, where they lie, instead of re-deriving them -- the given matrix holds a
+    // column's <= 5 values contiguously (one coalesced run per wave) where re-deriving them takes 5 thkcello and 18 metric loads per column, a third of
+    // the pass's L1 requests.  hcp: the matrix's colptr for this launch's columns (a slab's slice: entries count from hcp[0]), hx: its nzval, hnnz: entries.
+    const i64 *hcp;
+    const double *hx;
+    i64 hnnz;
     unsigned skip;     // bit m: matrix m is evaluated (T is the sum of all four) but neither counted nor written -- otmb_tm_args.only_t (bits 1-4),
                        // a given operator that the fill pass re-derives (otmb_tm_args.given), T itself when a foreign given operator makes it a sparse add
     u64 keep;          // the packed count word's fields of the matrices that ARE counted (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10)
@@ -427,6 +433,7 @@ struct Stencil {
     double tC, tE, tW, tS, tN;
     double eW_c, eE_c, eS_c, eN_c, dW_c, dE_c, dS_c, dN_c, eE_w, dE_w, eW_e, dW_e, eN_s, dN_s, eS_n, dS_n, ar, mld;
     double ztk, zta, ztb;
+    double hg[5];  // (HREAD) the first five entries of the given TκH's column c, in its row order: S, row-mates by index, N -- those that exist
 };
 
 // The regular-cell arithmetic on a Stencil -- THE one copy of it (src/matrixbuilding.jl:193-204, :244-296, :348-415, :426-435,
@@ -436,6 +443,11 @@ struct Stencil {
 // check when the fill pass does it (p.rho_in_fill): a separate branch right after the loads splits the scheduling region and
 // cost 6 % of the kernel (collecting ALL error checks into one branch at the end measured 2 % slower than this).
 #define NEG0 (-0.0)
+// q-th of five values, q known at run time (value selects only: an indexed access would put the array into scratch memory)
+__device__ __forceinline__ double pick5(const double (&g)[5], unsigned q) {
+    return q == 0 ? g[0] : (q == 1 ? g[1] : (q == 2 ? g[2] : (q == 3 ? g[3] : g[4])));
+}
+template <bool HREAD = false>
 __device__ __forceinline__ void column_compute(const TmParams &p, const Stencil &s, int i, int j, int k, i64 c, Column &col) {
     const int nx = p.nx, ny = p.ny, nz = p.nz, up = p.upwind;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
@@ -501,7 +513,24 @@ __device__ __forceinline__ void column_compute(const TmParams &p, const Stencil 
                    ((unsigned)aN << S_N) | ((unsigned)aB << S_B) | ((unsigned)(aA | aS | aW | aE | aN | aB) << S_SELF);
     }
     // ---- TκH (:348-415, :426-435); oppdir = south away from the seam row (:407) ----
-    {
+    if (HREAD) {
+        // the given (derived) matrix's own values: its column holds the rows S, row-mates in index order, N -- those whose cell is wet, and the
+        // diagonal iff any of them is (exactly col.phh / col.bef below, which the comparing pass verified against its colptr / rowval)
+        const unsigned any = (unsigned)(wW | wE | wS | wN);
+        unsigned q = 0;
+        const unsigned qS = q; q += wS;
+        // row-mates: W, SELF, E -- at the periodic wrap SELF, E, W (i == 0) or E, W, SELF (i == nx - 1)
+        const unsigned first_is_E = wrap1, self_first = wrap0;
+        unsigned qW, qC, qE;
+        if (first_is_E) { qE = q; q += wE; qW = q; q += wW; qC = q; q += any; }
+        else if (self_first) { qC = q; q += any; qE = q; q += wE; qW = q; q += wW; }
+        else { qW = q; q += wW; qC = q; q += any; qE = q; q += wE; }
+        const unsigned qN = q;
+        col.hh[S_S] = pick5(s.hg, qS); col.hh[S_WC] = pick5(s.hg, qW); col.hh[S_SELF] = pick5(s.hg, qC); col.hh[S_EC] = pick5(s.hg, qE);
+        col.hh[S_N] = pick5(s.hg, qN);
+        col.hh[S_A] = 0; col.hh[S_B] = 0; col.hh[S_FQ] = 0;
+        col.phh = ((unsigned)wW << S_WC) | ((unsigned)wE << S_EC) | ((unsigned)wS << S_S) | ((unsigned)wN << S_N) | (any << S_SELF);
+    } else {
         double ownW, inW, ownE, inE, ownS, inS, ownN, inN;
         h_pair(p.kH, tC, s.eW_c, s.tW, s.eE_w, s.dW_c, vC, s.dE_w, s.vW, ownW, inW);
         h_pair(p.kH, tC, s.eE_c, s.tE, s.eW_e, s.dE_c, vC, s.dW_e, s.vE, ownE, inE);
@@ -576,9 +605,10 @@ __device__ __forceinline__ i64 ldi(const char *b, unsigned byteoff) { return *(c
 // The two input checks that need no arithmetic (own pushes land in wet cells, ρ[c] is not NaN) are made with the counts
 // (fast_presence / facefluxes_kernel<COUNTS>), not here.
 // Returns whether Lwet3D holds c at the cell itself (the canonical-indices check, loaded with the stencil).
-template <int FUSED = 0>
+// HREAD: TκH's values come from the given matrix (p.hx at the column's offset hq) instead of thkcello and the 2-D metrics.
+template <int FUSED = 0, bool HREAD = false>
 __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &tb, unsigned oC, int i, int j, int k,
-                                            i64 c, Column &col, Stamps &st) {
+                                            i64 c, Column &col, Stamps &st, i64 hq = 0) {
     const int nx = p.nx, ny = p.ny, nz = p.nz;
     const bool hS = j > 0, hN = j + 1 < ny, hA = k > 0, hB = k + 1 < nz;
     const int di_e = (i + 1 < nx) ? 1 : 1 - nx, di_w = (i > 0) ? -1 : nx - 1;
@@ -617,18 +647,29 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
         rC = ldv(tb.rho, oC); rS = ldv(tb.rho, oS); rN = ldv(tb.rho, oN); rA = ldv(tb.rho, oA); rB = ldv(tb.rho, oB);
         rE = ldv(tb.rho, oE); rW = ldv(tb.rho, oW);
     }
-    const double tC = ldv(tb.thk, oC), tE = ldv(tb.thk, oE), tW = ldv(tb.thk, oW), tS = ldv(tb.thk, oS),
-                 tN = ldv(tb.thk, oN);
-    const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
-               *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
-    const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
-               *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
-    const double eW_c = ldv(eWp, s2), eE_c = ldv(eEp, s2), eS_c = ldv(eSp, s2), eN_c = ldv(eNp, s2);
-    const double dW_c = ldv(dWp, s2), dE_c = ldv(dEp, s2), dS_c = ldv(dSp, s2), dN_c = ldv(dNp, s2);
-    const double eE_w = ldv(eEp, sW), dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
-    const double eW_e = ldv(eWp, sE), dW_e = ldv(dWp, sE);
-    const double eN_s = ldv(eNp, sS), dN_s = ldv(dNp, sS);
-    const double eS_n = ldv(eSp, sN), dS_n = ldv(dSp, sN);  // oppdir = south away from the seam row (:407)
+    double hg0 = 0, hg1 = 0, hg2 = 0, hg3 = 0, hg4 = 0;
+    if (HREAD) {  // five consecutive entries from the column's first one (clamped to the array: entries beyond the column are never picked)
+        const i64 last = p.hnnz - 1;
+        const i64 q0 = hq < last ? hq : last, q1 = hq + 1 < last ? hq + 1 : last, q2 = hq + 2 < last ? hq + 2 : last, q3 = hq + 3 < last ? hq + 3 : last,
+                  q4 = hq + 4 < last ? hq + 4 : last;
+        hg0 = p.hx[q0]; hg1 = p.hx[q1]; hg2 = p.hx[q2]; hg3 = p.hx[q3]; hg4 = p.hx[q4];
+    }
+    double tC = 0, tE = 0, tW = 0, tS = 0, tN = 0;
+    double eW_c = 0, eE_c = 0, eS_c = 0, eN_c = 0, dW_c = 0, dE_c = 0, dS_c = 0, dN_c = 0, eE_w = 0, dE_w = 0, eW_e = 0, dW_e = 0, eN_s = 0, dN_s = 0, eS_n = 0, dS_n = 0;
+    if (!HREAD) {
+        tC = ldv(tb.thk, oC); tE = ldv(tb.thk, oE); tW = ldv(tb.thk, oW); tS = ldv(tb.thk, oS);
+        tN = ldv(tb.thk, oN);
+        const char *eWp = (const char *)p.edge[OTMB_DIR_WEST], *eEp = (const char *)p.edge[OTMB_DIR_EAST],
+                   *eSp = (const char *)p.edge[OTMB_DIR_SOUTH], *eNp = (const char *)p.edge[OTMB_DIR_NORTH];
+        const char *dWp = (const char *)p.dist[OTMB_DIR_WEST], *dEp = (const char *)p.dist[OTMB_DIR_EAST],
+                   *dSp = (const char *)p.dist[OTMB_DIR_SOUTH], *dNp = (const char *)p.dist[OTMB_DIR_NORTH];
+        eW_c = ldv(eWp, s2); eE_c = ldv(eEp, s2); eS_c = ldv(eSp, s2); eN_c = ldv(eNp, s2);
+        dW_c = ldv(dWp, s2); dE_c = ldv(dEp, s2); dS_c = ldv(dSp, s2); dN_c = ldv(dNp, s2);
+        eE_w = ldv(eEp, sW); dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
+        eW_e = ldv(eWp, sE); dW_e = ldv(dWp, sE);
+        eN_s = ldv(eNp, sS); dN_s = ldv(dNp, sS);
+        eS_n = ldv(eSp, sN); dS_n = ldv(dSp, sN);  // oppdir = south away from the seam row (:407)
+    }
     const double ar = ldv((const char *)p.area, s2), mld = ldd((const char *)p.ml, s2);
     // zt[k-1], zt[k], zt[k+1]: k is (nearly) uniform in a wave, so the four levels around the wave's first k come through the
     // scalar cache instead of three more vector loads; a wave that spans more than two levels (tiny grids) takes vector loads
@@ -665,7 +706,8 @@ __device__ __forceinline__ bool fast_column(const TmParams &p, const TileBase &t
     s.eW_c = eW_c; s.eE_c = eE_c; s.eS_c = eS_c; s.eN_c = eN_c; s.dW_c = dW_c; s.dE_c = dE_c; s.dS_c = dS_c; s.dN_c = dN_c;
     s.eE_w = eE_w; s.dE_w = dE_w; s.eW_e = eW_e; s.dW_e = dW_e; s.eN_s = eN_s; s.dN_s = dN_s; s.eS_n = eS_n; s.dS_n = dS_n;
     s.ar = ar; s.mld = mld; s.ztk = ztk; s.zta = zta; s.ztb = ztb;
-    column_compute(p, s, i, j, k, c, col);
+    s.hg[0] = hg0; s.hg[1] = hg1; s.hg[2] = hg2; s.hg[3] = hg3; s.hg[4] = hg4;
+    column_compute<HREAD>(p, s, i, j, k, c, col);
     return lC == c;
 }
 

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
 
 static_assert(TM_THREADS == (1 << FFC_TILE_SHIFT), "the counts in facefluxes are per tile of TM_THREADS columns");
 
-template <int FUSED = 0>  // FUSED: the fused step's fill pass (otmb_step_dev): five of the six fluxes re-derived from umo / vmo / ϕtop (1 Float64, 2 Float32)
+// FUSED: the fused step's fill pass (otmb_step_dev): five of the six fluxes re-derived from umo / vmo / ϕtop (1 Float64, 2 Float32).
+// HREAD: a given, derived TκH (otmb_tm_args.given) is READ where it lies instead of re-derived (TmParams.hcp / hx): fewer L1 requests per column.
+template <int FUSED = 0, bool HREAD = false>
 __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
@@ -209,6 +211,8 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 Lnext_own = (wcl + 1 < p.n_own) ? Lnext_ld : p.G;
     const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
+    i64 hq = 0;
+    if (HREAD) hq = p.hcp[wcl] - p.hcp[0];  // (with the index loads: the column's first entry in the given TκH)
     unsigned pre_sum = 0;
     i64 pre_off = 0;
     if (tid < TM_NF) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
             bool canonical;
             const bool regular = (p.nx >= 3) && !(p.topo == OTMB_TRIPOLAR && cell.j == p.ny - 1);
             {
-                if (regular) canonical = fast_column<FUSED>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st);  // (the value-free input checks ran with the counts)
+                if (regular) canonical = fast_column<FUSED, HREAD>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st, hq);  // (the value-free input checks ran with the counts)
                 else {
                     canonical = ldi(tb.lw, oC) == c;
                     if (canonical) build_column(p, cell, c, col);
@@ -747,6 +751,22 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
 
 
 // ---- host side ------------------------------------------------------------------------------
+// One launch site for the fill pass's instantiations: FUSED (the fused step's flux re-derivation) x HREAD (a given, derived TκH read where it
+// lies; OTMB_GIVEN_READ=0 re-derives it instead: A/B).
+static void launch_fill(otmb_ctx *ctx, const TmParams &p, int fused) {
+    static const bool env_read = [] { const char *e = getenv("OTMB_GIVEN_READ"); return !(e && e[0] == '0'); }();
+    const bool hread = env_read && p.hcp != nullptr && p.nx >= 3;
+    const dim3 grid(xcd_grid(p.nt_order, p.nheavy)), block(TM_THREADS);
+    if (hread) {
+        if (fused == 1) hipLaunchKernelGGL((tm_kernel<1, true>), grid, block, 0, ctx->stream, p);
+        else if (fused == 2) hipLaunchKernelGGL((tm_kernel<2, true>), grid, block, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((tm_kernel<0, true>), grid, block, 0, ctx->stream, p);
+    } else {
+        if (fused == 1) hipLaunchKernelGGL((tm_kernel<1, false>), grid, block, 0, ctx->stream, p);
+        else if (fused == 2) hipLaunchKernelGGL((tm_kernel<2, false>), grid, block, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((tm_kernel<0, false>), grid, block, 0, ctx->stream, p);
+    }
+}
 static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
     for (int f = 0; f < 6; ++f) p.phi[f] = a.phi[f];
@@ -757,6 +777,10 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.kH = a.kappa_h; p.kML = a.kappa_vml; p.kDeep = a.kappa_vdeep;
     p.nx = (int)a.nx; p.ny = (int)a.ny; p.nz = (int)a.nz; p.topo = a.topology; p.upwind = a.upwind;
     p.skip = pl ? pl->skip : ((a.only_t ? 0x1eu : 0u) | ((unsigned)a.skip_ops & 0x1fu));
+    p.hcp = nullptr; p.hx = nullptr; p.hnnz = 0;
+    if (pl && ((pl->derived >> OTMB_TKH) & 1u) && a.given[OTMB_TKH].nnz > 0) {  // (read by the HREAD fill kernels only)
+        p.hcp = (const i64 *)a.given[OTMB_TKH].colptr; p.hx = a.given[OTMB_TKH].nzval; p.hnnz = a.given[OTMB_TKH].nnz;
+    }
     p.keep = keep_mask(p.skip);
     p.P = a.nx * a.ny; p.G = p.P * a.nz;
     p.n_own = a.n_wet;
@@ -1193,7 +1217,7 @@ int32_t otmb_transportmatrix_fill_dev(otmb_ctx *ctx, int64_t *const colptr[5], i
     if (pl.ntiles > 0) {
         if ((rc = build_tile_order(ctx, pl.args, pl.ntiles, p))) return rc;
         KernelTimer kt(ctx, K_TM_FILL);
-        hipLaunchKernelGGL(tm_kernel<0>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+        launch_fill(ctx, p, 0);
     }
     if (pl.ntiles == 0) {  // (otherwise the fill kernel's last tile writes the closing colptr entries)
         KernelTimer kt(ctx, K_TM_FINISH);
@@ -1375,9 +1399,7 @@ static int32_t transportmatrix_dev_impl(otmb_ctx *ctx, const otmb_tm_args *a, in
 #endif
             if ((rc = build_tile_order(ctx, *a, ntiles, p))) return rc;
             KernelTimer kt(ctx, K_TM_FILL);
-            if (fu.kind == 1) hipLaunchKernelGGL(tm_kernel<1>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
-            else if (fu.kind == 2) hipLaunchKernelGGL(tm_kernel<2>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
-            else hipLaunchKernelGGL(tm_kernel<0>, dim3(xcd_grid(p.nt_order, p.nheavy)), dim3(TM_THREADS), 0, ctx->stream, p);
+            launch_fill(ctx, p, fu.kind);
         }
     }
     HIP_TRY(ctx, hipGetLastError());

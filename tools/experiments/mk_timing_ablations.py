@@ -45,22 +45,22 @@ __device__ __forceinline__ double ldv(const char *b, unsigned byteoff) { return 
         rE = ldv(tb.rho, oE); rW = ldv(tb.rho, oW);
 #endif
 """),
-("""    const double tC = ldv(tb.thk, oC), tE = ldv(tb.thk, oE), tW = ldv(tb.thk, oW), tS = ldv(tb.thk, oS),
-                 tN = ldv(tb.thk, oN);
+("""        tC = ldv(tb.thk, oC); tE = ldv(tb.thk, oE); tW = ldv(tb.thk, oW); tS = ldv(tb.thk, oS);
+        tN = ldv(tb.thk, oN);
 ""","""#ifdef OTMB_DBG_NOEW
-    const double tC = ldv(tb.thk, oC), tE = tC, tW = tC, tS = ldv(tb.thk, oS), tN = ldv(tb.thk, oN);
+        tC = ldv(tb.thk, oC); tE = tC; tW = tC; tS = ldv(tb.thk, oS); tN = ldv(tb.thk, oN);
 #else
-    const double tC = ldv(tb.thk, oC), tE = ldv(tb.thk, oE), tW = ldv(tb.thk, oW), tS = ldv(tb.thk, oS),
-                 tN = ldv(tb.thk, oN);
+        tC = ldv(tb.thk, oC); tE = ldv(tb.thk, oE); tW = ldv(tb.thk, oW); tS = ldv(tb.thk, oS);
+        tN = ldv(tb.thk, oN);
 #endif
 """),
-("""    const double eE_w = ldv(eEp, sW), dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
-    const double eW_e = ldv(eWp, sE), dW_e = ldv(dWp, sE);
+("""        eE_w = ldv(eEp, sW); dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
+        eW_e = ldv(eWp, sE); dW_e = ldv(dWp, sE);
 ""","""#ifdef OTMB_DBG_NOEW
-    const double eE_w = eE_c, dE_w = dE_c, eW_e = eW_c, dW_e = dW_c;
+        eE_w = eE_c; dE_w = dE_c; eW_e = eW_c; dW_e = dW_c;
 #else
-    const double eE_w = ldv(eEp, sW), dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
-    const double eW_e = ldv(eWp, sE), dW_e = ldv(dWp, sE);
+        eE_w = ldv(eEp, sW); dE_w = ldv(dEp, sW);  // west cell's east edge / distance to its east nbr
+        eW_e = ldv(eWp, sE); dW_e = ldv(dWp, sE);
 #endif
 """),
 ])

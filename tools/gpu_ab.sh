@@ -8,7 +8,7 @@
 set -o pipefail
 TAG=$1; ROUNDS=$2; WL=$3; STEPS=$4; shift 4
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/r05
+OUT=$REPO/gpurun_out/${OTMB_AB_DIR:-r06}
 mkdir -p "$OUT"
 cd "$REPO" || exit 1
 for r in $(seq 1 "$ROUNDS"); do
