@@ -8,7 +8,10 @@
 
 #define FF_THREADS 64
 #ifndef FF_KB
-#define FF_KB 6  // levels per chunk (two chunks are live: the one being processed and the one in flight)
+// levels per chunk (two chunks are live: the one being processed and the one in flight).  Round 6: 6 -> 3.  The counting kernels needed 184-202 VGPRs
+// with six levels (two waves per SIMD) and 119-128 with three (four waves); the march is a chain of dependent instructions, so the waves next to it are
+// what fills the issue slots: the fused step's facefluxes 0.897 -> 0.64 ms at 0.25 degree, everything else unchanged (profiles/r06/call12_ffkb_*.jsonl).
+#define FF_KB 3
 #endif
 
 // replace(x, NaN => 0.0, FillValue => 0.0) -- isequal semantics (:203, :215)
