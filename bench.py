@@ -560,6 +560,8 @@ def traffic_for(workload, kernel, args, world=1):
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if world != 1 or args.rho != "array" or tj.get("kernel_source_sha16") != kernel_source_hash():
             return None
+        if getattr(args, "given_ops", False):  # the profiling run with TκH and TκVdeep passed in: its own PMC passes, its own kernel variant
+            workload, kernel = workload + "_given", {"tm_kernel<fill>": "tm_kernel<fill, TκH read>"}.get(kernel, kernel)
         return tj.get("workloads", {}).get(workload, {}).get(kernel, {}).get("traffic_bytes")
     except (OSError, ValueError):
         return None
@@ -821,14 +823,42 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
                     gms = 1e3 * float(np.median(reps)) / args.steps
                     fill_ms = gk["tm_kernel<fill>"][0] / gk["tm_kernel<fill>"][1]
                     same = asm.nnz[0] == full_nnz[0] and asm.nnz[1] == full_nnz[1] and asm.nnz[3] == full_nnz[3]
+                    checks = int(asm.lib.otmb_ctx_given_checks(asm.ctx.handle))
+                    # ... and the same two operators as a caller holds them who built them with ANOTHER κ (the call's own κH / κVdeep left at their
+                    # defaults): the derived rows, other values -- the fill pass reads both where they lie (tm_kernel<., 3>)
+                    other = None
+                    try:
+                        ops["TκH"][2].mul_(0.5); ops["TκVdeep"][2].mul_(3.0)  # (in place: the assembler tells the library to look again)
+                        for _ in range(2):
+                            asm.step_async(umo, vmo, fill)
+                        asm.finish()
+                        ostates = [asm.ctx.given_state(MATS.index(m)) for m in ("TκH", "TκVdeep")]
+                        barrier()
+                        t0 = time.perf_counter()
+                        for _ in range(args.steps):
+                            asm.step_async(umo, vmo, fill)
+                        asm.finish()
+                        barrier()
+                        oms = 1e3 * (time.perf_counter() - t0) / args.steps
+                        asm.ctx.timing_enable(True)
+                        for _ in range(args.steps):
+                            asm.step_async(umo, vmo, fill)
+                        asm.finish()
+                        ok_ = asm.ctx.timing_collect()
+                        asm.ctx.timing_enable(False)
+                        other = {"what": "the two operators built with another κ (derived rows, other values): read by the fill pass, no sparse add, every protocol",
+                                 "given_state": ostates, "ms_per_step": oms, "kernels_ms": {k: round(v[0] / v[1], 5) for k, v in ok_.items()}}
+                    except Exception as e:  # an extra record must never cost the line
+                        other = {"error": f"{type(e).__name__}: {e}"[:200]}
                     return {"what": "transportmatrix with TκH and TκVdeep GIVEN (otmb_tm_args.given; src/matrixbuilding.jl:133-147), device resident, two-call "
-                                    "path; an extra record, NOT the headline: the two operators are neither counted, written nor read -- the fill pass "
-                                    "re-derives their values in registers (verdict of ONE comparing pass, cached) and T is the same bit for bit",
-                            "given_state": dict(zip(("TκH", "TκVdeep"), ("derived" if q == 1 else "foreign" if q == 2 else "not given" for q in states))),
+                                    "path; an extra record, NOT the headline: the two operators are neither counted nor written -- the fill pass reads TκH's "
+                                    "values where they lie and re-derives TκVdeep's in registers (verdict of ONE comparing pass, cached); T is the same bit for bit",
+                            "other_kappa": other,
+                            "given_state": dict(zip(("TκH", "TκVdeep"), ("derived" if q == 1 else "foreign" if q == 2 else "derived rows, other values" if q == 3 else "not given" for q in states))),
                             "ms_per_step": gms, "wet_cells_per_s": asm.N / (gms * 1e-3), "kernels_ms": {k: round(v[0] / v[1], 5) for k, v in gk.items()},
                             "fill_bytes": {"read": r, "written": w, "total": r + w, "full_build_total": full_r + full_w},
                             "fill_gbs": (r + w) / (fill_ms * 1e-3) / 1e9, "fill_frac_of_hbm_peak": (r + w) / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "nnz_T_Tadv_TkVML_as_in_the_full_build": bool(same), "comparing_passes": int(asm.lib.otmb_ctx_given_checks(asm.ctx.handle))}
+                            "nnz_T_Tadv_TkVML_as_in_the_full_build": bool(same), "comparing_passes": checks}
                 finally:
                     asm.set_given(TκH=None, TκVdeep=None)
                     asm.step_async(umo, vmo, fill)  # (the full build again: the roofline record below reads this object's nnz and matrices)

@@ -346,9 +346,13 @@ typedef struct {
                                   *    what this library derives for these gridmetrics / indices / κ ("derived": checked on the device by
                                   *    one pass that compares instead of stores, the verdict kept per context and operator until one of
                                   *    the arrays it names changes -- otmb_ctx_forget_given) is re-derived in registers by the fill pass:
-                                  *    its 16 nnz + 8 (N + 1) bytes are neither read nor written (29 % of the fill pass's bytes at 1 degree
-                                  *    for TκH + TκVdeep, 40 % of the bytes a host caller waits for).
-                                  *  - any other given matrix (another κ, another pattern, Tadv, TκVML) is "foreign": the built operators
+                                  *    its 16 nnz + 8 (N + 1) bytes are not written (29 % of the fill pass's bytes at 1 degree for
+                                  *    TκH + TκVdeep, 40 % of the bytes a host caller waits for); TκH's values are read where they lie when
+                                  *    that is cheaper than re-deriving them.
+                                  *  - A given TκH / TκVdeep with exactly the derived ROWS and other values -- built with another κ, which is
+                                  *    what a caller passes who leaves the call's own κH / κVdeep at their defaults -- is treated alike, and
+                                  *    the fill pass READS its values where they lie: T carries the given values, in every protocol.
+                                  *  - any other given matrix (another pattern, Tadv, TκVML) is "foreign": the built operators
                                   *    are written as usual and T is formed by the device sparse add (otmb_spadd_*_dev: left fold, exact
                                   *    zeros dropped) from the given arrays where they lie.  Two-phase entry points only
                                   *    (otmb_transportmatrix_plan[_dev] + fill / fetch: the plan's nnz[0] is then the sum of the four
@@ -360,7 +364,8 @@ typedef struct {
  * A device-resident caller that rewrites one of those arrays in place calls this before the next transportmatrix; the host-pointer
  * entry points do it themselves whenever they upload such an array (i.e. always, unless otmb_ctx_set_reuse_grid promises otherwise). */
 int32_t otmb_ctx_forget_given(otmb_ctx *ctx);
-/* Diagnostics: how the last plan / _dev call on this context treated operator m: 0 not given, 1 given and derived, 2 given and foreign. */
+/* Diagnostics: how the last plan / _dev call on this context treated operator m: 0 not given, 1 given and derived, 2 given and foreign,
+ * 3 given with the derived rows and other values (read by the fill pass). */
 int32_t otmb_ctx_given_state(const otmb_ctx *ctx, int32_t m);
 /* ... and how many comparing passes the context has run so far (a time loop with resident arrays runs ONE). */
 int64_t otmb_ctx_given_checks(const otmb_ctx *ctx);

@@ -301,7 +301,7 @@ class Context:
         self.check(self._lib.otmb_ctx_forget_given(self._h))
 
     def given_state(self, m):
-        """How the last plan / _dev call treated operator m (index into MATS): 0 not given, 1 given and derived, 2 given and foreign."""
+        """How the last plan / _dev call treated operator m (index into MATS): 0 not given, 1 given and derived, 2 given and foreign, 3 given with the derived rows and other values (another κ: read by the fill pass)."""
         return int(self._lib.otmb_ctx_given_state(self._h, int(m)))
 
     def use_own_stream(self):

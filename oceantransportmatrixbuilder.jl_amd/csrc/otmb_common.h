@@ -104,7 +104,7 @@ struct otmb_ctx {
     // ---- otmb_tm_args.given: is a given TκH / TκVdeep bit for bit what the fill pass derives?  One verdict per operator, keyed to every
     // array address and scalar the answer depends on, and to an epoch that otmb_ctx_forget_given (and every host upload of such an array) bumps.
     struct GivenVerdict {
-        bool valid = false, derived = false;
+        bool valid = false, derived = false, pattern = false;  // pattern: the same rows in the same order, other values (another κ)
         uint64_t epoch = 0;
         otmb_csc g = {nullptr, nullptr, nullptr, 0};
         const void *lwet3d = nullptr, *lwet = nullptr, *v3d = nullptr, *thk = nullptr, *edge[4] = {nullptr, nullptr, nullptr, nullptr},
@@ -114,7 +114,7 @@ struct otmb_ctx {
         double kappa = 0.0;
     } given_verdict[5];
     uint64_t given_epoch = 1;
-    int given_state[5] = {0, 0, 0, 0, 0};  // the last plan's treatment of operator m: 0 not given, 1 derived, 2 foreign (otmb_ctx_given_state)
+    int given_state[5] = {0, 0, 0, 0, 0};  // the last plan's treatment of operator m: 0 not given, 1 derived, 2 foreign, 3 derived pattern with other values (otmb_ctx_given_state)
     long given_checks = 0;                 // comparing passes run so far (tests: the verdict is cached)
     DevBuf given_tmp[6];                   // temporaries of the foreign path's sparse adds: two (colptr, rowval, nzval) triples
     CooPlan coo;

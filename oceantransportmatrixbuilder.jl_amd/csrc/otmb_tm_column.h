@@ -38,6 +38,12 @@ struct TmParams {
     const i64 *hcp;
     const double *hx;
     i64 hnnz;
+    // ... and a given TκVdeep whose ROWS are the derived ones but whose values are not (built with another κVdeep): its values are read (the DREAD
+    // instantiations of the fill kernel) and enter T in place of the derived ones.  (A TκH of that kind is read by the HREAD kernels, seam row included.)
+    const i64 *dcp;
+    const double *dx;
+    i64 dnnz;
+    int hmust;         // (host side) the given TκH's values are NOT the derived ones: reading them is not a choice (launch_fill)
     unsigned skip;     // bit m: matrix m is evaluated (T is the sum of all four) but neither counted nor written -- otmb_tm_args.only_t (bits 1-4),
                        // a given operator that the fill pass re-derives (otmb_tm_args.given), T itself when a foreign given operator makes it a sparse add
     u64 keep;          // the packed count word's fields of the matrices that ARE counted (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10)
@@ -795,6 +801,20 @@ __device__ __forceinline__ void general_presence(const TmParams &p, const Cell &
     const bool omC = ztk < mld;
     const bool mlB = wB & omC & (ztb < mld), mlA = wA & omC & (zta < mld);
     pml = ((unsigned)mlB << S_B) | ((unsigned)mlA << S_A) | ((unsigned)(mlA | mlB) << S_SELF);
+}
+
+// Values of a given operator read where they lie: the given column holds the derived column's rows in the derived order (the comparing
+// pass verified it), so slot s's entry is the popc(present & bef[s])-th of the column, which starts at entry q0 of x.
+template <unsigned SLOTS>
+__device__ __forceinline__ void given_values(double (&val)[NSLOT], unsigned pres, const unsigned (&bef)[NSLOT], const double *__restrict__ x, i64 q0, i64 nnz) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        if (!((SLOTS >> s) & 1u)) continue;
+        i64 q = q0 + (i64)__popc(pres & bef[s]);
+        q = q < nnz ? q : nnz - 1;  // (slots that are absent are never used; a verified column never reaches the clamp)
+        const double g = x[q];
+        val[s] = ((pres >> s) & 1u) ? g : val[s];
+    }
 }
 
 // T[r,c] = ((Tadv + TκH) + TκVML) + TκVdeep, absent operand = +0.0 (:147, map(+) semantics)

@@ -48,6 +48,7 @@ struct TmPlan {
     // otmb_tm_args.given: operators the caller passes (bit m).  derived: bit for bit what the fill pass computes -- re-derived in registers, not
     // materialised; foreign: any other matrix -- T is then the device sparse add of the four operands (two-phase protocol only)
     unsigned given = 0, derived = 0, foreign = 0;
+    unsigned read = 0;         // (subset of derived) the derived ROWS with other values: not materialised either, but the fill pass reads the values
     unsigned skip = 0;         // matrices the kernels neither count nor write (TmParams.skip)
     bool want_t = true;        // the caller wants T (otmb_tm_args.skip_ops bit 0 clear)
     i64 built_nnz[5] = {0, 0, 0, 0, 0};  // (foreign) the counts of the matrices the kernel writes; nnz[0] is then the sparse adds' bound
@@ -162,9 +163,13 @@ __global__ __launch_bounds__(TM_THREADS) void tm_count_kernel(const TmParams p, 
 static_assert(TM_THREADS == (1 << FFC_TILE_SHIFT), "the counts in facefluxes are per tile of TM_THREADS columns");
 
 // FUSED: the fused step's fill pass (otmb_step_dev): five of the six fluxes re-derived from umo / vmo / ϕtop (1 Float64, 2 Float32).
-// HREAD: a given, derived TκH (otmb_tm_args.given) is READ where it lies instead of re-derived (TmParams.hcp / hx): fewer L1 requests per column.
-template <int FUSED = 0, bool HREAD = false>
+// GIVEN (otmb_tm_args.given), bit 0 -- HREAD: a given TκH with the derived rows is READ where it lies instead of re-derived (TmParams.hcp / hx):
+// fewer L1 requests per column when its values are the derived ones, the only way when they are not (another κH); bit 1 -- DREAD: a given
+// TκVdeep with the derived rows and OTHER values (another κVdeep) is read likewise (TmParams.dcp / dx).  Instantiations, not branches: a uniform
+// branch on dx in the default kernel measured +1 ... 2 % (profiles/r06/call17_dx_*.jsonl).
+template <int FUSED = 0, int GIVEN = 0>
 __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const TmParams p) {
+    constexpr bool HREAD = (GIVEN & 1) != 0, DREAD = (GIVEN & 2) != 0;
     __shared__ u64 wave_tot[TM_THREADS / 64];
     __shared__ i64 s_prefix[TM_NF];
     __shared__ unsigned s_presum[TM_NF];
@@ -211,8 +216,9 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 Lnext_own = (wcl + 1 < p.n_own) ? Lnext_ld : p.G;
     const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
-    i64 hq = 0;
+    i64 hq = 0, dq = 0;
     if (HREAD) hq = p.hcp[wcl] - p.hcp[0];  // (with the index loads: the column's first entry in the given TκH)
+    if (DREAD) dq = p.dcp[wcl] - p.dcp[0];
     unsigned pre_sum = 0;
     i64 pre_off = 0;
     if (tid < TM_NF) {
@@ -279,13 +285,18 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
                 if (regular) canonical = fast_column<FUSED, HREAD>(p, tb, oC, cell.i, cell.j, cell.k, c, col, st, hq);  // (the value-free input checks ran with the counts)
                 else {
                     canonical = ldi(tb.lw, oC) == c;
-                    if (canonical) build_column(p, cell, c, col);
+                    if (canonical) {
+                        build_column(p, cell, c, col);
+                        // (seam row, nx < 3: the generic builder derived TκH's values; the given ones take their place)
+                        if (HREAD) given_values<(1u << S_S) | (1u << S_SELF) | (1u << S_EC) | (1u << S_WC) | (1u << S_FQ) | (1u << S_N)>(col.hh, col.phh, col.bef, p.hx, hq, p.hnnz);
+                    }
                 }
             }
             if (!canonical) {
                 raise_flag(p.flags, FLAG_NONCANONICAL);
             } else {
                 live = true;
+                if (DREAD) given_values<(1u << S_A) | (1u << S_SELF) | (1u << S_B)>(col.dp, col.pdp, col.bef, p.dx, dq, p.dnnz);
                 const unsigned uni = col.padv | col.phh | col.pml | col.pdp;
                 nU = __popc(uni);
                 nA = __popc(col.padv); nH = __popc(col.phh); nM = __popc(col.pml); nD = __popc(col.pdp);
@@ -474,9 +485,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
 // ---- otmb_tm_args.given: the COMPARING pass ------------------------------------------------------------------------------------
 // Is a given operator bit for bit what the fill pass would write?  One thread per column builds the column exactly as tm_kernel does
 // (fast_column / build_column: the one copy of the arithmetic) and, for every operator m in g.check, reads the given matrix's column:
-// same length, same rows in the same order, same value BITS (-0.0 is not +0.0, a NaN equals itself).  The given arrays may be a depth
+// same length, same rows in the same order (else: bit m of the verdict), same value BITS (-0.0 is not +0.0, a NaN equals itself; else: bit 8 + m --
+// the derived PATTERN with other values, e.g. built with another κ: the fill pass can still read it).  The given arrays may be a depth
 // slab's slice: column w holds entries [colptr[w] - colptr[0], colptr[w + 1] - colptr[0]) of rowval / nzval.  Nothing is stored but
-// the verdict: bit m of flags[FLAG_GIVEN_MISMATCH].  Once per grid and κ (the verdict is cached), so plain wet-rank order, no staging.
+// the verdict in flags[FLAG_GIVEN_MISMATCH].  Once per grid and κ (the verdict is cached), so plain wet-rank order, no staging.
 struct GivenCmp {
     const i64 *cp[5], *ri[5], *vx[5];  // the given matrices' colptr / rowval / nzval (value bits)
     i64 nnz[5];
@@ -529,13 +541,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_given_kernel
     }
     const unsigned vslots = (1u << S_A) | (1u << S_SELF) | (1u << S_B);
     const unsigned pm[5] = {0u, col.padv, col.phh, col.pml & vslots, col.pdp & vslots};
-    unsigned bad = 0;
+    unsigned bad = 0;  // bit m: the column's length or rows differ; bit 8 + m: only values do
 #pragma unroll
     for (int m = 1; m < TM_NF; ++m) {
         if (!((g.check >> m) & 1u)) continue;
         const i64 c0 = g.cp[m][0];
         const i64 lo = g.cp[m][w] - c0, hi = g.cp[m][w + 1] - c0;
-        bool ok = lo >= 0 && hi <= g.nnz[m] && hi - lo == (i64)__popc(pm[m]);
+        bool ok = lo >= 0 && hi <= g.nnz[m] && hi - lo == (i64)__popc(pm[m]), same = true;
         if (w == p.n_own - 1) ok &= hi == g.nnz[m];
         if (ok) {
 #pragma unroll
@@ -543,11 +555,13 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_given_kernel
                 if ((pm[m] >> sl) & 1u) {
                     const i64 q = lo + (i64)__popc(pm[m] & col.bef[sl]);
                     const double v = (m == 1) ? col.adv[sl] : (m == 2) ? col.hh[sl] : (m == 3) ? col.ml[sl] : col.dp[sl];
-                    ok &= (g.ri[m][q] == col.idx[sl]) & (g.vx[m][q] == __double_as_longlong(v));
+                    ok &= g.ri[m][q] == col.idx[sl];
+                    same &= g.vx[m][q] == __double_as_longlong(v);
                 }
             }
         }
         if (!ok) bad |= 1u << m;
+        else if (!same) bad |= 0x100u << m;
     }
     if (bad) atomicOr(&p.flags[FLAG_GIVEN_MISMATCH], (int)bad);
 }
@@ -751,21 +765,21 @@ static int32_t build_tile_order(otmb_ctx *ctx, const otmb_tm_args &a, i64 ntiles
 
 
 // ---- host side ------------------------------------------------------------------------------
-// One launch site for the fill pass's instantiations: FUSED (the fused step's flux re-derivation) x HREAD (a given, derived TκH read where it
-// lies; OTMB_GIVEN_READ=0 re-derives it instead: A/B).
+// One launch site for the fill pass's instantiations: FUSED (the fused step's flux re-derivation) x GIVEN (a given TκH / TκVdeep read where it lies).
+template <int GIVEN> static void launch_fill_given(otmb_ctx *ctx, const TmParams &p, int fused, dim3 grid, dim3 block) {
+    if (fused == 1) hipLaunchKernelGGL((tm_kernel<1, GIVEN>), grid, block, 0, ctx->stream, p);
+    else if (fused == 2) hipLaunchKernelGGL((tm_kernel<2, GIVEN>), grid, block, 0, ctx->stream, p);
+    else hipLaunchKernelGGL((tm_kernel<0, GIVEN>), grid, block, 0, ctx->stream, p);
+}
 static void launch_fill(otmb_ctx *ctx, const TmParams &p, int fused) {
     static const bool env_read = [] { const char *e = getenv("OTMB_GIVEN_READ"); return !(e && e[0] == '0'); }();
-    const bool hread = env_read && p.hcp != nullptr && p.nx >= 3;
+    // (a derived TκH: reading is a choice -- regular cells only, OTMB_GIVEN_READ=0 re-derives; the derived rows with other values: it is the only way)
+    const bool hread = p.hcp != nullptr && (p.hmust || (env_read && p.nx >= 3)), dread = p.dcp != nullptr;
     const dim3 grid(xcd_grid(p.nt_order, p.nheavy)), block(TM_THREADS);
-    if (hread) {
-        if (fused == 1) hipLaunchKernelGGL((tm_kernel<1, true>), grid, block, 0, ctx->stream, p);
-        else if (fused == 2) hipLaunchKernelGGL((tm_kernel<2, true>), grid, block, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((tm_kernel<0, true>), grid, block, 0, ctx->stream, p);
-    } else {
-        if (fused == 1) hipLaunchKernelGGL((tm_kernel<1, false>), grid, block, 0, ctx->stream, p);
-        else if (fused == 2) hipLaunchKernelGGL((tm_kernel<2, false>), grid, block, 0, ctx->stream, p);
-        else hipLaunchKernelGGL((tm_kernel<0, false>), grid, block, 0, ctx->stream, p);
-    }
+    if (hread && dread) launch_fill_given<3>(ctx, p, fused, grid, block);
+    else if (dread) launch_fill_given<2>(ctx, p, fused, grid, block);
+    else if (hread) launch_fill_given<1>(ctx, p, fused, grid, block);
+    else launch_fill_given<0>(ctx, p, fused, grid, block);
 }
 static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const TmPlan *pl) {
     memset(&p, 0, sizeof p);
@@ -778,8 +792,13 @@ static void fill_params(TmParams &p, const otmb_tm_args &a, otmb_ctx *ctx, const
     p.nx = (int)a.nx; p.ny = (int)a.ny; p.nz = (int)a.nz; p.topo = a.topology; p.upwind = a.upwind;
     p.skip = pl ? pl->skip : ((a.only_t ? 0x1eu : 0u) | ((unsigned)a.skip_ops & 0x1fu));
     p.hcp = nullptr; p.hx = nullptr; p.hnnz = 0;
+    p.dcp = nullptr; p.dx = nullptr; p.dnnz = 0;
+    if (pl && ((pl->read >> OTMB_TKVDEEP) & 1u) && a.given[OTMB_TKVDEEP].nnz > 0) {
+        p.dcp = (const i64 *)a.given[OTMB_TKVDEEP].colptr; p.dx = a.given[OTMB_TKVDEEP].nzval; p.dnnz = a.given[OTMB_TKVDEEP].nnz;
+    }
     if (pl && ((pl->derived >> OTMB_TKH) & 1u) && a.given[OTMB_TKH].nnz > 0) {  // (read by the HREAD fill kernels only)
         p.hcp = (const i64 *)a.given[OTMB_TKH].colptr; p.hx = a.given[OTMB_TKH].nzval; p.hnnz = a.given[OTMB_TKH].nnz;
+        p.hmust = (int)((pl->read >> OTMB_TKH) & 1u);
     }
     p.keep = keep_mask(p.skip);
     p.P = a.nx * a.ny; p.G = p.P * a.nz;
@@ -856,17 +875,18 @@ static bool verdict_matches(const otmb_ctx::GivenVerdict &v, const otmb_ctx *ctx
     }
     return true;
 }
-static void verdict_store(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, int m, bool derived) {
+static void verdict_store(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, int m, bool derived, bool pattern) {
     otmb_ctx::GivenVerdict &v = ctx->given_verdict[m];
-    v.valid = true; v.derived = derived; v.epoch = ctx->given_epoch; v.g = a.given[m];
+    v.valid = true; v.derived = derived; v.pattern = pattern; v.epoch = ctx->given_epoch; v.g = a.given[m];
     v.lwet3d = a.lwet3d; v.lwet = a.lwet; v.v3d = a.v3d; v.thk = a.thkcello; v.area = a.area2d; v.zt = a.zt;
     for (int d = 0; d < 4; ++d) { v.edge[d] = a.edge_length[d]; v.dist[d] = a.dist_nbr[d]; }
     v.nx = a.nx; v.ny = a.ny; v.nz = a.nz; v.n_wet = a.n_wet; v.wet_base = pl.wet_base; v.topo = a.topology;
     v.kappa = (m == OTMB_TKH) ? a.kappa_h : a.kappa_vdeep;
 }
-// the comparing pass over the operators in `check`; *derived: those that are bit for bit what the fill pass writes.  Synchronises.
-static int32_t verify_given(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, unsigned check, unsigned *derived) {
-    *derived = 0;
+// the comparing pass over the operators in `check`; *derived: those that are bit for bit what the fill pass writes; *pattern: those with
+// exactly its rows and other values.  Synchronises.
+static int32_t verify_given(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &pl, unsigned check, unsigned *derived, unsigned *pattern) {
+    *derived = *pattern = 0;
     if (a.n_wet == 0) {  // a 0 x 0 matrix: derived iff it is empty
         for (int m = 1; m < 5; ++m)
             if (((check >> m) & 1u) && a.given[m].nnz == 0) *derived |= 1u << m;
@@ -896,14 +916,18 @@ static int32_t verify_given(otmb_ctx *ctx, const otmb_tm_args &a, const TmPlan &
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, dflags, OTMB_NFLAGS_TM * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dflags, 0, OTMB_TM_STATE_BYTES, ctx->stream));  // (whatever the columns' arithmetic flagged is the real pass's to report)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *derived = check & ~(unsigned)ctx->h_flags[FLAG_GIVEN_MISMATCH];
+    const unsigned differs = (unsigned)ctx->h_flags[FLAG_GIVEN_MISMATCH], rows = differs & 0xffu, values = (differs >> 8) & 0xffu;
+    *derived = check & ~rows & ~values;
+    *pattern = check & ~rows & values;
     ctx->given_checks += 1;
     return OTMB_OK;
 }
-// Which operators does the caller pass, and how is each treated?  Sets pl.given / derived / foreign / skip and ctx->given_state.
+// Which operators does the caller pass, and how is each treated?  Sets pl.given / derived / read / foreign / skip and ctx->given_state.
 static int32_t classify_given(otmb_ctx *ctx, const otmb_tm_args &a, TmPlan &pl) {
+    // (OTMB_GIVEN_PATTERN=0: an operator with the derived rows and other values is treated as any foreign matrix -- A/B, tests of the sparse-add path)
+    static const bool env_pattern = [] { const char *e = getenv("OTMB_GIVEN_PATTERN"); return !(e && e[0] == '0'); }();
     pl.given = given_mask(a);
-    pl.derived = pl.foreign = 0;
+    pl.derived = pl.foreign = pl.read = 0;
     for (int m = 0; m < 5; ++m) { ctx->given_state[m] = 0; pl.built_nnz[m] = 0; }
     pl.skip = (a.only_t ? 0x1eu : 0u) | ((unsigned)a.skip_ops & 0x1fu);
     pl.want_t = !(pl.skip & 1u);
@@ -917,26 +941,31 @@ static int32_t classify_given(otmb_ctx *ctx, const otmb_tm_args &a, TmPlan &pl) 
         if (m == OTMB_TKH || m == OTMB_TKVDEEP) {  // functions of the grid and κ alone: worth a verdict that is kept
             if (verdict_matches(ctx->given_verdict[m], ctx, a, pl, m)) {
                 if (ctx->given_verdict[m].derived) pl.derived |= 1u << m;
+                if (ctx->given_verdict[m].pattern) pl.read |= 1u << m;
             } else {
                 check |= 1u << m;
             }
         }
     }
     if (check) {
-        unsigned d = 0;
+        unsigned d = 0, pt = 0;
         int32_t rc;
-        if ((rc = verify_given(ctx, a, pl, check, &d))) return rc;
+        if ((rc = verify_given(ctx, a, pl, check, &d, &pt))) return rc;
         for (int m = 1; m < 5; ++m)
-            if ((check >> m) & 1u) verdict_store(ctx, a, pl, m, (d >> m) & 1u);
+            if ((check >> m) & 1u) verdict_store(ctx, a, pl, m, (d >> m) & 1u, (pt >> m) & 1u);
         pl.derived |= d;
+        pl.read |= pt;
     }
+    // the derived rows with other values: not materialised either -- the fill pass reads the values where they lie
+    if (!env_pattern) pl.read = 0;
+    pl.derived |= pl.read;
     pl.foreign = pl.given & ~pl.derived;
     if (pl.foreign && pl.want_t && (pl.skip & 0x1eu & ~pl.given))
         return otmb_fail(ctx, OTMB_ERR_INVALID_ARG, "only_t / skip_ops with a foreign given operator: T is then a sum of materialised matrices");
     // nothing given is built; with a foreign operand T is not the kernel's business either (it is the device sparse add of the four)
     pl.skip |= pl.given | (pl.foreign ? 1u : 0u);
     for (int m = 1; m < 5; ++m)
-        if ((pl.given >> m) & 1u) ctx->given_state[m] = ((pl.derived >> m) & 1u) ? 1 : 2;
+        if ((pl.given >> m) & 1u) ctx->given_state[m] = ((pl.read >> m) & 1u) ? 3 : (((pl.derived >> m) & 1u) ? 1 : 2);
     return OTMB_OK;
 }
 

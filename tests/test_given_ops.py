@@ -132,39 +132,52 @@ def test_derived_operators_in_the_asynchronous_protocols(oracle, name):
         assert_csc_equal(got[m], rtm[m], f"afterwards: {m}")
 
 
-@pytest.mark.parametrize("name", ["tiny_rho3d", "even_fold_open", "small_rho3d"])
+@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_rho3d", "odd_nx_fold", "nx2", "even_fold_open", "small_rho3d"])
 def test_operators_built_with_another_kappa_enter_T_with_their_own_values(oracle, name):
-    """The reference adds the OBJECTS passed in (:147).  A TκH / TκVdeep built with another κ has the derived pattern and other values: it must
-    be classed foreign and T must carry ITS values -- equal to building everything with that κ -- never the re-derived ones."""
+    """The reference adds the OBJECTS passed in (:147).  A TκH / TκVdeep built with another κ has the derived rows and other values (state 3):
+    T must carry ITS values -- equal to building everything with that κ -- never the re-derived ones; the fill pass reads them where they lie,
+    in every protocol (two-phase, fused step with and without the one-pass count)."""
     g, gm, ref, rphi, rtm, asm, umo, vmo, fill = _setup(oracle, name)
     N = ref["N"]
     other = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, 123.0, g.kappaVML, 7.5e-5, True)
     for sub in (("TκH",), ("TκVdeep",), ("TκH", "TκVdeep")):
         ops = {m: (other[m] if m in sub else rtm[m]) for m in OPS}
-        asm.set_given(**{m: (_dev(asm, other[m]) if m in sub else None) for m in OPS})
-        phi = asm.facefluxes(umo, vmo, fill)
-        asm.out = None
-        asm.transportmatrix(phi)
-        assert [asm.ctx.given_state(MATS.index(m)) for m in sub] == [2] * len(sub)
-        got = asm.result_to_host()
         want = _fold(oracle, ops, N)
-        assert_csc_equal(got["T"], want, f"{sub} with another κ: T")
-        if sub == ("TκH", "TκVdeep"):
-            assert_csc_equal(got["T"], other["T"], "the same as building with those κ")
-        assert not np.array_equal(got["T"][2], rtm["T"][2])
-    # one given operator derived, the other foreign
+        asm.set_given(**{m: (_dev(asm, other[m]) if m in sub else None) for m in OPS})
+        for protocol in ("two-phase", "step", "step onepass"):
+            asm.out = None
+            if protocol == "two-phase":
+                asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
+            else:
+                asm.step(umo, vmo, fill, onepass=protocol.endswith("onepass"))
+            assert [asm.ctx.given_state(MATS.index(m)) for m in sub] == [3] * len(sub)
+            got = asm.result_to_host()
+            assert_csc_equal(got["T"], want, f"{sub} with another κ, {protocol}: T")
+            if sub == ("TκH", "TκVdeep"):
+                assert_csc_equal(got["T"], other["T"], "the same as building with those κ")
+            assert not np.array_equal(got["T"][2], rtm["T"][2])
+            for m in MATS[1:]:
+                if m not in sub:
+                    assert_csc_equal(got[m], rtm[m], f"{sub} with another κ, {protocol}: {m}")
+    # one given operator derived, the other with other values
     asm.set_given(TκH=_dev(asm, rtm["TκH"]), TκVdeep=_dev(asm, other["TκVdeep"]), Tadv=None, TκVML=None)
     phi = asm.facefluxes(umo, vmo, fill)
     asm.out = None
     asm.transportmatrix(phi)
-    assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (1, 2)
+    assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (1, 3)
     got = asm.result_to_host()
-    assert_csc_equal(got["T"], _fold(oracle, {**rtm, "TκVdeep": other["TκVdeep"]}, N), "derived TκH + foreign TκVdeep")
+    assert_csc_equal(got["T"], _fold(oracle, {**rtm, "TκVdeep": other["TκVdeep"]}, N), "derived TκH + TκVdeep of another κ")
+    asm.set_given(TκH=_dev(asm, other["TκH"]), TκVdeep=_dev(asm, rtm["TκVdeep"]), Tadv=None, TκVML=None)
+    asm.out = None
+    asm.step(umo, vmo, fill)
+    assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (3, 1)
+    assert_csc_equal(asm.result_to_host()["T"], _fold(oracle, {**rtm, "TκH": other["TκH"]}, N), "TκH of another κ + derived TκVdeep")
 
 
 def test_foreign_patterns_and_one_changed_bit(oracle):
-    """What makes a given TκH foreign: one value bit (-0.0 for +0.0 included), one row index, one column offset, a shorter matrix, an empty
-    one, a diagonal matrix.  Each is then ADDED as it is."""
+    """What a given TκH is taken for: one value bit changed (-0.0 for +0.0 included) leaves the derived rows -- state 3, the values are read;
+    one row index, one column offset, a shorter matrix, an empty one, a diagonal matrix are foreign -- state 2, the sparse add.  Either way
+    the matrix is ADDED as it is."""
     import scipy.sparse as sp
 
     g, gm, ref, rphi, rtm, asm, umo, vmo, fill = _setup(oracle, "small_rho3d")
@@ -200,7 +213,7 @@ def test_foreign_patterns_and_one_changed_bit(oracle):
         if H is None:
             continue
         st, got = run(H)
-        assert st == 2, what
+        assert st == (3 if what in ("one ulp", "a sign") else 2), what
         assert_csc_equal(got["T"], _fold(oracle, {**rtm, "TκH": H}, N), f"{what}: T")
         for m in ("Tadv", "TκVML", "TκVdeep"):
             assert_csc_equal(got[m], rtm[m], f"{what}: {m}")
@@ -215,7 +228,7 @@ def test_foreign_patterns_and_one_changed_bit(oracle):
     asm0.set_given(TκH=_dev(asm0, flipped))
     asm0.out = None
     asm0.transportmatrix(asm0.facefluxes(umo0, vmo0, fill0))
-    assert asm0.ctx.given_state(2) == 2
+    assert asm0.ctx.given_state(2) == 3
     got = asm0.result_to_host()
     assert_csc_equal(got["T"], _fold(oracle, {**rtm0, "TκH": flipped}, ref0["N"]), "signed zeros: T")
 
@@ -264,7 +277,7 @@ def test_the_verdict_is_cached_and_forgotten_when_an_array_changes(oracle):
     H[2][11] *= 2.0  # in place: torch bumps the tensor's version, the assembler tells the library to look again
     asm.out = None
     asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
-    assert _checks(asm) == c0 + 2 and (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (2, 1)
+    assert _checks(asm) == c0 + 2 and (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (3, 1)
     H2 = (rtm["TκH"][0], rtm["TκH"][1], H[2].cpu().numpy())
     assert_csc_equal(asm.result_to_host()["T"], _fold(oracle, {**rtm, "TκH": H2}, ref["N"]), "edited TκH: T")
     H[2][11] /= 2.0
@@ -273,7 +286,8 @@ def test_the_verdict_is_cached_and_forgotten_when_an_array_changes(oracle):
     asm.kappa = (asm.kappa[0], asm.kappa[1], 3.0e-5)  # another κVdeep: the given TκVdeep is no longer what would be derived
     asm.out = None
     asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
-    assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (1, 2)
+    assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (1, 3)
+    assert_csc_equal(asm.result_to_host()["T"], rtm["T"], "the given TκVdeep's values, not those of the call's κVdeep")
     asm.kappa = (g.kappaH, g.kappaVML, g.kappaVdeep)
     asm.area.mul_(1.0)  # an in-place op on a grid array (values unchanged): looked at again, still derived
     n = _checks(asm)
@@ -310,10 +324,10 @@ def test_errors_of_a_given_operator_are_not_raised_and_the_others_are(oracle):
     asm.edge[0][torch.nonzero(wet2)[3]] = float("nan")
     with pytest.raises(OtmbError, match="TκH contains NaNs."):
         asm.step(umo, vmo, fill)
-    asm.set_given(TκH=_dev(asm, rtm["TκH"]))  # (foreign now: the grid it is compared with has a NaN edge)
+    asm.set_given(TκH=_dev(asm, rtm["TκH"]))  # (other values now: the grid it is compared with has a NaN edge)
     asm.out = None
     asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
-    assert asm.ctx.given_state(2) == 2
+    assert asm.ctx.given_state(2) == 3
     assert_csc_equal(asm.result_to_host()["T"], rtm["T"], "NaN metric with TκH given: T")
     asm.edge[0].copy_(e0)
     asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
@@ -374,20 +388,34 @@ def test_host_api_returns_the_objects_passed_and_moves_fewer_bytes(api, oracle, 
     assert_csc_equal(tuple(tm.T), rtm["T"], f"slabs={slabs}: T from four given operators")
 
 
-def test_host_api_falls_back_to_the_sparse_add_for_foreign_operators(api, oracle):
-    """Another κ through the default (pipelined, multi-slab) call: the slabs refuse (GIVEN_FOREIGN), the host layer takes the two-phase call,
-    remembers it for the next time slice, and T carries the given values."""
+def test_host_api_another_kappa_is_pipelined_and_a_foreign_matrix_falls_back(api, oracle):
+    """Another κ through the default (pipelined, multi-slab) call: the derived rows with other values -- every slab reads its slice, no fall-back,
+    T carries the given values.  A matrix with other rows: the slabs refuse (GIVEN_FOREIGN), the host layer takes the two-phase call and
+    remembers it for the next time slice."""
     g, gm, ref, idx, rphi, rtm, kw = _host_case(api, oracle, (40, 30, 12, 62))
+    N = ref["N"]
     H2 = api.buildTκH(gridmetrics=gm, indices=idx, ρ=g.rho, κH=77.0)
-    other = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, 77.0, g.kappaVML, g.kappaVdeep, True)
+    D2 = api.buildTκVdeep(mlotst=g.mlotst, gridmetrics=gm, indices=idx, κVdeep=4.0e-5)
+    other = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, 77.0, g.kappaVML, 4.0e-5, True)
     assert_csc_equal(tuple(H2), other["TκH"], "buildTκH(κH = 77)")
+    assert_csc_equal(tuple(D2), other["TκVdeep"], "buildTκVdeep(κVdeep = 4e-5)")
+    seen = set(api._foreign_seen)
+    for call, slabs in enumerate((3, None, 0, 1)):
+        tm = api.transportmatrix(TκH=H2, TκVdeep=D2, slabs=slabs, **kw)  # (the call's own κH / κVdeep are the grid's defaults: not used, :141-143)
+        assert tm.TκH is H2 and tm.TκVdeep is D2
+        assert_csc_equal(tuple(tm.T), other["T"], f"call {call} (slabs={slabs}): T with TκH(77), TκVdeep(4e-5) given")
+        for m in ("Tadv", "TκVML"):
+            assert_csc_equal(tuple(tm[m]), rtm[m], m)
+    assert set(api._foreign_seen) == seen  # no fall-back was needed
+    Hd = api.SparseMatrixCSC(N, N, np.arange(1, N + 2, dtype=np.int64), np.arange(1, N + 1, dtype=np.int64), np.full(N, 2.5))
+    want = _fold(oracle, {**rtm, "TκH": (Hd.colptr, Hd.rowval, Hd.nzval)}, N)
     for call in range(2):
-        tm = api.transportmatrix(TκH=H2, slabs=3 if call == 0 else None, **kw)
-        assert tm.TκH is H2
-        assert_csc_equal(tuple(tm.T), other["T"], f"call {call}: T with TκH(77) given")
+        tm = api.transportmatrix(TκH=Hd, slabs=3 if call == 0 else None, **kw)
+        assert tm.TκH is Hd
+        assert_csc_equal(tuple(tm.T), want, f"call {call}: T with a diagonal TκH given")
         for m in ("Tadv", "TκVML", "TκVdeep"):
             assert_csc_equal(tuple(tm[m]), rtm[m], m)
-    assert api._foreign_key(dict(TκH=H2)) in api._foreign_seen
+    assert api._foreign_key(dict(TκH=Hd)) in api._foreign_seen
     with pytest.raises(ValueError):
         api.transportmatrix(TκH=api.SparseMatrixCSC(3, 3, np.ones(4, np.int64), np.zeros(0, np.int64), np.zeros(0)), **kw)
 

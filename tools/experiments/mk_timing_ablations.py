@@ -77,16 +77,13 @@ edit(os.path.join(TMP, 'otmb_transportmatrix.hip'),[
 """),
 ("""                else {
                     canonical = ldi(tb.lw, oC) == c;
-                    if (canonical) build_column(p, cell, c, col);
-                }
+                    if (canonical) {
 ""","""#ifdef OTMB_DBG_NOGENERIC  // timing experiment only (wrong on the seam row)
-                else { canonical = true; col.padv = col.phh = col.pml = col.pdp = 0; }
-#else
+                else if (true) { canonical = true; col.padv = col.phh = col.pml = col.pdp = 0; }
+#endif
                 else {
                     canonical = ldi(tb.lw, oC) == c;
-                    if (canonical) build_column(p, cell, c, col);
-                }
-#endif
+                    if (canonical) {
 """),
 ("""        if (live) {
             const unsigned q0 = ex[m] - wb[m];""","""#ifdef OTMB_DBG_NOLDS

@@ -20,10 +20,10 @@ dst = sys.argv[1]
 os.makedirs(dst, exist_ok=True)
 # kernel name patterns of the PMC summary -> the names bench.py uses (round 5: the fill pass is tm_kernel<1, 0>, the fused step's variants
 # -- tm_kernel<1, 1 | 2> and the ϕtop-only facefluxes, whose last template argument is true -- get their own entries)
-# (round 6: tm_kernel<FUSED, HREAD> -- <0, false> is the fill pass, <1 | 2, false> the fused step's with Float64 / Float32 transports, <., true> the
-# same with a given, derived TκH read where it lies instead of re-derived)
-names = {"tm_kernel<0, false>": "tm_kernel<fill>", "tm_kernel<1, false>": "tm_kernel<fill, fused>", "tm_kernel<2, false>": "tm_kernel<fill, fused>",
-         "tm_kernel<0, true>": "tm_kernel<fill, TκH read>", "tm_kernel<1, true>": "tm_kernel<fill, fused, TκH read>", "tm_kernel<2, true>": "tm_kernel<fill, fused, TκH read>",
+# (round 6: tm_kernel<FUSED, GIVEN> -- <0, 0> is the fill pass, <1 | 2, 0> the fused step's with Float64 / Float32 transports, <., 1> the same with
+# a given TκH read where it lies instead of re-derived; GIVEN 2 / 3 -- a TκVdeep of another κ read too -- are not profiled)
+names = {"tm_kernel<0, 0>": "tm_kernel<fill>", "tm_kernel<1, 0>": "tm_kernel<fill, fused>", "tm_kernel<2, 0>": "tm_kernel<fill, fused>",
+         "tm_kernel<0, 1>": "tm_kernel<fill, TκH read>", "tm_kernel<1, 1>": "tm_kernel<fill, fused, TκH read>", "tm_kernel<2, 1>": "tm_kernel<fill, fused, TκH read>",
          "tm_count_kernel": "tm_count_kernel"}
 
 
