@@ -632,6 +632,14 @@ def main(slab_backend_factory=None, cpu_rehearsal=False):
         if os.environ.get("OTMB_SHARE_GPU") == "1":
             local_rank = 0
         if not rehearsal:
+            # first contact: a node that shows fewer GPUs than ranks is the most likely first failure -- say so in one line, exit 3 like every
+            # other bring-up failure (device_count() does not initialise the GPU)
+            seen = torch.cuda.device_count()
+            if local_rank >= seen:
+                print(f"bench.py: rank {rank} (local rank {local_rank}): this node shows {seen} GPU(s) to this process, --gpus {world} needs "
+                      f"{local_rank + 1} or more (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: {os.environ.get('HIP_VISIBLE_DEVICES')!r} / "
+                      f"{os.environ.get('ROCR_VISIBLE_DEVICES')!r})", file=sys.stderr)
+                sys.exit(3)
             torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on the process's stdout when its first communicator comes up; stdout must carry
         # exactly one JSON line, so file descriptor 1 points at stderr until the result is printed
