@@ -52,6 +52,7 @@ struct otmb_ctx {
     int deal_heavy = 1;         // 0: the heavy tiles stay in the first XCD's share (experiments: OTMB_DEAL_HEAVY)
     unsigned order_nheavy = 0;  // the order's first entries are this many heavy tiles (tripolar seam row), dealt over the XCDs
     int ff_xcd_chunks = 1;    // facefluxes: XCD x takes the x-th contiguous eighth of the column blocks (0 = blockIdx order; experiments: OTMB_FF_XCD)
+    int ff_nt = -1;           // facefluxes' ϕ stores non-temporal (1), plain (0), by size (-1: beyond a gigabyte of fluxes) (experiments: OTMB_FF_NT)
     int ff_lds_south = 1;     // four-row facefluxes workgroups take a wave's south row from the neighbouring wave through LDS (experiments: OTMB_FF_LDS_SOUTH)
     int ff_rows = 0;          // facefluxes: rows per workgroup, 1 or 4; 0 = by grid size (experiments: OTMB_FF_ROWS)
     int count_order = 2;      // counting pass: 0 = blockIdx (wet-rank) order, 1 = XCD-contiguous eighths of wet-rank order, 2 = of the fill pass's tile order (default: HBM fetch 1.06-1.11 x its inputs instead of 2.1-2.7 x, +2-4 % of this pass's time; OTMB_COUNT_ORDER)

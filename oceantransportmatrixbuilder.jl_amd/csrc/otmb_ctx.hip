@@ -73,6 +73,7 @@ int32_t otmb_ctx_create(int32_t device_id, otmb_ctx **out) {
     if (const char *e = getenv("OTMB_FF_XCD")) c->ff_xcd_chunks = atoi(e);       // experiments (A/B in one library)
     if (const char *e = getenv("OTMB_FF_ROWS")) c->ff_rows = atoi(e);
     if (const char *e = getenv("OTMB_FF_LDS_SOUTH")) c->ff_lds_south = atoi(e);
+    if (const char *e = getenv("OTMB_FF_NT")) c->ff_nt = atoi(e);
     if (const char *e = getenv("OTMB_COUNT_ORDER")) c->count_order = atoi(e);
     if (const char *e = getenv("OTMB_DEAL_HEAVY")) c->deal_heavy = atoi(e);
     if (const char *e = getenv("OTMB_COUNT_IN_FF")) c->count_in_ff = atoi(e);  // A/B in one library

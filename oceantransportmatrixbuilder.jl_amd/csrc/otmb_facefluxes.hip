@@ -595,7 +595,7 @@ static int32_t facefluxes_impl(otmb_ctx *ctx, const void *umo, const void *vmo, 
     }
     {
     KernelTimer kt(ctx, K_FACEFLUXES);
-    const bool nt = (i64)48 * P * nz > (1ll << 30);  // six Float64 arrays beyond a gigabyte: streaming stores
+    const bool nt = ctx->ff_nt >= 0 ? ctx->ff_nt != 0 : (i64)48 * P * nz > (1ll << 30);  // six Float64 arrays beyond a gigabyte: streaming stores
 #define FF_LAUNCH(T, FL, NTS, R, CN)                                                                                                   \
     FF_LAUNCH_T(T, FL, NTS, R, CN, false)
 #define FF_LAUNCH_T(T, FL, NTS, R, CN, TO)                                                                                             \
