@@ -194,6 +194,70 @@ def test_large_grid_properties_and_subslab_oracle(oracle, workload, slab, protoc
     torch.cuda.empty_cache()
 
 
+def test_quarterdeg_given_operators_read_where_they_lie(oracle):
+    """otmb_tm_args.given at config 3's size, by a property that needs no CPU matrix: pass the grid's own TκH / TκVdeep back (derived: state 1)
+    and T, Tadv, TκVML are the full build's bit for bit; then change the CALL's κH / κVdeep -- the same two matrices now have the derived rows
+    and other values (state 3), the fill pass must read THEIR values (tm_kernel<., 3>), and T is still the first build's, bit for bit --
+    through the asynchronous two-call step, the fused step and the two-phase protocol."""
+    import torch
+
+    from otmb_amd import synthetic_device
+
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    if free < 70e9:
+        pytest.skip(f"needs 70 GB of free HBM, {free / 1e9:.0f} GB available")
+    dev = torch.device("cuda", 0)
+    dg = synthetic_device.make_device_grid("quarterdeg", dev)
+    asm = synthetic_device.assembler_for(dg)
+    asm.step_async(dg.umo, dg.vmo, dg.fill)
+    asm.finish()
+    nnz0 = list(asm.nnz)
+    keep = {m: tuple(t[: (asm.N + 1 if q == 0 else nnz0[MATS.index(m)])].clone() for q, t in enumerate(asm.out[m])) for m in ("T", "Tadv", "TκVML", "TκH", "TκVdeep")}
+    kappa0 = asm.kappa
+
+    def same_as_first(what):
+        assert [asm.nnz[k] for k in (0, 1, 3)] == [nnz0[k] for k in (0, 1, 3)], (what, asm.nnz, nnz0)
+        for m in ("T", "Tadv", "TκVML"):
+            k = nnz0[MATS.index(m)]
+            cp, rv, nz = asm.out[m]
+            assert torch.equal(cp[: asm.N + 1], keep[m][0]), (what, m, "colptr")
+            assert torch.equal(rv[:k], keep[m][1]), (what, m, "rowval")
+            assert torch.equal(nz[:k].view(torch.int64), keep[m][2].view(torch.int64)), (what, m, "nzval")
+
+    asm.set_given(TκH=keep["TκH"], TκVdeep=keep["TκVdeep"])
+    try:
+        asm.step_async(dg.umo, dg.vmo, dg.fill)
+        asm.finish()
+        assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (1, 1)
+        same_as_first("derived, asynchronous step")
+        asm.kappa = (kappa0[0] * 0.5, kappa0[1], kappa0[2] * 3.0)
+        asm.step_async(dg.umo, dg.vmo, dg.fill)
+        asm.finish()
+        assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (3, 3)
+        same_as_first("other values, asynchronous step")
+        if COUNTS_ON:
+            asm.step_fused_async(dg.umo, dg.vmo, dg.fill)
+            asm.finish()
+            assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (3, 3)
+            same_as_first("other values, fused step")
+        phi = asm.facefluxes(dg.umo, dg.vmo, dg.fill)
+        asm.transportmatrix(phi)
+        assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (3, 3)
+        same_as_first("other values, two-phase")
+        # ... and without the given operators the call's own κ are used: T differs
+        asm.set_given(TκH=None, TκVdeep=None)
+        asm.step_async(dg.umo, dg.vmo, dg.fill)
+        asm.finish()
+        k = nnz0[0]
+        assert asm.nnz[0] == k and not torch.equal(asm.out["T"][2][:k].view(torch.int64), keep["T"][2].view(torch.int64))
+    finally:
+        asm.set_given(TκH=None, TκVdeep=None)
+        asm.kappa = kappa0
+    del asm, dg, keep
+    torch.cuda.empty_cache()
+
+
 # ---- config 2's own content at its stated size ------------------------------------------------------------------------
 def test_access1deg_bolus_gm_velocity_matches_oracle(access1deg, oracle):
     """BASELINE.json configs[1] names the Redi/GM triads.  In the reference they never enter T (src/RediGM.jl:44); what exists is

@@ -1,10 +1,11 @@
 """transportmatrix(...; Tadv = ..., TκH = ..., TκVML = ..., TκVdeep = ...) -- src/matrixbuilding.jl:133-147: an operator that is passed in is NOT
 built, is returned as the very object passed, and T = ((Tadv + TκH) + TκVML) + TκVdeep is formed with it (run with -m gpu).
 
-The library's two ways (otmb_tm_args.given):
-  derived -- a given TκH / TκVdeep that is bit for bit what the fill pass computes for this grid and κ (one comparing pass, verdict cached) is
-             re-derived in registers: neither counted, stored nor copied home;
-  foreign -- any other matrix (another κ, another pattern, Tadv, TκVML): the built operators are written and T is the device sparse add of the
+The library's three ways (otmb_tm_args.given; otmb_ctx_given_state):
+  derived (1) -- a given TκH / TκVdeep that is bit for bit what the fill pass computes for this grid and κ (one comparing pass, verdict cached):
+             neither counted, stored nor copied home;
+  derived rows, other values (3) -- built with another κ, or edited: treated alike, and the fill pass READS its values where they lie;
+  foreign (2) -- any other matrix (another pattern, Tadv, TκVML): the built operators are written and T is the device sparse add of the
              four operands (two-phase protocol).
 Every combination is compared with the oracle: the built matrices against orc_transportmatrix, T against the left fold of orc_spadd over the
 operands actually used -- the GIVEN values, not re-derived ones."""
@@ -13,7 +14,7 @@ import itertools
 import numpy as np
 import pytest
 
-from helpers import CASES, MATS, assert_csc_equal, gridmetrics_of, make_case
+from helpers import COUNTS_ON, CASES, MATS, assert_csc_equal, gridmetrics_of, make_case
 
 pytestmark = pytest.mark.gpu
 OPS = MATS[1:]
@@ -172,6 +173,86 @@ def test_operators_built_with_another_kappa_enter_T_with_their_own_values(oracle
     asm.step(umo, vmo, fill)
     assert (asm.ctx.given_state(2), asm.ctx.given_state(4)) == (3, 1)
     assert_csc_equal(asm.result_to_host()["T"], _fold(oracle, {**rtm, "TκH": other["TκH"]}, N), "TκH of another κ + derived TκVdeep")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_grids_random_given_operators(oracle, seed):
+    """Differential sweep: random small grids (nx 2..11, tripolar / bipolar, with and without land, scalar / 3-D ρ, randomised metrics, both
+    weightings), a random subset of given operators, each either the oracle's own, one built with another κ, or the derived rows with
+    arbitrary values (NaN and signed zeros among them); two-phase call and -- when nothing is foreign -- the asynchronous and fused steps.
+    T is the oracle's left fold over the operands, bit for bit; what is built is the oracle's."""
+    import torch
+
+    from helpers import gridmetrics_of, randomize_metrics
+    from otmb_amd import synthetic
+    from otmb_amd.device import DeviceAssembler
+
+    rng = np.random.default_rng(4200 + seed)
+    nx, ny, nz = int(rng.integers(2, 12)), int(rng.integers(3, 9)), int(rng.integers(1, 7))
+    topo = "tripolar" if rng.random() < 0.65 else "bipolar"
+    upwind = bool(rng.random() < 0.7)
+    g = synthetic.make_grid(nx, ny, nz, seed=900 + seed, land_fraction=float(rng.choice([0.0, 0.15, 0.4])), topology=topo,
+                            rho=str(rng.choice(["scalar", "array"])))
+    gm = gridmetrics_of(g)
+    if rng.random() < 0.5 or (topo == "tripolar" and nx % 2 == 1):  # (odd nx on a tripolar grid: the fold-centre cell's real distance to itself is 0 -> NaN, :61)
+        randomize_metrics(gm, seed=seed)
+    ref = oracle.makeindices(gm.v3D)
+    N = ref["N"]
+    if N == 0:
+        pytest.skip("no wet cell")
+    fill = g.umo.properties["_FillValue"]
+    rphi = oracle.facefluxes(g.umo.data, g.vmo.data, ref["wet3D"], fill, gm.gridtopology.kind)
+    kap = (g.kappaH, g.kappaVML, g.kappaVdeep)
+    rtm = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, *kap, upwind)
+    other = oracle.transportmatrix(rphi, gm, ref, g.rho, g.mlotst, 61.0, 0.37, 2.5e-4, upwind)
+    asm = DeviceAssembler(0)
+    asm.set_grid(gm, g.mlotst, g.rho, *kap, upwind=upwind)
+    dev = asm.device
+    umo, vmo = (torch.from_numpy(np.ascontiguousarray(x.data.ravel(order="F"))).to(dev) for x in (g.umo, g.vmo))
+    for trial in range(3):
+        sub = [m for m in OPS if rng.random() < 0.5] or [OPS[int(rng.integers(0, 4))]]
+        ops, states = dict(rtm), {}
+        for m in sub:
+            kind = int(rng.integers(0, 3))
+            if kind == 1:
+                ops[m] = other[m]
+            elif kind == 2 and len(rtm[m][2]):
+                v = rng.standard_normal(len(rtm[m][2]))
+                v[rng.integers(0, len(v), size=max(1, len(v) // 7))] = rng.choice([0.0, -0.0, np.nan, 1e300, -1e-300], size=max(1, len(v) // 7))
+                ops[m] = (rtm[m][0], rtm[m][1], v)
+            same = ops[m] is rtm[m] or np.array_equal(ops[m][2].view(np.int64), rtm[m][2].view(np.int64))
+            states[m] = (1 if same else 3) if m in ("TκH", "TκVdeep") else 2
+        want = {m: ops[m] for m in OPS}
+        want["T"] = _fold(oracle, ops, N)
+        asm.set_given(**{m: (_dev(asm, ops[m]) if m in sub else None) for m in OPS})
+        fast = all(states[m] != 2 for m in sub) and COUNTS_ON
+        protocols = ["two-phase"] + (["async"] if fast else []) + (["fused"] if fast and nx >= 3 else [])  # (otmb_step_dev needs nx >= 3)
+        for protocol in protocols:
+            asm.out = None
+            if protocol == "two-phase":
+                asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
+            elif protocol == "async":
+                asm.step_async(umo, vmo, fill)
+                asm.finish()
+            else:
+                asm.step_fused_async(umo, vmo, fill)
+                asm.finish()
+            what = f"seed {seed} ({nx}x{ny}x{nz} {topo}, upwind={upwind}) trial {trial} given {sub} {protocol}"
+            assert {m: asm.ctx.given_state(MATS.index(m)) for m in sub} == states, what
+            got = asm.result_to_host()
+            for m in MATS:
+                if m in sub:
+                    continue
+                a, b = got[m], want[m]
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f"{what}: pattern of {m}"
+                assert np.array_equal(np.asarray(a[2]).view(np.int64), np.asarray(b[2]).view(np.int64)) or _same_but_nan_payload(a[2], b[2]), f"{what}: values of {m}"
+
+
+def _same_but_nan_payload(a, b):
+    """bit-equal except where both are NaN (an addition may return either operand's payload)"""
+    a, b = np.asarray(a), np.asarray(b)
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.array_equal(a[~nan].view(np.int64), b[~nan].view(np.int64)))
 
 
 def test_foreign_patterns_and_one_changed_bit(oracle):
