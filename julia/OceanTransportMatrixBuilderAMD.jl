@@ -282,9 +282,10 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
     if any(!isnothing, given)
         # matrixbuilding.jl:140-143: an operator that is passed in is NOT built -- nothing it alone would read is read (ϕ / ρ for Tadv, mlotst
         # for TκVML: harmless stand-ins take their place), it is returned as the very object passed (:149), and
-        # T = ((Tadv + TκH) + TκVML) + TκVdeep (:147) is formed with it (otmb_tm_args.given): a TκH / TκVdeep that is bit for bit what the
-        # library derives for this grid and κ is re-derived in registers -- neither uploaded again (reuse_grid), counted, stored nor copied
-        # home; any other matrix makes T the device sparse add of the four operands (the two-phase call: see the fallback below).
+        # T = ((Tadv + TκH) + TκVML) + TκVdeep (:147) is formed with it (otmb_tm_args.given): a TκH / TκVdeep with the rows the library
+        # derives for this grid -- built with this κ or another -- is neither uploaded again (reuse_grid), counted, stored nor copied home
+        # (the fill pass reads or re-derives its values); any other matrix makes T the device sparse add of the four operands (the two-phase
+        # call: see the fallback below).
         for (m, A) in enumerate(given)
             (A === nothing || size(A) == (indices.N, indices.N)) || throw(ArgumentError("$(MATNAMES[m]) is $(size(A, 1))x$(size(A, 2)), expected $(indices.N)x$(indices.N)"))
         end
@@ -323,7 +324,7 @@ function transportmatrix(; ϕ, mlotst, gridmetrics, indices, ρ,
         return fused(ϕ, mlotst, gridmetrics, indices, ρ, κH, κVML, κVdeep, upwind, operators, reuse_grid, reuse_fluxes, Int32(0), pinned, devices, given)
     catch e
         (e isa GivenForeign && given !== nothing) || rethrow()
-        # a given operator is not what the library derives (another κ, another pattern, Tadv, TκVML): T is then the device sparse add of
+        # a given operator does not have the rows the library derives (another pattern, Tadv, TκVML): T is then the device sparse add of
         # four materialised operands, which the single-context two-phase call does; remembered for the next time slice
         lock(() -> push!(FOREIGN_SEEN, fkey), CALL_LOCK)
         return two_phase()

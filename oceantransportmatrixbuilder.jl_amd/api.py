@@ -417,7 +417,7 @@ def transportmatrix(*, ϕ=None, phi=None, mlotst, gridmetrics, indices, ρ=None,
     except capi.OtmbError as e:
         if e.status != capi.GIVEN_FOREIGN or given is None:
             raise
-        # a given operator is not what the library derives for this grid and κ (another κ, another pattern, Tadv, TκVML): T is then the
+        # a given operator does not have the rows the library derives for this grid (another pattern, Tadv, TκVML): T is then the
         # device sparse add of four materialised operands, which the single-context two-phase call does
         _foreign_seen.add(fkey)
         return _transportmatrix_fused(*common, False, False, device if devices is None else list(devices)[0], 0, None, given)

@@ -159,9 +159,10 @@ class DeviceAssembler:
     # ---- operators the caller passes (transportmatrix's Tadv = / TκH = / TκVML = / TκVdeep = keywords, src/matrixbuilding.jl:133-143) ----
     def set_given(self, **ops):
         """ops: name -> (colptr, rowval, nzval) device tensors (int64, int64, float64; rowval / nzval exactly nnz long) or None.  A passed
-        operator is not built (otmb_tm_args.given): a TκH / TκVdeep that is bit for bit what the library derives for this grid and κ is
-        re-derived in registers by the fill pass -- neither read, written nor counted; any other matrix makes T a device sparse add (two-phase
-        protocol only: transportmatrix(); the asynchronous calls raise GIVEN_FOREIGN)."""
+        operator is not built (otmb_tm_args.given): a TκH / TκVdeep with the rows the library derives for this grid is neither written nor
+        counted -- its values are re-derived in registers or read where they lie (those of another κ included: ctx.given_state(m) == 3);
+        any other matrix makes T a device sparse add (two-phase protocol only: transportmatrix(); the asynchronous calls raise
+        GIVEN_FOREIGN)."""
         given = dict(getattr(self, "given", {}) or {})
         for name, triple in ops.items():
             if name not in MATS[1:]:
