@@ -217,8 +217,10 @@ __global__ __launch_bounds__(TM_THREADS, TM_WAVES_PER_SIMD) void tm_kernel(const
     const i64 Lmin = p.lwet[w0] - 1;
     const i64 Lmax = p.lwet[wlast] - 1;
     i64 hq = 0, dq = 0;
-    if (HREAD) hq = p.hcp[wcl] - p.hcp[0];  // (with the index loads: the column's first entry in the given TκH)
-    if (DREAD) dq = p.dcp[wcl] - p.dcp[0];
+    // (with the index loads: the column's first entry in the given matrix.  Never negative for the arrays the comparing pass saw; a device caller
+    // who rewrote them in place without otmb_ctx_forget_given gets wrong values, not a fault: the reads below are clamped into the arrays)
+    if (HREAD) { hq = p.hcp[wcl] - p.hcp[0]; hq = hq > 0 ? hq : 0; }
+    if (DREAD) { dq = p.dcp[wcl] - p.dcp[0]; dq = dq > 0 ? dq : 0; }
     unsigned pre_sum = 0;
     i64 pre_off = 0;
     if (tid < TM_NF) {
