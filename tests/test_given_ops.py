@@ -114,7 +114,7 @@ def test_derived_operators_in_the_asynchronous_protocols(oracle, name):
         for m in MATS:
             if m not in sub:
                 assert_csc_equal(got[m], rtm[m], f"{sub} pipeline: {m}")
-        if asm.nx >= 3:
+        if asm.nx >= 3 and COUNTS_ON:  # (otmb_step_dev needs the counts of its own facefluxes)
             asm.step_fused_async(umo, vmo, fill)
             asm.finish()
             got = asm.result_to_host()
