@@ -32,9 +32,10 @@ struct TmParams {
     const double *area, *zt, *ml;
     double kH, kML, kDeep;
     int nx, ny, nz, topo, upwind;
-    // (round 6) a given TκH that the comparing pass found DERIVED: its values, where they lie, instead of re-deriving them -- the given matrix holds a
-    // column's <= 5 values contiguously (one coalesced run per wave) where re-deriving them takes 5 thkcello and 18 metric loads per column, a third of
-    // the pass's L1 requests.  hcp: the matrix's colptr for this launch's columns (a slab's slice: entries count from hcp[0]), hx: its nzval, hnnz: entries.
+    // (round 6) a given TκH in which the comparing pass found the DERIVED ROWS: its values, where they lie, instead of re-deriving them -- the given
+    // matrix holds a column's <= 5 values contiguously (one coalesced run per wave) where re-deriving them takes 5 thkcello and 18 metric loads per column,
+    // a third of the pass's L1 requests; and when its values are NOT the derived ones (another κH: hmust) they are what T must carry.
+    // hcp: the matrix's colptr for this launch's columns (a slab's slice: entries count from hcp[0]), hx: its nzval, hnnz: entries.
     const i64 *hcp;
     const double *hx;
     i64 hnnz;
@@ -45,7 +46,7 @@ struct TmParams {
     i64 dnnz;
     int hmust;         // (host side) the given TκH's values are NOT the derived ones: reading them is not a choice (launch_fill)
     unsigned skip;     // bit m: matrix m is evaluated (T is the sum of all four) but neither counted nor written -- otmb_tm_args.only_t (bits 1-4),
-                       // a given operator that the fill pass re-derives (otmb_tm_args.given), T itself when a foreign given operator makes it a sparse add
+                       // a given operator with the derived rows (otmb_tm_args.given: values re-derived or read), T itself when a foreign given operator makes it a sparse add
     u64 keep;          // the packed count word's fields of the matrices that ARE counted (T:11 | Tadv:11 | TκH:11 | TκVML:10 | TκVdeep:10)
     int rho_in_fill;   // the ρ-NaN check (:233) is done by the fill pass (which loads ρ anyway) instead of the counting pass:
                        // set when both passes run before the flags are read (otmb_transportmatrix_dev)
@@ -520,7 +521,7 @@ __device__ __forceinline__ void column_compute(const TmParams &p, const Stencil 
     }
     // ---- TκH (:348-415, :426-435); oppdir = south away from the seam row (:407) ----
     if (HREAD) {
-        // the given (derived) matrix's own values: its column holds the rows S, row-mates in index order, N -- those whose cell is wet, and the
+        // the given matrix's own values: its column holds the derived rows -- S, row-mates in index order, N: those whose cell is wet, and the
         // diagonal iff any of them is (exactly col.phh / col.bef below, which the comparing pass verified against its colptr / rowval)
         const unsigned any = (unsigned)(wW | wE | wS | wN);
         unsigned q = 0;
