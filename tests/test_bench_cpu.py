@@ -61,6 +61,23 @@ def test_a_rank_that_never_arrives_ends_the_run_with_its_name():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_more_ranks_than_gpus_is_said_in_one_line_and_ends_the_run():
+    """First contact with a node that shows fewer GPUs than `--gpus N` asks for (here: none) -- the likeliest first failure of a multi-GPU
+    run: every rank that has no device says so in one line and exits 3 before any GPU or communicator call, the launcher names the rank and
+    returns 3 within seconds, nothing is printed on stdout (profiles/r06/call19_*: the same on a one-GPU box)."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert r.stdout.strip() == ""
+    assert "rank 1 (local rank 1): this node shows" in r.stderr and "--gpus 2 needs 2 or more" in r.stderr
+    assert "ended with status 3; the other ranks were stopped" in r.stderr
+
+
 def test_traffic_json_is_keyed_to_the_kernel_sources():
     """roofline.traffic comes from committed PMC passes: it must name the kernel sources it was measured on."""
     sys.path.insert(0, ROOT)
