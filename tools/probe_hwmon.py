@@ -68,7 +68,16 @@ def main():
         per.append((round(time.perf_counter() - t0, 3), round(k["tm_kernel<fill>"][0] / k["tm_kernel<fill>"][1], 5)))
     stop.set()
     th.join()
-    print(json.dumps({"fill_ms_by_time": per}))
+    # the series in runs: (start s, end s, n, mean ms) of consecutive samples within 2 % of the run's first one
+    runs = []
+    for t, v in per:
+        if runs and abs(v - runs[-1][4]) <= 0.02 * runs[-1][4]:
+            r = runs[-1]
+            r[1], r[2], r[3] = t, r[2] + 1, r[3] + v
+        else:
+            runs.append([t, t, 1, v, v])
+    print(json.dumps({"fill_ms_runs": [(r[0], r[1], r[2], round(r[3] / r[2], 5)) for r in runs], "samples": len(per),
+                      "min": min(v for _, v in per), "max": max(v for _, v in per)}))
     busy = {}
     for _, d in samples:
         for k, v in d.items():
