@@ -3,8 +3,9 @@
  *   makeindices(v3D) -> facefluxes(umo, vmo) -> transportmatrix(ϕ, …)      (src/matrixbuilding.jl:10-24, src/velocities.jl:190-255,
  *                                                                           src/matrixbuilding.jl:128-150)
  * on a small analytic grid: nx x ny x nz boxes of 1 degree x 1 degree x 10 m, a land column at i = 2, tripolar seam, mass transports
- * that are smooth functions of (i, j, k).  Prints N, the five nnz and the sum of T's values; tests/test_c_example.py compiles and
- * runs it on the GPU box and compares with the Python host layer on the same inputs.
+ * that are smooth functions of (i, j, k).  Prints N, the five nnz and the sum of T's values, then builds a second time slice with TκH and
+ * TκVdeep passed back (otmb_tm_args.given); tests/test_c_example.py compiles and runs it on the GPU box and compares with the Python host
+ * layer on the same inputs.
  *
  *   gcc -O2 -I include examples/otmb_c_example.c -L oceantransportmatrixbuilder.jl_amd/lib -lotmb_hip -Wl,-rpath,$PWD/oceantransportmatrixbuilder.jl_amd/lib -lm -o otmb_c_example
  */
@@ -89,6 +90,30 @@ int main(int argc, char **argv) {
     for (int64_t e = 0; e < final[OTMB_T]; ++e) { sumT += nzval[OTMB_T][e]; sumabs += fabs(nzval[OTMB_T][e]); }
     printf("N=%lld nnz=%lld,%lld,%lld,%lld,%lld colptrT_last=%lld sumT=%.17g sumabsT=%.17g\n", (long long)N, (long long)final[0],
            (long long)final[1], (long long)final[2], (long long)final[3], (long long)final[4], (long long)colptr[OTMB_T][N], sumT, sumabs);
+
+    /* The next time slice: TκH and TκVdeep depend on the grid and κ alone, so the caller passes them back (transportmatrix's TκH = / TκVdeep =
+     * keywords, src/matrixbuilding.jl:133-147; otmb_tm_args.given).  They are then neither built, counted nor copied home -- their nnz come
+     * back 0, their output pointers may be NULL -- and T is formed with the matrices passed: the same T, bit for bit. */
+    const int keep[2] = {OTMB_TKH, OTMB_TKVDEEP};
+    for (int q = 0; q < 2; ++q) {
+        const int m = keep[q];
+        a.given[m].colptr = colptr[m]; a.given[m].rowval = rowval[m]; a.given[m].nzval = nzval[m]; a.given[m].nnz = final[m];
+    }
+    int64_t nnz2[5], final2[5];
+    CHECK(otmb_transportmatrix_plan(ctx, &a, nnz2));
+    int64_t *colptr2[5] = {0}, *rowval2[5] = {0};
+    double *nzval2[5] = {0};
+    for (int m = 0; m < 5; ++m) {
+        if (m == OTMB_TKH || m == OTMB_TKVDEEP) continue;
+        colptr2[m] = malloc((N + 1) * 8);
+        rowval2[m] = malloc((nnz2[m] ? nnz2[m] : 1) * 8);
+        nzval2[m] = malloc((nnz2[m] ? nnz2[m] : 1) * 8);
+    }
+    CHECK(otmb_transportmatrix_fetch(ctx, colptr2, rowval2, nzval2, final2));
+    int same = final2[OTMB_T] == final[OTMB_T];
+    for (int64_t e = 0; same && e < final[OTMB_T]; ++e) same = rowval2[OTMB_T][e] == rowval[OTMB_T][e] && nzval2[OTMB_T][e] == nzval[OTMB_T][e];
+    printf("given_state=%d,%d nnz2=%lld,%lld,%lld,%lld,%lld T_same=%d\n", (int)otmb_ctx_given_state(ctx, OTMB_TKH), (int)otmb_ctx_given_state(ctx, OTMB_TKVDEEP),
+           (long long)final2[0], (long long)final2[1], (long long)final2[2], (long long)final2[3], (long long)final2[4], same);
     otmb_ctx_destroy(ctx);
     return 0;
 }

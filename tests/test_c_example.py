@@ -36,6 +36,10 @@ def test_c_program_builds_the_same_matrices_as_the_python_layer(tmp_path):
     r = subprocess.run([exe, str(nx), str(ny), str(nz)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr + r.stdout
     out = dict(kv.split("=") for kv in r.stdout.split())
+    # the second time slice: the two grid-constant operators passed back -- derived (state 1), not built (nnz 0), T the same bit for bit
+    assert out["given_state"] == "1,1" and out["T_same"] == "1"
+    first, second = [int(x) for x in out["nnz"].split(",")], [int(x) for x in out["nnz2"].split(",")]
+    assert second == [first[0], first[1], 0, first[3], 0]
     # the same inputs in numpy (the C program's formulas)
     i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
     dx = 111e3 * np.cos((np.arange(ny) - ny / 2.0) * 0.01)
