@@ -88,7 +88,7 @@ def test_every_subset_of_given_operators_two_phase(oracle, name, upwind):
     del torch
 
 
-@pytest.mark.parametrize("name", ["tiny_tripolar", "odd_nx_fold", "small_rho3d"])
+@pytest.mark.parametrize("name", ["tiny_tripolar", "odd_nx_fold", "small_rho3d", "float32_flux"])
 def test_derived_operators_in_the_asynchronous_protocols(oracle, name):
     """TκH / TκVdeep / both given and derived: otmb_transportmatrix_dev (count -> scan -> fill with the given fields masked out of the counts;
     counts from facefluxes and from the counting pass), a pipeline of steps, and the fused step.  Tadv / TκVML given: GIVEN_FOREIGN there."""
@@ -133,7 +133,7 @@ def test_derived_operators_in_the_asynchronous_protocols(oracle, name):
         assert_csc_equal(got[m], rtm[m], f"afterwards: {m}")
 
 
-@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_rho3d", "odd_nx_fold", "nx2", "even_fold_open", "small_rho3d"])
+@pytest.mark.parametrize("name", ["tiny_tripolar", "tiny_rho3d", "odd_nx_fold", "nx2", "even_fold_open", "small_rho3d", "float32_flux"])
 def test_operators_built_with_another_kappa_enter_T_with_their_own_values(oracle, name):
     """The reference adds the OBJECTS passed in (:147).  A TκH / TκVdeep built with another κ has the derived rows and other values (state 3):
     T must carry ITS values -- equal to building everything with that κ -- never the re-derived ones; the fill pass reads them where they lie,
@@ -145,10 +145,13 @@ def test_operators_built_with_another_kappa_enter_T_with_their_own_values(oracle
         ops = {m: (other[m] if m in sub else rtm[m]) for m in OPS}
         want = _fold(oracle, ops, N)
         asm.set_given(**{m: (_dev(asm, other[m]) if m in sub else None) for m in OPS})
-        for protocol in ("two-phase", "step", "step onepass"):
+        for protocol in ("two-phase", "step", "step onepass") + (("fused",) if asm.nx >= 3 and COUNTS_ON else ()):
             asm.out = None
             if protocol == "two-phase":
                 asm.transportmatrix(asm.facefluxes(umo, vmo, fill))
+            elif protocol == "fused":  # (otmb_step_dev: tm_kernel<1 | 2, GIVEN> -- Float64 / Float32 transports)
+                asm.step_fused_async(umo, vmo, fill)
+                asm.finish()
             else:
                 asm.step(umo, vmo, fill, onepass=protocol.endswith("onepass"))
             assert [asm.ctx.given_state(MATS.index(m)) for m in sub] == [3] * len(sub)
