@@ -104,6 +104,9 @@ def spawn_ranks(args):
             break
         time.sleep(0.2)
     rcs = [p.wait() for p in procs]
+    if failed is None:  # (every rank ended between two polls, some of them badly: the first of those is named all the same)
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+        failed = bad[0] if bad else None
     reader.join(timeout=5)
     out = (out_chunks[0] if out_chunks else b"").decode()
     line = next((l for l in out.splitlines() if l.startswith("{")), None)
